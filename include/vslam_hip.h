@@ -1,0 +1,261 @@
+/* vslam_hip.h — C ABI of the MI355X-native ProSLAM front end (libvslam_hip.so).
+ *
+ * Drop-in boundary for the per-frame hot path of Ssellu/vslam-pose-estimation-framework
+ * (a ProSLAM fork).  The reference has no FFI: its plug points are C++ virtuals wired in
+ * SLAMAssembly::_createStereoTracker (src/system/slam_assembly.cpp:61-76).  Each entry
+ * point below names the reference interface it replaces (paths relative to the reference
+ * repository root).  The header-only C++ shim that subclasses the reference classes and
+ * forwards to these calls is shim/proslam_hip_plugin.h; INTEGRATION.md shows the two lines
+ * a maintainer changes.
+ *
+ * Conventions
+ *   - plain C, no exceptions, no callbacks; every call returns 0 (VSLAM_OK) or a negative
+ *     vslam_status; vslam_last_error() gives the text (reference: std::runtime_error thrown
+ *     at stereo_framepoint_generator.cpp:30-33,75-78,139-142,468-471, caught in app.cpp:128).
+ *   - a context owns `n_streams` independent sequences ("streams": whole KITTI sequences
+ *     or chunks of one).  Every per-frame call processes ONE stereo pair per stream, all
+ *     streams in the same kernels (grid dimension = stream).  n_streams = 1 is the literal
+ *     drop-in for the reference's single tracker.
+ *   - images: 8-bit grayscale, row-major, `stride` bytes per row
+ *     (reference: Frame::intensityImageLeft/Right, CV_8UC1, src/types/frame.h:114-119).
+ *   - transforms: double[12], row-major 3x4 [R|t] (reference: TransformMatrix3D,
+ *     src/types/definitions.h:62).
+ *   - descriptors: 32 bytes (256 bit), Hamming norm (definitions.h:45-49).
+ *   - a context is single-caller (reference: one caller thread, app.cpp:96).
+ */
+#ifndef VSLAM_HIP_H
+#define VSLAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSLAM_MAX_REGIONS 16      /* detector grid cells (det_rows*det_cols)          */
+#define VSLAM_DESC_BYTES 32       /* SRRG_PROSLAM_DESCRIPTOR_SIZE_BITS=256            */
+#define VSLAM_MAX_EPI 8           /* maximum_epipolar_search_offset_pixels upper bound */
+
+typedef enum {
+  VSLAM_OK = 0,
+  VSLAM_ERR_INVALID = -1,   /* bad argument / null frame (reference: runtime_error)          */
+  VSLAM_ERR_NO_DEVICE = -2, /* HIP device or kernel image missing: the product path never   */
+                            /* falls back to a CPU implementation                           */
+  VSLAM_ERR_HIP = -3,       /* a HIP runtime call failed                                    */
+  VSLAM_ERR_CAPACITY = -4,  /* a fixed-capacity device buffer overflowed (keypoints/points) */
+  VSLAM_ERR_STATE = -5      /* call sequence violated (e.g. track before frame_begin)       */
+} vslam_status;
+
+typedef enum { VSLAM_LOCALIZING = 0, VSLAM_TRACKING = 1 } vslam_tracker_status; /* Frame::Status */
+
+/* All parameters the hot path reads.  Names follow the reference's YAML keys
+ * (configurations/configuration_kitti.yaml:49-134, src/types/parameters.h:64-330). */
+typedef struct vslam_config {
+  /* camera (src/types/camera.h): left == right intrinsics for a rectified pair */
+  int32_t rows, cols;
+  double K[9];          /* cameraMatrix(), row-major                                        */
+  double baseline_h[3]; /* Camera::baselineHomogeneous() of the right camera: (-fx*B, 0, 0) */
+
+  /* base_framepoint_generation */
+  int32_t det_rows, det_cols;            /* number_of_detectors_vertical / _horizontal      */
+  int32_t detector_threshold_minimum;    /* FAST thresholds (parameters.h:176-177)           */
+  int32_t detector_threshold_maximum;
+  double detector_threshold_maximum_change;
+  double target_number_of_keypoints_tolerance;
+  int32_t bin_size_pixels;
+  int32_t enable_keypoint_binning;
+  int32_t minimum_projection_tracking_distance_pixels;
+  int32_t maximum_projection_tracking_distance_pixels;
+  double minimum_descriptor_distance_tracking;
+  double maximum_descriptor_distance_tracking;
+  double maximum_reliable_depth_meters;
+  double maximum_depth_meters;
+  double minimum_depth_meters;
+
+  /* stereo_framepoint_generation */
+  double maximum_matching_distance_triangulation;
+  double minimum_disparity_pixels;
+  int32_t maximum_epipolar_search_offset_pixels;
+
+  /* tracking (PoseTracker3DParameters) */
+  int32_t minimum_track_length_for_landmark_creation;
+  int32_t minimum_number_of_landmarks_to_track;
+  double tunnel_vision_ratio;
+  double good_tracking_ratio;
+  int32_t enable_landmark_recovery;
+  double minimum_delta_angular_for_movement;
+  double minimum_delta_translational_for_movement;
+
+  /* tracking.aligner (AlignerParameters) */
+  double aligner_error_delta_for_convergence;
+  double aligner_maximum_error_kernel;
+  double aligner_damping;
+  int32_t aligner_maximum_number_of_iterations;
+  int32_t aligner_minimum_number_of_inliers;
+
+  /* landmark (LandmarkParameters, parameters.h:97-112) */
+  double landmark_maximum_error_squared_meters;
+  int32_t landmark_maximum_number_of_iterations;
+
+  /* capacities of the device-resident buffers (no reference counterpart: std::vector grows) */
+  int32_t max_keypoints;       /* per image                                                   */
+  int32_t max_points;          /* framepoints per frame                                       */
+  int32_t max_history_frames;  /* frames of per-point history kept for landmark refinement     */
+} vslam_config;
+
+/* Per-frame, per-stream report: the scalars PoseTracker3D / SLAMAssembly read back from the
+ * plug-ins (pose_tracker_3d.cpp:111,132,242-248,361; slam_assembly.cpp:644-742). */
+typedef struct vslam_frame_info {
+  int32_t frame_index;         /* frames processed by this stream so far (this one included)  */
+  int32_t status;              /* tracker status AFTER the frame (vslam_tracker_status)       */
+  int32_t status_at_start;     /* status the frame was created with                           */
+  int32_t n_keypoints_left, n_keypoints_right;   /* after the descriptor border filter        */
+  int32_t n_detected_left, n_detected_right;     /* raw FAST detections (controller input)    */
+  int32_t thresholds[VSLAM_MAX_REGIONS];         /* detector thresholds AFTER adjust          */
+  int32_t track_attempts;      /* 1 + recursive re-registrations (pose_tracker_3d.cpp:300)    */
+  int32_t n_tracked;           /* points linked by the final track() call                     */
+  int32_t n_lost;              /* lost list of the final track() call                         */
+  int32_t n_tracked_landmarks; /* numberOfTrackedLandmarks()                                  */
+  int32_t aligner_ran;         /* StereoUVAligner::converge() was called on the final points  */
+  int32_t aligner_iterations;  /* oneRound() calls of that converge()                         */
+  int32_t aligner_converged;   /* hasSystemConverged()                                        */
+  int32_t n_inliers, n_outliers;
+  double total_error;          /* totalError()                                                */
+  int32_t n_after_prune;       /* points surviving _prunePoints                               */
+  int32_t n_recovered;         /* points added by recoverPoints                               */
+  int32_t n_active_landmarks;  /* _number_of_active_landmarks                                 */
+  int32_t n_new_stereo;        /* points appended by compute()                                */
+  int32_t n_points;            /* frame->points().size() at the end of the frame              */
+  int32_t track_broken;        /* breakTrack() happened                                       */
+  int32_t fallback;            /* _fallbackEstimate() was used                                */
+  int32_t window_pixels;       /* _projection_tracking_distance_pixels after the frame        */
+  int32_t error_flags;         /* bit0 keypoint capacity, bit1 point capacity, bit2 history   */
+  double tau_track;            /* _current_descriptor_distance_tracking after the frame       */
+  double tau_triangulation;    /* _current_maximum_descriptor_distance_triangulation          */
+  double camera_left_to_world[12];  /* frame pose (robotToWorld with identity robot offset)   */
+  double previous_to_current[12];   /* motion prior kept for the next frame                   */
+} vslam_frame_info;
+
+typedef struct vslam_ctx vslam_ctx;
+
+/* ---- lifetime --------------------------------------------------------------------------
+ * Replaces: new StereoFramePointGenerator(params) + setCameraLeft/Right + configure(),
+ *           new StereoUVAligner(params) + setMaximum/MinimumReliableDepthMeters + configure(),
+ *           PoseTracker3D::configure()   (slam_assembly.cpp:61-76, pose_tracker_3d.cpp:11-21).
+ * `device` is the HIP device ordinal.  Fails with VSLAM_ERR_NO_DEVICE when no GPU is usable. */
+int vslam_create(const vslam_config* cfg, int device, int n_streams, vslam_ctx** out);
+void vslam_destroy(vslam_ctx* ctx);
+const char* vslam_last_error(const vslam_ctx* ctx); /* ctx may be NULL: last create() error */
+void vslam_default_config_kitti(vslam_config* cfg); /* configuration_kitti.yaml values, KITTI-00 calib */
+void vslam_default_config_euroc(vslam_config* cfg); /* configuration_euroc.yaml values                */
+/* Restart every stream as a fresh sequence (PoseTracker3D::configure, WorldMap::clear). */
+int vslam_reset(vslam_ctx* ctx);
+/* Use the caller's HIP stream (hipStream_t passed as void*) for all work of this context. */
+int vslam_set_hip_stream(vslam_ctx* ctx, void* hip_stream);
+
+/* ---- whole-frame entry point -------------------------------------------------------------
+ * Replaces PoseTracker3D::compute() (pose_tracker_3d.cpp:32-222) for every stream of the
+ * context: initialize -> track -> StereoUVAligner -> prune -> recoverPoints -> landmark
+ * update -> compute, with the tracker's control logic evaluated on the device.  Asynchronous
+ * on the context stream; no host synchronisation.
+ *   left/right: n_streams images each; image s starts at base + s*image_stride_bytes.
+ *   *_device variant: pointers are device memory (inputs already resident in HBM).
+ *   host variant: pointers are host memory, copied with hipMemcpy2DAsync first. */
+int vslam_process_device(vslam_ctx* ctx, const uint8_t* left, const uint8_t* right,
+                         int32_t row_stride_bytes, size_t image_stride_bytes);
+int vslam_process_host(vslam_ctx* ctx, const uint8_t* left, const uint8_t* right,
+                       int32_t row_stride_bytes, size_t image_stride_bytes);
+/* Block until all queued work of the context is done; returns the sticky error state. */
+int vslam_synchronize(vslam_ctx* ctx);
+
+/* ---- stage entry points (the reference's plug-in virtuals, one call each) ------------------
+ * These drive the same device code as vslam_process_* but leave the control flow to the
+ * caller (the shim's PoseTracker3D keeps the reference's own logic). All act on every stream. */
+
+/* StereoFramePointGenerator::initialize(frame, extract_features=true)
+ * (stereo_framepoint_generator.cpp:73-133): FAST per detector region + threshold controller
+ * (base_framepoint_generator.cpp:355-459), BRIEF-32, triangulation-distance rule, feature
+ * stores.  `localizing[s]` is Frame::status()==Localizing of the new frame. */
+int vslam_frame_begin(vslam_ctx* ctx, const uint8_t* left, const uint8_t* right,
+                      int32_t row_stride_bytes, size_t image_stride_bytes, int on_device);
+/* initialize(frame, extract_features=false): rebuild both feature stores (…:128-132). */
+int vslam_frame_restore(vslam_ctx* ctx);
+/* StereoFramePointGenerator::track (…:464-681) using the tracker state held in the context
+ * (prior, window, descriptor distance; setters below). */
+int vslam_track(vslam_ctx* ctx, int by_appearance);
+/* StereoUVAligner::initialize + converge (stereouv_aligner.cpp:10-69,210-264). */
+int vslam_align(vslam_ctx* ctx, int enable_inverse_depth_as_information);
+/* PoseTracker3D::_prunePoints + recoverPoints (pose_tracker_3d.cpp:437-472,
+ * stereo_framepoint_generator.cpp:683-869). */
+int vslam_prune_recover(vslam_ctx* ctx);
+/* PoseTracker3D::_updatePoints incl. Landmark create/update (pose_tracker_3d.cpp:475-520,
+ * landmark.cpp:8-33,66-167). */
+int vslam_update_points(vslam_ctx* ctx);
+/* StereoFramePointGenerator::compute (…:135-462). */
+int vslam_stereo_new(vslam_ctx* ctx);
+/* Tracker-owned state the reference pokes through setters
+ * (setProjectionTrackingDistancePixels, setMaximumDescriptorDistanceTracking,
+ * base_framepoint_generator.h:166-167; Frame::setRobotToWorld; Frame::setStatus). */
+int vslam_set_tracker_state(vslam_ctx* ctx, int stream, int status, const double prior[12],
+                            int window_pixels, double tau_track);
+int vslam_set_pose(vslam_ctx* ctx, int stream, const double camera_left_to_world[12]);
+
+/* ---- readback (synchronises the context stream) -------------------------------------------- */
+int vslam_get_frame_info(vslam_ctx* ctx, int stream, vslam_frame_info* out);
+/* Frame::keypointsLeft/Right + descriptorsLeft/Right (frame.h:64-67).  xy = (x,y) int16 pairs
+ * (FAST keypoints are integer pixels), score = KeyPoint::response, desc = n*32 bytes.
+ * Order: image row-major.  Any output pointer may be NULL.  cap = capacity in keypoints. */
+int vslam_get_keypoints(vslam_ctx* ctx, int stream, int side, int32_t cap, int32_t* n,
+                        int16_t* xy, int32_t* score, uint8_t* desc);
+/* Frame::points() of the current frame (frame.h:88-89) as SoA.
+ *   kp   : n*4 int16 (xL,yL,xR,yR)              FramePoint::keypointLeft/Right().pt
+ *   meta : n*6 int32 (hamming_LR, epipolar_offset, previous_index, track_length,
+ *                      landmark_updates, disparity)
+ *   cam  : n*3 double  cameraCoordinatesLeft()
+ *   lm   : n*3 double  landmark()->coordinates() (world), valid where landmark_updates>0
+ *   chi  : n double    StereoUVAligner::errors() of the point (-1 if none), inl: inliers() */
+int vslam_get_points(vslam_ctx* ctx, int stream, int32_t cap, int32_t* n, int16_t* kp,
+                     int32_t* meta, double* cam, double* lm);
+int vslam_get_aligner_result(vslam_ctx* ctx, int stream, int32_t cap, int32_t* n, double* chi,
+                             uint8_t* inlier, double T[12], double H[36]);
+/* The 8 chronometers SLAMAssembly::printReport prints (slam_assembly.cpp:703-742), seconds of
+ * device time accumulated per stage over all streams (HIP events): keypoint_detection,
+ * descriptor_extraction, point_triangulation, tracking, track_creation, pose_optimization,
+ * landmark_optimization, point_recovery. */
+int vslam_get_timers(vslam_ctx* ctx, double seconds[8]);
+int vslam_enable_timers(vslam_ctx* ctx, int on);
+
+/* ---- stand-alone kernels (unit parity, and the reference's optional knnMatch block) -------- */
+/* cv::FastFeatureDetector::detect on one ROI (base_framepoint_generator.cpp:12-25,367):
+ * FAST-9/16, non-max suppression, output row-major, coordinates relative to the ROI. */
+int vslam_fast_detect(vslam_ctx* ctx, const uint8_t* image_host, int32_t rows, int32_t cols,
+                      int32_t stride, int32_t roi_x, int32_t roi_y, int32_t roi_w, int32_t roi_h,
+                      int32_t threshold, int32_t cap, int32_t* n, int16_t* xy, int32_t* score);
+/* _descriptor_extractor->compute (base_framepoint_generator.cpp:431-438): BRIEF-32 at given
+ * integer keypoints; keypoints closer than 28 px to the border are removed (keep[i]=0). */
+int vslam_brief_describe(vslam_ctx* ctx, const uint8_t* image_host, int32_t rows, int32_t cols,
+                         int32_t stride, int32_t n, const int16_t* xy, uint8_t* keep, uint8_t* desc);
+/* matcher->knnMatch(query, train, k=2) of the use_matches block
+ * (stereo_framepoint_generator.cpp:168-206).  norm: 0 = NORM_HAMMING on the bytes,
+ * 1 = NORM_L2 on the bytes converted to float (what convertTo(CV_32F)+BRUTEFORCE computes).
+ * idx: nq*2 int32 (-1 if fewer than 2 train rows), dist: nq*2 float. Ties -> lowest index. */
+int vslam_knn2(vslam_ctx* ctx, int norm, int32_t nq, const uint8_t* query, int32_t nt,
+               const uint8_t* train, int32_t* idx, float* dist);
+/* StereoUVAligner on caller-provided correspondences (stereouv_aligner.cpp:72-264):
+ * moving n*3, fixed n*4, omega n, weight n. */
+int vslam_align_points(vslam_ctx* ctx, int32_t n, const double* moving, const double* fixed,
+                       const double* omega, const double* weight, const double T_init[12],
+                       double T_out[12], double* chi, uint8_t* inlier, int32_t* n_inliers,
+                       double* total_error, int32_t* iterations, double H_out[36]);
+
+/* ---- multi-GPU: trajectory assembly ---------------------------------------------------------
+ * No reference counterpart (single process).  The pose all-gather is issued by the host
+ * launcher through RCCL (torch.distributed backend "nccl"); these helpers pack/unpack. */
+int vslam_get_poses(vslam_ctx* ctx, int stream, int32_t first_frame, int32_t n_frames,
+                    double* camera_left_to_world /* n_frames*12 */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSLAM_HIP_H */

@@ -1,0 +1,1434 @@
+/* vslam_oracle.cpp — CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain, single-threaded C++ restatement of the reference's per-frame hot path
+ * (Ssellu/vslam-pose-estimation-framework, a ProSLAM fork).  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this library; the product (libvslam_hip.so) never does.
+ *
+ * PARITY STATUS: "parity unpinned" against the reference binary.  The reference cannot be built
+ * here (needs OpenCV 3 + xfeatures2d, Eigen, srrg_core, srrg_hbst, yaml-cpp, easy_profiler, g2o,
+ * Qt: none on this machine) and ships no tests, fixtures or golden vectors.
+ * The third-party arithmetic on the path is restated from the published algorithms:
+ *   - cv::FastFeatureDetector (FAST-9/16 + cornerScore + 3x3 strict NMS), OpenCV 3.x features2d
+ *   - cv::xfeatures2d::BriefDescriptorExtractor(32): integral image + 9x9 box tests, 28 px border;
+ *     the 256 test pairs are REPO-DEFINED (include/vslam_brief_pattern.h), OpenCV's table is absent
+ *   - cv::norm(NORM_HAMMING), BFMatcher::knnMatch(k=2)
+ *   - srrg_core::skew / v2t, Eigen fullPivLu / Isometry (branch "marchless", unpinned)
+ * It is pinned instead by an independent numpy restatement (tests/golden/make_golden.py) whose
+ * outputs are committed under tests/golden/.
+ *
+ * Every function cites the reference file:line it follows (paths relative to the reference root).
+ */
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../include/vslam_hip.h"
+#include "../include/vslam_brief_pattern.h"
+#include "../tools/synth/synth_scene.h"
+
+#define ORC_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+typedef double real; /* src/types/definitions.h:52 */
+
+/* ------------------------------------------------------------------------------------------
+ * small fixed-size math (Eigen / srrg_core restated)
+ * ---------------------------------------------------------------------------------------- */
+struct Tf { /* row-major 3x4 [R|t], TransformMatrix3D (definitions.h:62) */
+  real m[12];
+};
+inline Tf tf_identity() { Tf t; std::memset(t.m, 0, sizeof t.m); t.m[0] = t.m[5] = t.m[10] = 1; return t; }
+inline void tf_apply(const Tf& T, const real p[3], real out[3]) {
+  for (int i = 0; i < 3; ++i)
+    out[i] = ((T.m[4 * i + 0] * p[0] + T.m[4 * i + 1] * p[1]) + T.m[4 * i + 2] * p[2]) + T.m[4 * i + 3];
+}
+inline Tf tf_mul(const Tf& A, const Tf& B) { /* A*B */
+  Tf C;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j)
+      C.m[4 * i + j] = (A.m[4 * i + 0] * B.m[0 + j] + A.m[4 * i + 1] * B.m[4 + j]) + A.m[4 * i + 2] * B.m[8 + j];
+    C.m[4 * i + 3] = ((A.m[4 * i + 0] * B.m[3] + A.m[4 * i + 1] * B.m[7]) + A.m[4 * i + 2] * B.m[11]) + A.m[4 * i + 3];
+  }
+  return C;
+}
+inline Tf tf_inverse(const Tf& A) { /* Isometry inverse: [R^T | -R^T t] */
+  Tf C;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) C.m[4 * i + j] = A.m[4 * j + i];
+  for (int i = 0; i < 3; ++i)
+    C.m[4 * i + 3] = -((C.m[4 * i + 0] * A.m[3] + C.m[4 * i + 1] * A.m[7]) + C.m[4 * i + 2] * A.m[11]);
+  return C;
+}
+inline void mat3_mul_vec(const real K[9], const real p[3], real out[3]) {
+  for (int i = 0; i < 3; ++i) out[i] = (K[3 * i + 0] * p[0] + K[3 * i + 1] * p[1]) + K[3 * i + 2] * p[2];
+}
+
+/* srrg_core::v2t [recalled, SURVEY.md §8c]: translation = v[0:3]; rotation from the vector part of
+ * a unit quaternion (w = sqrt(1-|q|^2)); Eigen Quaternion::toRotationMatrix formula. */
+inline Tf v2t(const real v[6]) {
+  Tf T;
+  real qx = v[3], qy = v[4], qz = v[5], qw;
+  const real n2 = (qx * qx + qy * qy) + qz * qz;
+  if (n2 < 1) {
+    qw = std::sqrt(1 - n2);
+  } else {
+    const real n = std::sqrt(n2);
+    qx /= n; qy /= n; qz /= n; qw = 0;
+  }
+  const real tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+  const real twx = tx * qw, twy = ty * qw, twz = tz * qw;
+  const real txx = tx * qx, txy = ty * qx, txz = tz * qx;
+  const real tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+  T.m[0] = 1 - (tyy + tzz); T.m[1] = txy - twz;       T.m[2] = txz + twy;
+  T.m[4] = txy + twz;       T.m[5] = 1 - (txx + tzz); T.m[6] = tyz - twx;
+  T.m[8] = txz - twy;       T.m[9] = tyz + twx;       T.m[10] = 1 - (txx + tyy);
+  T.m[3] = v[0]; T.m[7] = v[1]; T.m[11] = v[2];
+  return T;
+}
+
+/* Eigen::FullPivLU<Matrix6>::solve restated: Gaussian elimination with full pivoting, pivot =
+ * first strict maximum of |a_ij| in column-major scan of the remaining corner. n <= 6. */
+template <int N>
+inline void full_piv_lu_solve(const real A_in[N * N], const real b_in[N], real x[N]) {
+  real A[N * N], b[N];
+  int colperm[N];
+  std::memcpy(A, A_in, sizeof A);
+  std::memcpy(b, b_in, sizeof b);
+  for (int i = 0; i < N; ++i) colperm[i] = i;
+  int rank = N;
+  for (int k = 0; k < N; ++k) {
+    int pr = k, pc = k;
+    real best = 0;
+    for (int j = k; j < N; ++j)
+      for (int i = k; i < N; ++i) {
+        const real a = std::fabs(A[i * N + j]);
+        if (a > best) { best = a; pr = i; pc = j; }
+      }
+    if (best == 0) { rank = k; break; }
+    if (pr != k) { for (int j = 0; j < N; ++j) std::swap(A[k * N + j], A[pr * N + j]); std::swap(b[k], b[pr]); }
+    if (pc != k) { for (int i = 0; i < N; ++i) std::swap(A[i * N + k], A[i * N + pc]); std::swap(colperm[k], colperm[pc]); }
+    for (int i = k + 1; i < N; ++i) {
+      const real f = A[i * N + k] / A[k * N + k];
+      A[i * N + k] = 0;
+      for (int j = k + 1; j < N; ++j) A[i * N + j] -= f * A[k * N + j];
+      b[i] -= f * b[k];
+    }
+  }
+  real y[N];
+  for (int i = 0; i < N; ++i) y[i] = 0;
+  for (int i = rank - 1; i >= 0; --i) {
+    real s = b[i];
+    for (int j = i + 1; j < rank; ++j) s -= A[i * N + j] * y[j];
+    y[i] = s / A[i * N + i];
+  }
+  for (int i = 0; i < N; ++i) x[colperm[i]] = y[i];
+}
+
+/* WorldMap::toOrientationRodrigues(R).norm() (src/types/world_map.h:143-147): the rotation angle
+ * as cv::Rodrigues computes it (matrix -> vector branch) [recalled]. */
+inline real rotation_angle(const Tf& T) {
+  const real rx = T.m[9] - T.m[6], ry = T.m[2] - T.m[8], rz = T.m[4] - T.m[1];
+  const real s = std::sqrt(((rx * rx + ry * ry) + rz * rz) * 0.25);
+  real c = ((T.m[0] + T.m[5]) + T.m[10] - 1) * 0.5;
+  c = c > 1 ? 1 : (c < -1 ? -1 : c);
+  if (s < 1e-5) return c > 0 ? 0.0 : M_PI;
+  return std::acos(c);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * FAST-9/16 with non-max suppression: cv::FastFeatureDetector::detect on a ROI view
+ * (reference call sites base_framepoint_generator.cpp:12-25 and :367; algorithm: OpenCV 3.x
+ * features2d/src/fast.cpp FAST_t<16> and fast_score.cpp cornerScore<16>) [recalled].
+ * ---------------------------------------------------------------------------------------- */
+const int kFastDx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+const int kFastDy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+
+/* returns the corner score (>= threshold) or 0 when (x,y) is not a FAST-9 corner */
+inline int fast_corner_score(const uint8_t* img, int stride, int x, int y, int threshold) {
+  const int v = img[y * stride + x];
+  {
+    /* high-speed rejection of fast.cpp: a 9-arc contains one pixel of every opposite pair */
+    const uint8_t* c = img + y * stride + x;
+    const int lo = v - threshold, hi = v + threshold;
+    const int p0 = c[3 * stride], p8 = c[-3 * stride], p4 = c[3], p12 = c[-3];
+    const bool dark = (p0 < lo || p8 < lo) && (p4 < lo || p12 < lo);
+    const bool bright = (p0 > hi || p8 > hi) && (p4 > hi || p12 > hi);
+    if (!dark && !bright) return 0;
+  }
+  int d[25];
+  for (int k = 0; k < 16; ++k) d[k] = v - (int)img[(y + kFastDy[k]) * stride + (x + kFastDx[k])];
+  for (int k = 16; k < 25; ++k) d[k] = d[k - 16];
+  /* corner iff >= 9 contiguous circle pixels are all darker (d > t) or all brighter (d < -t) */
+  bool corner = false;
+  int run_dark = 0, run_bright = 0;
+  for (int k = 0; k < 25 && !corner; ++k) {
+    run_dark = (d[k] > threshold) ? run_dark + 1 : 0;
+    run_bright = (d[k] < -threshold) ? run_bright + 1 : 0;
+    if (run_dark > 8 || run_bright > 8) corner = true;
+  }
+  if (!corner) return 0;
+  /* cornerScore<16>: largest threshold for which the pixel stays a corner */
+  int A = -1000, Bm = 1000;
+  for (int s = 0; s < 16; ++s) {
+    int mn = d[s], mx = d[s];
+    for (int j = 1; j < 9; ++j) { mn = std::min(mn, d[s + j]); mx = std::max(mx, d[s + j]); }
+    A = std::max(A, mn);
+    Bm = std::min(Bm, mx);
+  }
+  const int a0 = std::max(threshold, A);
+  const int b0 = std::min(-a0, Bm);
+  return -b0 - 1;
+}
+
+struct Keypoint {
+  int16_t x, y;
+  int32_t score;
+};
+
+/* detect on ROI (rx,ry,rw,rh) of an image; coordinates returned relative to the ROI */
+void fast_detect_roi(const uint8_t* img, int stride, int rx, int ry, int rw, int rh, int threshold,
+                     std::vector<Keypoint>& out) {
+  out.clear();
+  threshold = std::min(std::max(threshold, 0), 255);
+  if (rw < 7 || rh < 7) return;
+  const uint8_t* roi = img + (size_t)ry * stride + rx;
+  std::vector<uint8_t> score((size_t)rw * rh, 0);
+  for (int y = 3; y < rh - 3; ++y)
+    for (int x = 3; x < rw - 3; ++x) score[(size_t)y * rw + x] = (uint8_t)fast_corner_score(roi, stride, x, y, threshold);
+  for (int y = 3; y < rh - 3; ++y)
+    for (int x = 3; x < rw - 3; ++x) {
+      const int s = score[(size_t)y * rw + x];
+      if (!s) continue;
+      bool keep = true;
+      for (int dy = -1; dy <= 1 && keep; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          if (!dx && !dy) continue;
+          if (s <= score[(size_t)(y + dy) * rw + (x + dx)]) { keep = false; break; }
+        }
+      if (keep) out.push_back(Keypoint{(int16_t)x, (int16_t)y, s});
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * BRIEF-32: cv::xfeatures2d::BriefDescriptorExtractorImpl::compute restated [recalled]:
+ * integral image (CV_32S), KeyPointsFilter::runByImageBorder(28), pixelTests32 on 9x9 box sums.
+ * Reference call site: base_framepoint_generator.cpp:431-438.
+ * ---------------------------------------------------------------------------------------- */
+const int8_t kBriefPattern[256][4] = VSLAM_BRIEF_PATTERN_INIT;
+
+void integral_image(const uint8_t* img, int rows, int cols, int stride, std::vector<int32_t>& sum) {
+  sum.assign((size_t)(rows + 1) * (cols + 1), 0);
+  for (int y = 0; y < rows; ++y) {
+    int32_t acc = 0;
+    for (int x = 0; x < cols; ++x) {
+      acc += img[(size_t)y * stride + x];
+      sum[(size_t)(y + 1) * (cols + 1) + (x + 1)] = sum[(size_t)y * (cols + 1) + (x + 1)] + acc;
+    }
+  }
+}
+inline int32_t smoothed_sum(const std::vector<int32_t>& sum, int cols, int y, int x) {
+  const int W = cols + 1, h = VSLAM_BRIEF_KERNEL_HALF;
+  return sum[(size_t)(y + h + 1) * W + (x + h + 1)] - sum[(size_t)(y + h + 1) * W + (x - h)] -
+         sum[(size_t)(y - h) * W + (x + h + 1)] + sum[(size_t)(y - h) * W + (x - h)];
+}
+inline bool brief_inside(int rows, int cols, int x, int y) {
+  const int b = VSLAM_BRIEF_BORDER;
+  return x >= b && x < cols - b && y >= b && y < rows - b;
+}
+void brief_at(const std::vector<int32_t>& sum, int cols, int x, int y, uint8_t desc[32]) {
+  std::memset(desc, 0, 32);
+  for (int i = 0; i < 256; ++i) {
+    const int32_t a = smoothed_sum(sum, cols, y + kBriefPattern[i][0], x + kBriefPattern[i][1]);
+    const int32_t b = smoothed_sum(sum, cols, y + kBriefPattern[i][2], x + kBriefPattern[i][3]);
+    if (a < b) desc[i >> 3] |= (uint8_t)(0x80u >> (i & 7));
+  }
+}
+
+/* cv::norm(a, b, NORM_HAMMING) on 32 bytes (definitions.h:49) */
+inline int hamming32(const uint8_t* a, const uint8_t* b) {
+  int d = 0;
+  for (int i = 0; i < 32; ++i) d += __builtin_popcount((unsigned)(a[i] ^ b[i]));
+  return d;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * data model (src/types/frame_point.h, frame.h restated as PODs)
+ * ---------------------------------------------------------------------------------------- */
+struct Feature { /* IntensityFeature (frame_point.h:18-35): row=(int)pt.y, col=(int)pt.x */
+  int row, col;
+  int score;
+  uint8_t desc[32];
+};
+
+struct FeatureStore { /* IntensityFeatureMatcher (intensity_feature_matcher.{h,cpp}) */
+  int rows = 0, cols = 0;
+  std::vector<Feature> feats;  /* features of the image, id = position at setFeatures time  */
+  std::vector<int> vec;        /* feature_vector: ids, pruned / sorted in place             */
+  std::vector<int> lattice;    /* feature_lattice[row][col]: id or -1                       */
+  void configure(int r, int c) { rows = r; cols = c; lattice.assign((size_t)r * c, -1); }
+  /* setFeatures (intensity_feature_matcher.cpp:48-70): later duplicate overwrites the cell */
+  void set_features(const std::vector<Feature>& f) {
+    std::fill(lattice.begin(), lattice.end(), -1);
+    feats = f;
+    vec.resize(f.size());
+    for (size_t i = 0; i < f.size(); ++i) { vec[i] = (int)i; lattice[(size_t)f[i].row * cols + f[i].col] = (int)i; }
+  }
+  /* sortFeatureVector (:72-79); ties (same pixel) broken by id to stay deterministic */
+  void sort_vec() {
+    std::sort(vec.begin(), vec.end(), [this](int a, int b) {
+      const Feature &fa = feats[a], &fb = feats[b];
+      if (fa.row != fb.row) return fa.row < fb.row;
+      if (fa.col != fb.col) return fa.col < fb.col;
+      return a < b;
+    });
+  }
+  /* prune (:150-172): remove the given POSITIONS of vec, keep order */
+  void prune_positions(const std::set<uint32_t>& pos) {
+    size_t n = 0;
+    for (size_t i = 0; i < vec.size(); ++i)
+      if (!pos.count((uint32_t)i)) vec[n++] = vec[i];
+    vec.resize(n);
+  }
+  /* getMatchingFeatureInRectangularRegion (:81-148); returns feature id or -1 */
+  int match_in_region(int row_ref, int col_ref, const uint8_t* desc_ref, int r0, int r1, int c0, int c1,
+                      real max_dist, bool by_appearance, real& dist_best) const {
+    dist_best = max_dist;
+    int best = -1;
+    if (by_appearance) {
+      for (int r = r0; r < r1; ++r)
+        for (int c = c0; c < c1; ++c) {
+          const int id = lattice[(size_t)r * cols + c];
+          if (id < 0) continue;
+          const real d = hamming32(desc_ref, feats[id].desc);
+          if (d < dist_best) { dist_best = d; best = id; }
+        }
+    } else {
+      uint32_t pix_best = 10000;
+      for (int r = r0; r < r1; ++r)
+        for (int c = c0; c < c1; ++c) {
+          const int id = lattice[(size_t)r * cols + c];
+          if (id < 0) continue;
+          const real d = hamming32(desc_ref, feats[id].desc);
+          if (d < max_dist) {
+            const int32_t dr = row_ref - r, dc = col_ref - c;
+            const uint32_t pix = (uint32_t)(dr * dr + dc * dc);
+            if (pix < pix_best) { pix_best = pix; dist_best = d; best = id; }
+          }
+        }
+    }
+    return best;
+  }
+};
+
+struct Meas { /* Landmark::Measurement (landmark.h:22-36) */
+  int frame;
+  real cam[3];
+  real inv_depth;
+};
+struct Landmark { /* src/types/landmark.{h,cpp} (position part only) */
+  real w[3];
+  uint32_t updates;
+  std::vector<Meas> meas;
+};
+
+struct Point { /* FramePoint (frame_point.h:39-203) */
+  int xL, yL, xR, yR;       /* keypointLeft/Right().pt (integer valued)          */
+  uint8_t dL[32], dR[32];   /* descriptorLeft/Right                              */
+  int dist;                 /* descriptorDistanceTriangulation                   */
+  int epi;                  /* epipolarOffset                                    */
+  int prev;                 /* index of previous() in the previous frame, or -1  */
+  int track_len;            /* trackLength                                       */
+  int lm;                   /* landmark id (origin()->landmark()) or -1          */
+  bool has_next;            /* next() != nullptr                                 */
+  real cam[3];              /* cameraCoordinatesLeft                             */
+  real cam_lm[3];           /* cameraCoordinatesLeftLandmark                     */
+  real chi;                 /* aligner error of this point (readback only)       */
+  uint8_t inlier;
+};
+
+struct FrameRec {
+  Tf cam_to_world, world_to_cam;
+  std::vector<Point> points;
+};
+
+/* ------------------------------------------------------------------------------------------
+ * StereoUVAligner (src/aligners/stereouv_aligner.cpp:72-264, base_aligner.h:74-106)
+ * ---------------------------------------------------------------------------------------- */
+struct AlignerIO {
+  int n = 0;
+  std::vector<real> moving, fixed, omega, weight; /* n*3, n*4, n, n */
+  Tf T;
+  /* outputs */
+  std::vector<real> errors;
+  std::vector<uint8_t> inliers;
+  int n_inliers = 0, n_outliers = 0, iterations = 0, converged = 0;
+  real total_error = 0;
+  real H[36];
+};
+
+struct AlignerParams {
+  real K[9], baseline[3];
+  int rows, cols;
+  real min_depth, kernel, damping, delta;
+  int max_it, min_inliers;
+};
+
+/* linearize (:72-187) */
+void aligner_linearize(const AlignerParams& P, AlignerIO& io, bool ignore_outliers, real H[36], real b[6]) {
+  std::memset(H, 0, 36 * sizeof(real));
+  std::memset(b, 0, 6 * sizeof(real));
+  io.n_inliers = 0;
+  io.total_error = 0;
+  for (int u = 0; u < io.n; ++u) {
+    io.errors[u] = -1;
+    io.inliers[u] = 0;
+    real omega = io.omega[u];
+    real p[3];
+    tf_apply(io.T, &io.moving[3 * u], p);
+    if (p[2] < P.min_depth) continue;
+    real abcL[3], abcR[3];
+    mat3_mul_vec(P.K, p, abcL);
+    for (int i = 0; i < 3; ++i) abcR[i] = abcL[i] + P.baseline[i];
+    const real cL = abcL[2], cR = abcR[2];
+    const real uL = abcL[0] / cL, vL = abcL[1] / cL, uR = abcR[0] / cR, vR = abcR[1] / cR;
+    if (uL < 0 || uL > P.cols || vL < 0 || vL > P.rows) continue;
+    if (uR < 0 || uR > P.cols || vR < 0 || vR > P.rows) continue;
+    const real e[4] = {uL - io.fixed[4 * u + 0], vL - io.fixed[4 * u + 1], uR - io.fixed[4 * u + 2],
+                       vR - io.fixed[4 * u + 3]};
+    const real chi = omega * (((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]) + e[3] * e[3]);
+    io.errors[u] = chi;
+    if (chi > P.kernel) {
+      if (ignore_outliers) continue;
+      omega *= P.kernel / chi;
+    } else {
+      io.inliers[u] = 1;
+      ++io.n_inliers;
+    }
+    io.total_error += chi;
+    /* jacobian_transform = [w*I3 | -2*skew(p)] (:146-149); skew(p) = [[0,-pz,py],[pz,0,-px],[-py,px,0]] */
+    const real w = io.weight[u];
+    real Jt[3][6] = {{w, 0, 0, 0, 2 * p[2], -2 * p[1]},
+                     {0, w, 0, -2 * p[2], 0, 2 * p[0]},
+                     {0, 0, w, 2 * p[1], -2 * p[0], 0}};
+    real KJ[3][6];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 6; ++j)
+        KJ[i][j] = (P.K[3 * i + 0] * Jt[0][j] + P.K[3 * i + 1] * Jt[1][j]) + P.K[3 * i + 2] * Jt[2][j];
+    const real icL = 1 / cL, icR = 1 / cR, icL2 = icL * icL, icR2 = icR * icR;
+    const real JL[2][3] = {{icL, 0, -abcL[0] * icL2}, {0, icL, -abcL[1] * icL2}};
+    const real JR[2][3] = {{icR, 0, -abcR[0] * icR2}, {0, icR, -abcR[1] * icR2}};
+    real J[4][6];
+    for (int j = 0; j < 6; ++j) {
+      J[0][j] = (JL[0][0] * KJ[0][j] + JL[0][1] * KJ[1][j]) + JL[0][2] * KJ[2][j];
+      J[1][j] = (JL[1][0] * KJ[0][j] + JL[1][1] * KJ[1][j]) + JL[1][2] * KJ[2][j];
+      J[2][j] = (JR[0][0] * KJ[0][j] + JR[0][1] * KJ[1][j]) + JR[0][2] * KJ[2][j];
+      J[3][j] = (JR[1][0] * KJ[0][j] + JR[1][1] * KJ[1][j]) + JR[1][2] * KJ[2][j];
+    }
+    for (int r = 0; r < 6; ++r) {
+      for (int c = 0; c < 6; ++c)
+        H[6 * r + c] += omega * (((J[0][r] * J[0][c] + J[1][r] * J[1][c]) + J[2][r] * J[2][c]) + J[3][r] * J[3][c]);
+      b[r] += omega * (((J[0][r] * e[0] + J[1][r] * e[1]) + J[2][r] * e[2]) + J[3][r] * e[3]);
+    }
+  }
+  io.n_outliers = io.n - io.n_inliers;
+}
+
+/* oneRound (:190-207) */
+void aligner_one_round(const AlignerParams& P, AlignerIO& io, bool ignore_outliers) {
+  real b[6];
+  aligner_linearize(P, io, ignore_outliers, io.H, b);
+  for (int i = 0; i < 6; ++i) io.H[7 * i] += P.damping * io.n;
+  real nb[6], dx[6];
+  for (int i = 0; i < 6; ++i) nb[i] = -b[i];
+  full_piv_lu_solve<6>(io.H, nb, dx);
+  io.T = tf_mul(v2t(dx), io.T);
+  /* R <- R - 0.5*R*(R^T R - I) */
+  real R[9], RtR[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) R[3 * i + j] = io.T.m[4 * i + j];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      RtR[3 * i + j] = (R[0 + i] * R[0 + j] + R[3 + i] * R[3 + j]) + R[6 + i] * R[6 + j];
+      if (i == j) RtR[3 * i + j] -= 1;
+    }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      io.T.m[4 * i + j] = R[3 * i + j] - 0.5 * ((R[3 * i + 0] * RtR[j] + R[3 * i + 1] * RtR[3 + j]) + R[3 * i + 2] * RtR[6 + j]);
+  ++io.iterations;
+}
+
+/* converge (:210-264) */
+void aligner_converge(const AlignerParams& P, AlignerIO& io) {
+  io.errors.assign(io.n, -1);
+  io.inliers.assign(io.n, 0);
+  io.iterations = 0;
+  io.converged = 0;
+  std::memset(io.H, 0, sizeof io.H);
+  real total_error_previous = 0;
+  for (int it = 0; it < P.max_it; ++it) {
+    aligner_one_round(P, io, false);
+    if (P.delta > std::fabs(total_error_previous - io.total_error)) {
+      total_error_previous = io.total_error;
+      if (io.n_inliers > P.min_inliers && io.n_inliers > io.n_outliers) {
+        for (int it2 = 0; it2 < P.max_it; ++it2) {
+          aligner_one_round(P, io, true);
+          if (std::fabs(total_error_previous - io.total_error) < P.delta) {
+            total_error_previous = io.total_error;
+            break;
+          } else {
+            total_error_previous = io.total_error;
+          }
+        }
+      }
+      io.converged = 1;
+      break;
+    } else {
+      total_error_previous = io.total_error;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * one sequence: StereoFramePointGenerator + StereoUVAligner + PoseTracker3D control logic
+ * ---------------------------------------------------------------------------------------- */
+struct Region { int x, y, w, h; };
+
+struct Stream {
+  vslam_config cfg;
+  /* BaseFramePointGenerator::configure (base_framepoint_generator.cpp:165-329) */
+  std::vector<Region> regions;
+  std::vector<int> thr;        /* FAST detector thresholds (int, FastDetector::setThreshold rint) */
+  std::vector<real> thr_acc;   /* _detector_thresholds */
+  int n_detections = 0;
+  int rows_bin = 0, cols_bin = 0, target_kp = 0;
+  uint32_t target_per_detector = 0;
+  FeatureStore storeL, storeR;
+  std::vector<int32_t> sumL, sumR; /* integral images of the current frame (recoverPoints) */
+  std::vector<Feature> kpL, kpR;   /* Frame::keypoints/descriptors after the border filter */
+  int n_detected_left = 0, n_detected_right_raw = 0, n_detected_left_raw = 0;
+  real tau_tri;                /* _current_maximum_descriptor_distance_triangulation */
+  /* PoseTracker3D state (pose_tracker_3d.h:79-113) */
+  int status = VSLAM_LOCALIZING;
+  Tf prior = tf_identity();    /* _previous_to_current_camera */
+  int win = 0;                 /* _projection_tracking_distance_pixels */
+  real tau_track = 0;          /* _current_descriptor_distance_tracking */
+  uint32_t n_tracked_landmarks = 0, n_tracked_points = 0, n_tracked_landmarks_prev = 0, n_active_landmarks = 0;
+  Tf world_pose = tf_identity(); /* WorldMap::robot_to_world (identity robot offset) */
+  std::vector<FrameRec> frames;
+  std::vector<Landmark> landmarks;
+  std::vector<int> lost;       /* _lost_points: indices into the previous frame's points */
+  AlignerIO al;
+  bool aligner_valid = false;  /* aligner ran on the current frame->points() (quirk B.3) */
+  vslam_frame_info info;
+  std::vector<Tf> poses;
+
+  void configure(const vslam_config& c) {
+    cfg = c;
+    const int nv = cfg.det_rows, nh = cfg.det_cols;
+    const real ph = (real)cfg.rows / nv, pw = (real)cfg.cols / nh;
+    regions.clear();
+    for (int r = 0; r < nv; ++r)
+      for (int cc = 0; cc < nh; ++cc) {
+        int off_w = nh > 1 ? 2 : 0, off_h = nv > 1 ? 2 : 0, off_r = 0, off_c = 0;
+        if (r > 0) { off_r = -off_h; if (r < nv - 1) off_h *= 2; }
+        if (cc > 0) { off_c = -off_w; if (cc < nh - 1) off_w *= 2; }
+        Region R;
+        R.x = (int)(std::round(cc * pw) + off_c);
+        R.y = (int)(std::round(r * ph) + off_r);
+        R.w = (int)(pw + off_w);
+        R.h = (int)(ph + off_h);
+        regions.push_back(R);
+      }
+    thr.assign(regions.size(), cfg.detector_threshold_minimum);
+    thr_acc.assign(regions.size(), 0);
+    n_detections = 0;
+    cols_bin = (int)(std::floor((real)cfg.cols / cfg.bin_size_pixels) + 1);
+    rows_bin = (int)(std::floor((real)cfg.rows / cfg.bin_size_pixels) + 1);
+    target_kp = cols_bin * rows_bin;
+    target_per_detector = (uint32_t)((real)target_kp / (real)regions.size());
+    storeL.configure(cfg.rows, cfg.cols);
+    storeR.configure(cfg.rows, cfg.cols);
+    reset();
+  }
+  void reset() {
+    /* PoseTracker3D::configure (pose_tracker_3d.cpp:11-21) */
+    status = VSLAM_LOCALIZING;
+    prior = tf_identity();
+    win = cfg.maximum_projection_tracking_distance_pixels;
+    tau_track = cfg.minimum_descriptor_distance_tracking;
+    tau_tri = 0.1 * 256;
+    thr.assign(regions.size(), cfg.detector_threshold_minimum);
+    thr_acc.assign(regions.size(), 0);
+    n_detections = 0;
+    n_tracked_landmarks = n_tracked_points = n_tracked_landmarks_prev = n_active_landmarks = 0;
+    world_pose = tf_identity();
+    frames.clear();
+    landmarks.clear();
+    lost.clear();
+    poses.clear();
+    aligner_valid = false;
+    std::memset(&info, 0, sizeof info);
+  }
+
+  /* detectKeypoints (base_framepoint_generator.cpp:355-429): per-region FAST + controller */
+  void detect_keypoints(const uint8_t* img, int stride, std::vector<Keypoint>& out, int& n_raw) {
+    out.clear();
+    std::vector<Keypoint> kps;
+    for (size_t i = 0; i < regions.size(); ++i) {
+      const Region& R = regions[i];
+      fast_detect_roi(img, stride, R.x, R.y, R.w, R.h, thr[i], kps);
+      real t = thr[i];
+      const real target = (real)target_per_detector;
+      const real delta = ((real)kps.size() - target) / target;
+      if (delta < -cfg.target_number_of_keypoints_tolerance) {
+        const real change = std::max(delta, -cfg.detector_threshold_maximum_change);
+        t = t + std::min(change * t, -1.0);
+        if (t < cfg.detector_threshold_minimum) t = cfg.detector_threshold_minimum;
+      } else if (delta > cfg.target_number_of_keypoints_tolerance) {
+        const real change = std::min(delta, cfg.detector_threshold_maximum_change);
+        t += std::max(change * t, 1.0);
+        if (t > cfg.detector_threshold_maximum) t = cfg.detector_threshold_maximum;
+      }
+      thr_acc[i] += t;
+      for (Keypoint k : kps) { k.x = (int16_t)(k.x + R.x); k.y = (int16_t)(k.y + R.y); out.push_back(k); }
+    }
+    ++n_detections;
+    n_raw = (int)out.size();
+  }
+  /* adjustDetectorThresholds (:440-459) */
+  void adjust_thresholds() {
+    for (size_t i = 0; i < regions.size(); ++i) {
+      thr_acc[i] /= n_detections;
+      thr[i] = (int)std::rint(thr_acc[i]);
+      thr_acc[i] = 0;
+    }
+    n_detections = 0;
+  }
+  /* computeDescriptors (:431-438): border filter + BRIEF */
+  void compute_descriptors(const uint8_t* img, int stride, const std::vector<Keypoint>& kps,
+                           std::vector<int32_t>& sum, std::vector<Feature>& out) {
+    integral_image(img, cfg.rows, cfg.cols, stride, sum);
+    out.clear();
+    for (const Keypoint& k : kps) {
+      if (!brief_inside(cfg.rows, cfg.cols, k.x, k.y)) continue;
+      Feature f;
+      f.row = k.y; f.col = k.x; f.score = k.score;
+      brief_at(sum, cfg.cols, k.x, k.y, f.desc);
+      out.push_back(f);
+    }
+  }
+
+  /* StereoFramePointGenerator::initialize (stereo_framepoint_generator.cpp:73-133) */
+  void initialize(const uint8_t* L, const uint8_t* R, int stride, bool extract, int frame_status) {
+    if (extract) {
+      std::vector<Keypoint> kl, kr;
+      detect_keypoints(L, stride, kl, n_detected_left_raw);
+      detect_keypoints(R, stride, kr, n_detected_right_raw);
+      adjust_thresholds();
+      compute_descriptors(L, stride, kl, sumL, kpL);
+      compute_descriptors(R, stride, kr, sumR, kpR);
+      n_detected_left = (int)kpL.size();
+      if (frame_status == VSLAM_LOCALIZING) {
+        tau_tri = std::min(0.1 * 256, cfg.maximum_matching_distance_triangulation);
+      } else {
+        const real ratio = std::min((real)n_detected_left / target_kp, 1.0);
+        tau_tri = std::max(ratio * cfg.maximum_matching_distance_triangulation, 0.1 * 256);
+      }
+    }
+    storeL.set_features(kpL);
+    storeR.set_features(kpR);
+  }
+
+  /* getPointInLeftCamera (:871-895) */
+  void triangulate(int xL, int yL, int xR, int yR, real out[3]) const {
+    const real bx = cfg.baseline_h[0], fx = cfg.K[0], fy = cfg.K[4], cx = cfg.K[2], cy = cfg.K[5];
+    out[2] = bx / (real)(xR - xL);
+    out[0] = 1 / fx * ((real)xL - cx) * out[2];
+    out[1] = 1 / fy * ((real)(yL + yR) / 2.0 - cy) * out[2];
+  }
+
+  static bool to_int32(real v, int32_t& out) { /* C++ double->int32 truncation, guarded */
+    if (!(v > -2147483648.0 && v < 2147483648.0)) return false;
+    out = (int32_t)v;
+    return true;
+  }
+
+  /* StereoFramePointGenerator::track (:464-681) */
+  void track(FrameRec& cur, FrameRec& prev, const Tf& T, bool by_appearance) {
+    std::vector<Point>& pts = cur.points;
+    pts.clear();
+    lost.clear();
+    std::set<uint32_t> matchedL, matchedR;
+    n_tracked_landmarks = 0;
+    const int rows = cfg.rows, cols = cfg.cols, d = win;
+    for (size_t ip = 0; ip < prev.points.size(); ++ip) {
+      Point& pp = prev.points[ip];
+      real q[3], uvw[3];
+      tf_apply(T, pp.cam, q);
+      mat3_mul_vec(cfg.K, q, uvw);
+      if (!(uvw[2] > 0)) continue; /* quirk B.5: no positivity check in the reference */
+      int32_t col, row;
+      if (!to_int32(uvw[0] / uvw[2], col) || !to_int32(uvw[1] / uvw[2], row)) continue;
+      if (col < 0 || col > cols || row < 0 || row > rows) continue;
+      real dist_best = tau_track;
+      int r0 = std::max(row - d, 0), r1 = std::min(row + d + 1, rows);
+      int c0 = std::max(col - d, 0), c1 = std::min(col + d + 1, cols);
+      const int fl = storeL.match_in_region(row, col, pp.dL, r0, r1, c0, c1, tau_track, by_appearance, dist_best);
+      if (fl >= 0) {
+        const Feature& FL = storeL.feats[fl];
+        const float ex = (float)col - (float)FL.col, ey = (float)row - (float)FL.row; /* cv::Point2f */
+        real uvwR[3];
+        for (int i = 0; i < 3; ++i) uvwR[i] = uvw[i] + cfg.baseline_h[i];
+        int32_t colR, rowR;
+        if (!to_int32(uvwR[0] / uvwR[2] - ex, colR) || !to_int32(uvwR[1] / uvwR[2] - ey, rowR)) continue;
+        if (colR < 0 || colR > cols || rowR < 0 || rowR > rows) continue;
+        const int32_t k = (int32_t)std::fabs((real)pp.epi);
+        r0 = std::max(rowR - k, 0); r1 = std::min(rowR + k + 1, rows);
+        c0 = std::max(colR - d, 0); c1 = std::min(colR + d + 1, FL.col);
+        const int fr = storeR.match_in_region(rowR, colR, FL.desc, r0, r1, c0, c1, tau_tri, true, dist_best);
+        if (fr >= 0) {
+          const Feature& FR = storeR.feats[fr];
+          if (FL.col - FR.col < cfg.minimum_disparity_pixels) continue;
+          if (hamming32(FR.desc, pp.dR) > tau_track) continue;
+          for (int c = FR.col + 1; c < FL.col; ++c) {
+            int& cell = storeR.lattice[(size_t)FR.row * cols + c];
+            if (cell >= 0) { matchedR.insert((uint32_t)cell); cell = -1; }
+          }
+          Point np;
+          std::memset(&np, 0, sizeof np);
+          np.xL = FL.col; np.yL = FL.row; np.xR = FR.col; np.yR = FR.row;
+          std::memcpy(np.dL, FL.desc, 32); std::memcpy(np.dR, FR.desc, 32);
+          np.dist = (int)dist_best;
+          triangulate(np.xL, np.yL, np.xR, np.yR, np.cam);
+          np.prev = (int)ip;
+          np.track_len = pp.track_len + 1;
+          np.lm = pp.lm;
+          np.epi = FR.row - FL.row;
+          np.has_next = false;
+          np.chi = -1; np.inlier = 0;
+          pp.has_next = true;
+          pts.push_back(np);
+          matchedL.insert((uint32_t)fl);
+          matchedR.insert((uint32_t)fr);
+          storeL.lattice[(size_t)FL.row * cols + FL.col] = -1;
+          storeR.lattice[(size_t)FR.row * cols + FR.col] = -1;
+          if (pp.lm >= 0) ++n_tracked_landmarks;
+        }
+      }
+      if (!pp.has_next) lost.push_back((int)ip);
+    }
+    /* ids == positions here (fresh stores) */
+    storeL.prune_positions(matchedL);
+    storeR.prune_positions(matchedR);
+  }
+
+  /* StereoFramePointGenerator::compute (:135-462) */
+  int compute(FrameRec& cur) {
+    std::vector<Point>& pts = cur.points;
+    const size_t n_tracked = pts.size();
+    const int bin = cfg.bin_size_pixels;
+    std::vector<int> bin_map; /* index into `cand` (>=0) or -(tracked index)-2, -1 empty */
+    auto bin_of = [&](int row, int col, int& rb, int& cb) {
+      rb = (int)std::rint((real)row / bin);
+      cb = (int)std::rint((real)col / bin);
+      rb = std::min(rb, rows_bin - 1); /* quirk B.6: clamp the latent out-of-bounds index */
+      cb = std::min(cb, cols_bin - 1);
+    };
+    if (cfg.enable_keypoint_binning) {
+      bin_map.assign((size_t)rows_bin * cols_bin, -1);
+      for (size_t i = 0; i < n_tracked; ++i) {
+        int rb, cb;
+        bin_of(pts[i].yL, pts[i].xL, rb, cb);
+        bin_map[(size_t)rb * cols_bin + cb] = -(int)i - 2;
+      }
+    }
+    storeL.sort_vec();
+    storeR.sort_vec();
+    std::vector<Point> cand;
+    std::vector<int> offsets;
+    offsets.push_back(0);
+    for (int u = 1; u <= cfg.maximum_epipolar_search_offset_pixels; ++u) { offsets.push_back(u); offsets.push_back(-u); }
+    for (int o : offsets) {
+      std::vector<int>& FLv = storeL.vec;
+      std::vector<int>& FRv = storeR.vec;
+      std::set<uint32_t> mL, mR;
+      uint32_t iR = 0;
+      for (uint32_t iL = 0; iL < FLv.size(); iL++) {
+        if (iR == FRv.size()) break;
+        while (storeL.feats[FLv[iL]].row < storeR.feats[FRv[iR]].row + o) { iL++; if (iL == FLv.size()) break; }
+        if (iL == FLv.size()) break;
+        const Feature& fL = storeL.feats[FLv[iL]];
+        while (fL.row > storeR.feats[FRv[iR]].row + o) { iR++; if (iR == FRv.size()) break; }
+        if (iR == FRv.size()) break;
+        uint32_t is = iR;
+        real best = tau_tri;
+        uint32_t ibest = 0;
+        while (fL.row == storeR.feats[FRv[is]].row + o) {
+          if (fL.col - storeR.feats[FRv[is]].col < 0) break;
+          const real dd = hamming32(fL.desc, storeR.feats[FRv[is]].desc);
+          if (dd < best) { best = dd; ibest = is; }
+          is++;
+          if (is == FRv.size()) break;
+        }
+        if (best < tau_tri) {
+          const Feature& fR = storeR.feats[FRv[ibest]];
+          if (fL.col - fR.col < cfg.minimum_disparity_pixels) continue;
+          Point np;
+          std::memset(&np, 0, sizeof np);
+          np.xL = fL.col; np.yL = fL.row; np.xR = fR.col; np.yR = fR.row;
+          std::memcpy(np.dL, fL.desc, 32); std::memcpy(np.dR, fR.desc, 32);
+          np.dist = (int)best;
+          triangulate(np.xL, np.yL, np.xR, np.yR, np.cam);
+          np.prev = -1; np.track_len = 0; np.lm = -1; np.epi = o; np.has_next = false; np.chi = -1;
+          if (cfg.enable_keypoint_binning) {
+            int rb, cb;
+            bin_of(fL.row, fL.col, rb, cb);
+            int& cell = bin_map[(size_t)rb * cols_bin + cb];
+            if (cell != -1) {
+              if (cell >= 0) { /* occupant is an untracked candidate */
+                const Point& c = cand[cell];
+                if ((np.xL - np.xR) > (c.xL - c.xR) && np.dist <= c.dist) cell = (int)cand.size();
+              } /* tracked occupant (previous() != null): never replaced */
+            } else {
+              cell = (int)cand.size();
+            }
+          }
+          cand.push_back(np);
+          mL.insert(iL);
+          mR.insert(ibest);
+          storeL.lattice[(size_t)fL.row * cfg.cols + fL.col] = -1;
+          storeR.lattice[(size_t)fR.row * cfg.cols + fR.col] = -1;
+          iR = ibest + 1;
+        }
+      }
+      storeL.prune_positions(mL);
+      storeR.prune_positions(mR);
+    }
+    int added = 0;
+    if (cfg.enable_keypoint_binning) {
+      for (int r = 0; r < rows_bin; ++r)
+        for (int c = 0; c < cols_bin; ++c) {
+          const int cell = bin_map[(size_t)r * cols_bin + c];
+          if (cell >= 0) { pts.push_back(cand[cell]); ++added; }
+        }
+    } else {
+      for (const Point& p : cand) { pts.push_back(p); ++added; }
+    }
+    return added;
+  }
+
+  /* StereoFramePointGenerator::recoverPoints (:683-869) */
+  int recover(FrameRec& cur, FrameRec& prev) {
+    int recovered = 0;
+    const real* K = cfg.K;
+    for (int ip : lost) {
+      Point& pp = prev.points[ip];
+      if (pp.lm < 0) continue;
+      real pc[3], uL[3], uR[3];
+      tf_apply(cur.world_to_cam, landmarks[pp.lm].w, pc);
+      mat3_mul_vec(K, pc, uL);
+      for (int i = 0; i < 3; ++i) uR[i] = uL[i] + cfg.baseline_h[i];
+      if (uL[2] < cfg.minimum_depth_meters || uL[2] > cfg.maximum_depth_meters ||
+          uR[2] < cfg.minimum_depth_meters || uR[2] > cfg.maximum_depth_meters) continue;
+      const float pLx = (float)std::rint(uL[0] / uL[2]), pLy = (float)std::rint(uL[1] / uL[2]);
+      const float pRx = (float)std::rint(uR[0] / uR[2]), pRy = (float)std::rint(uR[1] / uR[2]);
+      const float border = 5 * 7.f; /* 5*keypoint.size, FAST size = 7 */
+      if (pLx < border + 1 || pLx > cfg.cols - border - 1 || pRx < border + 1 || pRx > cfg.cols - border - 1 ||
+          pLy < border + 1 || pLy > cfg.rows - border - 1 || pRy < border + 1 || pRy > cfg.rows - border - 1) continue;
+      const int xL = (int)pLx, yL = (int)pLy, xR = (int)pRx, yR = (int)pRy;
+      uint8_t dL[32], dR[32];
+      brief_at(sumL, cfg.cols, xL, yL, dL);
+      if (hamming32(pp.dL, dL) > tau_track) continue;
+      brief_at(sumR, cfg.cols, xR, yR, dR);
+      if ((real)(pLx - pRx) < cfg.minimum_disparity_pixels) continue;
+      if (hamming32(pp.dR, dR) > tau_track) continue;
+      const int dtri = hamming32(dL, dR);
+      if (dtri > tau_tri) continue;
+      Point np;
+      std::memset(&np, 0, sizeof np);
+      np.xL = xL; np.yL = yL; np.xR = xR; np.yR = yR;
+      std::memcpy(np.dL, dL, 32); std::memcpy(np.dR, dR, 32);
+      np.dist = dtri;
+      triangulate(xL, yL, xR, yR, np.cam);
+      np.prev = ip; np.track_len = pp.track_len + 1; np.lm = pp.lm; np.epi = 0; np.has_next = false; np.chi = -1;
+      pp.has_next = true;
+      cur.points.push_back(np);
+      ++recovered;
+    }
+    return recovered;
+  }
+
+  /* StereoUVAligner::initialize (stereouv_aligner.cpp:10-69) + converge */
+  void align(FrameRec& cur, FrameRec& prev, bool inverse_depth) {
+    const int n = (int)cur.points.size();
+    al.n = n;
+    al.moving.resize(3 * n); al.fixed.resize(4 * n); al.omega.resize(n); al.weight.resize(n);
+    for (int u = 0; u < n; ++u) {
+      const Point& p = cur.points[u];
+      const Point& pp = prev.points[p.prev];
+      al.fixed[4 * u + 0] = p.xL; al.fixed[4 * u + 1] = p.yL; al.fixed[4 * u + 2] = p.xR; al.fixed[4 * u + 3] = p.yR;
+      real om = 1;
+      if (pp.lm >= 0) {
+        for (int i = 0; i < 3; ++i) al.moving[3 * u + i] = pp.cam_lm[i];
+        om *= (1 + std::log((real)landmarks[pp.lm].updates));
+      } else {
+        for (int i = 0; i < 3; ++i) al.moving[3 * u + i] = pp.cam[i];
+      }
+      al.omega[u] = om;
+      al.weight[u] = inverse_depth ? std::min(cfg.maximum_reliable_depth_meters / p.cam[2], 1.0) : 1.0;
+    }
+    al.T = prior;
+    AlignerParams P = aligner_params();
+    aligner_converge(P, al);
+    for (int u = 0; u < n; ++u) { cur.points[u].chi = al.errors[u]; cur.points[u].inlier = al.inliers[u]; }
+    aligner_valid = true;
+  }
+  AlignerParams aligner_params() const {
+    AlignerParams P;
+    std::memcpy(P.K, cfg.K, sizeof P.K);
+    std::memcpy(P.baseline, cfg.baseline_h, sizeof P.baseline);
+    P.rows = cfg.rows; P.cols = cfg.cols;
+    P.min_depth = cfg.minimum_depth_meters; /* setMinimumReliableDepthMeters, slam_assembly.cpp:70 */
+    P.kernel = cfg.aligner_maximum_error_kernel; P.damping = cfg.aligner_damping;
+    P.delta = cfg.aligner_error_delta_for_convergence;
+    P.max_it = cfg.aligner_maximum_number_of_iterations; P.min_inliers = cfg.aligner_minimum_number_of_inliers;
+    return P;
+  }
+
+  /* PoseTracker3D::_track (pose_tracker_3d.cpp:225-298) */
+  void tracker_track(FrameRec& cur, FrameRec& prev, bool by_appearance) {
+    if (by_appearance) win = cfg.maximum_projection_tracking_distance_pixels;
+    aligner_valid = false;
+    track(cur, prev, prior, by_appearance);
+    n_tracked_points = (uint32_t)cur.points.size();
+    const real tracking_ratio = (real)n_tracked_points / (real)prev.points.size();
+    const real landmark_per_point = (real)n_tracked_landmarks / (real)n_tracked_points;
+    const real success_ratio = (real)n_tracked_points / (real)target_kp;
+    const int wmax = cfg.maximum_projection_tracking_distance_pixels, wmin = cfg.minimum_projection_tracking_distance_pixels;
+    if (tracking_ratio < cfg.good_tracking_ratio / 2) {
+      if (win < wmax) win = (int32_t)std::min(win * 1 / cfg.tunnel_vision_ratio, (real)wmax);
+    } else {
+      if (win > wmin) win = (int32_t)std::max(win * cfg.tunnel_vision_ratio, (real)wmin);
+    }
+    if (tracking_ratio < cfg.good_tracking_ratio ||
+        n_tracked_points < (uint32_t)cfg.aligner_minimum_number_of_inliers ||
+        (landmark_per_point < 0.5 && success_ratio < 0.25)) {
+      tau_track += 5;
+      if (tau_track > cfg.maximum_descriptor_distance_tracking) tau_track = cfg.maximum_descriptor_distance_tracking;
+    } else {
+      tau_track -= 5;
+      if (tau_track < cfg.minimum_descriptor_distance_tracking) tau_track = cfg.minimum_descriptor_distance_tracking;
+    }
+    ++info.track_attempts;
+  }
+  void fallback(FrameRec& cur, FrameRec& prev) { /* _fallbackEstimate (:551-566) */
+    prior = tf_identity();
+    set_pose(cur, prev.cam_to_world);
+    info.fallback = 1;
+  }
+  void set_pose(FrameRec& f, const Tf& c2w) { f.cam_to_world = c2w; f.world_to_cam = tf_inverse(c2w); }
+  /* accept-or-fallback block shared by :139-159 and :372-388 */
+  void accept_motion(FrameRec& cur, FrameRec& prev) {
+    const Tf& T = al.T;
+    const real dang = rotation_angle(T);
+    const real dtr = std::sqrt((T.m[3] * T.m[3] + T.m[7] * T.m[7]) + T.m[11] * T.m[11]);
+    if (dang > cfg.minimum_delta_angular_for_movement || dtr > cfg.minimum_delta_translational_for_movement) {
+      prior = T;
+      set_pose(cur, tf_mul(prev.cam_to_world, tf_inverse(prior)));
+    } else {
+      fallback(cur, prev);
+    }
+  }
+  void break_track(FrameRec& cur, FrameRec& prev) { /* breakTrack (:422-435) */
+    status = VSLAM_LOCALIZING;
+    set_pose(cur, prev.cam_to_world);
+    prior = tf_identity();
+    n_tracked_points = 0;
+    info.track_broken = 1;
+  }
+  /* _registerRecursive (:300-419) */
+  void register_recursive(FrameRec& cur, FrameRec& prev, const uint8_t* L, const uint8_t* R, int stride, int rec) {
+    const real rel = (real)n_tracked_landmarks / (real)n_tracked_landmarks_prev;
+    if (n_tracked_landmarks == 0 || rel < 0.1) {
+      if (rec < 2) {
+        prior = tf_identity();
+        initialize(L, R, stride, false, cur_status_at_start);
+        tracker_track(cur, prev, true);
+        register_recursive(cur, prev, L, R, stride, rec + 1);
+      } else {
+        break_track(cur, prev);
+      }
+      return;
+    }
+    align(cur, prev, true);
+    if ((uint32_t)al.n_inliers > (uint32_t)cfg.minimum_number_of_landmarks_to_track) {
+      accept_motion(cur, prev);
+    } else {
+      if (rec < 2) {
+        if (win < cfg.maximum_projection_tracking_distance_pixels) ++win;
+        initialize(L, R, stride, false, cur_status_at_start);
+        tracker_track(cur, prev, false);
+        register_recursive(cur, prev, L, R, stride, rec + 1);
+      } else {
+        break_track(cur, prev);
+      }
+    }
+  }
+  int cur_status_at_start = VSLAM_LOCALIZING;
+
+  /* _prunePoints (:437-472) */
+  void prune(FrameRec& cur, FrameRec& prev) {
+    std::vector<Point> kept;
+    if (aligner_valid) {
+      const real avg = al.total_error / (real)al.n;
+      for (size_t i = 0; i < cur.points.size(); ++i) {
+        bool keep;
+        if (avg < cfg.aligner_maximum_error_kernel) keep = al.inliers[i] != 0;
+        else keep = (al.errors[i] != -1 && al.errors[i] < 100 * cfg.aligner_maximum_error_kernel);
+        if (keep) kept.push_back(cur.points[i]);
+        else prev.points[cur.points[i].prev].has_next = false; /* FramePoint::clear (frame_point.cpp:57-82) */
+      }
+    } else {
+      /* quirk B.3: the reference reads stale aligner buffers here; defined rule: drop all */
+      for (const Point& p : cur.points) prev.points[p.prev].has_next = false;
+    }
+    cur.points.swap(kept);
+    n_tracked_points = (uint32_t)cur.points.size();
+  }
+
+  /* Landmark::Landmark (landmark.cpp:8-33) */
+  int create_landmark(int frame_index, int point_index) {
+    Landmark lm;
+    lm.w[0] = lm.w[1] = lm.w[2] = 0;
+    int f = frame_index, i = point_index;
+    while (i >= 0) {
+      Point& p = frames[f].points[i];
+      p.lm = (int)landmarks.size();
+      Meas m;
+      m.frame = f;
+      for (int k = 0; k < 3; ++k) m.cam[k] = p.cam[k];
+      m.inv_depth = 1 / p.cam[2];
+      lm.meas.push_back(m);
+      real wpt[3];
+      tf_apply(frames[f].cam_to_world, p.cam, wpt);
+      for (int k = 0; k < 3; ++k) lm.w[k] += wpt[k];
+      i = p.prev;
+      --f;
+    }
+    for (int k = 0; k < 3; ++k) lm.w[k] /= (real)lm.meas.size();
+    lm.updates = (uint32_t)lm.meas.size();
+    landmarks.push_back(lm);
+    return (int)landmarks.size() - 1;
+  }
+  /* Landmark::update (landmark.cpp:66-167) */
+  void update_landmark(Landmark& lm, int frame_index, const Point& p) {
+    Meas nm;
+    nm.frame = frame_index;
+    for (int k = 0; k < 3; ++k) nm.cam[k] = p.cam[k];
+    nm.inv_depth = 1 / p.cam[2];
+    lm.meas.push_back(nm);
+    real w[3] = {lm.w[0], lm.w[1], lm.w[2]};
+    real err_prev = 0;
+    for (int it = 0; it < cfg.landmark_maximum_number_of_iterations; ++it) {
+      real H[9] = {0}, b[3] = {0};
+      real err = 0;
+      uint32_t n_out = 0;
+      for (const Meas& m : lm.meas) {
+        const Tf& W2C = frames[m.frame].world_to_cam;
+        real s[3];
+        tf_apply(W2C, w, s);
+        if (s[2] <= 0) { ++n_out; continue; }
+        const real e[3] = {s[0] - m.cam[0], s[1] - m.cam[1], s[2] - m.cam[2]};
+        real om = m.inv_depth;
+        const real e2 = om * ((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]);
+        err += e2;
+        if (e2 > cfg.landmark_maximum_error_squared_meters) { om *= cfg.landmark_maximum_error_squared_meters / e2; ++n_out; }
+        /* J = R (world_to_cam.linear()); H += J^T om J ; b += J^T om e */
+        for (int r = 0; r < 3; ++r) {
+          for (int c = 0; c < 3; ++c)
+            H[3 * r + c] += om * ((W2C.m[0 + r] * W2C.m[0 + c] + W2C.m[4 + r] * W2C.m[4 + c]) + W2C.m[8 + r] * W2C.m[8 + c]);
+          b[r] += om * ((W2C.m[0 + r] * e[0] + W2C.m[4 + r] * e[1]) + W2C.m[8 + r] * e[2]);
+        }
+      }
+      real nb[3] = {-b[0], -b[1], -b[2]}, dx[3];
+      full_piv_lu_solve<3>(H, nb, dx);
+      for (int k = 0; k < 3; ++k) w[k] += dx[k];
+      if (std::fabs(err - err_prev) < 1e-5 || it == 999) {
+        const uint32_t n_in = (uint32_t)lm.meas.size() - n_out;
+        if (n_in > lm.updates) {
+          for (int k = 0; k < 3; ++k) lm.w[k] = w[k];
+          lm.updates = n_in;
+        } else if (n_in < n_out) {
+          real acc[3] = {0, 0, 0};
+          for (const Meas& m : lm.meas) {
+            real wp[3];
+            tf_apply(frames[m.frame].cam_to_world, m.cam, wp);
+            for (int k = 0; k < 3; ++k) acc[k] += wp[k];
+          }
+          for (int k = 0; k < 3; ++k) lm.w[k] = acc[k] / (real)lm.meas.size();
+        }
+        break;
+      }
+      err_prev = err;
+    }
+  }
+  /* _updatePoints (pose_tracker_3d.cpp:475-520) */
+  void update_points(int frame_index) {
+    FrameRec& cur = frames[frame_index];
+    n_active_landmarks = 0;
+    for (size_t i = 0; i < cur.points.size(); ++i) {
+      Point& p = cur.points[i];
+      if ((uint32_t)p.track_len < (uint32_t)cfg.minimum_track_length_for_landmark_creation) continue;
+      if (p.lm < 0) {
+        create_landmark(frame_index, (int)i);
+      } else {
+        update_landmark(landmarks[p.lm], frame_index, p);
+      }
+      tf_apply(cur.world_to_cam, landmarks[p.lm].w, p.cam_lm);
+      ++n_active_landmarks;
+    }
+  }
+
+  /* PoseTracker3D::compute (pose_tracker_3d.cpp:32-222) */
+  void process(const uint8_t* L, const uint8_t* R, int stride) {
+    const int findex = (int)frames.size();
+    std::memset(&info, 0, sizeof info);
+    info.frame_index = findex + 1;
+    info.status_at_start = status;
+    cur_status_at_start = status;
+    n_tracked_points = 0;
+    frames.emplace_back();
+    FrameRec& cur = frames[findex];
+    set_pose(cur, world_pose);
+    const bool has_prev = findex > 0;
+    initialize(L, R, stride, true, status);
+    if (has_prev) {
+      FrameRec& prev = frames[findex - 1];
+      for (Point& p : prev.points) p.has_next = false;
+      tracker_track(cur, prev, status == VSLAM_LOCALIZING);
+      if (status == VSLAM_LOCALIZING) {
+        if (n_tracked_points < (uint32_t)cfg.minimum_number_of_landmarks_to_track) {
+          fallback(cur, prev);
+        } else {
+          align(cur, prev, false);
+          if ((uint32_t)al.n_inliers < (uint32_t)cfg.minimum_number_of_landmarks_to_track) fallback(cur, prev);
+          else accept_motion(cur, prev);
+        }
+      } else {
+        register_recursive(cur, prev, L, R, stride, 0);
+      }
+    }
+    world_pose = cur.cam_to_world;
+    info.n_tracked = (int)cur.points.size();
+    info.n_lost = (int)lost.size();
+    info.n_tracked_landmarks = (int)n_tracked_landmarks;
+    if (has_prev) {
+      FrameRec& prev = frames[findex - 1];
+      info.aligner_ran = aligner_valid ? 1 : 0;
+      if (aligner_valid) {
+        info.aligner_iterations = al.iterations; info.aligner_converged = al.converged;
+        info.n_inliers = al.n_inliers; info.n_outliers = al.n_outliers; info.total_error = al.total_error;
+      }
+      prune(cur, prev);
+      info.n_after_prune = (int)cur.points.size();
+      if (cfg.enable_landmark_recovery) {
+        info.n_recovered = recover(cur, prev);
+        n_tracked_points = (uint32_t)cur.points.size();
+      }
+    }
+    update_points(findex);
+    if (n_active_landmarks > (uint32_t)cfg.minimum_number_of_landmarks_to_track) status = VSLAM_TRACKING;
+    info.n_new_stereo = compute(cur);
+    n_tracked_landmarks_prev = n_active_landmarks;
+    /* report */
+    info.status = status;
+    info.n_keypoints_left = (int)kpL.size(); info.n_keypoints_right = (int)kpR.size();
+    info.n_detected_left = n_detected_left_raw; info.n_detected_right = n_detected_right_raw;
+    for (size_t i = 0; i < thr.size() && i < VSLAM_MAX_REGIONS; ++i) info.thresholds[i] = thr[i];
+    info.n_active_landmarks = (int)n_active_landmarks;
+    info.n_points = (int)cur.points.size();
+    info.window_pixels = win;
+    info.tau_track = tau_track;
+    info.tau_triangulation = tau_tri;
+    std::memcpy(info.camera_left_to_world, cur.cam_to_world.m, sizeof(real) * 12);
+    std::memcpy(info.previous_to_current, prior.m, sizeof(real) * 12);
+    poses.push_back(cur.cam_to_world);
+  }
+};
+
+} /* namespace */
+
+struct orc_ctx {
+  std::vector<Stream> streams;
+  std::string err;
+};
+
+/* ------------------------------------------------------------------------------------------
+ * C entry points: same shapes as include/vslam_hip.h, prefix orc_
+ * ---------------------------------------------------------------------------------------- */
+static void fill_common_defaults(vslam_config* c) {
+  std::memset(c, 0, sizeof *c);
+  c->det_rows = 1; c->det_cols = 1;
+  c->detector_threshold_minimum = 20; c->detector_threshold_maximum = 100;
+  c->detector_threshold_maximum_change = 0.1; c->target_number_of_keypoints_tolerance = 0.1;
+  c->bin_size_pixels = 15; c->enable_keypoint_binning = 1;
+  c->minimum_projection_tracking_distance_pixels = 15; c->maximum_projection_tracking_distance_pixels = 50;
+  c->minimum_descriptor_distance_tracking = 25.6; c->maximum_descriptor_distance_tracking = 51.2;
+  c->maximum_reliable_depth_meters = 15; c->maximum_depth_meters = 1000; c->minimum_depth_meters = 0.1;
+  c->maximum_matching_distance_triangulation = 51.2; c->minimum_disparity_pixels = 1;
+  c->maximum_epipolar_search_offset_pixels = 0;
+  c->minimum_track_length_for_landmark_creation = 1; c->minimum_number_of_landmarks_to_track = 5;
+  c->tunnel_vision_ratio = 0.5; c->good_tracking_ratio = 0.2; c->enable_landmark_recovery = 1;
+  c->minimum_delta_angular_for_movement = 0.001; c->minimum_delta_translational_for_movement = 0.01;
+  c->aligner_error_delta_for_convergence = 1e-3; c->aligner_maximum_error_kernel = 4; c->aligner_damping = 5;
+  c->aligner_maximum_number_of_iterations = 1000; c->aligner_minimum_number_of_inliers = 100;
+  c->landmark_maximum_error_squared_meters = 25; c->landmark_maximum_number_of_iterations = 100;
+  c->max_keypoints = 16384; c->max_points = 8192; c->max_history_frames = 512;
+}
+ORC_API void orc_default_config_kitti(vslam_config* c) { /* configurations/configuration_kitti.yaml:49-134 */
+  fill_common_defaults(c);
+  c->rows = 376; c->cols = 1241;
+  const double K[9] = {718.856, 0, 607.1928, 0, 718.856, 185.2157, 0, 0, 1};
+  std::memcpy(c->K, K, sizeof K);
+  c->baseline_h[0] = -386.1448; /* KITTI-00 calib.txt P1(0,3) */
+}
+ORC_API void orc_default_config_euroc(vslam_config* c) { /* configurations/configuration_euroc.yaml:47-116 */
+  fill_common_defaults(c);
+  c->rows = 480; c->cols = 752;
+  const double K[9] = {458.654, 0, 367.215, 0, 457.296, 248.375, 0, 0, 1};
+  std::memcpy(c->K, K, sizeof K);
+  c->baseline_h[0] = -458.654 * 0.11;
+  c->det_rows = 2; c->det_cols = 2;
+  c->detector_threshold_minimum = 10; c->detector_threshold_maximum = 30; c->detector_threshold_maximum_change = 1.0;
+  c->bin_size_pixels = 20;
+  c->minimum_descriptor_distance_tracking = 25; c->maximum_descriptor_distance_tracking = 50;
+  c->maximum_reliable_depth_meters = 5; c->maximum_depth_meters = 100;
+  c->maximum_matching_distance_triangulation = 50;
+  c->minimum_track_length_for_landmark_creation = 2; c->good_tracking_ratio = 0.25;
+  c->aligner_damping = 0;
+}
+
+ORC_API int orc_create(const vslam_config* cfg, int /*device*/, int n_streams, orc_ctx** out) {
+  if (!cfg || !out || n_streams < 1 || cfg->rows < 64 || cfg->cols < 64) return VSLAM_ERR_INVALID;
+  if (cfg->det_rows * cfg->det_cols > VSLAM_MAX_REGIONS || cfg->det_rows < 1 || cfg->det_cols < 1) return VSLAM_ERR_INVALID;
+  if (!(-cfg->baseline_h[0] / cfg->K[0] > 0)) return VSLAM_ERR_INVALID; /* stereo_framepoint_generator.cpp:28-34 */
+  orc_ctx* c = new orc_ctx;
+  c->streams.resize(n_streams);
+  for (Stream& s : c->streams) s.configure(*cfg);
+  *out = c;
+  return VSLAM_OK;
+}
+ORC_API void orc_destroy(orc_ctx* c) { delete c; }
+ORC_API int orc_reset(orc_ctx* c) { for (Stream& s : c->streams) s.reset(); return VSLAM_OK; }
+ORC_API int orc_process_host(orc_ctx* c, const uint8_t* L, const uint8_t* R, int32_t stride, size_t image_stride) {
+  if (!c || !L || !R) return VSLAM_ERR_INVALID;
+  for (size_t s = 0; s < c->streams.size(); ++s) c->streams[s].process(L + s * image_stride, R + s * image_stride, stride);
+  return VSLAM_OK;
+}
+ORC_API int orc_get_frame_info(orc_ctx* c, int s, vslam_frame_info* out) {
+  if (!c || s < 0 || s >= (int)c->streams.size() || !out) return VSLAM_ERR_INVALID;
+  *out = c->streams[s].info;
+  return VSLAM_OK;
+}
+ORC_API int orc_get_keypoints(orc_ctx* c, int s, int side, int32_t cap, int32_t* n, int16_t* xy, int32_t* score, uint8_t* desc) {
+  if (!c || s < 0 || s >= (int)c->streams.size() || !n) return VSLAM_ERR_INVALID;
+  const std::vector<Feature>& k = side ? c->streams[s].kpR : c->streams[s].kpL;
+  *n = (int32_t)k.size();
+  if ((int32_t)k.size() > cap) return VSLAM_ERR_CAPACITY;
+  for (size_t i = 0; i < k.size(); ++i) {
+    if (xy) { xy[2 * i] = (int16_t)k[i].col; xy[2 * i + 1] = (int16_t)k[i].row; }
+    if (score) score[i] = k[i].score;
+    if (desc) std::memcpy(desc + 32 * i, k[i].desc, 32);
+  }
+  return VSLAM_OK;
+}
+ORC_API int orc_get_points(orc_ctx* c, int s, int32_t cap, int32_t* n, int16_t* kp, int32_t* meta, double* cam, double* lm) {
+  if (!c || s < 0 || s >= (int)c->streams.size() || !n) return VSLAM_ERR_INVALID;
+  Stream& st = c->streams[s];
+  if (st.frames.empty()) { *n = 0; return VSLAM_OK; }
+  const std::vector<Point>& p = st.frames.back().points;
+  *n = (int32_t)p.size();
+  if ((int32_t)p.size() > cap) return VSLAM_ERR_CAPACITY;
+  for (size_t i = 0; i < p.size(); ++i) {
+    if (kp) { kp[4 * i] = (int16_t)p[i].xL; kp[4 * i + 1] = (int16_t)p[i].yL; kp[4 * i + 2] = (int16_t)p[i].xR; kp[4 * i + 3] = (int16_t)p[i].yR; }
+    if (meta) {
+      meta[6 * i + 0] = p[i].dist; meta[6 * i + 1] = p[i].epi; meta[6 * i + 2] = p[i].prev; meta[6 * i + 3] = p[i].track_len;
+      meta[6 * i + 4] = p[i].lm >= 0 ? (int32_t)st.landmarks[p[i].lm].updates : 0;
+      meta[6 * i + 5] = p[i].xL - p[i].xR;
+    }
+    if (cam) for (int k = 0; k < 3; ++k) cam[3 * i + k] = p[i].cam[k];
+    if (lm) for (int k = 0; k < 3; ++k) lm[3 * i + k] = p[i].lm >= 0 ? st.landmarks[p[i].lm].w[k] : 0.0;
+  }
+  return VSLAM_OK;
+}
+ORC_API int orc_get_aligner_result(orc_ctx* c, int s, int32_t cap, int32_t* n, double* chi, uint8_t* inlier, double T[12], double H[36]) {
+  if (!c || s < 0 || s >= (int)c->streams.size() || !n) return VSLAM_ERR_INVALID;
+  const AlignerIO& a = c->streams[s].al;
+  *n = a.n;
+  if (a.n > cap) return VSLAM_ERR_CAPACITY;
+  for (int i = 0; i < a.n; ++i) { if (chi) chi[i] = a.errors[i]; if (inlier) inlier[i] = a.inliers[i]; }
+  if (T) std::memcpy(T, a.T.m, sizeof(double) * 12);
+  if (H) std::memcpy(H, a.H, sizeof(double) * 36);
+  return VSLAM_OK;
+}
+ORC_API int orc_get_poses(orc_ctx* c, int s, int32_t first, int32_t nf, double* out) {
+  if (!c || s < 0 || s >= (int)c->streams.size() || !out) return VSLAM_ERR_INVALID;
+  const std::vector<Tf>& p = c->streams[s].poses;
+  if (first < 0 || first + nf > (int32_t)p.size()) return VSLAM_ERR_INVALID;
+  for (int i = 0; i < nf; ++i) std::memcpy(out + 12 * i, p[first + i].m, sizeof(double) * 12);
+  return VSLAM_OK;
+}
+
+/* ---- stand-alone stages ------------------------------------------------------------------ */
+ORC_API int orc_fast_detect(orc_ctx*, const uint8_t* img, int32_t rows, int32_t cols, int32_t stride, int32_t rx, int32_t ry,
+                            int32_t rw, int32_t rh, int32_t threshold, int32_t cap, int32_t* n, int16_t* xy, int32_t* score) {
+  if (!img || !n || rx < 0 || ry < 0 || rx + rw > cols || ry + rh > rows) return VSLAM_ERR_INVALID;
+  std::vector<Keypoint> k;
+  fast_detect_roi(img, stride, rx, ry, rw, rh, threshold, k);
+  *n = (int32_t)k.size();
+  if ((int32_t)k.size() > cap) return VSLAM_ERR_CAPACITY;
+  for (size_t i = 0; i < k.size(); ++i) { xy[2 * i] = k[i].x; xy[2 * i + 1] = k[i].y; if (score) score[i] = k[i].score; }
+  return VSLAM_OK;
+}
+ORC_API int orc_brief_describe(orc_ctx*, const uint8_t* img, int32_t rows, int32_t cols, int32_t stride, int32_t n,
+                               const int16_t* xy, uint8_t* keep, uint8_t* desc) {
+  if (!img || !xy || !keep || !desc) return VSLAM_ERR_INVALID;
+  std::vector<int32_t> sum;
+  integral_image(img, rows, cols, stride, sum);
+  for (int i = 0; i < n; ++i) {
+    const int x = xy[2 * i], y = xy[2 * i + 1];
+    keep[i] = brief_inside(rows, cols, x, y) ? 1 : 0;
+    if (keep[i]) brief_at(sum, cols, x, y, desc + 32 * i);
+    else std::memset(desc + 32 * i, 0, 32);
+  }
+  return VSLAM_OK;
+}
+/* knnMatch(k=2) of the use_matches block (stereo_framepoint_generator.cpp:168-206) */
+ORC_API int orc_knn2(orc_ctx*, int norm, int32_t nq, const uint8_t* q, int32_t nt, const uint8_t* t, int32_t* idx, float* dist) {
+  if (!q || !t || !idx || !dist) return VSLAM_ERR_INVALID;
+  for (int i = 0; i < nq; ++i) {
+    int64_t b0 = INT64_MAX, b1 = INT64_MAX;
+    int i0 = -1, i1 = -1;
+    for (int j = 0; j < nt; ++j) {
+      int64_t d;
+      if (norm == 0) d = hamming32(q + 32 * i, t + 32 * j);
+      else { d = 0; for (int k = 0; k < 32; ++k) { const int e = (int)q[32 * i + k] - (int)t[32 * j + k]; d += e * e; } }
+      if (d < b0) { b1 = b0; i1 = i0; b0 = d; i0 = j; }
+      else if (d < b1) { b1 = d; i1 = j; }
+    }
+    idx[2 * i] = i0; idx[2 * i + 1] = i1;
+    dist[2 * i] = i0 < 0 ? 0.f : (norm == 0 ? (float)b0 : std::sqrt((float)b0));
+    dist[2 * i + 1] = i1 < 0 ? 0.f : (norm == 0 ? (float)b1 : std::sqrt((float)b1));
+  }
+  return VSLAM_OK;
+}
+ORC_API int orc_align_points(orc_ctx* c, int32_t n, const double* moving, const double* fixed, const double* omega,
+                             const double* weight, const double T_init[12], double T_out[12], double* chi, uint8_t* inlier,
+                             int32_t* n_inliers, double* total_error, int32_t* iterations, double H_out[36]) {
+  if (!c || c->streams.empty() || n < 0) return VSLAM_ERR_INVALID;
+  AlignerIO io;
+  io.n = n;
+  io.moving.assign(moving, moving + 3 * n); io.fixed.assign(fixed, fixed + 4 * n);
+  io.omega.assign(omega, omega + n); io.weight.assign(weight, weight + n);
+  std::memcpy(io.T.m, T_init, sizeof(double) * 12);
+  AlignerParams P = c->streams[0].aligner_params();
+  aligner_converge(P, io);
+  if (T_out) std::memcpy(T_out, io.T.m, sizeof(double) * 12);
+  for (int i = 0; i < n; ++i) { if (chi) chi[i] = io.errors[i]; if (inlier) inlier[i] = io.inliers[i]; }
+  if (n_inliers) *n_inliers = io.n_inliers;
+  if (total_error) *total_error = io.total_error;
+  if (iterations) *iterations = io.iterations;
+  if (H_out) std::memcpy(H_out, io.H, sizeof(double) * 36);
+  return VSLAM_OK;
+}
+/* one linearize() call: H (36), b (6), total error, inliers — for the golden first-iteration check */
+ORC_API int orc_align_linearize(orc_ctx* c, int32_t n, const double* moving, const double* fixed, const double* omega,
+                                const double* weight, const double T[12], int ignore_outliers, double H[36], double b[6],
+                                double* total_error, int32_t* n_inliers, double* chi, uint8_t* inlier) {
+  if (!c || c->streams.empty()) return VSLAM_ERR_INVALID;
+  AlignerIO io;
+  io.n = n;
+  io.moving.assign(moving, moving + 3 * n); io.fixed.assign(fixed, fixed + 4 * n);
+  io.omega.assign(omega, omega + n); io.weight.assign(weight, weight + n);
+  io.errors.assign(n, -1); io.inliers.assign(n, 0);
+  std::memcpy(io.T.m, T, sizeof(double) * 12);
+  AlignerParams P = c->streams[0].aligner_params();
+  aligner_linearize(P, io, ignore_outliers != 0, H, b);
+  *total_error = io.total_error; *n_inliers = io.n_inliers;
+  for (int i = 0; i < n; ++i) { if (chi) chi[i] = io.errors[i]; if (inlier) inlier[i] = io.inliers[i]; }
+  return VSLAM_OK;
+}
+/* threshold controller on scripted counts (base_framepoint_generator.cpp:382-415,440-459), 1 region */
+ORC_API int orc_controller_run(const vslam_config* cfg, int32_t n_frames, const int32_t* counts_left,
+                               const int32_t* counts_right, int32_t target_per_detector, int32_t* thresholds_out) {
+  int thr = cfg->detector_threshold_minimum;
+  for (int f = 0; f < n_frames; ++f) {
+    real acc = 0;
+    const int32_t counts[2] = {counts_left[f], counts_right[f]};
+    for (int s = 0; s < 2; ++s) {
+      real t = thr;
+      const real delta = ((real)counts[s] - (real)target_per_detector) / (real)target_per_detector;
+      if (delta < -cfg->target_number_of_keypoints_tolerance) {
+        t = t + std::min(std::max(delta, -cfg->detector_threshold_maximum_change) * t, -1.0);
+        if (t < cfg->detector_threshold_minimum) t = cfg->detector_threshold_minimum;
+      } else if (delta > cfg->target_number_of_keypoints_tolerance) {
+        t += std::max(std::min(delta, cfg->detector_threshold_maximum_change) * t, 1.0);
+        if (t > cfg->detector_threshold_maximum) t = cfg->detector_threshold_maximum;
+      }
+      acc += t;
+    }
+    thr = (int)std::rint(acc / 2);
+    thresholds_out[f] = thr;
+  }
+  return VSLAM_OK;
+}
+/* stereo sweep + binning on caller-provided features (compute(), :135-462), no tracked points.
+ * featL/featR: n*2 int32 (row,col); returns matches as (iL_id, iR_id, dist, epi) in output order */
+ORC_API int orc_stereo_match(const vslam_config* cfg, double tau_tri, int32_t nL, const int32_t* rcL, const uint8_t* dL,
+                             int32_t nR, const int32_t* rcR, const uint8_t* dR, int32_t cap, int32_t* n_out, int32_t* out4) {
+  Stream s;
+  s.configure(*cfg);
+  s.tau_tri = tau_tri;
+  std::vector<Feature> fl(nL), fr(nR);
+  for (int i = 0; i < nL; ++i) { fl[i].row = rcL[2 * i]; fl[i].col = rcL[2 * i + 1]; fl[i].score = 0; std::memcpy(fl[i].desc, dL + 32 * i, 32); }
+  for (int i = 0; i < nR; ++i) { fr[i].row = rcR[2 * i]; fr[i].col = rcR[2 * i + 1]; fr[i].score = 0; std::memcpy(fr[i].desc, dR + 32 * i, 32); }
+  s.storeL.set_features(fl);
+  s.storeR.set_features(fr);
+  FrameRec cur;
+  s.compute(cur);
+  *n_out = (int32_t)cur.points.size();
+  if ((int32_t)cur.points.size() > cap) return VSLAM_ERR_CAPACITY;
+  for (size_t i = 0; i < cur.points.size(); ++i) {
+    const Point& p = cur.points[i];
+    /* recover ids by coordinates (unique pixels in the fixtures) */
+    int il = -1, ir = -1;
+    for (int k = 0; k < nL; ++k) if (fl[k].row == p.yL && fl[k].col == p.xL) il = k;
+    for (int k = 0; k < nR; ++k) if (fr[k].row == p.yR && fr[k].col == p.xR) ir = k;
+    out4[4 * i + 0] = il; out4[4 * i + 1] = ir; out4[4 * i + 2] = p.dist; out4[4 * i + 3] = p.epi;
+  }
+  return VSLAM_OK;
+}
+
+/* ---- synthetic data + trajectory error (test / bench infrastructure) ---------------------- */
+ORC_API void orc_synth_default_kitti(synth_scene* s) { synth_default_kitti(s); }
+ORC_API void orc_synth_pose(const synth_scene* s, int k, double cam_to_world[12]) {
+  double R[9], t[3];
+  synth_pose(s, k, R, t);
+  for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) cam_to_world[4 * i + j] = R[3 * i + j]; cam_to_world[4 * i + 3] = t[i]; }
+}
+ORC_API void orc_synth_render(const synth_scene* s, int frame, uint8_t* left, uint8_t* right, int32_t stride) {
+  double R[9], t[3];
+  synth_pose(s, frame, R, t);
+  for (int y = 0; y < s->rows; ++y)
+    for (int x = 0; x < s->cols; ++x) {
+      left[(size_t)y * stride + x] = synth_pixel(s, R, t, frame, 0, x, y);
+      right[(size_t)y * stride + x] = synth_pixel(s, R, t, frame, 1, x, y);
+    }
+}

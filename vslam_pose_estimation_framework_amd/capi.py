@@ -1,0 +1,272 @@
+"""ctypes view of include/vslam_hip.h.
+
+`CApi(path, prefix)` binds one shared library that exports the C ABI with the given symbol
+prefix.  The product binds `libvslam_hip.so` with prefix ``vslam_`` (see ``hip.py``); the test
+suite binds the CPU oracle with prefix ``orc_`` through ``tests/_oracle.py``.  Nothing in this
+package loads the oracle.
+"""
+import ctypes as C
+import numpy as np
+
+MAX_REGIONS = 16
+
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_STATE = 0, -1, -2, -3, -4, -5
+LOCALIZING, TRACKING = 0, 1
+
+
+class Config(C.Structure):
+    """struct vslam_config (include/vslam_hip.h)."""
+    _fields_ = [
+        ("rows", C.c_int32), ("cols", C.c_int32),
+        ("K", C.c_double * 9), ("baseline_h", C.c_double * 3),
+        ("det_rows", C.c_int32), ("det_cols", C.c_int32),
+        ("detector_threshold_minimum", C.c_int32), ("detector_threshold_maximum", C.c_int32),
+        ("detector_threshold_maximum_change", C.c_double),
+        ("target_number_of_keypoints_tolerance", C.c_double),
+        ("bin_size_pixels", C.c_int32), ("enable_keypoint_binning", C.c_int32),
+        ("minimum_projection_tracking_distance_pixels", C.c_int32),
+        ("maximum_projection_tracking_distance_pixels", C.c_int32),
+        ("minimum_descriptor_distance_tracking", C.c_double),
+        ("maximum_descriptor_distance_tracking", C.c_double),
+        ("maximum_reliable_depth_meters", C.c_double),
+        ("maximum_depth_meters", C.c_double),
+        ("minimum_depth_meters", C.c_double),
+        ("maximum_matching_distance_triangulation", C.c_double),
+        ("minimum_disparity_pixels", C.c_double),
+        ("maximum_epipolar_search_offset_pixels", C.c_int32),
+        ("minimum_track_length_for_landmark_creation", C.c_int32),
+        ("minimum_number_of_landmarks_to_track", C.c_int32),
+        ("tunnel_vision_ratio", C.c_double), ("good_tracking_ratio", C.c_double),
+        ("enable_landmark_recovery", C.c_int32),
+        ("minimum_delta_angular_for_movement", C.c_double),
+        ("minimum_delta_translational_for_movement", C.c_double),
+        ("aligner_error_delta_for_convergence", C.c_double),
+        ("aligner_maximum_error_kernel", C.c_double),
+        ("aligner_damping", C.c_double),
+        ("aligner_maximum_number_of_iterations", C.c_int32),
+        ("aligner_minimum_number_of_inliers", C.c_int32),
+        ("landmark_maximum_error_squared_meters", C.c_double),
+        ("landmark_maximum_number_of_iterations", C.c_int32),
+        ("max_keypoints", C.c_int32), ("max_points", C.c_int32), ("max_history_frames", C.c_int32),
+    ]
+
+    def copy(self):
+        c = Config()
+        C.memmove(C.byref(c), C.byref(self), C.sizeof(Config))
+        return c
+
+
+class FrameInfo(C.Structure):
+    """struct vslam_frame_info (include/vslam_hip.h)."""
+    _fields_ = [
+        ("frame_index", C.c_int32), ("status", C.c_int32), ("status_at_start", C.c_int32),
+        ("n_keypoints_left", C.c_int32), ("n_keypoints_right", C.c_int32),
+        ("n_detected_left", C.c_int32), ("n_detected_right", C.c_int32),
+        ("thresholds", C.c_int32 * MAX_REGIONS),
+        ("track_attempts", C.c_int32), ("n_tracked", C.c_int32), ("n_lost", C.c_int32),
+        ("n_tracked_landmarks", C.c_int32), ("aligner_ran", C.c_int32),
+        ("aligner_iterations", C.c_int32), ("aligner_converged", C.c_int32),
+        ("n_inliers", C.c_int32), ("n_outliers", C.c_int32), ("total_error", C.c_double),
+        ("n_after_prune", C.c_int32), ("n_recovered", C.c_int32),
+        ("n_active_landmarks", C.c_int32), ("n_new_stereo", C.c_int32), ("n_points", C.c_int32),
+        ("track_broken", C.c_int32), ("fallback", C.c_int32), ("window_pixels", C.c_int32),
+        ("error_flags", C.c_int32), ("tau_track", C.c_double), ("tau_triangulation", C.c_double),
+        ("camera_left_to_world", C.c_double * 12), ("previous_to_current", C.c_double * 12),
+    ]
+
+    def as_dict(self):
+        d = {}
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            d[name] = list(v) if hasattr(v, "__len__") else v
+        return d
+
+
+class VslamError(RuntimeError):
+    """Raised for a negative vslam_status (the reference throws std::runtime_error)."""
+
+    def __init__(self, code, text):
+        super().__init__("vslam status %d: %s" % (code, text))
+        self.code = code
+
+
+def _p(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype)) if a is not None else None
+
+
+class CApi(object):
+    """One loaded library + one context (n_streams independent sequences)."""
+
+    def __init__(self, lib_path, prefix):
+        self.lib = C.CDLL(lib_path)
+        self.prefix = prefix
+        self.ctx = None
+
+    def fn(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    def has(self, name):
+        return hasattr(self.lib, self.prefix + name)
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def default_config(self, which="kitti"):
+        cfg = Config()
+        self.fn("default_config_" + which)(C.byref(cfg))
+        return cfg
+
+    def create(self, cfg, device=0, n_streams=1):
+        self.destroy()
+        ctx = C.c_void_p()
+        f = self.fn("create")
+        f.restype = C.c_int
+        rc = f(C.byref(cfg), C.c_int(device), C.c_int(n_streams), C.byref(ctx))
+        if rc != OK:
+            raise VslamError(rc, self.last_error(None))
+        self.ctx = ctx
+        self.cfg = cfg.copy()
+        self.n_streams = n_streams
+        return self
+
+    def destroy(self):
+        if self.ctx is not None:
+            self.fn("destroy")(self.ctx)
+            self.ctx = None
+
+    def last_error(self, ctx):
+        if not self.has("last_error"):
+            return ""
+        f = self.fn("last_error")
+        f.restype = C.c_char_p
+        s = f(ctx)
+        return s.decode() if s else ""
+
+    def check(self, rc):
+        if rc != OK:
+            raise VslamError(rc, self.last_error(self.ctx))
+
+    def reset(self):
+        self.check(self.fn("reset")(self.ctx))
+
+    # -- whole frame --------------------------------------------------------------------------
+    def process_host(self, left, right):
+        """left/right: uint8 arrays [n_streams, rows, stride] (C-contiguous)."""
+        left = np.ascontiguousarray(left, dtype=np.uint8)
+        right = np.ascontiguousarray(right, dtype=np.uint8)
+        if left.ndim == 2:
+            left, right = left[None], right[None]
+        assert left.shape == right.shape and left.shape[0] == self.n_streams
+        assert left.shape[1] == self.cfg.rows and left.shape[2] >= self.cfg.cols
+        stride = left.shape[2]
+        self.check(self.fn("process_host")(self.ctx, _p(left, C.c_uint8), _p(right, C.c_uint8),
+                                           C.c_int32(stride), C.c_size_t(left.shape[1] * stride)))
+
+    def process_device(self, left_ptr, right_ptr, row_stride, image_stride):
+        self.check(self.fn("process_device")(self.ctx, C.c_void_p(left_ptr), C.c_void_p(right_ptr),
+                                             C.c_int32(row_stride), C.c_size_t(image_stride)))
+
+    def synchronize(self):
+        self.check(self.fn("synchronize")(self.ctx))
+
+    # -- readback -----------------------------------------------------------------------------
+    def frame_info(self, stream=0):
+        fi = FrameInfo()
+        self.check(self.fn("get_frame_info")(self.ctx, C.c_int(stream), C.byref(fi)))
+        return fi
+
+    def keypoints(self, stream=0, side=0):
+        cap = int(self.cfg.max_keypoints)
+        n = C.c_int32()
+        xy = np.zeros((cap, 2), np.int16)
+        score = np.zeros(cap, np.int32)
+        desc = np.zeros((cap, 32), np.uint8)
+        self.check(self.fn("get_keypoints")(self.ctx, C.c_int(stream), C.c_int(side), C.c_int32(cap), C.byref(n),
+                                            _p(xy, C.c_int16), _p(score, C.c_int32), _p(desc, C.c_uint8)))
+        k = n.value
+        return xy[:k].copy(), score[:k].copy(), desc[:k].copy()
+
+    def points(self, stream=0):
+        cap = int(self.cfg.max_points)
+        n = C.c_int32()
+        kp = np.zeros((cap, 4), np.int16)
+        meta = np.zeros((cap, 6), np.int32)
+        cam = np.zeros((cap, 3), np.float64)
+        lm = np.zeros((cap, 3), np.float64)
+        self.check(self.fn("get_points")(self.ctx, C.c_int(stream), C.c_int32(cap), C.byref(n), _p(kp, C.c_int16),
+                                         _p(meta, C.c_int32), _p(cam, C.c_double), _p(lm, C.c_double)))
+        k = n.value
+        return dict(kp=kp[:k].copy(), meta=meta[:k].copy(), cam=cam[:k].copy(), lm=lm[:k].copy())
+
+    def aligner_result(self, stream=0):
+        cap = int(self.cfg.max_points)
+        n = C.c_int32()
+        chi = np.zeros(cap, np.float64)
+        inl = np.zeros(cap, np.uint8)
+        T = np.zeros(12, np.float64)
+        H = np.zeros(36, np.float64)
+        self.check(self.fn("get_aligner_result")(self.ctx, C.c_int(stream), C.c_int32(cap), C.byref(n),
+                                                 _p(chi, C.c_double), _p(inl, C.c_uint8), _p(T, C.c_double),
+                                                 _p(H, C.c_double)))
+        k = n.value
+        return dict(chi=chi[:k].copy(), inlier=inl[:k].copy(), T=T.reshape(3, 4), H=H.reshape(6, 6))
+
+    def poses(self, stream, first, count):
+        out = np.zeros((count, 12), np.float64)
+        self.check(self.fn("get_poses")(self.ctx, C.c_int(stream), C.c_int32(first), C.c_int32(count),
+                                        _p(out, C.c_double)))
+        return out.reshape(count, 3, 4)
+
+    # -- stand-alone stages ---------------------------------------------------------------------
+    def fast_detect(self, image, roi, threshold, cap=65536):
+        image = np.ascontiguousarray(image, np.uint8)
+        rows, stride = image.shape
+        x, y, w, h = roi
+        n = C.c_int32()
+        xy = np.zeros((cap, 2), np.int16)
+        score = np.zeros(cap, np.int32)
+        self.check(self.fn("fast_detect")(self.ctx, _p(image, C.c_uint8), C.c_int32(rows), C.c_int32(stride),
+                                          C.c_int32(stride), C.c_int32(x), C.c_int32(y), C.c_int32(w), C.c_int32(h),
+                                          C.c_int32(threshold), C.c_int32(cap), C.byref(n), _p(xy, C.c_int16),
+                                          _p(score, C.c_int32)))
+        return xy[:n.value].copy(), score[:n.value].copy()
+
+    def brief_describe(self, image, xy):
+        image = np.ascontiguousarray(image, np.uint8)
+        xy = np.ascontiguousarray(xy, np.int16)
+        rows, stride = image.shape
+        n = xy.shape[0]
+        keep = np.zeros(n, np.uint8)
+        desc = np.zeros((n, 32), np.uint8)
+        self.check(self.fn("brief_describe")(self.ctx, _p(image, C.c_uint8), C.c_int32(rows), C.c_int32(stride),
+                                             C.c_int32(stride), C.c_int32(n), _p(xy, C.c_int16), _p(keep, C.c_uint8),
+                                             _p(desc, C.c_uint8)))
+        return keep, desc
+
+    def knn2(self, query, train, norm=0):
+        query = np.ascontiguousarray(query, np.uint8)
+        train = np.ascontiguousarray(train, np.uint8)
+        nq, nt = query.shape[0], train.shape[0]
+        idx = np.zeros((nq, 2), np.int32)
+        dist = np.zeros((nq, 2), np.float32)
+        self.check(self.fn("knn2")(self.ctx, C.c_int(norm), C.c_int32(nq), _p(query, C.c_uint8), C.c_int32(nt),
+                                   _p(train, C.c_uint8), _p(idx, C.c_int32), _p(dist, C.c_float)))
+        return idx, dist
+
+    def align_points(self, moving, fixed, omega, weight, T_init):
+        moving = np.ascontiguousarray(moving, np.float64)
+        fixed = np.ascontiguousarray(fixed, np.float64)
+        omega = np.ascontiguousarray(omega, np.float64)
+        weight = np.ascontiguousarray(weight, np.float64)
+        T_init = np.ascontiguousarray(T_init, np.float64).reshape(12)
+        n = moving.shape[0]
+        T = np.zeros(12, np.float64)
+        chi = np.zeros(n, np.float64)
+        inl = np.zeros(n, np.uint8)
+        ninl, its = C.c_int32(), C.c_int32()
+        err = C.c_double()
+        H = np.zeros(36, np.float64)
+        self.check(self.fn("align_points")(self.ctx, C.c_int32(n), _p(moving, C.c_double), _p(fixed, C.c_double),
+                                           _p(omega, C.c_double), _p(weight, C.c_double), _p(T_init, C.c_double),
+                                           _p(T, C.c_double), _p(chi, C.c_double), _p(inl, C.c_uint8), C.byref(ninl),
+                                           C.byref(err), C.byref(its), _p(H, C.c_double)))
+        return dict(T=T.reshape(3, 4), chi=chi, inlier=inl, n_inliers=ninl.value, total_error=err.value,
+                    iterations=its.value, H=H.reshape(6, 6))
