@@ -1,0 +1,459 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz: known-answer vectors for the hot path.
+
+The reference ships no tests or fixtures and cannot be built or imported here
+(C++ on OpenCV3/Eigen/srrg_*; nothing was attempted or denied), so these vectors come from an
+INDEPENDENT numpy / pure-Python restatement of the same published algorithms, written without
+looking at oracle/vslam_oracle.cpp's code paths: FAST uses the literal OpenCV loop structure
+(threshold table + run counting + cornerScore's two min/max sweeps), BRIEF sums 9x9 windows
+directly instead of using an integral image, the aligner is written with numpy matrices
+(skew, K, projection Jacobians) and solved with numpy.linalg.  The oracle and the HIP path are
+both checked against these files.
+
+Run:  python tests/golden/make_golden.py        (rewrites the .npz files deterministically)
+"""
+import os
+import re
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+
+
+# ---------------------------------------------------------------------------------------------
+def hamming(a, b):
+    return int(np.unpackbits(np.bitwise_xor(a, b)).sum())
+
+
+def gen_hamming(rng):
+    a = rng.integers(0, 256, (70, 32), dtype=np.uint8)
+    b = rng.integers(0, 256, (70, 32), dtype=np.uint8)
+    a[64] = 0; b[64] = 0
+    a[65] = 0; b[65] = 255
+    a[66] = 255; b[66] = 255
+    a[67] = 0; b[67] = 0; b[67, 31] = 1
+    a[68] = 0; b[68] = 0; b[68, 0] = 0x80
+    a[69] = 0xAA; b[69] = 0x55
+    d = np.array([hamming(a[i], b[i]) for i in range(70)], np.int32)
+    q = rng.integers(0, 256, (257, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (129, 32), dtype=np.uint8)
+    t[5] = t[77]            # exact tie between two train rows -> lowest index first
+    q[3] = t[5]             # zero distance
+    q[200] = q[3]
+    D = np.array([[hamming(q[i], t[j]) for j in range(129)] for i in range(257)], np.int64)
+    order = np.argsort(D, axis=1, kind="stable")[:, :2]
+    dist_h = np.take_along_axis(D, order, 1).astype(np.float32)
+    qs, ts = q.astype(np.int64), t.astype(np.int64)
+    D2 = ((qs[:, None, :] - ts[None, :, :]) ** 2).sum(-1)
+    order2 = np.argsort(D2, axis=1, kind="stable")[:, :2]
+    dist_l2 = np.sqrt(np.take_along_axis(D2, order2, 1).astype(np.float32))
+    np.savez_compressed(os.path.join(HERE, "hamming.npz"), a=a, b=b, d=d, q=q, t=t,
+                        idx_h=order.astype(np.int32), dist_h=dist_h, idx_l2=order2.astype(np.int32),
+                        dist_l2=dist_l2.astype(np.float32))
+
+
+# ---------------------------------------------------------------------------------------------
+CIRCLE = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2),
+          (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]  # (dx, dy), OpenCV makeOffsets(16)
+
+
+def corner_score16(img, x, y, threshold):
+    """OpenCV fast_score.cpp cornerScore<16>, literal."""
+    v = int(img[y, x])
+    d = [v - int(img[y + CIRCLE[k % 16][1], x + CIRCLE[k % 16][0]]) for k in range(25)]
+    a0 = threshold
+    for k in range(0, 16, 2):
+        a = min(d[k + 1], d[k + 2], d[k + 3])
+        if a <= a0:
+            continue
+        a = min(a, d[k + 4], d[k + 5], d[k + 6], d[k + 7], d[k + 8])
+        a0 = max(a0, min(a, d[k]))
+        a0 = max(a0, min(a, d[k + 9]))
+    b0 = -a0
+    for k in range(0, 16, 2):
+        b = max(d[k + 1], d[k + 2], d[k + 3], d[k + 4], d[k + 5])
+        if b >= b0:
+            continue
+        b = max(b, d[k + 6], d[k + 7], d[k + 8])
+        b0 = min(b0, max(b, d[k]))
+        b0 = min(b0, max(b, d[k + 9]))
+    return -b0 - 1
+
+
+def fast9_16(img, threshold):
+    """OpenCV fast.cpp FAST_t<16> with nonmaxSuppression=true; returns list of (x, y, score)."""
+    rows, cols = img.shape
+    threshold = min(max(threshold, 0), 255)
+    scores = np.zeros((rows, cols), np.int32)
+    for y in range(3, rows - 3):
+        for x in range(3, cols - 3):
+            v = int(img[y, x])
+            tab = []
+            for k in range(25):
+                p = int(img[y + CIRCLE[k % 16][1], x + CIRCLE[k % 16][0]])
+                tab.append(1 if p < v - threshold else (2 if p > v + threshold else 0))
+            is_corner = False
+            for flag in (1, 2):
+                count = 0
+                for k in range(25):
+                    if tab[k] == flag:
+                        count += 1
+                        if count > 8:
+                            is_corner = True
+                            break
+                    else:
+                        count = 0
+                if is_corner:
+                    break
+            if is_corner:
+                scores[y, x] = corner_score16(img, x, y, threshold) & 0xFF  # stored as uchar
+    out = []
+    for y in range(3, rows - 3):
+        for x in range(3, cols - 3):
+            s = scores[y, x]
+            if s == 0:
+                continue
+            nb = scores[y - 1:y + 2, x - 1:x + 2].copy()
+            nb[1, 1] = -1
+            if (s > nb).all():
+                out.append((x, y, int(s)))
+    return out
+
+
+def block_image(rng, rows, cols, cell):
+    g = rng.integers(20, 236, (rows // cell + 2, cols // cell + 2))
+    img = np.kron(g, np.ones((cell, cell), np.int64))[:rows, :cols]
+    img = img + rng.integers(-3, 4, img.shape)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def gen_fast(rng):
+    imgs, names = [], []
+    # 1: isolated bright pixel blob on dark ground, 2: straight edge (no corner), 3: L corner
+    a = np.full((32, 40), 40, np.uint8); a[15:18, 19:22] = 200
+    b = np.full((32, 40), 40, np.uint8); b[:, 20:] = 180
+    c = np.full((32, 40), 40, np.uint8); c[16:, 20:] = 180
+    # 4: plateau: two equal-score neighbours must BOTH be suppressed (strict >)
+    d = np.full((32, 40), 40, np.uint8); d[15, 19] = 220; d[15, 20] = 220
+    # 5: exactly 8 contiguous brighter pixels (not a corner) vs 9 (corner)
+    e8 = np.full((16, 16), 100, np.uint8); e9 = np.full((16, 16), 100, np.uint8)
+    for k in range(8):
+        e8[8 + CIRCLE[k][1], 8 + CIRCLE[k][0]] = 160
+    for k in range(9):
+        e9[8 + CIRCLE[k][1], 8 + CIRCLE[k][0]] = 160
+    imgs += [a, b, c, d, e8, e9]
+    names += ["blob", "edge", "lcorner", "plateau", "arc8", "arc9"]
+    imgs.append(block_image(rng, 48, 64, 6)); names.append("blocks6")
+    imgs.append(block_image(rng, 64, 96, 9)); names.append("blocks9")
+    imgs.append(rng.integers(0, 256, (40, 56), dtype=np.uint8)); names.append("noise")
+    out = {}
+    for img, name in zip(imgs, names):
+        out["img_" + name] = img
+        for thr in (10, 20, 50):
+            kp = fast9_16(img, thr)
+            out["kp_%s_%d" % (name, thr)] = np.array(kp, np.int32).reshape(-1, 3)
+    # ROI semantics: detection on a sub-rectangle uses the ROI's own 3 px border
+    big = block_image(rng, 64, 96, 7)
+    roi = (10, 7, 60, 40)
+    sub = big[roi[1]:roi[1] + roi[3], roi[0]:roi[0] + roi[2]]
+    out["img_roi"] = big
+    out["roi"] = np.array(roi, np.int32)
+    out["kp_roi_20"] = np.array(fast9_16(sub, 20), np.int32).reshape(-1, 3)
+    np.savez_compressed(os.path.join(HERE, "fast.npz"), **out)
+
+
+# ---------------------------------------------------------------------------------------------
+def read_brief_pattern():
+    txt = open(os.path.join(ROOT, "include", "vslam_brief_pattern.h")).read()
+    nums = re.findall(r"\{(-?\d+),(-?\d+),(-?\d+),(-?\d+)\}", txt)
+    assert len(nums) == 256
+    return np.array(nums, np.int64)
+
+
+def brief32(img, x, y, pat):
+    im = img.astype(np.int64)
+
+    def box(yy, xx):
+        return int(im[yy - 4:yy + 5, xx - 4:xx + 5].sum())
+    bits = [1 if box(y + p[0], x + p[1]) < box(y + p[2], x + p[3]) else 0 for p in pat]
+    return np.packbits(np.array(bits, np.uint8))  # MSB first within each byte
+
+
+def gen_brief(rng):
+    pat = read_brief_pattern()
+    img = block_image(rng, 96, 128, 5)
+    pts = [(28, 28), (99, 67), (64, 48), (27, 40), (40, 27), (100, 50), (50, 68), (70, 33), (31, 60), (90, 29)]
+    pts += [(int(rng.integers(28, 100)), int(rng.integers(28, 68))) for _ in range(22)]
+    keep, desc = [], []
+    for (x, y) in pts:
+        inside = (28 <= x < 128 - 28) and (28 <= y < 96 - 28)
+        keep.append(1 if inside else 0)
+        desc.append(brief32(img, x, y, pat) if inside else np.zeros(32, np.uint8))
+    np.savez_compressed(os.path.join(HERE, "brief.npz"), img=img, xy=np.array(pts, np.int16),
+                        keep=np.array(keep, np.uint8), desc=np.array(desc, np.uint8))
+
+
+# ---------------------------------------------------------------------------------------------
+def gen_controller():
+    # base_framepoint_generator.cpp:382-415,440-459 with the KITTI yaml values, one region
+    tol, maxchg, tmin, tmax, target = 0.1, 0.1, 20, 100, 2158
+    counts = [(5005, 4900), (4600, 4700), (3000, 3100), (2200, 2150), (2158, 2158), (1200, 1100), (100, 50),
+              (0, 0), (2500, 1800), (9000, 9000), (9000, 9000), (9000, 9000), (2380, 2380), (1941, 1941)]
+    counts += [(20000, 20000)] * 20 + [(10, 10)] * 25
+    thr = tmin
+    out = []
+    for (cl, cr) in counts:
+        acc = 0.0
+        for c in (cl, cr):
+            t = float(thr)
+            delta = (float(c) - target) / target
+            if delta < -tol:
+                t = t + min(max(delta, -maxchg) * t, -1.0)
+                t = max(t, float(tmin))
+            elif delta > tol:
+                t = t + max(min(delta, maxchg) * t, 1.0)
+                t = min(t, float(tmax))
+            acc += t
+        thr = int(np.rint(acc / 2))  # std::rint: half to even, as numpy
+        out.append(thr)
+    np.savez_compressed(os.path.join(HERE, "controller.npz"), counts=np.array(counts, np.int32),
+                        thresholds=np.array(out, np.int32), target=np.int32(target))
+
+
+# ---------------------------------------------------------------------------------------------
+KITTI_K = np.array([[718.856, 0, 607.1928], [0, 718.856, 185.2157], [0, 0, 1.0]])
+KITTI_B = np.array([-386.1448, 0, 0.0])
+
+
+def skew(p):
+    return np.array([[0, -p[2], p[1]], [p[2], 0, -p[0]], [-p[1], p[0], 0.0]])
+
+
+def v2t(v):
+    q = np.array(v[3:6], float)
+    n2 = q @ q
+    if n2 < 1:
+        w = np.sqrt(1 - n2)
+    else:
+        q = q / np.sqrt(n2)
+        w = 0.0
+    x, y, z = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = v[0:3]
+    return T
+
+
+def linearize(T, moving, fixed, omega, weight, ignore_outliers, kernel=4.0, min_depth=0.1, rows=376, cols=1241):
+    H = np.zeros((6, 6)); b = np.zeros(6); E = 0.0; ninl = 0
+    n = len(moving)
+    chi_out = -np.ones(n); inl = np.zeros(n, np.uint8)
+    for u in range(n):
+        p = T[:3, :3] @ moving[u] + T[:3, 3]
+        if p[2] < min_depth:
+            continue
+        abcL = KITTI_K @ p
+        abcR = abcL + KITTI_B
+        uvL = abcL[:2] / abcL[2]
+        uvR = abcR[:2] / abcR[2]
+        if uvL[0] < 0 or uvL[0] > cols or uvL[1] < 0 or uvL[1] > rows:
+            continue
+        if uvR[0] < 0 or uvR[0] > cols or uvR[1] < 0 or uvR[1] > rows:
+            continue
+        e = np.concatenate([uvL, uvR]) - fixed[u]
+        om = omega[u]
+        chi = om * (e @ e)
+        chi_out[u] = chi
+        if chi > kernel:
+            if ignore_outliers:
+                continue
+            om = om * kernel / chi
+        else:
+            inl[u] = 1
+            ninl += 1
+        E += chi
+        Jt = np.hstack([weight[u] * np.eye(3), -2 * skew(p)])
+        KJ = KITTI_K @ Jt
+        JL = np.array([[1 / abcL[2], 0, -abcL[0] / abcL[2] ** 2], [0, 1 / abcL[2], -abcL[1] / abcL[2] ** 2]])
+        JR = np.array([[1 / abcR[2], 0, -abcR[0] / abcR[2] ** 2], [0, 1 / abcR[2], -abcR[1] / abcR[2] ** 2]])
+        J = np.vstack([JL @ KJ, JR @ KJ])
+        H += om * (J.T @ J)
+        b += om * (J.T @ e)
+    return H, b, E, ninl, chi_out, inl
+
+
+def converge(T, moving, fixed, omega, weight, damping=5.0, delta=1e-3, max_it=1000, min_inl=100):
+    its = 0
+    Eprev = 0.0
+
+    def one_round(T, ignore):
+        H, b, E, ninl, chi, inl = linearize(T, moving, fixed, omega, weight, ignore)
+        H = H + damping * len(moving) * np.eye(6)
+        dx = np.linalg.solve(H, -b)
+        T = v2t(dx) @ T
+        R = T[:3, :3]
+        T[:3, :3] = R - 0.5 * R @ (R.T @ R - np.eye(3))
+        return T, H, E, ninl, chi, inl
+    for it in range(max_it):
+        T, H, E, ninl, chi, inl = one_round(T, False); its += 1
+        if delta > abs(Eprev - E):
+            Eprev = E
+            if ninl > min_inl and ninl > len(moving) - ninl:
+                for it2 in range(max_it):
+                    T, H, E, ninl, chi, inl = one_round(T, True); its += 1
+                    conv = abs(Eprev - E) < delta
+                    Eprev = E
+                    if conv:
+                        break
+            break
+        Eprev = E
+    return T, H, E, ninl, chi, inl, its
+
+
+def gen_aligner(rng):
+    out = {}
+    for name, n, noise, outlier_frac in (("m64_clean", 64, 0.0, 0.0), ("m512_noisy", 512, 0.4, 0.1),
+                                         ("m300_pixel", 300, -1.0, 0.05)):
+        # points in the previous camera frame, KITTI-like depth range
+        X = np.stack([rng.uniform(-8, 8, n), rng.uniform(-1.5, 1.6, n), rng.uniform(5, 45, n)], 1)
+        # true motion previous->current: 0.9 m forward, small yaw
+        vtrue = np.array([0.02, -0.01, -0.9, 0.001, 0.012, -0.0005])
+        Ttrue = v2t(vtrue)
+        P = (Ttrue[:3, :3] @ X.T).T + Ttrue[:3, 3]
+        aL = (KITTI_K @ P.T).T
+        aR = aL + KITTI_B
+        fixed = np.hstack([aL[:, :2] / aL[:, 2:3], aR[:, :2] / aR[:, 2:3]])
+        if noise > 0:
+            fixed = fixed + rng.normal(0, noise, fixed.shape)
+        elif noise < 0:
+            fixed = np.rint(fixed)           # integer keypoints, as FAST delivers
+        nout = int(outlier_frac * n)
+        if nout:
+            fixed[:nout] += rng.uniform(-30, 30, (nout, 4))
+        # a few degenerate rows: behind the camera / projecting outside the image
+        X[-1] = [0.0, 0.0, -3.0]
+        X[-2] = [60.0, 0.0, 6.0]
+        omega = np.where(rng.random(n) < 0.5, 1.0, 1.0 + np.log(rng.integers(2, 30, n)))
+        weight = np.minimum(15.0 / P[:, 2], 1.0)
+        T0 = np.eye(4)
+        H, b, E, ninl, chi, inl = linearize(T0, X, fixed, omega, weight, False)
+        Tc, Hc, Ec, ninlc, chic, inlc, its = converge(T0.copy(), X, fixed, omega, weight)
+        out.update({name + "_moving": X, name + "_fixed": fixed, name + "_omega": omega, name + "_weight": weight,
+                    name + "_H0": H, name + "_b0": b, name + "_E0": E, name + "_ninl0": np.int32(ninl),
+                    name + "_chi0": chi, name + "_inl0": inl, name + "_T": Tc[:3, :], name + "_ninl": np.int32(ninlc),
+                    name + "_E": Ec, name + "_its": np.int32(its), name + "_inl": inlc, name + "_Ttrue": Ttrue[:3, :]})
+    np.savez_compressed(os.path.join(HERE, "aligner.npz"), **out)
+
+
+# ---------------------------------------------------------------------------------------------
+def stereo_sweep(rcL, dL, rcR, dR, tau, min_disp, offsets):
+    """compute() restated row by row (stereo_framepoint_generator.cpp:278-426): rows are independent,
+    inside a row the right cursor only moves forward past accepted matches."""
+    aliveL = np.ones(len(rcL), bool); aliveR = np.ones(len(rcR), bool)
+    out = []
+    for o in offsets:
+        orderL = sorted([i for i in range(len(rcL)) if aliveL[i]], key=lambda i: (rcL[i][0], rcL[i][1]))
+        orderR = sorted([i for i in range(len(rcR)) if aliveR[i]], key=lambda i: (rcR[i][0], rcR[i][1]))
+        rows = sorted(set(rcL[i][0] for i in orderL))
+        matched = []
+        exhausted = False
+        for r in rows:
+            if exhausted:
+                break
+            Ls = [i for i in orderL if rcL[i][0] == r]
+            Rs = [j for j in orderR if rcR[j][0] + o == r]
+            start = 0
+            for i in Ls:
+                best, bj = tau, -1
+                k = start
+                while k < len(Rs):
+                    j = Rs[k]
+                    if rcL[i][1] - rcR[j][1] < 0:
+                        break
+                    d = hamming(dL[i], dR[j])
+                    if d < best:
+                        best, bj = d, k
+                    k += 1
+                if bj >= 0:
+                    j = Rs[bj]
+                    if rcL[i][1] - rcR[j][1] < min_disp:
+                        continue
+                    matched.append((i, j, best, o))
+                    start = bj + 1
+                    # the reference stops the whole sweep once the right list is exhausted
+                    if start == len(Rs) and j == orderR[-1]:
+                        exhausted = True
+                        break
+        for (i, j, d, oo) in matched:
+            aliveL[i] = False; aliveR[j] = False
+        out += matched
+    return out
+
+
+def gen_stereo(rng):
+    cases = {}
+    # hand-made: ties (first/lowest col wins), col_R > col_L stop, min-disparity continue w/o advance,
+    # ordering constraint (cursor jumps behind the accepted right feature)
+    base = rng.integers(0, 256, (8, 32), dtype=np.uint8)
+
+    def near(d, k):
+        x = d.copy()
+        bits = np.unpackbits(x)
+        bits[:k] ^= 1
+        return np.packbits(bits)
+    rcL = [(10, 100), (10, 140), (10, 180), (12, 50), (12, 60), (20, 300), (20, 301), (25, 90)]
+    dL = [base[0], base[1], base[2], base[3], base[3], base[4], base[5], base[6]]
+    rcR = [(10, 60), (10, 90), (10, 139), (10, 150), (12, 50), (12, 55), (20, 250), (20, 300), (20, 400), (25, 95), (30, 5)]
+    dR = [near(base[0], 5), near(base[0], 5), near(base[1], 3), near(base[2], 2), near(base[3], 1), near(base[3], 1),
+          near(base[4], 4), near(base[5], 4), base[5], base[6], base[7]]
+    cases["hand"] = (rcL, dL, rcR, dR)
+    # random: 40 rows, a few features per row, right = left shifted by a disparity with bit noise
+    rcL, dL, rcR, dR = [], [], [], []
+    for r in range(30, 70):
+        cols = sorted(set(int(c) for c in rng.integers(40, 600, rng.integers(1, 7))))
+        for c in cols:
+            d = rng.integers(0, 256, 32, dtype=np.uint8)
+            rcL.append((r, c)); dL.append(d)
+            if rng.random() < 0.8:
+                disp = int(rng.integers(0, 35))
+                rr = r + (int(rng.integers(-1, 2)) if rng.random() < 0.3 else 0)
+                rcR.append((rr, c - disp)); dR.append(near(d, int(rng.integers(0, 40))))
+        for _ in range(int(rng.integers(0, 3))):
+            rcR.append((r, int(rng.integers(0, 640)))); dR.append(rng.integers(0, 256, 32, dtype=np.uint8))
+    # unique pixels only (a pixel holds one feature after FAST NMS)
+    seen, keep = set(), []
+    for k, p in enumerate(rcR):
+        if p not in seen:
+            seen.add(p); keep.append(k)
+    rcR = [rcR[k] for k in keep]; dR = [dR[k] for k in keep]
+    cases["random"] = (rcL, dL, rcR, dR)
+    out = {}
+    for name, (rcL, dL, rcR, dR) in cases.items():
+        for epi in (0, 1):
+            offsets = [0] + [s * u for u in range(1, epi + 1) for s in (1, -1)]
+            m = stereo_sweep(rcL, dL, rcR, dR, 25.6 if name == "hand" else 30.0, 1.0, offsets)
+            out["%s_epi%d_matches" % (name, epi)] = np.array(m, np.int32).reshape(-1, 4)
+        out[name + "_rcL"] = np.array(rcL, np.int32); out[name + "_dL"] = np.array(dL, np.uint8)
+        out[name + "_rcR"] = np.array(rcR, np.int32); out[name + "_dR"] = np.array(dR, np.uint8)
+    out["hand_tau"] = np.float64(25.6); out["random_tau"] = np.float64(30.0)
+    np.savez_compressed(os.path.join(HERE, "stereo.npz"), **out)
+
+
+def main():
+    rng = np.random.default_rng(20261003)
+    gen_hamming(rng)
+    gen_fast(rng)
+    gen_brief(rng)
+    gen_controller()
+    gen_aligner(rng)
+    gen_stereo(rng)
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+
+
+if __name__ == "__main__":
+    main()

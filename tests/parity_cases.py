@@ -1,0 +1,72 @@
+"""Golden-vector checks shared by the oracle tests (CPU) and the HIP tests (GPU).
+
+Every function takes an object with the CApi interface (oracle: prefix orc_, product: vslam_)."""
+import ctypes as C
+
+import numpy as np
+
+FAST_NAMES = ["blob", "edge", "lcorner", "plateau", "arc8", "arc9", "blocks6", "blocks9", "noise"]
+
+
+def check_hamming_knn(api, g):
+    a, b, d = g["a"], g["b"], g["d"]
+    # pairwise popcounts through the N x M kernel: query i vs train {b[i], b[i]} -> both neighbours = d[i]
+    for i in range(a.shape[0]):
+        idx, dist = api.knn2(a[i:i + 1], np.stack([b[i], b[i]]), norm=0)
+        assert idx.tolist() == [[0, 1]]
+        assert dist[0, 0] == d[i] and dist[0, 1] == d[i]
+    idx, dist = api.knn2(g["q"], g["t"], norm=0)
+    np.testing.assert_array_equal(idx, g["idx_h"])
+    np.testing.assert_array_equal(dist, g["dist_h"])
+    idx, dist = api.knn2(g["q"], g["t"], norm=1)
+    np.testing.assert_array_equal(idx, g["idx_l2"])
+    np.testing.assert_array_equal(dist, g["dist_l2"])
+    # ragged / empty
+    idx, dist = api.knn2(g["q"][:5], g["t"][:1], norm=0)
+    assert (idx[:, 0] == 0).all() and (idx[:, 1] == -1).all()
+    idx, dist = api.knn2(g["q"][:0], g["t"], norm=0)
+    assert idx.shape == (0, 2)
+
+
+def check_fast(api, g):
+    for name in FAST_NAMES:
+        img = g["img_" + name]
+        for thr in (10, 20, 50):
+            exp = g["kp_%s_%d" % (name, thr)]
+            xy, score = api.fast_detect(img, (0, 0, img.shape[1], img.shape[0]), thr)
+            got = np.concatenate([xy.astype(np.int32), score[:, None]], 1)
+            np.testing.assert_array_equal(got, exp, err_msg="%s thr %d" % (name, thr))
+    img = g["img_roi"]
+    x, y, w, h = [int(v) for v in g["roi"]]
+    xy, score = api.fast_detect(img, (x, y, w, h), 20)
+    got = np.concatenate([xy.astype(np.int32), score[:, None]], 1)
+    np.testing.assert_array_equal(got, g["kp_roi_20"])
+
+
+def check_brief(api, g):
+    keep, desc = api.brief_describe(g["img"], g["xy"])
+    np.testing.assert_array_equal(keep, g["keep"])
+    np.testing.assert_array_equal(desc[keep > 0], g["desc"][g["keep"] > 0])
+
+
+ALIGNER_CASES = ["m64_clean", "m512_noisy", "m300_pixel"]
+
+
+def check_aligner(api, g, rtol_pose=1e-9):
+    for name in ALIGNER_CASES:
+        T0 = np.eye(4)[:3]
+        r = api.align_points(g[name + "_moving"], g[name + "_fixed"], g[name + "_omega"], g[name + "_weight"], T0)
+        Tg = g[name + "_T"]
+        rel = np.linalg.norm(r["T"] - Tg) / np.linalg.norm(Tg)
+        assert rel <= rtol_pose, (name, rel)
+        assert r["n_inliers"] == int(g[name + "_ninl"]), name
+        np.testing.assert_array_equal(r["inlier"], g[name + "_inl"], err_msg=name)
+        assert r["iterations"] == int(g[name + "_its"]), name
+        np.testing.assert_allclose(r["total_error"], float(g[name + "_E"]), rtol=1e-7, atol=1e-9)
+        assert np.allclose(r["H"], r["H"].T, rtol=1e-12, atol=1e-9)
+    # exact recovery of a known SE3 from noise-free measurements (converge leaves the last update applied)
+    r = api.align_points(g["m64_clean_moving"], g["m64_clean_fixed"], np.ones(64), np.ones(64), np.eye(4)[:3])
+    Tt = g["m64_clean_Ttrue"]
+    assert np.linalg.norm(r["T"] - Tt) / np.linalg.norm(Tt) < 1e-4
+    # skipped points (behind the camera / outside the image) keep error -1 and count as outliers
+    assert r["chi"][-1] == -1 and r["chi"][-2] == -1 and r["inlier"][-1] == 0

@@ -1,0 +1,82 @@
+"""The CPU oracle against the committed golden vectors (tests/golden, made by an independent
+numpy restatement: tests/golden/make_golden.py).  Runs without a GPU."""
+import ctypes as C
+
+import numpy as np
+
+import parity_cases as pc
+from vslam_pose_estimation_framework_amd.capi import Config
+
+
+def test_hamming_and_knn2(oracle, golden):
+    pc.check_hamming_knn(oracle, golden["hamming"])
+
+
+def test_fast_known_answers(oracle, golden):
+    pc.check_fast(oracle, golden["fast"])
+
+
+def test_brief_known_answers(oracle, golden):
+    pc.check_brief(oracle, golden["brief"])
+
+
+def test_aligner_known_answers(oracle, golden):
+    pc.check_aligner(oracle, golden["aligner"])
+
+
+def test_aligner_first_linearization(oracle, golden):
+    g = golden["aligner"]
+    for name in pc.ALIGNER_CASES:
+        n = g[name + "_moving"].shape[0]
+        H = np.zeros(36); b = np.zeros(6); E = C.c_double(); ninl = C.c_int32()
+        chi = np.zeros(n); inl = np.zeros(n, np.uint8)
+        T0 = np.ascontiguousarray(np.eye(4)[:3].reshape(12))
+        arrs = [np.ascontiguousarray(g[name + k], np.float64) for k in ("_moving", "_fixed", "_omega", "_weight")]
+        rc = oracle.lib.orc_align_linearize(oracle.ctx, C.c_int32(n), *[a.ctypes.data_as(C.c_void_p) for a in arrs],
+                                            T0.ctypes.data_as(C.c_void_p), C.c_int(0), H.ctypes.data_as(C.c_void_p),
+                                            b.ctypes.data_as(C.c_void_p), C.byref(E), C.byref(ninl),
+                                            chi.ctypes.data_as(C.c_void_p), inl.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        np.testing.assert_allclose(H.reshape(6, 6), g[name + "_H0"], rtol=1e-10, atol=1e-6)
+        np.testing.assert_allclose(b, g[name + "_b0"], rtol=1e-10, atol=1e-6)
+        np.testing.assert_allclose(E.value, float(g[name + "_E0"]), rtol=1e-12)
+        assert ninl.value == int(g[name + "_ninl0"])
+        np.testing.assert_allclose(chi, g[name + "_chi0"], rtol=1e-10, atol=1e-12)
+        np.testing.assert_array_equal(inl, g[name + "_inl0"])
+
+
+def test_threshold_controller(oracle, golden):
+    g = golden["controller"]
+    cfg = oracle.default_config("kitti")
+    counts = g["counts"]
+    n = counts.shape[0]
+    cl = np.ascontiguousarray(counts[:, 0]); cr = np.ascontiguousarray(counts[:, 1])
+    out = np.zeros(n, np.int32)
+    rc = oracle.lib.orc_controller_run(C.byref(cfg), C.c_int32(n), cl.ctypes.data_as(C.c_void_p),
+                                       cr.ctypes.data_as(C.c_void_p), C.c_int32(int(g["target"])),
+                                       out.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    np.testing.assert_array_equal(out, g["thresholds"])
+    assert out.min() >= cfg.detector_threshold_minimum and out.max() <= cfg.detector_threshold_maximum
+
+
+def test_stereo_sweep(oracle, golden):
+    g = golden["stereo"]
+    for name in ("hand", "random"):
+        for epi in (0, 1):
+            cfg = oracle.default_config("kitti")
+            cfg.rows, cfg.cols = 128, 640
+            cfg.enable_keypoint_binning = 0
+            cfg.maximum_epipolar_search_offset_pixels = epi
+            rcL = np.ascontiguousarray(g[name + "_rcL"]); dL = np.ascontiguousarray(g[name + "_dL"])
+            rcR = np.ascontiguousarray(g[name + "_rcR"]); dR = np.ascontiguousarray(g[name + "_dR"])
+            cap = 4096
+            out = np.zeros((cap, 4), np.int32); n = C.c_int32()
+            rc = oracle.lib.orc_stereo_match(C.byref(cfg), C.c_double(float(g[name + "_tau"])), C.c_int32(len(rcL)),
+                                             rcL.ctypes.data_as(C.c_void_p), dL.ctypes.data_as(C.c_void_p),
+                                             C.c_int32(len(rcR)), rcR.ctypes.data_as(C.c_void_p),
+                                             dR.ctypes.data_as(C.c_void_p), C.c_int32(cap), C.byref(n),
+                                             out.ctypes.data_as(C.c_void_p))
+            assert rc == 0
+            np.testing.assert_array_equal(out[:n.value], g["%s_epi%d_matches" % (name, epi)],
+                                          err_msg="%s epi %d" % (name, epi))
