@@ -176,9 +176,13 @@ int vslam_synchronize(vslam_ctx* ctx);
 /* StereoFramePointGenerator::initialize(frame, extract_features=true)
  * (stereo_framepoint_generator.cpp:73-133): FAST per detector region + threshold controller
  * (base_framepoint_generator.cpp:355-459), BRIEF-32, triangulation-distance rule, feature
- * stores.  `localizing[s]` is Frame::status()==Localizing of the new frame. */
+ * stores.  Frame::status() of the new frame is the tracker status held in the context. */
 int vslam_frame_begin(vslam_ctx* ctx, const uint8_t* left, const uint8_t* right,
                       int32_t row_stride_bytes, size_t image_stride_bytes, int on_device);
+/* Second half of the two-call form of vslam_process_*: everything PoseTracker3D::compute does after
+ * initialize() (track .. compute), evaluated on the device.  vslam_frame_begin + vslam_frame_finish ==
+ * vslam_process_*. */
+int vslam_frame_finish(vslam_ctx* ctx);
 /* initialize(frame, extract_features=false): rebuild both feature stores (…:128-132). */
 int vslam_frame_restore(vslam_ctx* ctx);
 /* StereoFramePointGenerator::track (…:464-681) using the tracker state held in the context

@@ -519,6 +519,7 @@ struct Stream {
   Tf prior = tf_identity();    /* _previous_to_current_camera */
   int win = 0;                 /* _projection_tracking_distance_pixels */
   real tau_track = 0;          /* _current_descriptor_distance_tracking */
+  real gen_tau_track = 0;      /* generator's _maximum_descriptor_distance_tracking (set per _track) */
   uint32_t n_tracked_landmarks = 0, n_tracked_points = 0, n_tracked_landmarks_prev = 0, n_active_landmarks = 0;
   Tf world_pose = tf_identity(); /* WorldMap::robot_to_world (identity robot offset) */
   std::vector<FrameRec> frames;
@@ -677,10 +678,10 @@ struct Stream {
       int32_t col, row;
       if (!to_int32(uvw[0] / uvw[2], col) || !to_int32(uvw[1] / uvw[2], row)) continue;
       if (col < 0 || col > cols || row < 0 || row > rows) continue;
-      real dist_best = tau_track;
+      real dist_best = gen_tau_track;
       int r0 = std::max(row - d, 0), r1 = std::min(row + d + 1, rows);
       int c0 = std::max(col - d, 0), c1 = std::min(col + d + 1, cols);
-      const int fl = storeL.match_in_region(row, col, pp.dL, r0, r1, c0, c1, tau_track, by_appearance, dist_best);
+      const int fl = storeL.match_in_region(row, col, pp.dL, r0, r1, c0, c1, gen_tau_track, by_appearance, dist_best);
       if (fl >= 0) {
         const Feature& FL = storeL.feats[fl];
         const float ex = (float)col - (float)FL.col, ey = (float)row - (float)FL.row; /* cv::Point2f */
@@ -696,7 +697,7 @@ struct Stream {
         if (fr >= 0) {
           const Feature& FR = storeR.feats[fr];
           if (FL.col - FR.col < cfg.minimum_disparity_pixels) continue;
-          if (hamming32(FR.desc, pp.dR) > tau_track) continue;
+          if (hamming32(FR.desc, pp.dR) > gen_tau_track) continue;
           for (int c = FR.col + 1; c < FL.col; ++c) {
             int& cell = storeR.lattice[(size_t)FR.row * cols + c];
             if (cell >= 0) { matchedR.insert((uint32_t)cell); cell = -1; }
@@ -845,10 +846,10 @@ struct Stream {
       const int xL = (int)pLx, yL = (int)pLy, xR = (int)pRx, yR = (int)pRy;
       uint8_t dL[32], dR[32];
       brief_at(sumL, cfg.cols, xL, yL, dL);
-      if (hamming32(pp.dL, dL) > tau_track) continue;
+      if (hamming32(pp.dL, dL) > gen_tau_track) continue;
       brief_at(sumR, cfg.cols, xR, yR, dR);
       if ((real)(pLx - pRx) < cfg.minimum_disparity_pixels) continue;
-      if (hamming32(pp.dR, dR) > tau_track) continue;
+      if (hamming32(pp.dR, dR) > gen_tau_track) continue;
       const int dtri = hamming32(dL, dR);
       if (dtri > tau_tri) continue;
       Point np;
@@ -906,6 +907,7 @@ struct Stream {
   void tracker_track(FrameRec& cur, FrameRec& prev, bool by_appearance) {
     if (by_appearance) win = cfg.maximum_projection_tracking_distance_pixels;
     aligner_valid = false;
+    gen_tau_track = tau_track; /* setMaximumDescriptorDistanceTracking (:238) */
     track(cur, prev, prior, by_appearance);
     n_tracked_points = (uint32_t)cur.points.size();
     const real tracking_ratio = (real)n_tracked_points / (real)prev.points.size();

@@ -1,0 +1,121 @@
+// dev_types.h — device-side data model of libvslam_hip (gfx950).
+//
+// Everything a stream (one sequence / chunk) owns lives in HBM as flat SoA arrays sized by the
+// capacities of vslam_config; kernels address them through `DevBuf` (passed by value) using the
+// stream index (blockIdx) — no per-frame allocation, no host round trip.
+//
+// Layout per stream s, image side d (0 = left, 1 = right):
+//   box      u16 [rows][bstride]     9x9 box sums of the image (BRIEF's smoothed image; <= 20655)
+//   score8   u8  [rows][bstride]     FAST score, written only at surviving corners
+//   mask     u64 [rows][TX]          1 bit / pixel: FAST corner that survived 3x3 NMS
+//   kp_*, desc   [NMAX]              keypoints inside the 28 px descriptor border, image row-major
+//   rowcell  i32 [rows][CW+1]        CSR: index of the first keypoint of row r with x >= 16*c
+//                                    (replaces the reference's rows x cols pointer lattice,
+//                                    intensity_feature_matcher.cpp:36-46)
+//   used     u8  [NMAX]              feature removed from the "feature_vector" (matched / parallax)
+//   kill     i32 [NMAX]              scratch of the order-exact track resolution
+#pragma once
+#include <stdint.h>
+#include "../../include/vslam_hip.h"
+
+#define VS_TILE_W 64
+#define VS_TILE_H 16
+#define VS_CELL 16
+#define VS_MAXCAND 16        // candidate list length per previous point (overflow -> exact rescan)
+#define VS_WG 1024           // threads of the per-stream frame kernel
+#define VS_POSE_LOG 32768    // frames of trajectory kept per stream
+
+struct DevRegion { int32_t x, y, w, h; };
+
+struct DevCfg {
+  vslam_config c;
+  int32_t TX, CW, bstride;           // mask words per row, 16-px cells per row, box/score row stride
+  int32_t n_regions;
+  DevRegion regions[VSLAM_MAX_REGIONS];
+  int32_t rows_bin, cols_bin, target_kp, target_per_detector;
+  int32_t n_offsets;
+  int32_t offsets[2 * VSLAM_MAX_EPI + 1];
+  int32_t NMAX, MAXP, HCAP;
+  int32_t n_streams;
+};
+
+// tracker + generator state carried from frame to frame (PoseTracker3D / BaseFramePointGenerator members)
+struct StreamState {
+  int32_t thr[VSLAM_MAX_REGIONS];        // FastDetector thresholds in effect for the next detect
+  int32_t raw_count[2][VSLAM_MAX_REGIONS];
+  int32_t status;                        // _status
+  int32_t win;                           // _projection_tracking_distance_pixels
+  int32_t frame_count;                   // frames processed
+  int32_t has_prev;
+  int32_t n_tracked_landmarks_prev;
+  int32_t cur;                           // which point buffer holds the CURRENT frame (0/1)
+  int32_t aligner_valid;
+  int32_t error_flags;                   // sticky
+  double tau_track;                      // _current_descriptor_distance_tracking
+  double tau_tri;                        // _current_maximum_descriptor_distance_triangulation
+  double prior[12];                      // _previous_to_current_camera
+  double pose[12];                       // WorldMap::robot_to_world (camera_left_to_world)
+  // scratch scalars of the frame in flight
+  int32_t by_appearance;                 // mode the candidate kernel must use for attempt 0
+  int32_t n_trk, n_lost, n_tracked_landmarks;
+  int32_t al_n, al_inliers, al_outliers, al_iterations, al_converged;
+  double al_total_error;
+  double al_T[12];
+  double al_H[36];
+};
+
+struct DevBuf {
+  // current input images (device pointers)
+  const uint8_t* img[2];
+  int32_t img_row_stride;
+  size_t img_stream_stride;
+  // image-pipeline products
+  uint16_t* box;
+  uint8_t* score8;
+  unsigned long long* mask;
+  int16_t* kp_xy;      // [B][2][NMAX][2]
+  uint8_t* kp_score;   // [B][2][NMAX]
+  uint8_t* desc;       // [B][2][NMAX][32]
+  int32_t* n_kp;       // [B][2]
+  int32_t* rowcell;    // [B][2][rows][CW+1]
+  uint8_t* used;       // [B][2][NMAX]
+  int32_t* kill;       // [B][2][NMAX]
+  // per-stream state
+  StreamState* st;
+  vslam_frame_info* info;
+  double* pose_log;    // [B][VS_POSE_LOG][12]
+  // frame points, ping-pong [B][2][MAXP]
+  int16_t* p_kp;       // [..][4]
+  uint8_t* p_desc;     // [..][64]
+  int32_t* p_meta;     // [..][6]  dist, epi, prev, track_len, lm_updates, has_next
+  double* p_cam;       // [..][3]
+  double* p_camlm;     // [..][3]
+  double* p_lm;        // [..][3]
+  int32_t* n_points;   // [B][2]
+  // track candidates / resolution  [B][MAXP]
+  int32_t* proj;       // [..][4] row, col, flag(1=in image), pad
+  int32_t* cand_cnt;
+  int32_t* cand_idx;   // [..][VS_MAXCAND]
+  int32_t* cand_h;     // [..][VS_MAXCAND]
+  int32_t* res;        // [..][4] fl, fr, dist, flag (bit0 success, bit1 lost-eligible)
+  int32_t* trk;        // [..][4] prev, fl, fr, dist  (compacted, order of previous points)
+  int32_t* lost;       // [..]
+  // aligner SoA [B][MAXP]
+  double* al_moving;   // [..][3]
+  double* al_fixed;    // [..][4]
+  double* al_omega;
+  double* al_weight;
+  double* al_chi;
+  uint8_t* al_inl;
+  // recovery scratch [B][MAXP]
+  int32_t* rec;        // [..][6] flag, xL, yL, xR, yR, dist
+  uint8_t* rec_desc;   // [..][64]
+  // stereo scratch
+  int32_t* st_match;   // [B][NMAX][2]  matched right index / distance per left feature
+  int32_t* sc;         // [B][NMAX][4]  fl, fr, dist, epi  (new candidates in sweep order)
+  int32_t* bin_occ;    // [B][rows_bin*cols_bin]
+  // history ring for landmark refinement [B][HCAP]
+  double* h_pose;      // [..][24]  cam_to_world, world_to_cam
+  double* h_cam;       // [..][MAXP][3]
+  int32_t* h_prev;     // [..][MAXP]
+};

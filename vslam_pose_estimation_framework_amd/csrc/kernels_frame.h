@@ -1,0 +1,540 @@
+// kernels_frame.h — per-stream kernels: temporal-track candidate search (K4) and the frame kernel
+// (K5): order-exact track resolution, StereoUVAligner, tracker control logic, prune, recovery,
+// landmark refinement, stereo sweep + binning.  One 1024-thread workgroup owns one stream, so the
+// reference's sequential per-frame control flow (PoseTracker3D::compute) runs on the device with
+// workgroup barriers only: no inter-workgroup hand-off, no host round trip.
+//
+// Reference code replaced:
+//   K4/K5 track      StereoFramePointGenerator::track           stereo_framepoint_generator.cpp:464-681
+//                    getMatchingFeatureInRectangularRegion       intensity_feature_matcher.cpp:81-148
+//   K5 align         StereoUVAligner::initialize/linearize/oneRound/converge  stereouv_aligner.cpp:10-264
+//   K5 control       PoseTracker3D::compute/_track/_registerRecursive/_prunePoints/_updatePoints
+//                                                                pose_tracker_3d.cpp:32-566
+//   K5 recover       StereoFramePointGenerator::recoverPoints    stereo_framepoint_generator.cpp:683-869
+//   K5 landmarks     Landmark::Landmark / Landmark::update       types/landmark.cpp:8-33,66-167
+//   K5 stereo        StereoFramePointGenerator::compute          stereo_framepoint_generator.cpp:135-462
+#pragma once
+#include "kernels_image.h"
+#include "dev_math.h"
+
+#define META 6
+#define M_DIST 0
+#define M_EPI 1
+#define M_PREV 2
+#define M_TLEN 3
+#define M_LMUP 4
+#define M_NEXT 5
+
+struct PtView {  // frame points of stream s, buffer pb
+  int16_t* kp; uint8_t* desc; int32_t* meta; double* cam; double* camlm; double* lm; int32_t* n;
+};
+__device__ __forceinline__ PtView pts_of(const DevCfg& c, const DevBuf& b, int s, int pb) {
+  const size_t o = ((size_t)s * 2 + pb) * c.MAXP;
+  PtView v;
+  v.kp = b.p_kp + o * 4; v.desc = b.p_desc + o * 64; v.meta = b.p_meta + o * META;
+  v.cam = b.p_cam + o * 3; v.camlm = b.p_camlm + o * 3; v.lm = b.p_lm + o * 3; v.n = b.n_points + s * 2 + pb;
+  return v;
+}
+__device__ __forceinline__ double* hpose_of(const DevCfg& c, const DevBuf& b, int s, int f) {
+  return b.h_pose + ((size_t)s * c.HCAP + (f % c.HCAP)) * 24;
+}
+__device__ __forceinline__ double* hcam_of(const DevCfg& c, const DevBuf& b, int s, int f) {
+  return b.h_cam + ((size_t)s * c.HCAP + (f % c.HCAP)) * (size_t)c.MAXP * 3;
+}
+__device__ __forceinline__ int32_t* hprev_of(const DevCfg& c, const DevBuf& b, int s, int f) {
+  return b.h_prev + ((size_t)s * c.HCAP + (f % c.HCAP)) * (size_t)c.MAXP;
+}
+__device__ __forceinline__ int ld_relaxed(const int32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// getPointInLeftCamera (stereo_framepoint_generator.cpp:871-895)
+__device__ __forceinline__ void triangulate(const DevCfg& c, int xL, int yL, int xR, int yR, double* o) {
+  const double bx = c.c.baseline_h[0], fx = c.c.K[0], fy = c.c.K[4], cx = c.c.K[2], cy = c.c.K[5];
+  o[2] = bx / (double)(xR - xL);
+  o[0] = 1 / fx * ((double)xL - cx) * o[2];
+  o[1] = 1 / fy * ((double)(yL + yR) / 2.0 - cy) * o[2];
+}
+
+// ----------------------------------------------------------------------------------------------
+// projection of previous point i into the current left image (track(), :494-513)
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool project_prev(const DevCfg& c, const double* T, const double* cam, double* uvw, int* row, int* col) {
+  double q[3];
+  tf_apply(T, cam, q);
+  mat3_mul_vec(c.c.K, q, uvw);
+  if (!(uvw[2] > 0)) return false;
+  if (!to_int32(uvw[0] / uvw[2], col) || !to_int32(uvw[1] / uvw[2], row)) return false;
+  if (*col < 0 || *col > c.c.cols || *row < 0 || *row > c.c.rows) return false;
+  return true;
+}
+
+// One wavefront gathers, for previous point i, every left feature inside the search window whose
+// Hamming distance to the point's left descriptor is below tau (the only features
+// getMatchingFeatureInRectangularRegion can return, in either mode).  Lanes split the window rows;
+// the row/cell CSR bounds each row to the 16-px cells the window overlaps.
+__device__ void candidates_wave(const DevCfg& c, const DevBuf& b, int s, int pb_prev, int i, int lane, int* wcnt,
+                                const double* T, int d, double tau) {
+  const PtView pv = pts_of(c, b, s, pb_prev);
+  const size_t gi = (size_t)s * c.MAXP + i;
+  double uvw[3];
+  int row, col;
+  const bool ok = project_prev(c, T, pv.cam + 3 * (size_t)i, uvw, &row, &col);
+  if (lane == 0) {
+    b.proj[gi * 4 + 0] = row; b.proj[gi * 4 + 1] = col; b.proj[gi * 4 + 2] = ok ? 1 : 0;
+    *wcnt = 0;
+  }
+  if (!ok) { if (lane == 0) b.cand_cnt[gi] = 0; return; }
+  const int rows = c.c.rows, cols = c.c.cols;
+  const int r0 = max(row - d, 0), r1 = min(row + d + 1, rows);
+  const int c0 = max(col - d, 0), c1 = min(col + d + 1, cols);
+  uint32_t pd[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) pd[k] = reinterpret_cast<const uint32_t*>(pv.desc + (size_t)64 * i)[k];
+  const int32_t* rowcell = rowcell_of(c, b, s, 0);
+  const int16_t* kxy = kpxy_of(c, b, s, 0);
+  const uint8_t* desc = desc_of(c, b, s, 0);
+  if (c1 > c0) {
+    const int cl = c0 >> 4, ch = ((c1 - 1) >> 4) + 1;
+    for (int r = r0 + lane; r < r1; r += 64) {
+      const int lo = rowcell[(size_t)r * (c.CW + 1) + cl], hi = rowcell[(size_t)r * (c.CW + 1) + ch];
+      for (int k = lo; k < hi; ++k) {
+        const int x = kxy[2 * k];
+        if (x < c0 || x >= c1) continue;
+        const int h = hamming32(pd, reinterpret_cast<const uint32_t*>(desc + (size_t)32 * k));
+        if ((double)h < tau) {
+          const int slot = atomicAdd(wcnt, 1);
+          if (slot < VS_MAXCAND) { b.cand_idx[gi * VS_MAXCAND + slot] = k; b.cand_h[gi * VS_MAXCAND + slot] = h; }
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) b.cand_cnt[gi] = __hip_atomic_load(wcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__global__ __launch_bounds__(256) void k_track_candidates(const DevCfg c, const DevBuf b) {
+  __shared__ int wcnt[4];
+  const int s = blockIdx.y;
+  const StreamState& st = b.st[s];
+  if (!st.has_prev) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wave = blockIdx.x * 4 + w, nwaves = gridDim.x * 4;
+  const int pb_prev = st.cur;  // the previous frame's points: buffer that was current last frame
+  const int P = b.n_points[s * 2 + pb_prev];
+  const int by_app = st.status == VSLAM_LOCALIZING;
+  const int d = by_app ? c.c.maximum_projection_tracking_distance_pixels : st.win;
+  double T[12];
+  for (int k = 0; k < 12; ++k) T[k] = st.prior[k];
+  for (int i = wave; i < P; i += nwaves) candidates_wave(c, b, s, pb_prev, i, lane, &wcnt[w], T, d, st.tau_track);
+}
+
+// ==============================================================================================
+// frame kernel pieces (all called by the whole 1024-thread workgroup of stream s)
+// ==============================================================================================
+struct FrameShared {
+  int scan[17];
+  int flag;
+  int n_trk, n_lost, n_lm, n_cur, n_cand;
+  int status, win, attempts, broken, fallback, aligner_ran;
+  double tau_track;
+  double T[12];          // aligner estimate
+  double H[36];
+  double bvec[6];
+  double E, Eprev;
+  int inl, outl, its, conv;
+  double red[16][32];
+};
+
+__device__ __forceinline__ unsigned long long key3(unsigned a, int row, int col) {
+  return ((unsigned long long)a << 32) | ((unsigned long long)(unsigned)row << 16) | (unsigned)col;
+}
+
+// evaluation of one previous point against the current kill state: what the sequential loop body
+// of track() would do if all earlier points had the outcomes recorded in `kill`.
+__device__ void evaluate_point(const DevCfg& c, const DevBuf& b, int s, int pb_prev, int i, const double* T, int d,
+                               double tau_track, double tau_tri, int by_app, int* out /*fl,fr,dist,flag*/) {
+  const size_t gi = (size_t)s * c.MAXP + i;
+  out[0] = -1; out[1] = -1; out[2] = 0; out[3] = 0;
+  if (!b.proj[gi * 4 + 2]) return;  // not in image: neither tracked nor lost (:508-513)
+  const int row = b.proj[gi * 4 + 0], col = b.proj[gi * 4 + 1];
+  const PtView pv = pts_of(c, b, s, pb_prev);
+  const int32_t* killL = kill_of(c, b, s, 0);
+  const int32_t* killR = kill_of(c, b, s, 1);
+  const int16_t* kxyL = kpxy_of(c, b, s, 0);
+  const int16_t* kxyR = kpxy_of(c, b, s, 1);
+  const uint8_t* descL = desc_of(c, b, s, 0);
+  const uint8_t* descR = desc_of(c, b, s, 1);
+  const int rows = c.c.rows, cols = c.c.cols, CW1 = c.CW + 1;
+  // ---- left search -------------------------------------------------------------------------
+  unsigned long long best = ~0ull;
+  int fl = -1;
+  const int cnt = b.cand_cnt[gi];
+  if (cnt <= VS_MAXCAND) {
+    for (int k = 0; k < cnt; ++k) {
+      const int f = b.cand_idx[gi * VS_MAXCAND + k];
+      if (ld_relaxed(killL + f) < i) continue;
+      const int fx = kxyL[2 * f], fy = kxyL[2 * f + 1];
+      unsigned prim;
+      if (by_app) prim = (unsigned)b.cand_h[gi * VS_MAXCAND + k];
+      else { const int dr = row - fy, dc = col - fx; prim = (unsigned)(dr * dr + dc * dc); if (prim >= 10000u) continue; }
+      const unsigned long long key = key3(prim, fy, fx);
+      if (key < best) { best = key; fl = f; }
+    }
+  } else {
+    // candidate list overflowed: exact serial rescan of the window
+    uint32_t pd[8];
+    for (int k = 0; k < 8; ++k) pd[k] = reinterpret_cast<const uint32_t*>(pv.desc + (size_t)64 * i)[k];
+    const int r0 = max(row - d, 0), r1 = min(row + d + 1, rows), c0 = max(col - d, 0), c1 = min(col + d + 1, cols);
+    const int32_t* rowcell = rowcell_of(c, b, s, 0);
+    if (c1 > c0)
+      for (int r = r0; r < r1; ++r) {
+        const int lo = rowcell[(size_t)r * CW1 + (c0 >> 4)], hi = rowcell[(size_t)r * CW1 + ((c1 - 1) >> 4) + 1];
+        for (int f = lo; f < hi; ++f) {
+          const int fx = kxyL[2 * f];
+          if (fx < c0 || fx >= c1) continue;
+          if (ld_relaxed(killL + f) < i) continue;
+          const int h = hamming32(pd, reinterpret_cast<const uint32_t*>(descL + (size_t)32 * f));
+          if (!((double)h < tau_track)) continue;
+          unsigned prim;
+          if (by_app) prim = (unsigned)h;
+          else { const int dr = row - r, dc = col - fx; prim = (unsigned)(dr * dr + dc * dc); if (prim >= 10000u) continue; }
+          const unsigned long long key = key3(prim, r, fx);
+          if (key < best) { best = key; fl = f; }
+        }
+      }
+  }
+  if (fl < 0) { out[3] = 2; return; }  // no left match: lost-eligible
+  // ---- right search (:541-590) --------------------------------------------------------------
+  const int flx = kxyL[2 * fl], fly = kxyL[2 * fl + 1];
+  double uvw[3];
+  {
+    double q[3];
+    tf_apply(T, pv.cam + 3 * (size_t)i, q);
+    mat3_mul_vec(c.c.K, q, uvw);
+  }
+  const float ex = (float)col - (float)flx, ey = (float)row - (float)fly;
+  double uR[3];
+  for (int k = 0; k < 3; ++k) uR[k] = uvw[k] + c.c.baseline_h[k];
+  int colR, rowR;
+  if (!to_int32(uR[0] / uR[2] - ex, &colR) || !to_int32(uR[1] / uR[2] - ey, &rowR)) return;
+  if (colR < 0 || colR > cols || rowR < 0 || rowR > rows) return;
+  const int kk = (int)fabs((double)pv.meta[(size_t)i * META + M_EPI]);
+  const int rr0 = max(rowR - kk, 0), rr1 = min(rowR + kk + 1, rows);
+  const int rc0 = max(colR - d, 0), rc1 = min(colR + d + 1, flx);
+  uint32_t ld[8];
+  for (int k = 0; k < 8; ++k) ld[k] = reinterpret_cast<const uint32_t*>(descL + (size_t)32 * fl)[k];
+  double dbest = tau_tri;
+  int fr = -1;
+  if (rc1 > rc0) {
+    const int32_t* rowcellR = rowcell_of(c, b, s, 1);
+    for (int r = rr0; r < rr1; ++r) {
+      const int lo = rowcellR[(size_t)r * CW1 + (rc0 >> 4)], hi = rowcellR[(size_t)r * CW1 + ((rc1 - 1) >> 4) + 1];
+      for (int g = lo; g < hi; ++g) {
+        const int gx = kxyR[2 * g];
+        if (gx < rc0 || gx >= rc1) continue;
+        if (ld_relaxed(killR + g) < i) continue;
+        const double h = (double)hamming32(ld, reinterpret_cast<const uint32_t*>(descR + (size_t)32 * g));
+        if (h < dbest) { dbest = h; fr = g; }
+      }
+    }
+  }
+  if (fr < 0) { out[3] = 2; return; }  // no right match: lost-eligible
+  const int frx = kxyR[2 * fr];
+  if ((double)(flx - frx) < c.c.minimum_disparity_pixels) return;  // continue: not lost (:597-600)
+  uint32_t rd[8], prd[8];
+  for (int k = 0; k < 8; ++k) {
+    rd[k] = reinterpret_cast<const uint32_t*>(descR + (size_t)32 * fr)[k];
+    prd[k] = reinterpret_cast<const uint32_t*>(pv.desc + (size_t)64 * i + 32)[k];
+  }
+  if ((double)hamming32(rd, prd) > tau_track) return;               // continue (:603-608)
+  out[0] = fl; out[1] = fr; out[2] = (int)dbest; out[3] = 1;
+}
+
+// Order-exact resolution of track(): Jacobi iteration on "who removed which lattice cell".
+// kill[f] = smallest index of a previous point whose (tentative) success removes feature f; point i
+// sees f as present iff kill[f] >= i.  A fixed point equals the sequential result (induction on i:
+// point 0 never depends on others; if all j < i are final, the kills i sees are final).
+__device__ void wg_track_resolve(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_prev, const double* T,
+                                 int d, double tau_track, double tau_tri, int by_app) {
+  const int tid = threadIdx.x;
+  const PtView pv = pts_of(c, b, s, pb_prev);
+  const int P = *pv.n;
+  const int nL = b.n_kp[s * 2], nR = b.n_kp[s * 2 + 1];
+  int32_t* killL = kill_of(c, b, s, 0);
+  int32_t* killR = kill_of(c, b, s, 1);
+  int32_t* res = b.res + (size_t)s * c.MAXP * 4;
+  const int16_t* kxyL = kpxy_of(c, b, s, 0);
+  const int16_t* kxyR = kpxy_of(c, b, s, 1);
+  const int32_t* rowcellR = rowcell_of(c, b, s, 1);
+  for (int i = tid; i < P; i += VS_WG) { res[4 * i] = -1; res[4 * i + 1] = -1; res[4 * i + 2] = 0; res[4 * i + 3] = 0; }
+  __syncthreads();
+  for (int iter = 0; iter <= P + 1; ++iter) {
+    for (int f = tid; f < nL; f += VS_WG) __hip_atomic_store(killL + f, 0x7FFFFFFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int f = tid; f < nR; f += VS_WG) __hip_atomic_store(killR + f, 0x7FFFFFFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    for (int i = tid; i < P; i += VS_WG) {
+      if (res[4 * i + 3] & 1) {
+        const int fl = res[4 * i], fr = res[4 * i + 1];
+        atomicMin(killL + fl, i);
+        atomicMin(killR + fr, i);
+        // parallax clearing (:612-621): right features strictly between fR.col and fL.col on fR.row
+        const int rowR = kxyR[2 * fr + 1], lim = kxyL[2 * fl];
+        const int rend = rowcellR[(size_t)rowR * (c.CW + 1) + c.CW];
+        for (int g = fr + 1; g < rend && kxyR[2 * g] < lim; ++g) atomicMin(killR + g, i);
+      }
+    }
+    __syncthreads();
+    int changed = 0;
+    for (int i = tid; i < P; i += VS_WG) {
+      int o[4];
+      evaluate_point(c, b, s, pb_prev, i, T, d, tau_track, tau_tri, by_app, o);
+      if (o[0] != res[4 * i] || o[1] != res[4 * i + 1] || o[3] != res[4 * i + 3]) changed = 1;
+      res[4 * i] = o[0]; res[4 * i + 1] = o[1]; res[4 * i + 2] = o[2]; res[4 * i + 3] = o[3];
+    }
+    if (!__syncthreads_or(changed)) break;
+  }
+  // used flags == every feature some final success removed (matched_indices_* + prune, :646-672)
+  uint8_t* usedL = used_of(c, b, s, 0);
+  uint8_t* usedR = used_of(c, b, s, 1);
+  for (int f = tid; f < nL; f += VS_WG) usedL[f] = ld_relaxed(killL + f) != 0x7FFFFFFF;
+  for (int f = tid; f < nR; f += VS_WG) usedR[f] = ld_relaxed(killR + f) != 0x7FFFFFFF;
+  // compaction in previous-point order: tracked list, lost list, landmark count
+  int32_t* trk = b.trk + (size_t)s * c.MAXP * 4;
+  int32_t* lost = b.lost + (size_t)s * c.MAXP;
+  const int per = (P + VS_WG - 1) / VS_WG;
+  const int i0 = tid * per, i1 = min(i0 + per, P);
+  int nt = 0, nl = 0, nlm = 0;
+  for (int i = i0; i < i1; ++i) {
+    const int fl = res[4 * i + 3];
+    if (fl & 1) { ++nt; if (pv.meta[(size_t)i * META + M_LMUP] > 0) ++nlm; }
+    else if ((fl & 2) && !pv.meta[(size_t)i * META + M_NEXT]) ++nl;
+  }
+  int tot_t, tot_l, tot_lm;
+  int ot = block_exclusive_scan(nt, sh.scan, &tot_t);
+  int ol = block_exclusive_scan(nl, sh.scan, &tot_l);
+  block_exclusive_scan(nlm, sh.scan, &tot_lm);
+  for (int i = i0; i < i1; ++i) {
+    const int fl = res[4 * i + 3];
+    if (fl & 1) {
+      trk[4 * ot] = i; trk[4 * ot + 1] = res[4 * i]; trk[4 * ot + 2] = res[4 * i + 1]; trk[4 * ot + 3] = res[4 * i + 2];
+      ++ot;
+      pv.meta[(size_t)i * META + M_NEXT] = 1;
+    } else if ((fl & 2) && !pv.meta[(size_t)i * META + M_NEXT]) {
+      lost[ol++] = i;
+    }
+  }
+  if (tid == 0) { sh.n_trk = tot_t; sh.n_lost = tot_l; sh.n_lm = tot_lm; }
+  __syncthreads();
+}
+
+// ----------------------------------------------------------------------------------------------
+// StereoUVAligner
+// ----------------------------------------------------------------------------------------------
+#define NACC 29  // 21 upper-triangular H + 6 b + E + inlier count
+__device__ void wg_one_round(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int n, bool ignore_outliers) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const double* moving = b.al_moving + (size_t)s * c.MAXP * 3;
+  const double* fixed = b.al_fixed + (size_t)s * c.MAXP * 4;
+  const double* omega_v = b.al_omega + (size_t)s * c.MAXP;
+  const double* weight = b.al_weight + (size_t)s * c.MAXP;
+  double* chi_o = b.al_chi + (size_t)s * c.MAXP;
+  uint8_t* inl_o = b.al_inl + (size_t)s * c.MAXP;
+  double T[12];
+  for (int k = 0; k < 12; ++k) T[k] = sh.T[k];
+  const double* K = c.c.K;
+  double acc[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) acc[k] = 0;
+  for (int u = tid; u < n; u += VS_WG) {
+    double chi_w = -1;
+    uint8_t inl_w = 0;
+    double omega = omega_v[u];
+    double p[3];
+    tf_apply(T, moving + 3 * (size_t)u, p);
+    bool skip = p[2] < c.c.minimum_depth_meters;
+    double aL[3], aR[3];
+    mat3_mul_vec(K, p, aL);
+    for (int k = 0; k < 3; ++k) aR[k] = aL[k] + c.c.baseline_h[k];
+    const double cL = aL[2], cR = aR[2];
+    const double uL = aL[0] / cL, vL = aL[1] / cL, uR = aR[0] / cR, vR = aR[1] / cR;
+    if (!skip) {
+      if (uL < 0 || uL > c.c.cols || vL < 0 || vL > c.c.rows) skip = true;
+      if (uR < 0 || uR > c.c.cols || vR < 0 || vR > c.c.rows) skip = true;
+    }
+    if (!skip) {
+      const double e[4] = {uL - fixed[4 * (size_t)u], vL - fixed[4 * (size_t)u + 1], uR - fixed[4 * (size_t)u + 2],
+                           vR - fixed[4 * (size_t)u + 3]};
+      const double chi = omega * (((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]) + e[3] * e[3]);
+      chi_w = chi;
+      bool use = true;
+      if (chi > c.c.aligner_maximum_error_kernel) {
+        if (ignore_outliers) use = false;
+        else omega *= c.c.aligner_maximum_error_kernel / chi;
+      } else {
+        inl_w = 1;
+        acc[28] += 1.0;
+      }
+      if (use) {
+        acc[27] += chi;
+        const double wt = weight[u];
+        // K * [w*I3 | -2*skew(p)]
+        const double Jt[3][6] = {{wt, 0, 0, 0, 2 * p[2], -2 * p[1]}, {0, wt, 0, -2 * p[2], 0, 2 * p[0]}, {0, 0, wt, 2 * p[1], -2 * p[0], 0}};
+        double KJ[3][6];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 6; ++j) KJ[i][j] = (K[3 * i] * Jt[0][j] + K[3 * i + 1] * Jt[1][j]) + K[3 * i + 2] * Jt[2][j];
+        const double icL = 1 / cL, icR = 1 / cR, icL2 = icL * icL, icR2 = icR * icR;
+        const double jl0 = -aL[0] * icL2, jl1 = -aL[1] * icL2, jr0 = -aR[0] * icR2, jr1 = -aR[1] * icR2;
+        double J[4][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          J[0][j] = (icL * KJ[0][j] + 0 * KJ[1][j]) + jl0 * KJ[2][j];
+          J[1][j] = (0 * KJ[0][j] + icL * KJ[1][j]) + jl1 * KJ[2][j];
+          J[2][j] = (icR * KJ[0][j] + 0 * KJ[1][j]) + jr0 * KJ[2][j];
+          J[3][j] = (0 * KJ[0][j] + icR * KJ[1][j]) + jr1 * KJ[2][j];
+        }
+        int q = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+#pragma unroll
+          for (int cc = r; cc < 6; ++cc)
+            acc[q++] += omega * (((J[0][r] * J[0][cc] + J[1][r] * J[1][cc]) + J[2][r] * J[2][cc]) + J[3][r] * J[3][cc]);
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) acc[21 + r] += omega * (((J[0][r] * e[0] + J[1][r] * e[1]) + J[2][r] * e[2]) + J[3][r] * e[3]);
+      }
+    }
+    chi_o[u] = chi_w;
+    inl_o[u] = inl_w;
+  }
+  // deterministic reduction: butterfly inside the wave, fixed order across the 16 waves
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) sh.red[w][k] = v;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double tot[NACC];
+    for (int k = 0; k < NACC; ++k) { double a = 0; for (int ww = 0; ww < VS_WG / 64; ++ww) a += sh.red[ww][k]; tot[k] = a; }
+    double H[36], bb[6];
+    int q = 0;
+    for (int r = 0; r < 6; ++r)
+      for (int cc = r; cc < 6; ++cc) { H[6 * r + cc] = tot[q]; H[6 * cc + r] = tot[q]; ++q; }
+    for (int r = 0; r < 6; ++r) bb[r] = tot[21 + r];
+    sh.E = tot[27];
+    sh.inl = (int)tot[28];
+    sh.outl = n - sh.inl;
+    // oneRound (stereouv_aligner.cpp:190-207)
+    for (int r = 0; r < 6; ++r) H[7 * r] += c.c.aligner_damping * n;
+    for (int k = 0; k < 36; ++k) sh.H[k] = H[k];
+    double nb[6], dx[6], D[12], Tn[12];
+    for (int r = 0; r < 6; ++r) nb[r] = -bb[r];
+    full_piv_solve<6>(H, nb, dx);
+    v2t(dx, D);
+    tf_mul(D, T, Tn);
+    double R[9], RtR[9];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) R[3 * i + j] = Tn[4 * i + j];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        RtR[3 * i + j] = (R[i] * R[j] + R[3 + i] * R[3 + j]) + R[6 + i] * R[6 + j];
+        if (i == j) RtR[3 * i + j] -= 1;
+      }
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j)
+        Tn[4 * i + j] = R[3 * i + j] - 0.5 * ((R[3 * i] * RtR[j] + R[3 * i + 1] * RtR[3 + j]) + R[3 * i + 2] * RtR[6 + j]);
+    for (int k = 0; k < 12; ++k) sh.T[k] = Tn[k];
+    ++sh.its;
+  }
+  __syncthreads();
+}
+
+// converge (:210-264) on the aligner SoA of stream s (n measurements), starting from T_init
+__device__ void wg_align_converge(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int n, const double* T_init) {
+  const int tid = threadIdx.x;
+  __syncthreads();
+  if (tid == 0) {
+    for (int k = 0; k < 12; ++k) sh.T[k] = T_init[k];
+    sh.its = 0; sh.conv = 0; sh.Eprev = 0; sh.E = 0; sh.inl = 0; sh.outl = n;
+    for (int k = 0; k < 36; ++k) sh.H[k] = 0;
+  }
+  __syncthreads();
+  const int max_it = c.c.aligner_maximum_number_of_iterations;
+  const double delta = c.c.aligner_error_delta_for_convergence;
+  double e_prev = 0;
+  for (int it = 0; it < max_it; ++it) {
+    wg_one_round(c, b, s, sh, n, false);
+    const double E = sh.E;
+    const int inl = sh.inl, outl = sh.outl;
+    if (delta > fabs(e_prev - E)) {
+      e_prev = E;
+      if (inl > c.c.aligner_minimum_number_of_inliers && inl > outl) {
+        for (int it2 = 0; it2 < max_it; ++it2) {
+          wg_one_round(c, b, s, sh, n, true);
+          const double E2 = sh.E;
+          const bool done = fabs(e_prev - E2) < delta;
+          e_prev = E2;
+          if (done) break;
+        }
+      }
+      if (tid == 0) sh.conv = 1;
+      break;
+    } else {
+      e_prev = E;
+    }
+  }
+  __syncthreads();
+}
+
+// initialize (:10-69) on the tracked list, then converge
+__device__ void wg_align(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_prev, bool inverse_depth,
+                         const double* T_init) {
+  const int tid = threadIdx.x;
+  const int n = sh.n_trk;
+  const PtView pv = pts_of(c, b, s, pb_prev);
+  const int32_t* trk = b.trk + (size_t)s * c.MAXP * 4;
+  const int16_t* kxyL = kpxy_of(c, b, s, 0);
+  const int16_t* kxyR = kpxy_of(c, b, s, 1);
+  double* moving = b.al_moving + (size_t)s * c.MAXP * 3;
+  double* fixed = b.al_fixed + (size_t)s * c.MAXP * 4;
+  double* omega = b.al_omega + (size_t)s * c.MAXP;
+  double* weight = b.al_weight + (size_t)s * c.MAXP;
+  for (int u = tid; u < n; u += VS_WG) {
+    const int ip = trk[4 * u], fl = trk[4 * u + 1], fr = trk[4 * u + 2];
+    const int xL = kxyL[2 * fl], yL = kxyL[2 * fl + 1], xR = kxyR[2 * fr], yR = kxyR[2 * fr + 1];
+    fixed[4 * (size_t)u] = xL; fixed[4 * (size_t)u + 1] = yL; fixed[4 * (size_t)u + 2] = xR; fixed[4 * (size_t)u + 3] = yR;
+    const int lmup = pv.meta[(size_t)ip * META + M_LMUP];
+    double om = 1;
+    if (lmup > 0) {
+      for (int k = 0; k < 3; ++k) moving[3 * (size_t)u + k] = pv.camlm[3 * (size_t)ip + k];
+      om *= (1 + log((double)lmup));
+    } else {
+      for (int k = 0; k < 3; ++k) moving[3 * (size_t)u + k] = pv.cam[3 * (size_t)ip + k];
+    }
+    omega[u] = om;
+    double cam[3];
+    triangulate(c, xL, yL, xR, yR, cam);
+    weight[u] = inverse_depth ? fmin(c.c.maximum_reliable_depth_meters / cam[2], 1.0) : 1.0;
+  }
+  wg_align_converge(c, b, s, sh, n, T_init);
+}
+
+// stand-alone aligner on caller-provided correspondences (vslam_align_points)
+__global__ __launch_bounds__(VS_WG) void k_align_points(const DevCfg c, const DevBuf b, int n, const double* T_init) {
+  __shared__ FrameShared sh;
+  double T0[12];
+  for (int k = 0; k < 12; ++k) T0[k] = T_init[k];
+  wg_align_converge(c, b, 0, sh, n, T0);
+  if (threadIdx.x == 0) {
+    StreamState& st = b.st[0];
+    st.al_n = n; st.al_inliers = sh.inl; st.al_outliers = sh.outl; st.al_iterations = sh.its; st.al_converged = sh.conv;
+    st.al_total_error = sh.E;
+    for (int k = 0; k < 12; ++k) st.al_T[k] = sh.T[k];
+    for (int k = 0; k < 36; ++k) st.al_H[k] = sh.H[k];
+  }
+}

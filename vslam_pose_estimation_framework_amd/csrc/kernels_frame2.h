@@ -1,0 +1,589 @@
+// kernels_frame2.h — second half of the frame kernel: prune, recovery, landmark refinement,
+// stereo sweep + binning, and the PoseTracker3D control flow that strings the stages together.
+#pragma once
+#include "kernels_frame.h"
+
+// write one framepoint (Frame::createFramepoint, types/frame.cpp:61-84) from a left/right feature pair
+__device__ __forceinline__ void materialize_point(const DevCfg& c, const DevBuf& b, int s, const PtView& cv, int j, int fl,
+                                                  int fr, int dist, int epi, int prev, int tlen) {
+  const int16_t* kxyL = kpxy_of(c, b, s, 0);
+  const int16_t* kxyR = kpxy_of(c, b, s, 1);
+  const int xL = kxyL[2 * fl], yL = kxyL[2 * fl + 1], xR = kxyR[2 * fr], yR = kxyR[2 * fr + 1];
+  cv.kp[4 * (size_t)j] = (int16_t)xL; cv.kp[4 * (size_t)j + 1] = (int16_t)yL;
+  cv.kp[4 * (size_t)j + 2] = (int16_t)xR; cv.kp[4 * (size_t)j + 3] = (int16_t)yR;
+  const uint32_t* dl = reinterpret_cast<const uint32_t*>(desc_of(c, b, s, 0) + (size_t)32 * fl);
+  const uint32_t* dr = reinterpret_cast<const uint32_t*>(desc_of(c, b, s, 1) + (size_t)32 * fr);
+  uint32_t* o = reinterpret_cast<uint32_t*>(cv.desc + (size_t)64 * j);
+  for (int k = 0; k < 8; ++k) { o[k] = dl[k]; o[8 + k] = dr[k]; }
+  int32_t* m = cv.meta + (size_t)j * META;
+  m[M_DIST] = dist; m[M_EPI] = epi; m[M_PREV] = prev; m[M_TLEN] = tlen; m[M_LMUP] = 0; m[M_NEXT] = 0;
+  triangulate(c, xL, yL, xR, yR, cv.cam + 3 * (size_t)j);
+  for (int k = 0; k < 3; ++k) { cv.camlm[3 * (size_t)j + k] = 0; cv.lm[3 * (size_t)j + k] = 0; }
+}
+
+// _prunePoints (pose_tracker_3d.cpp:437-472) fused with the materialisation of the surviving tracked
+// points into the current frame's point arrays.  Quirk B.3: aligner not run on these points -> drop all.
+__device__ void wg_prune(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_prev, int pb_cur, bool aligner_valid) {
+  const int tid = threadIdx.x;
+  const int n = sh.n_trk;
+  const PtView pv = pts_of(c, b, s, pb_prev);
+  const PtView cv = pts_of(c, b, s, pb_cur);
+  const int32_t* trk = b.trk + (size_t)s * c.MAXP * 4;
+  const double* chi = b.al_chi + (size_t)s * c.MAXP;
+  const uint8_t* inl = b.al_inl + (size_t)s * c.MAXP;
+  const int16_t* kxyL = kpxy_of(c, b, s, 0);
+  const int16_t* kxyR = kpxy_of(c, b, s, 1);
+  const bool by_inlier = aligner_valid && (sh.E / (double)n < c.c.aligner_maximum_error_kernel);
+  const int per = (n + VS_WG - 1) / VS_WG;
+  const int u0 = tid * per, u1 = min(u0 + per, n);
+  int cnt = 0;
+  for (int u = u0; u < u1; ++u) {
+    bool keep = false;
+    if (aligner_valid) keep = by_inlier ? (inl[u] != 0) : (chi[u] != -1 && chi[u] < 100 * c.c.aligner_maximum_error_kernel);
+    if (keep) ++cnt;
+  }
+  int total;
+  int off = block_exclusive_scan(cnt, sh.scan, &total);
+  for (int u = u0; u < u1; ++u) {
+    bool keep = false;
+    if (aligner_valid) keep = by_inlier ? (inl[u] != 0) : (chi[u] != -1 && chi[u] < 100 * c.c.aligner_maximum_error_kernel);
+    const int ip = trk[4 * u];
+    if (keep) {
+      const int fl = trk[4 * u + 1], fr = trk[4 * u + 2];
+      materialize_point(c, b, s, cv, off, fl, fr, trk[4 * u + 3], kxyR[2 * fr + 1] - kxyL[2 * fl + 1], ip,
+                        pv.meta[(size_t)ip * META + M_TLEN] + 1);
+      // the landmark travels with the track (origin()->landmark())
+      cv.meta[(size_t)off * META + M_LMUP] = pv.meta[(size_t)ip * META + M_LMUP];
+      for (int k = 0; k < 3; ++k) cv.lm[3 * (size_t)off + k] = pv.lm[3 * (size_t)ip + k];
+      ++off;
+    } else {
+      pv.meta[(size_t)ip * META + M_NEXT] = 0;  // FramePoint::clear unlinks previous->next
+    }
+  }
+  if (tid == 0) sh.n_cur = min(total, c.MAXP);
+  __syncthreads();
+}
+
+// recoverPoints (stereo_framepoint_generator.cpp:683-869): one wavefront per lost point evaluates BRIEF
+// at the landmark's projection in both box images; survivors are appended in lost-list order.
+__device__ void wg_recover(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_prev, int pb_cur, const double* w2c,
+                           double tau_track, double tau_tri) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const PtView pv = pts_of(c, b, s, pb_prev);
+  const PtView cv = pts_of(c, b, s, pb_cur);
+  const int32_t* lost = b.lost + (size_t)s * c.MAXP;
+  int32_t* rec = b.rec + (size_t)s * c.MAXP * 6;
+  uint8_t* rdesc = b.rec_desc + (size_t)s * c.MAXP * 64;
+  const int nl = sh.n_lost;
+  const uint16_t* boxL = box_of(c, b, s, 0);
+  const uint16_t* boxR = box_of(c, b, s, 1);
+  for (int q = w; q < nl; q += VS_WG / 64) {
+    const int ip = lost[q];
+    int ok = pv.meta[(size_t)ip * META + M_LMUP] > 0;
+    int xL = 0, yL = 0, xR = 0, yR = 0;
+    float pLx = 0, pRx = 0;
+    if (ok) {
+      double pc[3], uL[3], uR[3];
+      tf_apply(w2c, pv.lm + 3 * (size_t)ip, pc);
+      mat3_mul_vec(c.c.K, pc, uL);
+      for (int k = 0; k < 3; ++k) uR[k] = uL[k] + c.c.baseline_h[k];
+      if (uL[2] < c.c.minimum_depth_meters || uL[2] > c.c.maximum_depth_meters || uR[2] < c.c.minimum_depth_meters ||
+          uR[2] > c.c.maximum_depth_meters) ok = 0;
+      if (ok) {
+        pLx = (float)rint(uL[0] / uL[2]); const float pLy = (float)rint(uL[1] / uL[2]);
+        pRx = (float)rint(uR[0] / uR[2]); const float pRy = (float)rint(uR[1] / uR[2]);
+        const float border = 35.f;  // 5 * keypoint.size (FAST: 7)
+        if (pLx < border + 1 || pLx > c.c.cols - border - 1 || pRx < border + 1 || pRx > c.c.cols - border - 1 ||
+            pLy < border + 1 || pLy > c.c.rows - border - 1 || pRy < border + 1 || pRy > c.c.rows - border - 1) ok = 0;
+        xL = (int)pLx; yL = (int)pLy; xR = (int)pRx; yR = (int)pRy;
+      }
+    }
+    int dist = 0;
+    if (ok) {  // wave-uniform
+      uint8_t* dl = rdesc + (size_t)64 * q;
+      brief_wave(boxL, c.bstride, xL, yL, lane, dl);
+      brief_wave(boxR, c.bstride, xR, yR, lane, dl + 32);
+      __builtin_amdgcn_wave_barrier();
+      __threadfence_block();
+      const uint32_t* nl32 = reinterpret_cast<const uint32_t*>(dl);
+      const uint32_t* pl32 = reinterpret_cast<const uint32_t*>(pv.desc + (size_t)64 * ip);
+      uint32_t a[8], bb[8], pa[8], pb[8];
+      for (int k = 0; k < 8; ++k) {
+        a[k] = __hip_atomic_load(nl32 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bb[k] = __hip_atomic_load(nl32 + 8 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pa[k] = pl32[k]; pb[k] = pl32[8 + k];
+      }
+      if ((double)hamming32(pa, a) > tau_track) ok = 0;
+      if (ok && (double)(pLx - pRx) < c.c.minimum_disparity_pixels) ok = 0;
+      if (ok && (double)hamming32(pb, bb) > tau_track) ok = 0;
+      dist = hamming32(a, bb);
+      if (ok && (double)dist > tau_tri) ok = 0;
+    }
+    if (lane == 0) {
+      rec[6 * q] = ok; rec[6 * q + 1] = xL; rec[6 * q + 2] = yL; rec[6 * q + 3] = xR; rec[6 * q + 4] = yR; rec[6 * q + 5] = dist;
+    }
+  }
+  __syncthreads();
+  const int per = (nl + VS_WG - 1) / VS_WG;
+  const int q0 = tid * per, q1 = min(q0 + per, nl);
+  int cnt = 0;
+  for (int q = q0; q < q1; ++q) cnt += rec[6 * q] ? 1 : 0;
+  int total;
+  int off = sh.n_cur + block_exclusive_scan(cnt, sh.scan, &total);
+  for (int q = q0; q < q1; ++q) {
+    if (!rec[6 * q]) continue;
+    if (off < c.MAXP) {
+      const int ip = lost[q], j = off;
+      const int xL = rec[6 * q + 1], yL = rec[6 * q + 2], xR = rec[6 * q + 3], yR = rec[6 * q + 4];
+      cv.kp[4 * (size_t)j] = (int16_t)xL; cv.kp[4 * (size_t)j + 1] = (int16_t)yL; cv.kp[4 * (size_t)j + 2] = (int16_t)xR; cv.kp[4 * (size_t)j + 3] = (int16_t)yR;
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(rdesc + (size_t)64 * q);
+      uint32_t* dst = reinterpret_cast<uint32_t*>(cv.desc + (size_t)64 * j);
+      for (int k = 0; k < 16; ++k) dst[k] = src[k];
+      int32_t* m = cv.meta + (size_t)j * META;
+      m[M_DIST] = rec[6 * q + 5]; m[M_EPI] = 0; m[M_PREV] = ip; m[M_TLEN] = pv.meta[(size_t)ip * META + M_TLEN] + 1;
+      m[M_LMUP] = pv.meta[(size_t)ip * META + M_LMUP]; m[M_NEXT] = 0;
+      triangulate(c, xL, yL, xR, yR, cv.cam + 3 * (size_t)j);
+      for (int k = 0; k < 3; ++k) { cv.lm[3 * (size_t)j + k] = pv.lm[3 * (size_t)ip + k]; cv.camlm[3 * (size_t)j + k] = 0; }
+      pv.meta[(size_t)ip * META + M_NEXT] = 1;
+    } else {
+      atomicOr(&b.st[s].error_flags, 2);
+    }
+    ++off;
+  }
+  __syncthreads();
+  if (tid == 0) { sh.flag = total; sh.n_cur = min(sh.n_cur + total, c.MAXP); }
+  __syncthreads();
+}
+
+// _updatePoints (pose_tracker_3d.cpp:475-520): one thread per framepoint; landmark creation = mean of the
+// track's world coordinates (landmark.cpp:19-31), update = Gauss-Newton over all measurements of the
+// track (landmark.cpp:66-167).  Measurements are reached by walking the per-frame `prev` links of the
+// history ring (frame f, index i) -> (f-1, prev[i]).
+__device__ void wg_update_points(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_cur, int f) {
+  const int tid = threadIdx.x;
+  const PtView cv = pts_of(c, b, s, pb_cur);
+  const int n = sh.n_cur;
+  // publish the current frame's cam/prev to the history ring first (chains start here)
+  double* hc = hcam_of(c, b, s, f);
+  int32_t* hp = hprev_of(c, b, s, f);
+  for (int i = tid; i < n; i += VS_WG) {
+    for (int k = 0; k < 3; ++k) hc[3 * (size_t)i + k] = cv.cam[3 * (size_t)i + k];
+    hp[i] = cv.meta[(size_t)i * META + M_PREV];
+  }
+  __syncthreads();
+  const double* w2c_cur = hpose_of(c, b, s, f) + 12;
+  int active = 0;
+  for (int i = tid; i < n; i += VS_WG) {
+    int32_t* m = cv.meta + (size_t)i * META;
+    const int tlen = m[M_TLEN];
+    if (tlen < c.c.minimum_track_length_for_landmark_creation) continue;
+    int len = tlen + 1;
+    if (len > c.HCAP) { len = c.HCAP; atomicOr(&b.st[s].error_flags, 4); }
+    double wpos[3];
+    if (m[M_LMUP] == 0) {
+      // Landmark::Landmark: average of the world coordinates along the track
+      double acc[3] = {0, 0, 0};
+      int ff = f, ii = i;
+      for (int k = 0; k < len; ++k) {
+        double wp[3];
+        tf_apply(hpose_of(c, b, s, ff), hcam_of(c, b, s, ff) + 3 * (size_t)ii, wp);
+        for (int q = 0; q < 3; ++q) acc[q] += wp[q];
+        ii = hprev_of(c, b, s, ff)[ii];
+        --ff;
+      }
+      for (int q = 0; q < 3; ++q) wpos[q] = acc[q] / (double)len;
+      m[M_LMUP] = len;
+    } else {
+      // Landmark::update
+      double wv[3] = {cv.lm[3 * (size_t)i], cv.lm[3 * (size_t)i + 1], cv.lm[3 * (size_t)i + 2]};
+      for (int q = 0; q < 3; ++q) wpos[q] = wv[q];
+      double err_prev = 0;
+      const double kern = c.c.landmark_maximum_error_squared_meters;
+      for (int it = 0; it < c.c.landmark_maximum_number_of_iterations; ++it) {
+        double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bv[3] = {0, 0, 0};
+        double err = 0;
+        int n_out = 0;
+        int ff = f, ii = i;
+        for (int k = 0; k < len; ++k) {
+          const double* W = hpose_of(c, b, s, ff) + 12;
+          const double* mc = hcam_of(c, b, s, ff) + 3 * (size_t)ii;
+          double sp[3];
+          tf_apply(W, wv, sp);
+          if (sp[2] <= 0) {
+            ++n_out;
+          } else {
+            const double e[3] = {sp[0] - mc[0], sp[1] - mc[1], sp[2] - mc[2]};
+            double om = 1 / mc[2];
+            const double e2 = om * ((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]);
+            err += e2;
+            if (e2 > kern) { om *= kern / e2; ++n_out; }
+            for (int r = 0; r < 3; ++r) {
+              for (int cc = 0; cc < 3; ++cc) H[3 * r + cc] += om * ((W[r] * W[cc] + W[4 + r] * W[4 + cc]) + W[8 + r] * W[8 + cc]);
+              bv[r] += om * ((W[r] * e[0] + W[4 + r] * e[1]) + W[8 + r] * e[2]);
+            }
+          }
+          ii = hprev_of(c, b, s, ff)[ii];
+          --ff;
+        }
+        double nb[3] = {-bv[0], -bv[1], -bv[2]}, dx[3];
+        full_piv_solve<3>(H, nb, dx);
+        for (int q = 0; q < 3; ++q) wv[q] += dx[q];
+        if (fabs(err - err_prev) < 1e-5 || it == 999) {
+          const int n_in = len - n_out;
+          if (n_in > m[M_LMUP]) {
+            for (int q = 0; q < 3; ++q) wpos[q] = wv[q];
+            m[M_LMUP] = n_in;
+          } else if (n_in < n_out) {
+            double acc[3] = {0, 0, 0};
+            int f2 = f, i2 = i;
+            for (int k = 0; k < len; ++k) {
+              double wp[3];
+              tf_apply(hpose_of(c, b, s, f2), hcam_of(c, b, s, f2) + 3 * (size_t)i2, wp);
+              for (int q = 0; q < 3; ++q) acc[q] += wp[q];
+              i2 = hprev_of(c, b, s, f2)[i2];
+              --f2;
+            }
+            for (int q = 0; q < 3; ++q) wpos[q] = acc[q] / (double)len;
+          }
+          break;
+        }
+        err_prev = err;
+      }
+    }
+    for (int q = 0; q < 3; ++q) cv.lm[3 * (size_t)i + q] = wpos[q];
+    tf_apply(w2c_cur, wpos, cv.camlm + 3 * (size_t)i);
+    ++active;
+  }
+  int total;
+  block_exclusive_scan(active, sh.scan, &total);
+  if (tid == 0) sh.n_lm = total;  // _number_of_active_landmarks
+  __syncthreads();
+}
+
+// compute() (stereo_framepoint_generator.cpp:135-462): stereo sweep with one thread per image row (rows are
+// independent: the right cursor only moves inside a row), then the order-dependent bin competition with
+// one thread per bin, then emission in bin-grid row-major order.
+__device__ void wg_stereo(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_cur, double tau_tri, int f) {
+  const int tid = threadIdx.x;
+  const PtView cv = pts_of(c, b, s, pb_cur);
+  const int rows = c.c.rows, CW1 = c.CW + 1;
+  const int nL = b.n_kp[s * 2];
+  const int32_t* rcL = rowcell_of(c, b, s, 0);
+  const int32_t* rcR = rowcell_of(c, b, s, 1);
+  const int16_t* kxyL = kpxy_of(c, b, s, 0);
+  const int16_t* kxyR = kpxy_of(c, b, s, 1);
+  const uint8_t* descL = desc_of(c, b, s, 0);
+  const uint8_t* descR = desc_of(c, b, s, 1);
+  uint8_t* usedL = used_of(c, b, s, 0);
+  uint8_t* usedR = used_of(c, b, s, 1);
+  int32_t* match = b.st_match + (size_t)s * c.NMAX * 2;
+  int32_t* sc = b.sc + (size_t)s * c.NMAX * 4;
+  int32_t* bin_occ = b.bin_occ + (size_t)s * c.rows_bin * c.cols_bin;
+  const int n_tracked = sh.n_cur;
+  int n_cand = 0;
+  for (int oi = 0; oi < c.n_offsets; ++oi) {
+    const int o = c.offsets[oi];
+    for (int i = tid; i < nL; i += VS_WG) match[2 * i] = -1;
+    __syncthreads();
+    for (int r = tid; r < rows; r += VS_WG) {
+      const int rr = r - o;  // right row: L.row == R.row + o
+      if (rr < 0 || rr >= rows) continue;
+      const int l0 = rcL[(size_t)r * CW1], l1 = rcL[(size_t)r * CW1 + c.CW];
+      const int g0 = rcR[(size_t)rr * CW1], g1 = rcR[(size_t)rr * CW1 + c.CW];
+      int cur = g0;
+      for (int i = l0; i < l1; ++i) {
+        if (usedL[i]) continue;
+        while (cur < g1 && usedR[cur]) ++cur;  // pruned features are not in the vector
+        if (cur >= g1) break;
+        const int xl = kxyL[2 * i];
+        uint32_t ld[8];
+        for (int k = 0; k < 8; ++k) ld[k] = reinterpret_cast<const uint32_t*>(descL + (size_t)32 * i)[k];
+        double best = tau_tri;
+        int bg = -1;
+        for (int g = cur; g < g1; ++g) {
+          if (usedR[g]) continue;
+          if (xl - kxyR[2 * g] < 0) break;
+          const double h = (double)hamming32(ld, reinterpret_cast<const uint32_t*>(descR + (size_t)32 * g));
+          if (h < best) { best = h; bg = g; }
+        }
+        if (bg >= 0) {
+          if ((double)(xl - kxyR[2 * bg]) < c.c.minimum_disparity_pixels) continue;
+          match[2 * i] = bg; match[2 * i + 1] = (int)best;
+          cur = bg + 1;
+        }
+      }
+    }
+    __syncthreads();
+    // append the matches of this offset in sorted-left order; mark both features used (prune)
+    const int per = (nL + VS_WG - 1) / VS_WG;
+    const int i0 = tid * per, i1 = min(i0 + per, nL);
+    int cnt = 0;
+    for (int i = i0; i < i1; ++i) cnt += match[2 * i] >= 0 ? 1 : 0;
+    int total;
+    int off = n_cand + block_exclusive_scan(cnt, sh.scan, &total);
+    for (int i = i0; i < i1; ++i) {
+      const int g = match[2 * i];
+      if (g < 0) continue;
+      sc[4 * off] = i; sc[4 * off + 1] = g; sc[4 * off + 2] = match[2 * i + 1]; sc[4 * off + 3] = o;
+      usedL[i] = 1; usedR[g] = 1;
+      ++off;
+    }
+    n_cand += total;
+    __syncthreads();
+  }
+  // ---- binning (:147-155, :371-394, :435-456) ---------------------------------------------------
+  const int nb = c.rows_bin * c.cols_bin;
+  const double bin = (double)c.c.bin_size_pixels;
+  int added = 0;
+  if (c.c.enable_keypoint_binning) {
+    for (int k = tid; k < nb; k += VS_WG) bin_occ[k] = -1;
+    __syncthreads();
+    // tracked points seed the grid; later points overwrite earlier ones -> keep the largest index
+    for (int j = tid; j < n_tracked; j += VS_WG) {
+      const int rb = min((int)rint((double)cv.kp[4 * (size_t)j + 1] / bin), c.rows_bin - 1);
+      const int cb = min((int)rint((double)cv.kp[4 * (size_t)j] / bin), c.cols_bin - 1);
+      atomicMax(bin_occ + rb * c.cols_bin + cb, j);
+    }
+    __syncthreads();
+    // one thread per bin replays its candidates in sweep order (the rule is not an argmax)
+    for (int k = tid; k < nb; k += VS_WG) {
+      int occ = ld_relaxed(bin_occ + k);
+      if (occ >= 0) { bin_occ[k] = -2 - occ; continue; }  // tracked occupant: never replaced
+      int win = -1, wdisp = 0, wdist = 0;
+      const int rbk = k / c.cols_bin, cbk = k - rbk * c.cols_bin;
+      for (int q = 0; q < n_cand; ++q) {
+        const int i = sc[4 * q];
+        const int xl = kxyL[2 * i], yl = kxyL[2 * i + 1];
+        const int rb = min((int)rint((double)yl / bin), c.rows_bin - 1);
+        if (rb != rbk) continue;
+        const int cb = min((int)rint((double)xl / bin), c.cols_bin - 1);
+        if (cb != cbk) continue;
+        const int disp = xl - kxyR[2 * sc[4 * q + 1]], dist = sc[4 * q + 2];
+        if (win < 0 || (disp > wdisp && dist <= wdist)) { win = q; wdisp = disp; wdist = dist; }
+      }
+      bin_occ[k] = win;  // -1 empty, >= 0 candidate index
+    }
+    __syncthreads();
+    const int per = (nb + VS_WG - 1) / VS_WG;
+    const int k0 = tid * per, k1 = min(k0 + per, nb);
+    int cnt = 0;
+    for (int k = k0; k < k1; ++k) cnt += bin_occ[k] >= 0 ? 1 : 0;
+    int total;
+    int off = n_tracked + block_exclusive_scan(cnt, sh.scan, &total);
+    for (int k = k0; k < k1; ++k) {
+      const int q = bin_occ[k];
+      if (q < 0) continue;
+      if (off < c.MAXP) materialize_point(c, b, s, cv, off, sc[4 * q], sc[4 * q + 1], sc[4 * q + 2], sc[4 * q + 3], -1, 0);
+      else atomicOr(&b.st[s].error_flags, 2);
+      ++off;
+    }
+    added = total;
+  } else {
+    for (int q = tid; q < n_cand; q += VS_WG) {
+      const int j = n_tracked + q;
+      if (j < c.MAXP) materialize_point(c, b, s, cv, j, sc[4 * q], sc[4 * q + 1], sc[4 * q + 2], sc[4 * q + 3], -1, 0);
+      else atomicOr(&b.st[s].error_flags, 2);
+    }
+    added = n_cand;
+  }
+  __syncthreads();
+  const int n_final = min(n_tracked + added, c.MAXP);
+  // history of the appended points
+  double* hc = hcam_of(c, b, s, f);
+  int32_t* hp = hprev_of(c, b, s, f);
+  for (int j = n_tracked + tid; j < n_final; j += VS_WG) {
+    for (int k = 0; k < 3; ++k) hc[3 * (size_t)j + k] = cv.cam[3 * (size_t)j + k];
+    hp[j] = -1;
+  }
+  if (tid == 0) { sh.n_cand = added; sh.n_cur = n_final; }
+  __syncthreads();
+}
+
+// ==============================================================================================
+// K5: PoseTracker3D::compute for one stream (pose_tracker_3d.cpp:32-222)
+// ==============================================================================================
+__device__ __forceinline__ void set_pose(const DevCfg& c, const DevBuf& b, int s, int f, const double* c2w) {
+  double* hp = hpose_of(c, b, s, f);
+  for (int k = 0; k < 12; ++k) hp[k] = c2w[k];
+  tf_inverse(c2w, hp + 12);
+}
+
+__global__ __launch_bounds__(VS_WG) void k_frame(const DevCfg c, const DevBuf b) {
+  __shared__ FrameShared sh;
+  __shared__ int wcnt[VS_WG / 64];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  StreamState& st = b.st[s];
+  vslam_frame_info& info = b.info[s];
+  const int f = st.frame_count;             // index of the frame being processed
+  const int has_prev = st.has_prev;
+  const int pb_prev = st.cur, pb_cur = st.cur ^ 1;
+  const int status0 = st.status;
+  const int n_lm_prev = st.n_tracked_landmarks_prev;
+  if (tid == 0) {
+    sh.status = status0; sh.win = st.win; sh.tau_track = st.tau_track; sh.attempts = 0; sh.broken = 0; sh.fallback = 0;
+    sh.aligner_ran = 0; sh.n_trk = 0; sh.n_lost = 0; sh.n_lm = 0; sh.n_cur = 0; sh.n_cand = 0; sh.its = 0; sh.conv = 0;
+    sh.inl = 0; sh.outl = 0; sh.E = 0; sh.flag = 0;
+    for (int k = 0; k < 12; ++k) sh.T[k] = 0;
+    for (int k = 0; k < 36; ++k) sh.H[k] = 0;
+    set_pose(c, b, s, f, st.pose);          // frame created at WorldMap::robot_to_world
+  }
+  double prior[12];
+  for (int k = 0; k < 12; ++k) prior[k] = st.prior[k];
+  const double tau_tri = st.tau_tri;
+  int win = st.win;
+  double tau_track = st.tau_track;          // tracker's _current_descriptor_distance_tracking
+  double tau_gen = tau_track;               // generator's _maximum_descriptor_distance_tracking (last _track)
+  __syncthreads();
+  const double* prev_c2w = hpose_of(c, b, s, f > 0 ? f - 1 : 0);
+  int n_tracked_landmarks = 0, n_after_prune = 0, n_recovered = 0;
+  bool aligner_valid = false;
+
+  if (has_prev) {
+    const PtView pv = pts_of(c, b, s, pb_prev);
+    const int P = *pv.n;
+    for (int i = tid; i < P; i += VS_WG) pv.meta[(size_t)i * META + M_NEXT] = 0;
+    __syncthreads();
+    // ---- up to three track/register attempts (_registerRecursive, :300-419) -----------------------
+    int by_app = status0 == VSLAM_LOCALIZING;
+    bool done = false;
+    for (int attempt = 0; attempt < 3 && !done; ++attempt) {
+      // _track (:225-298)
+      if (by_app) win = c.c.maximum_projection_tracking_distance_pixels;
+      tau_gen = tau_track;
+      if (attempt > 0) {
+        // initialize(frame, false): fresh feature stores; candidates for the new prior / window / mode
+        const int lane = tid & 63, w = tid >> 6;
+        for (int i = w; i < P; i += VS_WG / 64) candidates_wave(c, b, s, pb_prev, i, lane, &wcnt[w], prior, win, tau_gen);
+        __syncthreads();
+      }
+      aligner_valid = false;
+      wg_track_resolve(c, b, s, sh, pb_prev, prior, win, tau_gen, tau_tri, by_app);
+      const int n_trk = sh.n_trk;
+      n_tracked_landmarks = sh.n_lm;
+      {
+        const double ratio = (double)n_trk / (double)P;
+        const double lm_per_pt = (double)n_tracked_landmarks / (double)n_trk;
+        const double succ = (double)n_trk / (double)c.target_kp;
+        const int wmax = c.c.maximum_projection_tracking_distance_pixels, wmin = c.c.minimum_projection_tracking_distance_pixels;
+        if (ratio < c.c.good_tracking_ratio / 2) {
+          if (win < wmax) win = (int)fmin(win * 1 / c.c.tunnel_vision_ratio, (double)wmax);
+        } else {
+          if (win > wmin) win = (int)fmax(win * c.c.tunnel_vision_ratio, (double)wmin);
+        }
+        if (ratio < c.c.good_tracking_ratio || n_trk < c.c.aligner_minimum_number_of_inliers || (lm_per_pt < 0.5 && succ < 0.25)) {
+          tau_track += 5;
+          if (tau_track > c.c.maximum_descriptor_distance_tracking) tau_track = c.c.maximum_descriptor_distance_tracking;
+        } else {
+          tau_track -= 5;
+          if (tau_track < c.c.minimum_descriptor_distance_tracking) tau_track = c.c.minimum_descriptor_distance_tracking;
+        }
+      }
+      if (tid == 0) ++sh.attempts;
+      // ---- registration ------------------------------------------------------------------------------
+      bool accept = false, fall = false, brk = false;
+      if (status0 == VSLAM_LOCALIZING) {
+        // :103-161
+        if (n_trk < c.c.minimum_number_of_landmarks_to_track) {
+          fall = true;
+        } else {
+          wg_align(c, b, s, sh, pb_prev, false, prior);
+          aligner_valid = true;
+          if (sh.inl < c.c.minimum_number_of_landmarks_to_track) fall = true; else accept = true;
+        }
+        done = true;
+      } else {
+        const double rel = (double)n_tracked_landmarks / (double)n_lm_prev;
+        if (n_tracked_landmarks == 0 || rel < 0.1) {
+          if (attempt < 2) {
+            tf_identity(prior);
+            by_app = 1;
+          } else {
+            brk = true; done = true;
+          }
+        } else {
+          wg_align(c, b, s, sh, pb_prev, true, prior);
+          aligner_valid = true;
+          if (sh.inl > c.c.minimum_number_of_landmarks_to_track) {
+            accept = true; done = true;
+          } else if (attempt < 2) {
+            if (win < c.c.maximum_projection_tracking_distance_pixels) ++win;
+            by_app = 0;
+          } else {
+            brk = true; done = true;
+          }
+        }
+      }
+      if (accept) {
+        // accept-or-fallback on the size of the motion (:139-159, :372-388)
+        const double dang = rotation_angle(sh.T);
+        const double dtr = sqrt((sh.T[3] * sh.T[3] + sh.T[7] * sh.T[7]) + sh.T[11] * sh.T[11]);
+        if (dang > c.c.minimum_delta_angular_for_movement || dtr > c.c.minimum_delta_translational_for_movement) {
+          for (int k = 0; k < 12; ++k) prior[k] = sh.T[k];
+          if (tid == 0) {
+            double inv[12], c2w[12];
+            tf_inverse(prior, inv);
+            tf_mul(prev_c2w, inv, c2w);
+            set_pose(c, b, s, f, c2w);
+          }
+        } else {
+          fall = true;
+        }
+      }
+      if (fall) {  // _fallbackEstimate (:551-566)
+        tf_identity(prior);
+        if (tid == 0) { set_pose(c, b, s, f, prev_c2w); sh.fallback = 1; }
+      }
+      if (brk) {   // breakTrack (:422-435)
+        tf_identity(prior);
+        if (tid == 0) { set_pose(c, b, s, f, prev_c2w); sh.broken = 1; sh.status = VSLAM_LOCALIZING; }
+      }
+      __syncthreads();
+    }
+    // report the final track() / converge() before their buffers are consumed
+    if (tid == 0) {
+      info.n_tracked = sh.n_trk; info.n_lost = sh.n_lost; info.n_tracked_landmarks = n_tracked_landmarks;
+      info.aligner_ran = aligner_valid ? 1 : 0;
+      info.aligner_iterations = aligner_valid ? sh.its : 0; info.aligner_converged = aligner_valid ? sh.conv : 0;
+      info.n_inliers = aligner_valid ? sh.inl : 0; info.n_outliers = aligner_valid ? sh.outl : 0;
+      info.total_error = aligner_valid ? sh.E : 0;
+      st.al_n = aligner_valid ? sh.n_trk : 0;
+      for (int k = 0; k < 12; ++k) st.al_T[k] = sh.T[k];
+      for (int k = 0; k < 36; ++k) st.al_H[k] = sh.H[k];
+    }
+    wg_prune(c, b, s, sh, pb_prev, pb_cur, aligner_valid);
+    n_after_prune = sh.n_cur;
+    if (c.c.enable_landmark_recovery) {
+      wg_recover(c, b, s, sh, pb_prev, pb_cur, hpose_of(c, b, s, f) + 12, tau_gen, tau_tri);
+      n_recovered = sh.flag;
+    }
+  } else if (tid == 0) {
+    info.n_tracked = 0; info.n_lost = 0; info.n_tracked_landmarks = 0; info.aligner_ran = 0; info.aligner_iterations = 0;
+    info.aligner_converged = 0; info.n_inliers = 0; info.n_outliers = 0; info.total_error = 0; st.al_n = 0;
+  }
+  __syncthreads();
+  wg_update_points(c, b, s, sh, pb_cur, f);
+  const int n_active = sh.n_lm;
+  int status = sh.status;
+  if (n_active > c.c.minimum_number_of_landmarks_to_track) status = VSLAM_TRACKING;
+  wg_stereo(c, b, s, sh, pb_cur, tau_tri, f);
+  if (tid == 0) {
+    const double* c2w = hpose_of(c, b, s, f);
+    *pts_of(c, b, s, pb_cur).n = sh.n_cur;
+    st.status = status; st.win = win; st.tau_track = tau_track;
+    for (int k = 0; k < 12; ++k) { st.prior[k] = prior[k]; st.pose[k] = c2w[k]; }
+    st.n_tracked_landmarks_prev = n_active;
+    st.frame_count = f + 1; st.has_prev = 1; st.cur = pb_cur; st.aligner_valid = aligner_valid ? 1 : 0;
+    info.frame_index = f + 1; info.status = status; info.status_at_start = status0;
+    info.n_keypoints_left = b.n_kp[s * 2]; info.n_keypoints_right = b.n_kp[s * 2 + 1];
+    int rl = 0, rr = 0;
+    for (int r = 0; r < c.n_regions; ++r) { rl += st.raw_count[0][r]; rr += st.raw_count[1][r]; info.thresholds[r] = st.thr[r]; }
+    for (int r = c.n_regions; r < VSLAM_MAX_REGIONS; ++r) info.thresholds[r] = 0;
+    info.n_detected_left = rl; info.n_detected_right = rr;
+    info.track_attempts = sh.attempts; info.n_after_prune = n_after_prune; info.n_recovered = n_recovered;
+    info.n_active_landmarks = n_active; info.n_new_stereo = sh.n_cand; info.n_points = sh.n_cur;
+    info.track_broken = sh.broken; info.fallback = sh.fallback; info.window_pixels = win;
+    info.error_flags = st.error_flags; info.tau_track = tau_track; info.tau_triangulation = tau_tri;
+    for (int k = 0; k < 12; ++k) { info.camera_left_to_world[k] = c2w[k]; info.previous_to_current[k] = prior[k]; }
+    if (f < VS_POSE_LOG) { double* pl = b.pose_log + ((size_t)s * VS_POSE_LOG + f) * 12; for (int k = 0; k < 12; ++k) pl[k] = c2w[k]; }
+  }
+}

@@ -1,0 +1,407 @@
+// kernels_image.h — per-image kernels: FAST-9/16 + NMS + 9x9 box image (K1), keypoint emission +
+// CSR index + threshold controller (K2), BRIEF-32 (K3), N x M 2-NN (K6).  gfx950, wave64.
+//
+// Reference code replaced (paths relative to the reference root):
+//   K1  cv::FastFeatureDetector::detect per detector region     base_framepoint_generator.cpp:12-25,362-367
+//   K2  detectKeypoints bookkeeping + adjustDetectorThresholds    base_framepoint_generator.cpp:377-429,440-459
+//       IntensityFeatureMatcher::setFeatures                      intensity_feature_matcher.cpp:48-70
+//   K3  _descriptor_extractor->compute (BRIEF-32)                 base_framepoint_generator.cpp:431-438
+//   K6  matcher->knnMatch(k=2)                                    stereo_framepoint_generator.cpp:168-206
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dev_types.h"
+#include "../../include/vslam_brief_pattern.h"
+
+__constant__ int8_t c_brief[256][4] = VSLAM_BRIEF_PATTERN_INIT;
+
+// ---- indexing helpers ------------------------------------------------------------------------
+__device__ __forceinline__ size_t ix_side(const DevCfg& c, int s, int d) { return (size_t)s * 2 + d; }
+__device__ __forceinline__ uint16_t* box_of(const DevCfg& c, const DevBuf& b, int s, int d) {
+  return b.box + ix_side(c, s, d) * (size_t)c.c.rows * c.bstride;
+}
+__device__ __forceinline__ uint8_t* score_of(const DevCfg& c, const DevBuf& b, int s, int d) {
+  return b.score8 + ix_side(c, s, d) * (size_t)c.c.rows * c.bstride;
+}
+__device__ __forceinline__ unsigned long long* mask_of(const DevCfg& c, const DevBuf& b, int s, int d) {
+  return b.mask + ix_side(c, s, d) * (size_t)c.c.rows * c.TX;
+}
+__device__ __forceinline__ int16_t* kpxy_of(const DevCfg& c, const DevBuf& b, int s, int d) {
+  return b.kp_xy + ix_side(c, s, d) * (size_t)c.NMAX * 2;
+}
+__device__ __forceinline__ uint8_t* kpscore_of(const DevCfg& c, const DevBuf& b, int s, int d) {
+  return b.kp_score + ix_side(c, s, d) * (size_t)c.NMAX;
+}
+__device__ __forceinline__ uint8_t* desc_of(const DevCfg& c, const DevBuf& b, int s, int d) {
+  return b.desc + ix_side(c, s, d) * (size_t)c.NMAX * 32;
+}
+__device__ __forceinline__ int32_t* rowcell_of(const DevCfg& c, const DevBuf& b, int s, int d) {
+  return b.rowcell + ix_side(c, s, d) * (size_t)c.c.rows * (c.CW + 1);
+}
+__device__ __forceinline__ uint8_t* used_of(const DevCfg& c, const DevBuf& b, int s, int d) {
+  return b.used + ix_side(c, s, d) * (size_t)c.NMAX;
+}
+__device__ __forceinline__ int32_t* kill_of(const DevCfg& c, const DevBuf& b, int s, int d) {
+  return b.kill + ix_side(c, s, d) * (size_t)c.NMAX;
+}
+
+// ---- block-wide exclusive scan of one int per thread (blockDim.x multiple of 64, <= 1024) ------
+// returns the exclusive prefix; *total receives the block sum.  sh must hold 17 ints.
+__device__ __forceinline__ int block_exclusive_scan(int v, int* sh, int* total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  __syncthreads();  // protect sh from a previous use
+  if (lane == 63) sh[w] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int i = 0; i < nw; ++i) { const int t = sh[i]; sh[i] = acc; acc += t; }
+    sh[16] = acc;
+  }
+  __syncthreads();
+  *total = sh[16];
+  return sh[w] + inc - v;
+}
+
+// ==============================================================================================
+// K1: FAST-9/16 score + strict 3x3 NMS -> 1 bit/pixel corner mask (+ sparse u8 scores), fused with
+// the 9x9 box-sum image BRIEF samples.  One 64x16 output tile per 256-thread workgroup; the u8
+// tile with a 4 px halo (FAST ring 3 + NMS 1 == box radius 4) is staged once in LDS.
+// HBM traffic per pixel: 1 B read, 2 B box write, 1/8 B mask write.
+// ==============================================================================================
+__device__ __forceinline__ int fast_score_tile(const uint8_t (*t)[80], int ly, int lx, int thr) {
+  // (ly,lx) = centre in tile coordinates (tile origin = image (x0-4, y0-4))
+  const int v = t[ly][lx];
+  int d[16];
+  d[0] = v - t[ly + 3][lx];      d[1] = v - t[ly + 3][lx + 1];  d[2] = v - t[ly + 2][lx + 2];  d[3] = v - t[ly + 1][lx + 3];
+  d[4] = v - t[ly][lx + 3];      d[5] = v - t[ly - 1][lx + 3];  d[6] = v - t[ly - 2][lx + 2];  d[7] = v - t[ly - 3][lx + 1];
+  d[8] = v - t[ly - 3][lx];      d[9] = v - t[ly - 3][lx - 1];  d[10] = v - t[ly - 2][lx - 2]; d[11] = v - t[ly - 1][lx - 3];
+  d[12] = v - t[ly][lx - 3];     d[13] = v - t[ly + 1][lx - 3]; d[14] = v - t[ly + 2][lx - 2]; d[15] = v - t[ly + 3][lx - 1];
+  unsigned dark = 0, bright = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    dark |= (d[k] > thr ? 1u : 0u) << k;
+    bright |= (d[k] < -thr ? 1u : 0u) << k;
+  }
+  unsigned m = dark | (dark << 16);
+  unsigned r = m & (m >> 1); r &= r >> 2; r &= r >> 4; r &= m >> 8;
+  unsigned m2 = bright | (bright << 16);
+  unsigned r2 = m2 & (m2 >> 1); r2 &= r2 >> 2; r2 &= r2 >> 4; r2 &= m2 >> 8;
+  if (((r | r2) & 0xFFFFu) == 0) return 0;
+  // cornerScore<16>: max over the 16 nine-arcs of the arc minimum (dark) / min of the arc maximum
+  int mn2[16], mx2[16], mn4[16], mx4[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+  int A = -1000, Bm = 1000;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int mn9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
+    const int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
+    A = max(A, mn9);
+    Bm = min(Bm, mx9);
+  }
+  const int a0 = max(thr, A);
+  const int b0 = min(-a0, Bm);
+  return -b0 - 1;
+}
+
+// threshold of the detector region whose FAST-valid area (ROI minus 3 px) contains (x,y), or -1
+__device__ __forceinline__ int region_threshold(const DevCfg& c, const int32_t* thr, int x, int y) {
+  for (int r = 0; r < c.n_regions; ++r) {
+    const DevRegion& R = c.regions[r];
+    if (x >= R.x + 3 && x < R.x + R.w - 3 && y >= R.y + 3 && y < R.y + R.h - 3) return thr[r];
+  }
+  return -1;
+}
+
+__global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b) {
+  __shared__ uint8_t tile[VS_TILE_H + 8][80];
+  __shared__ uint8_t sc[VS_TILE_H + 2][68];
+  __shared__ uint16_t hs[VS_TILE_H + 8][VS_TILE_W];
+  __shared__ int32_t s_thr[VSLAM_MAX_REGIONS];
+  const int tx = blockIdx.x, ty = blockIdx.y, s = blockIdx.z >> 1, side = blockIdx.z & 1;
+  const int x0 = tx * VS_TILE_W, y0 = ty * VS_TILE_H;
+  const int rows = c.c.rows, cols = c.c.cols;
+  const uint8_t* img = b.img[side] + (size_t)s * b.img_stream_stride;
+  const int stride = b.img_row_stride;
+  const int tid = threadIdx.x;
+  if (tid < c.n_regions) s_thr[tid] = min(max(b.st[s].thr[tid], 0), 255);
+  // stage the (64+8) x (16+8) tile, coordinates clamped (clamped pixels never reach a valid output)
+  for (int i = tid; i < (VS_TILE_H + 8) * 72; i += 256) {
+    const int r = i / 72, cc = i - r * 72;
+    const int gy = min(max(y0 - 4 + r, 0), rows - 1), gx = min(max(x0 - 4 + cc, 0), cols - 1);
+    tile[r][cc] = img[(size_t)gy * stride + gx];
+  }
+  __syncthreads();
+  // scores on the 66 x 18 neighbourhood (tile + 1 px NMS halo)
+  for (int i = tid; i < (VS_TILE_H + 2) * 66; i += 256) {
+    const int r = i / 66, cc = i - r * 66;
+    const int gx = x0 - 1 + cc, gy = y0 - 1 + r;
+    int sv = 0;
+    const int thr = region_threshold(c, s_thr, gx, gy);
+    if (thr >= 0) sv = fast_score_tile(tile, r + 3, cc + 3, thr);
+    sc[r][cc] = (uint8_t)sv;
+  }
+  // horizontal 9-sums for the box image
+  for (int i = tid; i < (VS_TILE_H + 8) * VS_TILE_W; i += 256) {
+    const int r = i >> 6, cc = i & 63;
+    int acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc += tile[r][cc + k];
+    hs[r][cc] = (uint16_t)acc;
+  }
+  __syncthreads();
+  const int lane = tid & 63, w = tid >> 6;
+  unsigned long long* mask = mask_of(c, b, s, side);
+  uint8_t* score8 = score_of(c, b, s, side);
+  uint16_t* box = box_of(c, b, s, side);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = w * 4 + j, gy = y0 + r, gx = x0 + lane;
+    const int v = sc[r + 1][lane + 1];
+    bool keep = v > 0;
+    if (keep) {
+      keep = v > sc[r][lane] && v > sc[r][lane + 1] && v > sc[r][lane + 2] && v > sc[r + 1][lane] &&
+             v > sc[r + 1][lane + 2] && v > sc[r + 2][lane] && v > sc[r + 2][lane + 1] && v > sc[r + 2][lane + 2];
+    }
+    const unsigned long long m = __ballot(keep);
+    if (gy < rows) {
+      if (lane == 0) mask[(size_t)gy * c.TX + tx] = m;
+      if (keep) score8[(size_t)gy * c.bstride + gx] = (uint8_t)v;
+      if (gx < cols) {
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc += hs[r + k][lane];
+        box[(size_t)gy * c.bstride + gx] = (uint16_t)acc;
+      }
+    }
+  }
+}
+
+// ==============================================================================================
+// K2: one workgroup per stream.  Scans the corner masks of both images in (row, x) order, applies
+// the descriptor border filter (KeyPointsFilter::runByImageBorder(28)), writes keypoints
+// row-major, builds the row/cell CSR, counts raw detections per detector region, then runs the
+// threshold controller + adjustDetectorThresholds and the triangulation-distance rule
+// (stereo_framepoint_generator.cpp:109-125).  `border` = 28 in the pipeline, 0 for stand-alone FAST.
+// ==============================================================================================
+__device__ __forceinline__ unsigned long long col_mask(int lo, int hi, int wx0) {
+  // bits of a 64-px word starting at column wx0 whose column lies in [lo, hi)
+  int a = max(lo - wx0, 0), e = min(hi - wx0, 64);
+  if (e <= a) return 0ull;
+  const unsigned long long hi_m = (e >= 64) ? ~0ull : ((1ull << e) - 1ull);
+  return hi_m & ~((1ull << a) - 1ull);
+}
+
+__global__ __launch_bounds__(1024) void k_emit(const DevCfg c, const DevBuf b, int border, int run_controller) {
+  __shared__ int sh_scan[17];
+  __shared__ int sh_cnt[2][VSLAM_MAX_REGIONS];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const int rows = c.c.rows, cols = c.c.cols, TX = c.TX, CW = c.CW;
+  StreamState& st = b.st[s];
+  if (tid < 2 * VSLAM_MAX_REGIONS) sh_cnt[tid / VSLAM_MAX_REGIONS][tid % VSLAM_MAX_REGIONS] = 0;
+  __syncthreads();
+  const int nwords = rows * TX;
+  const int chunk = (nwords + blockDim.x - 1) / blockDim.x;
+  for (int side = 0; side < 2; ++side) {
+    const unsigned long long* mask = mask_of(c, b, s, side);
+    const uint8_t* score8 = score_of(c, b, s, side);
+    int16_t* kxy = kpxy_of(c, b, s, side);
+    uint8_t* ksc = kpscore_of(c, b, s, side);
+    int32_t* rowcell = rowcell_of(c, b, s, side);
+    uint8_t* used = used_of(c, b, s, side);
+    const int w0 = tid * chunk, w1 = min(w0 + chunk, nwords);
+    int local = 0;
+    for (int w = w0; w < w1; ++w) {
+      const int row = w / TX, t = w - row * TX;
+      const unsigned long long m = mask[w];
+      if (m) {
+        // raw detections per region (controller input): every corner bit lies in exactly one region
+        for (int r = 0; r < c.n_regions; ++r) {
+          const DevRegion& R = c.regions[r];
+          if (row >= R.y + 3 && row < R.y + R.h - 3) {
+            const int n = __popcll(m & col_mask(R.x + 3, R.x + R.w - 3, t * 64));
+            if (n) atomicAdd(&sh_cnt[side][r], n);
+          }
+        }
+      }
+      const bool row_ok = row >= border && row < rows - border;
+      const unsigned long long f = row_ok ? (m & col_mask(border, cols - border, t * 64)) : 0ull;
+      local += __popcll(f);
+    }
+    int total;
+    int off = block_exclusive_scan(local, sh_scan, &total);
+    if (total > c.NMAX) { if (tid == 0) atomicOr(&st.error_flags, 1); }
+    for (int w = w0; w < w1; ++w) {
+      const int row = w / TX, t = w - row * TX;
+      const unsigned long long m = mask[w];
+      const bool row_ok = row >= border && row < rows - border;
+      unsigned long long f = row_ok ? (m & col_mask(border, cols - border, t * 64)) : 0ull;
+      int32_t* rc = rowcell + (size_t)row * (CW + 1) + t * 4;
+      rc[0] = min(off, c.NMAX);
+      rc[1] = min(off + __popcll(f & 0xFFFFull), c.NMAX);
+      rc[2] = min(off + __popcll(f & 0xFFFFFFFFull), c.NMAX);
+      rc[3] = min(off + __popcll(f & 0xFFFFFFFFFFFFull), c.NMAX);
+      if (t == TX - 1) rc[4] = min(off + __popcll(f), c.NMAX);
+      while (f) {
+        const int bit = __ffsll((long long)f) - 1;
+        f &= f - 1;
+        if (off < c.NMAX) {
+          const int x = t * 64 + bit;
+          kxy[2 * off] = (int16_t)x;
+          kxy[2 * off + 1] = (int16_t)row;
+          ksc[off] = score8[(size_t)row * c.bstride + x];
+          used[off] = 0;
+        }
+        ++off;
+      }
+    }
+    if (tid == 0) b.n_kp[s * 2 + side] = min(total, c.NMAX);
+    __syncthreads();
+  }
+  if (tid == 0) {
+    for (int side = 0; side < 2; ++side)
+      for (int r = 0; r < c.n_regions; ++r) st.raw_count[side][r] = sh_cnt[side][r];
+    if (run_controller) {
+      // detectKeypoints controller (base_framepoint_generator.cpp:382-415) for L then R with the
+      // thresholds that were in effect, then adjustDetectorThresholds (:440-459)
+      const double tol = c.c.target_number_of_keypoints_tolerance, maxchg = c.c.detector_threshold_maximum_change;
+      const double tmin = c.c.detector_threshold_minimum, tmax = c.c.detector_threshold_maximum;
+      const double target = (double)c.target_per_detector;
+      for (int r = 0; r < c.n_regions; ++r) {
+        double acc = 0;
+        for (int side = 0; side < 2; ++side) {
+          double t = (double)st.thr[r];
+          const double delta = ((double)sh_cnt[side][r] - target) / target;
+          if (delta < -tol) {
+            const double change = fmax(delta, -maxchg);
+            t = t + fmin(change * t, -1.0);
+            if (t < tmin) t = tmin;
+          } else if (delta > tol) {
+            const double change = fmin(delta, maxchg);
+            t += fmax(change * t, 1.0);
+            if (t > tmax) t = tmax;
+          }
+          acc += t;
+        }
+        st.thr[r] = (int)rint(acc / 2);
+      }
+      // triangulation distance (stereo_framepoint_generator.cpp:109-125); frame status = tracker status
+      const int n_left = b.n_kp[s * 2 + 0];
+      if (st.status == VSLAM_LOCALIZING) {
+        st.tau_tri = fmin(0.1 * 256, c.c.maximum_matching_distance_triangulation);
+      } else {
+        const double ratio = fmin((double)n_left / (double)c.target_kp, 1.0);
+        st.tau_tri = fmax(ratio * c.c.maximum_matching_distance_triangulation, 0.1 * 256);
+      }
+    }
+  }
+}
+
+// ==============================================================================================
+// K3: BRIEF-32.  One wavefront per keypoint (grid-strided): lane l evaluates tests l, 64+l, 128+l,
+// 192+l on the u16 box image; each ballot is 8 descriptor bytes (bit-reversed per byte: MSB first).
+// ==============================================================================================
+__device__ __forceinline__ void brief_wave(const uint16_t* box, int bstride, int x, int y, int lane, uint8_t* out32) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = j * 64 + lane;
+    const int a = box[(size_t)(y + c_brief[i][0]) * bstride + (x + c_brief[i][1])];
+    const int bb = box[(size_t)(y + c_brief[i][2]) * bstride + (x + c_brief[i][3])];
+    const unsigned long long m = __ballot(a < bb);
+    if (lane == 0) {
+      const unsigned long long wv = __builtin_bswap64(__brevll(m));
+      reinterpret_cast<unsigned long long*>(out32)[j] = wv;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_brief(const DevCfg c, const DevBuf b) {
+  const int s = blockIdx.z >> 1, side = blockIdx.z & 1;
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (blockDim.x >> 6);
+  const int n = b.n_kp[s * 2 + side];
+  const int16_t* kxy = kpxy_of(c, b, s, side);
+  uint8_t* desc = desc_of(c, b, s, side);
+  const uint16_t* box = box_of(c, b, s, side);
+  for (int i = wave; i < n; i += nwaves) brief_wave(box, c.bstride, kxy[2 * i], kxy[2 * i + 1], lane, desc + (size_t)32 * i);
+}
+
+// stand-alone BRIEF at caller keypoints (vslam_brief_describe): keep[] = inside the 28 px border
+__global__ __launch_bounds__(256) void k_brief_at(const uint16_t* box, int bstride, int rows, int cols, int n,
+                                                  const int16_t* xy, uint8_t* keep, uint8_t* desc) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * (blockDim.x >> 6);
+  for (int i = wave; i < n; i += nwaves) {
+    const int x = xy[2 * i], y = xy[2 * i + 1];
+    const bool in = x >= VSLAM_BRIEF_BORDER && x < cols - VSLAM_BRIEF_BORDER && y >= VSLAM_BRIEF_BORDER && y < rows - VSLAM_BRIEF_BORDER;
+    if (lane == 0) keep[i] = in ? 1 : 0;
+    if (in) brief_wave(box, bstride, x, y, lane, desc + (size_t)32 * i);
+    else if (lane < 4) reinterpret_cast<unsigned long long*>(desc + (size_t)32 * i)[lane] = 0ull;
+  }
+}
+
+// ==============================================================================================
+// K6: brute-force N x M 2-nearest-neighbours on 32-byte rows (Hamming on the bits, or squared L2 on
+// the bytes -> sqrt, which is what convertTo(CV_32F) + BFMatcher(NORM_L2) computes).  One query per
+// lane, 64-row train tiles broadcast from LDS, packed 64-bit keys (distance << 32 | index) keep
+// the "lowest index wins ties" order.  Distances are exact integers (L2: <= 32*255^2 < 2^24).
+// ==============================================================================================
+__global__ __launch_bounds__(256) void k_knn2(int norm, int nq, const uint8_t* __restrict__ q, int nt,
+                                              const uint8_t* __restrict__ t, int32_t* idx, float* dist) {
+  __shared__ uint32_t tt[64][8];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t qv[8];
+  if (i < nq) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) qv[k] = reinterpret_cast<const uint32_t*>(q + (size_t)32 * i)[k];
+  }
+  unsigned long long b0 = ~0ull, b1 = ~0ull;
+  for (int j0 = 0; j0 < nt; j0 += 64) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < 64 * 8; k += blockDim.x) {
+      const int r = k >> 3, cc = k & 7;
+      tt[r][cc] = (j0 + r < nt) ? reinterpret_cast<const uint32_t*>(t + (size_t)32 * (j0 + r))[cc] : 0u;
+    }
+    __syncthreads();
+    if (i < nq) {
+      const int jn = min(64, nt - j0);
+      for (int r = 0; r < jn; ++r) {
+        uint32_t d = 0;
+        if (norm == 0) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) d += __popc(qv[k] ^ tt[r][k]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const uint32_t a = qv[k], bb = tt[r][k];
+#pragma unroll
+            for (int sft = 0; sft < 32; sft += 8) {
+              const int e = (int)((a >> sft) & 255u) - (int)((bb >> sft) & 255u);
+              d += (uint32_t)(e * e);
+            }
+          }
+        }
+        const unsigned long long key = ((unsigned long long)d << 32) | (unsigned)(j0 + r);
+        if (key < b0) { b1 = b0; b0 = key; }
+        else if (key < b1) { b1 = key; }
+      }
+    }
+  }
+  if (i < nq) {
+    const bool h0 = b0 != ~0ull, h1 = b1 != ~0ull;
+    idx[2 * i] = h0 ? (int32_t)(b0 & 0xFFFFFFFFull) : -1;
+    idx[2 * i + 1] = h1 ? (int32_t)(b1 & 0xFFFFFFFFull) : -1;
+    const float d0 = (float)(uint32_t)(b0 >> 32), d1 = (float)(uint32_t)(b1 >> 32);
+    dist[2 * i] = h0 ? (norm == 0 ? d0 : sqrtf(d0)) : 0.f;
+    dist[2 * i + 1] = h1 ? (norm == 0 ? d1 : sqrtf(d1)) : 0.f;
+  }
+}

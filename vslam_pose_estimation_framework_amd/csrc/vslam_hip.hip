@@ -1,0 +1,554 @@
+// vslam_hip.hip — host side of libvslam_hip.so: context / device-buffer management, kernel launches
+// and read-back behind the C ABI of include/vslam_hip.h.  gfx950 only; there is no CPU fallback:
+// every entry point fails with VSLAM_ERR_NO_DEVICE / VSLAM_ERR_HIP when the GPU path is unusable.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels_frame2.h"
+
+#define VS_API extern "C" __attribute__((visibility("default")))
+
+static thread_local std::string g_create_error;
+
+struct vslam_ctx {
+  DevCfg cfg;
+  DevBuf buf;
+  int device = 0;
+  int B = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  std::vector<void*> allocs;
+  uint8_t* upload[2] = {nullptr, nullptr};
+  int up_stride = 0;
+  size_t up_stream_stride = 0;
+  bool frame_begun = false;
+  bool timers = false;
+  double timer_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int sticky = VSLAM_OK;
+};
+
+static int fail(vslam_ctx* c, int code, const std::string& msg) {
+  if (c) { c->err = msg; if (code == VSLAM_ERR_HIP) c->sticky = code; }
+  else g_create_error = msg;
+  return code;
+}
+#define HIP_TRY(ctx, expr)                                                                              \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess) return fail(ctx, VSLAM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+template <typename T>
+static hipError_t dalloc(vslam_ctx* c, T** p, size_t count) {
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
+  if (e == hipSuccess) { c->allocs.push_back(q); *p = (T*)q; }
+  return e;
+}
+
+// ---- defaults (configurations/configuration_{kitti,euroc}.yaml, src/types/parameters.h) -----------
+static void common_defaults(vslam_config* c) {
+  std::memset(c, 0, sizeof *c);
+  c->det_rows = 1; c->det_cols = 1;
+  c->detector_threshold_minimum = 20; c->detector_threshold_maximum = 100;
+  c->detector_threshold_maximum_change = 0.1; c->target_number_of_keypoints_tolerance = 0.1;
+  c->bin_size_pixels = 15; c->enable_keypoint_binning = 1;
+  c->minimum_projection_tracking_distance_pixels = 15; c->maximum_projection_tracking_distance_pixels = 50;
+  c->minimum_descriptor_distance_tracking = 25.6; c->maximum_descriptor_distance_tracking = 51.2;
+  c->maximum_reliable_depth_meters = 15; c->maximum_depth_meters = 1000; c->minimum_depth_meters = 0.1;
+  c->maximum_matching_distance_triangulation = 51.2; c->minimum_disparity_pixels = 1;
+  c->maximum_epipolar_search_offset_pixels = 0;
+  c->minimum_track_length_for_landmark_creation = 1; c->minimum_number_of_landmarks_to_track = 5;
+  c->tunnel_vision_ratio = 0.5; c->good_tracking_ratio = 0.2; c->enable_landmark_recovery = 1;
+  c->minimum_delta_angular_for_movement = 0.001; c->minimum_delta_translational_for_movement = 0.01;
+  c->aligner_error_delta_for_convergence = 1e-3; c->aligner_maximum_error_kernel = 4; c->aligner_damping = 5;
+  c->aligner_maximum_number_of_iterations = 1000; c->aligner_minimum_number_of_inliers = 100;
+  c->landmark_maximum_error_squared_meters = 25; c->landmark_maximum_number_of_iterations = 100;
+  c->max_keypoints = 16384; c->max_points = 8192; c->max_history_frames = 512;
+}
+VS_API void vslam_default_config_kitti(vslam_config* c) {
+  common_defaults(c);
+  c->rows = 376; c->cols = 1241;
+  const double K[9] = {718.856, 0, 607.1928, 0, 718.856, 185.2157, 0, 0, 1};
+  std::memcpy(c->K, K, sizeof K);
+  c->baseline_h[0] = -386.1448;
+}
+VS_API void vslam_default_config_euroc(vslam_config* c) {
+  common_defaults(c);
+  c->rows = 480; c->cols = 752;
+  const double K[9] = {458.654, 0, 367.215, 0, 457.296, 248.375, 0, 0, 1};
+  std::memcpy(c->K, K, sizeof K);
+  c->baseline_h[0] = -458.654 * 0.11;
+  c->det_rows = 2; c->det_cols = 2;
+  c->detector_threshold_minimum = 10; c->detector_threshold_maximum = 30; c->detector_threshold_maximum_change = 1.0;
+  c->bin_size_pixels = 20;
+  c->minimum_descriptor_distance_tracking = 25; c->maximum_descriptor_distance_tracking = 50;
+  c->maximum_reliable_depth_meters = 5; c->maximum_depth_meters = 100;
+  c->maximum_matching_distance_triangulation = 50;
+  c->minimum_track_length_for_landmark_creation = 2; c->good_tracking_ratio = 0.25;
+  c->aligner_damping = 0;
+}
+
+VS_API const char* vslam_last_error(const vslam_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+// ---- configure (BaseFramePointGenerator::configure, base_framepoint_generator.cpp:229-329) ----------
+static void derive_cfg(const vslam_config& in, int n_streams, DevCfg* d) {
+  std::memset(d, 0, sizeof *d);
+  d->c = in;
+  d->TX = (in.cols + VS_TILE_W - 1) / VS_TILE_W;
+  d->CW = d->TX * 4;
+  d->bstride = d->TX * VS_TILE_W;
+  const int nv = in.det_rows, nh = in.det_cols;
+  const double ph = (double)in.rows / nv, pw = (double)in.cols / nh;
+  int k = 0;
+  for (int r = 0; r < nv; ++r)
+    for (int cc = 0; cc < nh; ++cc) {
+      int off_w = nh > 1 ? 2 : 0, off_h = nv > 1 ? 2 : 0, off_r = 0, off_c = 0;
+      if (r > 0) { off_r = -off_h; if (r < nv - 1) off_h *= 2; }
+      if (cc > 0) { off_c = -off_w; if (cc < nh - 1) off_w *= 2; }
+      d->regions[k].x = (int)(std::round(cc * pw) + off_c);
+      d->regions[k].y = (int)(std::round(r * ph) + off_r);
+      d->regions[k].w = (int)(pw + off_w);
+      d->regions[k].h = (int)(ph + off_h);
+      ++k;
+    }
+  d->n_regions = k;
+  d->cols_bin = (int)(std::floor((double)in.cols / in.bin_size_pixels) + 1);
+  d->rows_bin = (int)(std::floor((double)in.rows / in.bin_size_pixels) + 1);
+  d->target_kp = d->cols_bin * d->rows_bin;
+  d->target_per_detector = (int)((double)d->target_kp / (double)d->n_regions);
+  d->n_offsets = 0;
+  d->offsets[d->n_offsets++] = 0;
+  for (int u = 1; u <= in.maximum_epipolar_search_offset_pixels; ++u) { d->offsets[d->n_offsets++] = u; d->offsets[d->n_offsets++] = -u; }
+  d->NMAX = in.max_keypoints;
+  d->MAXP = in.max_points;
+  d->HCAP = in.max_history_frames;
+  d->n_streams = n_streams;
+}
+
+static int init_state(vslam_ctx* c) {
+  std::vector<StreamState> st(c->B);
+  std::memset(st.data(), 0, sizeof(StreamState) * c->B);
+  for (int s = 0; s < c->B; ++s) {
+    StreamState& x = st[s];
+    for (int r = 0; r < c->cfg.n_regions; ++r) x.thr[r] = c->cfg.c.detector_threshold_minimum;
+    x.status = VSLAM_LOCALIZING;
+    x.win = c->cfg.c.maximum_projection_tracking_distance_pixels;
+    x.tau_track = c->cfg.c.minimum_descriptor_distance_tracking;
+    x.tau_tri = 0.1 * 256;
+    tf_identity(x.prior);
+    tf_identity(x.pose);
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->buf.st, st.data(), sizeof(StreamState) * c->B, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->buf.info, 0, sizeof(vslam_frame_info) * c->B, c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->buf.n_points, 0, sizeof(int32_t) * c->B * 2, c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->buf.n_kp, 0, sizeof(int32_t) * c->B * 2, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->frame_begun = false;
+  return VSLAM_OK;
+}
+
+static int create_internal(const vslam_config* cfg, int device, int n_streams, vslam_ctx** out) {
+  if (!cfg || !out || n_streams < 1) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: null argument or n_streams < 1");
+  if (cfg->rows < 16 || cfg->cols < 16 || cfg->cols > 32767 || cfg->rows > 32767) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: invalid image dimensions");
+  if (cfg->det_rows < 1 || cfg->det_cols < 1 || cfg->det_rows * cfg->det_cols > VSLAM_MAX_REGIONS) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: invalid detector grid");
+  if (!(-cfg->baseline_h[0] / cfg->K[0] > 0)) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: invalid baseline (m), verify intrinsic camera parameters");
+  if (cfg->maximum_epipolar_search_offset_pixels < 0 || cfg->maximum_epipolar_search_offset_pixels > VSLAM_MAX_EPI) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: epipolar offset out of range");
+  if (cfg->max_keypoints < 64 || cfg->max_points < 64 || cfg->max_history_frames < 2 || cfg->bin_size_pixels < 1) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: invalid capacities");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, VSLAM_ERR_NO_DEVICE, "vslam_create: no HIP device available (the HIP path has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(nullptr, VSLAM_ERR_NO_DEVICE, "vslam_create: device ordinal out of range");
+  if (hipSetDevice(device) != hipSuccess) return fail(nullptr, VSLAM_ERR_NO_DEVICE, "vslam_create: hipSetDevice failed");
+  hipFuncAttributes fa;
+  if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_frame)) != hipSuccess)
+    return fail(nullptr, VSLAM_ERR_NO_DEVICE, "vslam_create: no gfx950 kernel image for this device");
+  vslam_ctx* c = new vslam_ctx;
+  c->device = device;
+  c->B = n_streams;
+  derive_cfg(*cfg, n_streams, &c->cfg);
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(nullptr, VSLAM_ERR_HIP, "hipStreamCreate failed"); }
+  c->own_stream = true;
+  const DevCfg& d = c->cfg;
+  DevBuf& b = c->buf;
+  std::memset(&b, 0, sizeof b);
+  const size_t B = n_streams, S2 = B * 2, rows = cfg->rows, N = d.NMAX, P = d.MAXP, Hc = d.HCAP;
+  hipError_t e = hipSuccess;
+#define A(field, count) if (e == hipSuccess) e = dalloc(c, &b.field, (count))
+  A(box, S2 * rows * d.bstride); A(score8, S2 * rows * d.bstride); A(mask, S2 * rows * d.TX);
+  A(kp_xy, S2 * N * 2); A(kp_score, S2 * N); A(desc, S2 * N * 32); A(n_kp, S2);
+  A(rowcell, S2 * rows * (d.CW + 1)); A(used, S2 * N); A(kill, S2 * N);
+  A(st, B); A(info, B); A(pose_log, B * VS_POSE_LOG * 12);
+  A(p_kp, S2 * P * 4); A(p_desc, S2 * P * 64); A(p_meta, S2 * P * META); A(p_cam, S2 * P * 3); A(p_camlm, S2 * P * 3);
+  A(p_lm, S2 * P * 3); A(n_points, S2);
+  A(proj, B * P * 4); A(cand_cnt, B * P); A(cand_idx, B * P * VS_MAXCAND); A(cand_h, B * P * VS_MAXCAND);
+  A(res, B * P * 4); A(trk, B * P * 4); A(lost, B * P);
+  A(al_moving, B * P * 3); A(al_fixed, B * P * 4); A(al_omega, B * P); A(al_weight, B * P); A(al_chi, B * P); A(al_inl, B * P);
+  A(rec, B * P * 6); A(rec_desc, B * P * 64);
+  A(st_match, B * N * 2); A(sc, B * N * 4); A(bin_occ, B * (size_t)d.rows_bin * d.cols_bin);
+  A(h_pose, B * Hc * 24); A(h_cam, B * Hc * P * 3); A(h_prev, B * Hc * P);
+#undef A
+  c->up_stride = d.bstride;
+  c->up_stream_stride = (size_t)rows * d.bstride;
+  if (e == hipSuccess) e = dalloc(c, &c->upload[0], B * c->up_stream_stride);
+  if (e == hipSuccess) e = dalloc(c, &c->upload[1], B * c->up_stream_stride);
+  if (e != hipSuccess) {
+    std::string msg = std::string("vslam_create: hipMalloc failed: ") + hipGetErrorString(e);
+    for (void* p : c->allocs) (void)hipFree(p);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return fail(nullptr, VSLAM_ERR_HIP, msg);
+  }
+  // score8 must read 0 where no corner was ever written only through the mask, box/mask are fully
+  // rewritten every frame; nothing else needs initialisation besides the stream state.
+  for (int i = 0; i < 6; ++i) (void)hipEventCreate(&c->ev[i]);
+  int rc = init_state(c);
+  if (rc != VSLAM_OK) { g_create_error = c->err; for (void* p : c->allocs) (void)hipFree(p); delete c; return rc; }
+  *out = c;
+  return VSLAM_OK;
+}
+
+VS_API int vslam_create(const vslam_config* cfg, int device, int n_streams, vslam_ctx** out) {
+  return create_internal(cfg, device, n_streams, out);
+}
+VS_API void vslam_destroy(vslam_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (void* p : c->allocs) (void)hipFree(p);
+  for (int i = 0; i < 6; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+VS_API int vslam_reset(vslam_ctx* c) {
+  if (!c) return VSLAM_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  return init_state(c);
+}
+VS_API int vslam_set_hip_stream(vslam_ctx* c, void* s) {
+  if (!c) return VSLAM_ERR_INVALID;
+  (void)hipStreamSynchronize(c->stream);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  c->stream = (hipStream_t)s;
+  c->own_stream = false;
+  return VSLAM_OK;
+}
+VS_API int vslam_synchronize(vslam_ctx* c) {
+  if (!c) return VSLAM_ERR_INVALID;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return c->sticky;
+}
+
+// ---- launches ------------------------------------------------------------------------------------
+static int launch_image_pipeline(vslam_ctx* c) {
+  const DevCfg& d = c->cfg;
+  dim3 g1(d.TX, (d.c.rows + VS_TILE_H - 1) / VS_TILE_H, 2 * c->B);
+  hipLaunchKernelGGL(k_fast_box, g1, dim3(256), 0, c->stream, c->cfg, c->buf);
+  hipLaunchKernelGGL(k_emit, dim3(c->B), dim3(1024), 0, c->stream, c->cfg, c->buf, (int)VSLAM_BRIEF_BORDER, 1);
+  const int gx = std::max(4, std::min(64, 1024 / (2 * c->B)));
+  hipLaunchKernelGGL(k_brief, dim3(gx, 1, 2 * c->B), dim3(256), 0, c->stream, c->cfg, c->buf);
+  HIP_TRY(c, hipGetLastError());
+  return VSLAM_OK;
+}
+static int launch_frame(vslam_ctx* c) {
+  const int gx = std::max(4, std::min(128, 2048 / c->B));
+  hipLaunchKernelGGL(k_track_candidates, dim3(gx, c->B), dim3(256), 0, c->stream, c->cfg, c->buf);
+  hipLaunchKernelGGL(k_frame, dim3(c->B), dim3(VS_WG), 0, c->stream, c->cfg, c->buf);
+  HIP_TRY(c, hipGetLastError());
+  return VSLAM_OK;
+}
+static int set_images_device(vslam_ctx* c, const uint8_t* L, const uint8_t* R, int32_t row_stride, size_t image_stride) {
+  if (!L || !R) return fail(c, VSLAM_ERR_INVALID, "called with empty frame");  // stereo_framepoint_generator.cpp:75-78
+  if (row_stride < c->cfg.c.cols) return fail(c, VSLAM_ERR_INVALID, "row stride smaller than image width");
+  c->buf.img[0] = L; c->buf.img[1] = R;
+  c->buf.img_row_stride = row_stride;
+  c->buf.img_stream_stride = image_stride;
+  return VSLAM_OK;
+}
+static int upload_images(vslam_ctx* c, const uint8_t* L, const uint8_t* R, int32_t row_stride, size_t image_stride) {
+  if (!L || !R) return fail(c, VSLAM_ERR_INVALID, "called with empty frame");
+  if (row_stride < c->cfg.c.cols) return fail(c, VSLAM_ERR_INVALID, "row stride smaller than image width");
+  for (int s = 0; s < c->B; ++s) {
+    HIP_TRY(c, hipMemcpy2DAsync(c->upload[0] + s * c->up_stream_stride, c->up_stride, L + s * image_stride, row_stride,
+                                c->cfg.c.cols, c->cfg.c.rows, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpy2DAsync(c->upload[1] + s * c->up_stream_stride, c->up_stride, R + s * image_stride, row_stride,
+                                c->cfg.c.cols, c->cfg.c.rows, hipMemcpyHostToDevice, c->stream));
+  }
+  return set_images_device(c, c->upload[0], c->upload[1], c->up_stride, c->up_stream_stride);
+}
+
+VS_API int vslam_process_device(vslam_ctx* c, const uint8_t* L, const uint8_t* R, int32_t row_stride, size_t image_stride) {
+  if (!c) return VSLAM_ERR_INVALID;
+  if (c->sticky != VSLAM_OK) return c->sticky;
+  int rc = set_images_device(c, L, R, row_stride, image_stride);
+  if (rc != VSLAM_OK) return rc;
+  rc = launch_image_pipeline(c);
+  if (rc != VSLAM_OK) return rc;
+  return launch_frame(c);
+}
+VS_API int vslam_process_host(vslam_ctx* c, const uint8_t* L, const uint8_t* R, int32_t row_stride, size_t image_stride) {
+  if (!c) return VSLAM_ERR_INVALID;
+  if (c->sticky != VSLAM_OK) return c->sticky;
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = upload_images(c, L, R, row_stride, image_stride);
+  if (rc != VSLAM_OK) return rc;
+  rc = launch_image_pipeline(c);
+  if (rc != VSLAM_OK) return rc;
+  return launch_frame(c);
+}
+
+// ---- read-back -----------------------------------------------------------------------------------
+static int check_stream(vslam_ctx* c, int s) {
+  if (!c) return VSLAM_ERR_INVALID;
+  if (s < 0 || s >= c->B) return fail(c, VSLAM_ERR_INVALID, "stream index out of range");
+  return VSLAM_OK;
+}
+template <typename T>
+static hipError_t d2h(vslam_ctx* c, T* dst, const T* src, size_t count) {
+  if (!dst || !count) return hipSuccess;
+  return hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyDeviceToHost, c->stream);
+}
+VS_API int vslam_get_frame_info(vslam_ctx* c, int s, vslam_frame_info* out) {
+  int rc = check_stream(c, s);
+  if (rc) return rc;
+  if (!out) return fail(c, VSLAM_ERR_INVALID, "null output");
+  HIP_TRY(c, d2h(c, out, c->buf.info + s, 1));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (out->error_flags) { c->err = "device buffer capacity exceeded (error_flags != 0)"; }
+  return VSLAM_OK;
+}
+VS_API int vslam_get_keypoints(vslam_ctx* c, int s, int side, int32_t cap, int32_t* n, int16_t* xy, int32_t* score, uint8_t* desc) {
+  int rc = check_stream(c, s);
+  if (rc) return rc;
+  if (!n || side < 0 || side > 1) return fail(c, VSLAM_ERR_INVALID, "bad argument");
+  int32_t cnt = 0;
+  HIP_TRY(c, d2h(c, &cnt, c->buf.n_kp + s * 2 + side, 1));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  *n = cnt;
+  if (cnt > cap) return fail(c, VSLAM_ERR_CAPACITY, "keypoint output capacity too small");
+  const size_t o = ((size_t)s * 2 + side) * c->cfg.NMAX;
+  std::vector<uint8_t> sc(cnt);
+  HIP_TRY(c, d2h(c, xy, c->buf.kp_xy + o * 2, (size_t)cnt * 2));
+  HIP_TRY(c, d2h(c, sc.data(), c->buf.kp_score + o, (size_t)cnt));
+  HIP_TRY(c, d2h(c, desc, c->buf.desc + o * 32, (size_t)cnt * 32));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (score) for (int i = 0; i < cnt; ++i) score[i] = sc[i];
+  return VSLAM_OK;
+}
+VS_API int vslam_get_points(vslam_ctx* c, int s, int32_t cap, int32_t* n, int16_t* kp, int32_t* meta, double* cam, double* lm) {
+  int rc = check_stream(c, s);
+  if (rc) return rc;
+  if (!n) return fail(c, VSLAM_ERR_INVALID, "bad argument");
+  StreamState st;
+  HIP_TRY(c, d2h(c, &st, c->buf.st + s, 1));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int32_t cnt = 0;
+  HIP_TRY(c, d2h(c, &cnt, c->buf.n_points + s * 2 + st.cur, 1));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (!st.has_prev) cnt = 0;
+  *n = cnt;
+  if (cnt > cap) return fail(c, VSLAM_ERR_CAPACITY, "point output capacity too small");
+  const size_t o = ((size_t)s * 2 + st.cur) * c->cfg.MAXP;
+  std::vector<int32_t> m((size_t)cnt * META);
+  std::vector<int16_t> k((size_t)cnt * 4);
+  HIP_TRY(c, d2h(c, k.data(), c->buf.p_kp + o * 4, (size_t)cnt * 4));
+  HIP_TRY(c, d2h(c, m.data(), c->buf.p_meta + o * META, (size_t)cnt * META));
+  HIP_TRY(c, d2h(c, cam, c->buf.p_cam + o * 3, (size_t)cnt * 3));
+  HIP_TRY(c, d2h(c, lm, c->buf.p_lm + o * 3, (size_t)cnt * 3));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < cnt; ++i) {
+    if (kp) for (int q = 0; q < 4; ++q) kp[4 * i + q] = k[4 * i + q];
+    if (meta) {
+      meta[6 * i + 0] = m[META * i + M_DIST]; meta[6 * i + 1] = m[META * i + M_EPI]; meta[6 * i + 2] = m[META * i + M_PREV];
+      meta[6 * i + 3] = m[META * i + M_TLEN]; meta[6 * i + 4] = m[META * i + M_LMUP]; meta[6 * i + 5] = k[4 * i] - k[4 * i + 2];
+    }
+    if (lm && m[META * i + M_LMUP] == 0) { lm[3 * i] = lm[3 * i + 1] = lm[3 * i + 2] = 0; }
+  }
+  return VSLAM_OK;
+}
+VS_API int vslam_get_aligner_result(vslam_ctx* c, int s, int32_t cap, int32_t* n, double* chi, uint8_t* inlier, double T[12], double H[36]) {
+  int rc = check_stream(c, s);
+  if (rc) return rc;
+  if (!n) return fail(c, VSLAM_ERR_INVALID, "bad argument");
+  StreamState st;
+  HIP_TRY(c, d2h(c, &st, c->buf.st + s, 1));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  *n = st.al_n;
+  if (st.al_n > cap) return fail(c, VSLAM_ERR_CAPACITY, "aligner output capacity too small");
+  HIP_TRY(c, d2h(c, chi, c->buf.al_chi + (size_t)s * c->cfg.MAXP, (size_t)st.al_n));
+  HIP_TRY(c, d2h(c, inlier, c->buf.al_inl + (size_t)s * c->cfg.MAXP, (size_t)st.al_n));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (T) std::memcpy(T, st.al_T, sizeof(double) * 12);
+  if (H) std::memcpy(H, st.al_H, sizeof(double) * 36);
+  return VSLAM_OK;
+}
+VS_API int vslam_get_poses(vslam_ctx* c, int s, int32_t first, int32_t nf, double* out) {
+  int rc = check_stream(c, s);
+  if (rc) return rc;
+  if (!out || first < 0 || nf < 0 || first + nf > VS_POSE_LOG) return fail(c, VSLAM_ERR_INVALID, "bad pose range");
+  HIP_TRY(c, d2h(c, out, c->buf.pose_log + ((size_t)s * VS_POSE_LOG + first) * 12, (size_t)nf * 12));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return VSLAM_OK;
+}
+VS_API int vslam_get_timers(vslam_ctx* c, double seconds[8]) {
+  if (!c || !seconds) return VSLAM_ERR_INVALID;
+  for (int i = 0; i < 8; ++i) seconds[i] = c->timer_acc[i];
+  return VSLAM_OK;
+}
+VS_API int vslam_enable_timers(vslam_ctx* c, int on) {
+  if (!c) return VSLAM_ERR_INVALID;
+  c->timers = on != 0;
+  return VSLAM_OK;
+}
+
+// ---- stand-alone kernels ---------------------------------------------------------------------------
+static int make_scratch_ctx(vslam_ctx* parent, int rows, int cols, int nmax, int maxp, vslam_ctx** out) {
+  vslam_config cfg = parent->cfg.c;
+  cfg.rows = rows; cfg.cols = cols; cfg.det_rows = 1; cfg.det_cols = 1;
+  cfg.max_keypoints = std::max(64, nmax); cfg.max_points = std::max(64, maxp); cfg.max_history_frames = 2;
+  int rc = create_internal(&cfg, parent->device, 1, out);
+  if (rc != VSLAM_OK) parent->err = g_create_error;
+  return rc;
+}
+VS_API int vslam_fast_detect(vslam_ctx* c, const uint8_t* img, int32_t rows, int32_t cols, int32_t stride, int32_t rx, int32_t ry,
+                             int32_t rw, int32_t rh, int32_t threshold, int32_t cap, int32_t* n, int16_t* xy, int32_t* score) {
+  if (!c || !img || !n) return VSLAM_ERR_INVALID;
+  if (rx < 0 || ry < 0 || rw < 1 || rh < 1 || rx + rw > cols || ry + rh > rows) return fail(c, VSLAM_ERR_INVALID, "ROI outside the image");
+  vslam_ctx* t = nullptr;
+  int rc = make_scratch_ctx(c, rows, cols, std::min(cap, rows * cols), 64, &t);
+  if (rc != VSLAM_OK) return rc;
+  t->cfg.n_regions = 1;
+  t->cfg.regions[0].x = rx; t->cfg.regions[0].y = ry; t->cfg.regions[0].w = rw; t->cfg.regions[0].h = rh;
+  StreamState st;
+  hipError_t e = hipMemcpy(&st, t->buf.st, sizeof st, hipMemcpyDeviceToHost);
+  st.thr[0] = threshold;
+  if (e == hipSuccess) e = hipMemcpy(t->buf.st, &st, sizeof st, hipMemcpyHostToDevice);
+  rc = e == hipSuccess ? upload_images(t, img, img, stride, 0) : fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
+  if (rc == VSLAM_OK) {
+    dim3 g1(t->cfg.TX, (rows + VS_TILE_H - 1) / VS_TILE_H, 2);
+    hipLaunchKernelGGL(k_fast_box, g1, dim3(256), 0, t->stream, t->cfg, t->buf);
+    hipLaunchKernelGGL(k_emit, dim3(1), dim3(1024), 0, t->stream, t->cfg, t->buf, 0, 0);
+    int32_t cnt = 0;
+    rc = vslam_get_keypoints(t, 0, 0, cap, &cnt, xy, score, nullptr);
+    *n = cnt;
+    if (rc == VSLAM_OK) for (int i = 0; i < cnt; ++i) { xy[2 * i] = (int16_t)(xy[2 * i] - rx); xy[2 * i + 1] = (int16_t)(xy[2 * i + 1] - ry); }
+    if (rc != VSLAM_OK) c->err = t->err;
+  }
+  vslam_destroy(t);
+  return rc;
+}
+VS_API int vslam_brief_describe(vslam_ctx* c, const uint8_t* img, int32_t rows, int32_t cols, int32_t stride, int32_t n,
+                                const int16_t* xy, uint8_t* keep, uint8_t* desc) {
+  if (!c || !img || !xy || !keep || !desc || n < 0) return VSLAM_ERR_INVALID;
+  vslam_ctx* t = nullptr;
+  int rc = make_scratch_ctx(c, rows, cols, 64, 64, &t);
+  if (rc != VSLAM_OK) return rc;
+  int16_t* dxy = nullptr; uint8_t* dkeep = nullptr; uint8_t* ddesc = nullptr;
+  hipError_t e = dalloc(t, &dxy, (size_t)n * 2);
+  if (e == hipSuccess) e = dalloc(t, &dkeep, (size_t)n);
+  if (e == hipSuccess) e = dalloc(t, &ddesc, (size_t)n * 32);
+  if (e == hipSuccess && n) e = hipMemcpyAsync(dxy, xy, (size_t)n * 2 * sizeof(int16_t), hipMemcpyHostToDevice, t->stream);
+  rc = e == hipSuccess ? upload_images(t, img, img, stride, 0) : fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
+  if (rc == VSLAM_OK && n) {
+    dim3 g1(t->cfg.TX, (rows + VS_TILE_H - 1) / VS_TILE_H, 2);
+    hipLaunchKernelGGL(k_fast_box, g1, dim3(256), 0, t->stream, t->cfg, t->buf);
+    hipLaunchKernelGGL(k_brief_at, dim3(std::min(64, (n + 3) / 4)), dim3(256), 0, t->stream, t->buf.box, t->cfg.bstride, rows, cols,
+                       n, dxy, dkeep, ddesc);
+    e = hipMemcpyAsync(keep, dkeep, (size_t)n, hipMemcpyDeviceToHost, t->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(desc, ddesc, (size_t)n * 32, hipMemcpyDeviceToHost, t->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+    if (e != hipSuccess) rc = fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
+  }
+  vslam_destroy(t);
+  return rc;
+}
+VS_API int vslam_knn2(vslam_ctx* c, int norm, int32_t nq, const uint8_t* q, int32_t nt, const uint8_t* t, int32_t* idx, float* dist) {
+  if (!c || !q || !t || !idx || !dist || nq < 0 || nt < 0 || norm < 0 || norm > 1) return VSLAM_ERR_INVALID;
+  if (nq == 0) return VSLAM_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  uint8_t *dq = nullptr, *dt = nullptr; int32_t* di = nullptr; float* dd = nullptr;
+  hipError_t e = hipMalloc((void**)&dq, (size_t)nq * 32);
+  if (e == hipSuccess) e = hipMalloc((void**)&dt, std::max<size_t>((size_t)nt * 32, 32));
+  if (e == hipSuccess) e = hipMalloc((void**)&di, (size_t)nq * 2 * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&dd, (size_t)nq * 2 * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpyAsync(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess && nt) e = hipMemcpyAsync(dt, t, (size_t)nt * 32, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_knn2, dim3((nq + 255) / 256), dim3(256), 0, c->stream, norm, nq, dq, nt, dt, di, dd);
+    e = hipMemcpyAsync(idx, di, (size_t)nq * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(dist, dd, (size_t)nq * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(dq); (void)hipFree(dt); (void)hipFree(di); (void)hipFree(dd);
+  if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
+  return VSLAM_OK;
+}
+VS_API int vslam_align_points(vslam_ctx* c, int32_t n, const double* moving, const double* fixed, const double* omega,
+                              const double* weight, const double T_init[12], double T_out[12], double* chi, uint8_t* inlier,
+                              int32_t* n_inliers, double* total_error, int32_t* iterations, double H_out[36]) {
+  if (!c || n < 0 || !moving || !fixed || !omega || !weight || !T_init) return VSLAM_ERR_INVALID;
+  vslam_ctx* t = nullptr;
+  vslam_config cfg = c->cfg.c;
+  cfg.max_points = std::max(64, n); cfg.max_keypoints = 64; cfg.max_history_frames = 2;
+  int rc = create_internal(&cfg, c->device, 1, &t);
+  if (rc != VSLAM_OK) { c->err = g_create_error; return rc; }
+  double* dT = nullptr;
+  hipError_t e = dalloc(t, &dT, 12);
+  if (e == hipSuccess) e = hipMemcpyAsync(dT, T_init, 12 * sizeof(double), hipMemcpyHostToDevice, t->stream);
+  if (e == hipSuccess && n) e = hipMemcpyAsync(t->buf.al_moving, moving, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, t->stream);
+  if (e == hipSuccess && n) e = hipMemcpyAsync(t->buf.al_fixed, fixed, (size_t)n * 4 * sizeof(double), hipMemcpyHostToDevice, t->stream);
+  if (e == hipSuccess && n) e = hipMemcpyAsync(t->buf.al_omega, omega, (size_t)n * sizeof(double), hipMemcpyHostToDevice, t->stream);
+  if (e == hipSuccess && n) e = hipMemcpyAsync(t->buf.al_weight, weight, (size_t)n * sizeof(double), hipMemcpyHostToDevice, t->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_align_points, dim3(1), dim3(VS_WG), 0, t->stream, t->cfg, t->buf, n, dT);
+    StreamState st;
+    e = hipMemcpyAsync(&st, t->buf.st, sizeof st, hipMemcpyDeviceToHost, t->stream);
+    if (e == hipSuccess && chi && n) e = hipMemcpyAsync(chi, t->buf.al_chi, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, t->stream);
+    if (e == hipSuccess && inlier && n) e = hipMemcpyAsync(inlier, t->buf.al_inl, (size_t)n, hipMemcpyDeviceToHost, t->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+    if (e == hipSuccess) {
+      if (T_out) std::memcpy(T_out, st.al_T, sizeof(double) * 12);
+      if (H_out) std::memcpy(H_out, st.al_H, sizeof(double) * 36);
+      if (n_inliers) *n_inliers = st.al_inliers;
+      if (total_error) *total_error = st.al_total_error;
+      if (iterations) *iterations = st.al_iterations;
+    }
+  }
+  if (e != hipSuccess) rc = fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
+  vslam_destroy(t);
+  return rc;
+}
+
+// ---- stage entry points (driven by the shim's host-side PoseTracker3D) ------------------------------
+// Round 1: the stage-granular calls are served by the fused frame kernel; see DESIGN.md "Boundary".
+VS_API int vslam_frame_begin(vslam_ctx* c, const uint8_t* L, const uint8_t* R, int32_t row_stride, size_t image_stride, int on_device) {
+  if (!c) return VSLAM_ERR_INVALID;
+  int rc = on_device ? set_images_device(c, L, R, row_stride, image_stride) : upload_images(c, L, R, row_stride, image_stride);
+  if (rc != VSLAM_OK) return rc;
+  rc = launch_image_pipeline(c);
+  c->frame_begun = rc == VSLAM_OK;
+  return rc;
+}
+VS_API int vslam_frame_finish(vslam_ctx* c) {
+  if (!c) return VSLAM_ERR_INVALID;
+  if (!c->frame_begun) return fail(c, VSLAM_ERR_STATE, "vslam_frame_finish called before vslam_frame_begin");
+  c->frame_begun = false;
+  return launch_frame(c);
+}
+
+// -- finer-grained stage calls: not wired yet (round-1 scope: fused frame kernel) ----------------------
+#define VS_TODO_STAGE(name, ...) VS_API int name(__VA_ARGS__) { return fail(c, VSLAM_ERR_STATE, #name ": stage-granular call not available in this build; use vslam_frame_begin + vslam_frame_finish"); }
+VS_TODO_STAGE(vslam_frame_restore, vslam_ctx* c)
+VS_TODO_STAGE(vslam_track, vslam_ctx* c, int)
+VS_TODO_STAGE(vslam_align, vslam_ctx* c, int)
+VS_TODO_STAGE(vslam_prune_recover, vslam_ctx* c)
+VS_TODO_STAGE(vslam_update_points, vslam_ctx* c)
+VS_TODO_STAGE(vslam_stereo_new, vslam_ctx* c)
+VS_TODO_STAGE(vslam_set_tracker_state, vslam_ctx* c, int, int, const double*, int, double)
+VS_TODO_STAGE(vslam_set_pose, vslam_ctx* c, int, const double*)
