@@ -190,6 +190,7 @@ __device__ void wg_update_points(const DevCfg& c, const DevBuf& b, int s, FrameS
         for (int q = 0; q < 3; ++q) acc[q] += wp[q];
         ii = hprev_of(c, b, s, ff)[ii];
         --ff;
+        if (ii < 0 && k + 1 < len) { len = k + 1; break; }
       }
       for (int q = 0; q < 3; ++q) wpos[q] = acc[q] / (double)len;
       m[M_LMUP] = len;
@@ -224,6 +225,7 @@ __device__ void wg_update_points(const DevCfg& c, const DevBuf& b, int s, FrameS
           }
           ii = hprev_of(c, b, s, ff)[ii];
           --ff;
+          if (ii < 0) break;
         }
         double nb[3] = {-bv[0], -bv[1], -bv[2]}, dx[3];
         full_piv_solve<3>(H, nb, dx);
@@ -242,6 +244,7 @@ __device__ void wg_update_points(const DevCfg& c, const DevBuf& b, int s, FrameS
               for (int q = 0; q < 3; ++q) acc[q] += wp[q];
               i2 = hprev_of(c, b, s, f2)[i2];
               --f2;
+              if (i2 < 0) break;
             }
             for (int q = 0; q < 3; ++q) wpos[q] = acc[q] / (double)len;
           }
