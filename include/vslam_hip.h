@@ -229,6 +229,11 @@ int vslam_get_aligner_result(vslam_ctx* ctx, int stream, int32_t cap, int32_t* n
  * landmark_optimization, point_recovery. */
 int vslam_get_timers(vslam_ctx* ctx, double seconds[8]);
 int vslam_enable_timers(vslam_ctx* ctx, int on);
+/* Per-kernel device time (HIP events on the context stream, recorded while timers are enabled):
+ * accumulated milliseconds and launch counts of k_fast_box, k_emit, k_brief, k_track_candidates, k_frame.
+ * Used by bench.py for the roofline of the dominant kernel.  Synchronises; vslam_enable_timers(ctx,1)
+ * clears the accumulators. */
+int vslam_get_kernel_times(vslam_ctx* ctx, double ms[5], int32_t launches[5]);
 
 /* ---- stand-alone kernels (unit parity, and the reference's optional knnMatch block) -------- */
 /* cv::FastFeatureDetector::detect on one ROI (base_framepoint_generator.cpp:12-25,367):
@@ -258,6 +263,9 @@ int vslam_align_points(vslam_ctx* ctx, int32_t n, const double* moving, const do
  * launcher through RCCL (torch.distributed backend "nccl"); these helpers pack/unpack. */
 int vslam_get_poses(vslam_ctx* ctx, int stream, int32_t first_frame, int32_t n_frames,
                     double* camera_left_to_world /* n_frames*12 */);
+/* Same, for ALL streams, into DEVICE memory (dst[stream][frame][12], asynchronous on the context
+ * stream): the send buffer of the RCCL all-gather. */
+int vslam_copy_poses_device(vslam_ctx* ctx, int32_t first_frame, int32_t n_frames, double* dst_device);
 
 #ifdef __cplusplus
 }

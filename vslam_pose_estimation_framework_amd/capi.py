@@ -270,3 +270,34 @@ class CApi(object):
                                            C.byref(err), C.byref(its), _p(H, C.c_double)))
         return dict(T=T.reshape(3, 4), chi=chi, inlier=inl, n_inliers=ninl.value, total_error=err.value,
                     iterations=its.value, H=H.reshape(6, 6))
+
+
+def _extra_methods():
+    def copy_poses_device(self, first, count, dst_ptr):
+        self.check(self.fn("copy_poses_device")(self.ctx, C.c_int32(first), C.c_int32(count), C.c_void_p(dst_ptr)))
+
+    def enable_timers(self, on=True):
+        self.check(self.fn("enable_timers")(self.ctx, C.c_int(1 if on else 0)))
+
+    def kernel_times(self):
+        ms = (C.c_double * 5)()
+        n = (C.c_int32 * 5)()
+        self.check(self.fn("get_kernel_times")(self.ctx, ms, n))
+        names = ["k_fast_box", "k_emit", "k_brief", "k_track_candidates", "k_frame"]
+        return {names[i]: (ms[i], n[i]) for i in range(5)}
+
+    def timers(self):
+        sec = (C.c_double * 8)()
+        self.check(self.fn("get_timers")(self.ctx, sec))
+        names = ["keypoint_detection", "descriptor_extraction", "point_triangulation", "tracking", "track_creation",
+                 "pose_optimization", "landmark_optimization", "point_recovery"]
+        return {names[i]: sec[i] for i in range(8)}
+
+    def set_hip_stream(self, stream_ptr):
+        self.check(self.fn("set_hip_stream")(self.ctx, C.c_void_p(stream_ptr)))
+
+    for f in (copy_poses_device, enable_timers, kernel_times, timers, set_hip_stream):
+        setattr(CApi, f.__name__, f)
+
+
+_extra_methods()

@@ -62,6 +62,9 @@ struct StreamState {
   double al_total_error;
   double al_T[12];
   double al_H[36];
+  // in-kernel chronometers (wall_clock64 ticks, 100 MHz): tracking, pose_optimization, point_recovery,
+  // landmark_optimization, track_creation (== point_triangulation)
+  unsigned long long ticks[5];
 };
 
 struct DevBuf {

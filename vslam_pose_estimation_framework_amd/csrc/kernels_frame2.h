@@ -454,13 +454,17 @@ __global__ __launch_bounds__(VS_WG) void k_frame(const DevCfg c, const DevBuf b)
       if (by_app) win = c.c.maximum_projection_tracking_distance_pixels;
       tau_gen = tau_track;
       if (attempt > 0) {
+        const unsigned long long tc = wall_clock64();
         // initialize(frame, false): fresh feature stores; candidates for the new prior / window / mode
         const int lane = tid & 63, w = tid >> 6;
         for (int i = w; i < P; i += VS_WG / 64) candidates_wave(c, b, s, pb_prev, i, lane, &wcnt[w], prior, win, tau_gen);
         __syncthreads();
+        if (tid == 0) st.ticks[0] += wall_clock64() - tc;
       }
       aligner_valid = false;
+      unsigned long long t0 = wall_clock64();
       wg_track_resolve(c, b, s, sh, pb_prev, prior, win, tau_gen, tau_tri, by_app);
+      if (tid == 0) st.ticks[0] += wall_clock64() - t0;
       const int n_trk = sh.n_trk;
       n_tracked_landmarks = sh.n_lm;
       {
@@ -489,7 +493,9 @@ __global__ __launch_bounds__(VS_WG) void k_frame(const DevCfg c, const DevBuf b)
         if (n_trk < c.c.minimum_number_of_landmarks_to_track) {
           fall = true;
         } else {
+          const unsigned long long ta = wall_clock64();
           wg_align(c, b, s, sh, pb_prev, false, prior);
+          if (tid == 0) st.ticks[1] += wall_clock64() - ta;
           aligner_valid = true;
           if (sh.inl < c.c.minimum_number_of_landmarks_to_track) fall = true; else accept = true;
         }
@@ -504,7 +510,9 @@ __global__ __launch_bounds__(VS_WG) void k_frame(const DevCfg c, const DevBuf b)
             brk = true; done = true;
           }
         } else {
+          const unsigned long long ta = wall_clock64();
           wg_align(c, b, s, sh, pb_prev, true, prior);
+          if (tid == 0) st.ticks[1] += wall_clock64() - ta;
           aligner_valid = true;
           if (sh.inl > c.c.minimum_number_of_landmarks_to_track) {
             accept = true; done = true;
@@ -556,20 +564,26 @@ __global__ __launch_bounds__(VS_WG) void k_frame(const DevCfg c, const DevBuf b)
     wg_prune(c, b, s, sh, pb_prev, pb_cur, aligner_valid);
     n_after_prune = sh.n_cur;
     if (c.c.enable_landmark_recovery) {
+      const unsigned long long tr = wall_clock64();
       wg_recover(c, b, s, sh, pb_prev, pb_cur, hpose_of(c, b, s, f) + 12, tau_gen, tau_tri);
       n_recovered = sh.flag;
+      if (tid == 0) st.ticks[2] += wall_clock64() - tr;
     }
   } else if (tid == 0) {
     info.n_tracked = 0; info.n_lost = 0; info.n_tracked_landmarks = 0; info.aligner_ran = 0; info.aligner_iterations = 0;
     info.aligner_converged = 0; info.n_inliers = 0; info.n_outliers = 0; info.total_error = 0; st.al_n = 0;
   }
   __syncthreads();
+  const unsigned long long tu = wall_clock64();
   wg_update_points(c, b, s, sh, pb_cur, f);
+  if (tid == 0) st.ticks[3] += wall_clock64() - tu;
   const int n_active = sh.n_lm;
   int status = sh.status;
   if (n_active > c.c.minimum_number_of_landmarks_to_track) status = VSLAM_TRACKING;
+  const unsigned long long ts = wall_clock64();
   wg_stereo(c, b, s, sh, pb_cur, tau_tri, f);
   if (tid == 0) {
+    st.ticks[4] += wall_clock64() - ts;
     const double* c2w = hpose_of(c, b, s, f);
     *pts_of(c, b, s, pb_cur).n = sh.n_cur;
     st.status = status; st.win = win; st.tau_track = tau_track;

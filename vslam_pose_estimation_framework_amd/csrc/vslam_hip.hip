@@ -31,6 +31,11 @@ struct vslam_ctx {
   bool timers = false;
   double timer_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  struct EvRec { hipEvent_t a, b; int k; };
+  std::vector<EvRec> evrec;
+  std::vector<hipEvent_t> evpool;
+  double kern_ms[5] = {0, 0, 0, 0, 0};
+  int kern_n[5] = {0, 0, 0, 0, 0};
   int sticky = VSLAM_OK;
 };
 
@@ -52,6 +57,29 @@ static hipError_t dalloc(vslam_ctx* c, T** p, size_t count) {
   if (e == hipSuccess) { c->allocs.push_back(q); *p = (T*)q; }
   return e;
 }
+
+// ---- optional per-kernel timing (HIP events on the context stream) -----------------------------------
+static hipEvent_t ev_get(vslam_ctx* c) {
+  if (!c->evpool.empty()) { hipEvent_t e = c->evpool.back(); c->evpool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+struct KernelTimer {
+  vslam_ctx* c; int k; hipEvent_t a = nullptr;
+  KernelTimer(vslam_ctx* c_, int k_) : c(c_), k(k_) { if (c->timers) { a = ev_get(c); (void)hipEventRecord(a, c->stream); } }
+  ~KernelTimer() { if (a) { hipEvent_t b = ev_get(c); (void)hipEventRecord(b, c->stream); c->evrec.push_back({a, b, k}); } }
+};
+static void harvest_events(vslam_ctx* c) {
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& r : c->evrec) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { c->kern_ms[r.k] += ms; c->kern_n[r.k] += 1; }
+    c->evpool.push_back(r.a); c->evpool.push_back(r.b);
+  }
+  c->evrec.clear();
+}
+
 
 // ---- defaults (configurations/configuration_{kitti,euroc}.yaml, src/types/parameters.h) -----------
 static void common_defaults(vslam_config* c) {
@@ -223,6 +251,8 @@ VS_API void vslam_destroy(vslam_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   for (void* p : c->allocs) (void)hipFree(p);
   for (int i = 0; i < 6; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  harvest_events(c);
+  for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -245,21 +275,22 @@ VS_API int vslam_synchronize(vslam_ctx* c) {
   return c->sticky;
 }
 
+
 // ---- launches ------------------------------------------------------------------------------------
 static int launch_image_pipeline(vslam_ctx* c) {
   const DevCfg& d = c->cfg;
   dim3 g1(d.TX, (d.c.rows + VS_TILE_H - 1) / VS_TILE_H, 2 * c->B);
-  hipLaunchKernelGGL(k_fast_box, g1, dim3(256), 0, c->stream, c->cfg, c->buf);
-  hipLaunchKernelGGL(k_emit, dim3(c->B), dim3(1024), 0, c->stream, c->cfg, c->buf, (int)VSLAM_BRIEF_BORDER, 1);
+  { KernelTimer t(c, 0); hipLaunchKernelGGL(k_fast_box, g1, dim3(256), 0, c->stream, c->cfg, c->buf); }
+  { KernelTimer t(c, 1); hipLaunchKernelGGL(k_emit, dim3(c->B), dim3(1024), 0, c->stream, c->cfg, c->buf, (int)VSLAM_BRIEF_BORDER, 1); }
   const int gx = std::max(4, std::min(64, 1024 / (2 * c->B)));
-  hipLaunchKernelGGL(k_brief, dim3(gx, 1, 2 * c->B), dim3(256), 0, c->stream, c->cfg, c->buf);
+  { KernelTimer t(c, 2); hipLaunchKernelGGL(k_brief, dim3(gx, 1, 2 * c->B), dim3(256), 0, c->stream, c->cfg, c->buf); }
   HIP_TRY(c, hipGetLastError());
   return VSLAM_OK;
 }
 static int launch_frame(vslam_ctx* c) {
   const int gx = std::max(4, std::min(128, 2048 / c->B));
-  hipLaunchKernelGGL(k_track_candidates, dim3(gx, c->B), dim3(256), 0, c->stream, c->cfg, c->buf);
-  hipLaunchKernelGGL(k_frame, dim3(c->B), dim3(VS_WG), 0, c->stream, c->cfg, c->buf);
+  { KernelTimer t(c, 3); hipLaunchKernelGGL(k_track_candidates, dim3(gx, c->B), dim3(256), 0, c->stream, c->cfg, c->buf); }
+  { KernelTimer t(c, 4); hipLaunchKernelGGL(k_frame, dim3(c->B), dim3(VS_WG), 0, c->stream, c->cfg, c->buf); }
   HIP_TRY(c, hipGetLastError());
   return VSLAM_OK;
 }
@@ -396,13 +427,40 @@ VS_API int vslam_get_poses(vslam_ctx* c, int s, int32_t first, int32_t nf, doubl
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return VSLAM_OK;
 }
+VS_API int vslam_copy_poses_device(vslam_ctx* c, int32_t first, int32_t nf, double* dst) {
+  if (!c || !dst || first < 0 || nf < 0 || first + nf > VS_POSE_LOG) return VSLAM_ERR_INVALID;
+  HIP_TRY(c, hipMemcpy2DAsync(dst, (size_t)nf * 12 * sizeof(double), c->buf.pose_log + (size_t)first * 12,
+                              (size_t)VS_POSE_LOG * 12 * sizeof(double), (size_t)nf * 12 * sizeof(double), c->B,
+                              hipMemcpyDeviceToDevice, c->stream));
+  return VSLAM_OK;
+}
 VS_API int vslam_get_timers(vslam_ctx* c, double seconds[8]) {
   if (!c || !seconds) return VSLAM_ERR_INVALID;
-  for (int i = 0; i < 8; ++i) seconds[i] = c->timer_acc[i];
+  harvest_events(c);
+  std::vector<StreamState> st(c->B);
+  HIP_TRY(c, hipMemcpy(st.data(), c->buf.st, sizeof(StreamState) * c->B, hipMemcpyDeviceToHost));
+  double ph[5] = {0, 0, 0, 0, 0};
+  for (int s = 0; s < c->B; ++s) for (int k = 0; k < 5; ++k) ph[k] += (double)st[s].ticks[k] * 1e-8 / c->B;  // 100 MHz ticks
+  seconds[0] = (c->kern_ms[0] + c->kern_ms[1]) * 1e-3;  // keypoint_detection: FAST/NMS + emission/controller
+  seconds[1] = c->kern_ms[2] * 1e-3;                    // descriptor_extraction
+  seconds[2] = ph[4];                                   // point_triangulation (compute())
+  seconds[3] = c->kern_ms[3] * 1e-3 + ph[0];            // tracking: candidate search + resolution
+  seconds[4] = ph[4];                                   // track_creation (tracker's timer around compute())
+  seconds[5] = ph[1];                                   // pose_optimization
+  seconds[6] = ph[3];                                   // landmark_optimization
+  seconds[7] = ph[2];                                   // point_recovery
+  return VSLAM_OK;
+}
+VS_API int vslam_get_kernel_times(vslam_ctx* c, double ms[5], int32_t launches[5]) {
+  if (!c || !ms || !launches) return VSLAM_ERR_INVALID;
+  harvest_events(c);
+  for (int k = 0; k < 5; ++k) { ms[k] = c->kern_ms[k]; launches[k] = c->kern_n[k]; }
   return VSLAM_OK;
 }
 VS_API int vslam_enable_timers(vslam_ctx* c, int on) {
   if (!c) return VSLAM_ERR_INVALID;
+  harvest_events(c);
+  if (on && !c->timers) { for (int k = 0; k < 5; ++k) { c->kern_ms[k] = 0; c->kern_n[k] = 0; } }
   c->timers = on != 0;
   return VSLAM_OK;
 }

@@ -1,0 +1,57 @@
+"""Frame-sharding of a sequence into chunks (streams) across streams-per-GPU and GPUs, and trajectory
+assembly from per-chunk poses.
+
+The reference is a single process; frames of one sequence depend on each other (threshold feedback,
+tracker state, landmarks), so a sequence is cut into contiguous chunks that start `overlap` frames early:
+each chunk re-localises on its overlap frames and contributes only its own range.  Chunks are chained by
+the rigid transform that maps the chunk's estimate of the last frame of the preceding range onto the
+preceding chunk's estimate of that frame.  The only inter-GPU exchange is one all-gather of the per-chunk
+3x4 poses (96 B/frame)."""
+import numpy as np
+
+from .evaluation import inv34, mul34
+
+
+def plan_chunks(total_frames, n_chunks, overlap):
+    """[(first_frame_processed, first_unique_frame, end_frame)] for every chunk."""
+    L = -(-total_frames // n_chunks)
+    plan = []
+    for c in range(n_chunks):
+        first_unique = min(c * L, total_frames)
+        end = min((c + 1) * L, total_frames)
+        start = max(0, first_unique - overlap)
+        plan.append((start, first_unique, end))
+    return plan, L
+
+
+def assemble_trajectory(chunk_poses, plan):
+    """chunk_poses[c]: array [n_processed_c, 3, 4] (camera-to-chunk-world), plan from plan_chunks.
+    Returns [total, 3, 4] in the first chunk's world frame."""
+    total = plan[-1][2]
+    G = np.zeros((total, 3, 4))
+    anchor = np.hstack([np.eye(3), np.zeros((3, 1))])
+    for c, (start, first, end) in enumerate(plan):
+        P = np.asarray(chunk_poses[c]).reshape(-1, 3, 4)
+        if end <= first:
+            continue
+        if c > 0 and first > start:
+            f0 = first - 1
+            anchor = mul34(G[f0], inv34(P[f0 - start]))
+        elif c > 0:
+            anchor = mul34(G[first - 1], inv34(P[0])) if first > 0 else anchor
+        for f in range(first, end):
+            G[f] = mul34(anchor, P[f - start])
+    return G
+
+
+def gather_poses(local_poses, group=None):
+    """All-gather of per-rank pose blocks [chunks_per_rank, frames, 12] (torch tensor, any device) ->
+    [world*chunks_per_rank, frames, 12].  One collective per run; RCCL on GPUs, gloo in CPU tests."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local_poses
+    world = dist.get_world_size(group)
+    out = torch.empty((world,) + tuple(local_poses.shape), dtype=local_poses.dtype, device=local_poses.device)
+    dist.all_gather_into_tensor(out, local_poses.contiguous(), group=group)
+    return out.reshape((world * local_poses.shape[0],) + tuple(local_poses.shape[1:]))
