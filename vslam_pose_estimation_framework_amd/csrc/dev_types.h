@@ -22,7 +22,7 @@
 #define VS_TILE_H 16
 #define VS_CELL 16
 #define VS_MAXCAND 16        // candidate list length per previous point (overflow -> exact rescan)
-#define VS_WG 1024           // threads of the per-stream frame kernel
+#define VS_WG 512            // threads of the per-stream frame kernel
 #define VS_POSE_LOG 32768    // frames of trajectory kept per stream
 
 struct DevRegion { int32_t x, y, w, h; };
@@ -65,6 +65,9 @@ struct StreamState {
   // in-kernel chronometers (wall_clock64 ticks, 100 MHz): tracking, pose_optimization, point_recovery,
   // landmark_optimization, track_creation (== point_triangulation)
   unsigned long long ticks[5];
+  // stage-granular API (the shim's host-driven PoseTracker3D): values handed from one stage call to the next
+  double tau_gen;                        // generator's _maximum_descriptor_distance_tracking (last track())
+  int32_t n_cur, n_active, n_after_prune, n_recovered, n_new, track_calls;
 };
 
 struct DevBuf {

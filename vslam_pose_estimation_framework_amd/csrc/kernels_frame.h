@@ -113,7 +113,9 @@ __device__ void candidates_wave(const DevCfg& c, const DevBuf& b, int s, int pb_
   if (lane == 0) b.cand_cnt[gi] = __hip_atomic_load(wcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-__global__ __launch_bounds__(256) void k_track_candidates(const DevCfg c, const DevBuf b) {
+__global__ __launch_bounds__(256) void k_track_candidates(const DevCfg c, const DevBuf b, int mode) {
+  // mode < 0: fused path (appearance iff the tracker is Localizing, window forced to max in that case);
+  // mode 0/1: stage path, window and distance exactly as set through vslam_set_tracker_state
   __shared__ int wcnt[4];
   const int s = blockIdx.y;
   const StreamState& st = b.st[s];
@@ -122,8 +124,8 @@ __global__ __launch_bounds__(256) void k_track_candidates(const DevCfg c, const 
   const int wave = blockIdx.x * 4 + w, nwaves = gridDim.x * 4;
   const int pb_prev = st.cur;  // the previous frame's points: buffer that was current last frame
   const int P = b.n_points[s * 2 + pb_prev];
-  const int by_app = st.status == VSLAM_LOCALIZING;
-  const int d = by_app ? c.c.maximum_projection_tracking_distance_pixels : st.win;
+  const int by_app = mode < 0 ? (st.status == VSLAM_LOCALIZING) : mode;
+  const int d = (mode < 0 && by_app) ? c.c.maximum_projection_tracking_distance_pixels : st.win;
   double T[12];
   for (int k = 0; k < 12; ++k) T[k] = st.prior[k];
   for (int i = wave; i < P; i += nwaves) candidates_wave(c, b, s, pb_prev, i, lane, &wcnt[w], T, d, st.tau_track);
@@ -331,6 +333,74 @@ __device__ void wg_track_resolve(const DevCfg& c, const DevBuf& b, int s, FrameS
 // ----------------------------------------------------------------------------------------------
 // StereoUVAligner
 // ----------------------------------------------------------------------------------------------
+// Eigen::FullPivLU<Matrix6>::solve on one wavefront.  Element (row i, col j) of the matrix sits in lane
+// 6*j+i (column-major, so "first strict maximum in column-major order" is the lowest set bit of a ballot),
+// the right-hand side in lanes 36..41.  Arithmetic per element is the serial algorithm's (same operands,
+// same order), so the result is bit-identical to dev_math.h full_piv_solve<6> / the CPU oracle.
+__device__ __forceinline__ void wave_solve6(double a, int lane, double* x) {
+  const int j = lane / 6, i = lane - 6 * j;
+  const int row = lane < 36 ? i : (lane < 42 ? lane - 36 : -1);
+  unsigned perm = 0x543210u;
+  int rank = 6;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    if (rank == 6) {
+      const bool elig = lane < 36 && i >= k && j >= k;
+      const double v = elig ? fabs(a) : -1.0;
+      double m = v;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+      if (!(m > 0)) {
+        rank = k;
+      } else {
+        const unsigned long long bal = __ballot(elig && v == m);
+        const int pl = __ffsll((long long)bal) - 1;
+        const int pc = pl / 6, pr = pl - 6 * pc;
+        if (pr != k) {
+          int src = lane;
+          if (row == k) src = lane - k + pr; else if (row == pr) src = lane - pr + k;
+          a = __shfl(a, src, 64);
+        }
+        if (pc != k) {
+          int src = lane;
+          if (lane < 36) { if (j == k) src = pc * 6 + i; else if (j == pc) src = k * 6 + i; }
+          a = __shfl(a, src, 64);
+          const unsigned pk = (perm >> (4 * k)) & 15u, pp = (perm >> (4 * pc)) & 15u;
+          perm = (perm & ~((15u << (4 * k)) | (15u << (4 * pc)))) | (pp << (4 * k)) | (pk << (4 * pc));
+        }
+        const double akk = __shfl(a, k * 6 + k, 64);
+        const double aik = __shfl(a, k * 6 + (row < 0 ? 0 : row), 64);
+        const double akj = __shfl(a, lane < 36 ? j * 6 + k : 36 + k, 64);
+        if (row > k) {
+          const double f = aik / akk;
+          if (lane < 36) { if (j == k) a = 0; else if (j > k) a = a - f * akj; }
+          else a = a - f * akj;
+        }
+      }
+    }
+  }
+  double y[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int ii = 5; ii >= 0; --ii) {
+    double sv = __shfl(a, 36 + ii, 64);
+#pragma unroll
+    for (int jj = ii + 1; jj < 6; ++jj) {
+      const double aij = __shfl(a, jj * 6 + ii, 64);
+      if (jj < rank) sv -= aij * y[jj];
+    }
+    const double aii = __shfl(a, ii * 6 + ii, 64);
+    if (ii < rank) y[ii] = sv / aii;
+  }
+#pragma unroll
+  for (int q = 0; q < 6; ++q) x[q] = 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int dst = (int)((perm >> (4 * k)) & 15u);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) if (dst == q) x[q] = y[k];
+  }
+}
+
 #define NACC 29  // 21 upper-triangular H + 6 b + E + inlier count
 __device__ void wg_one_round(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int n, bool ignore_outliers) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -409,47 +479,62 @@ __device__ void wg_one_round(const DevCfg& c, const DevBuf& b, int s, FrameShare
     chi_o[u] = chi_w;
     inl_o[u] = inl_w;
   }
-  // deterministic reduction: butterfly inside the wave, fixed order across the 16 waves
+  // deterministic reduction: butterfly inside the wave, fixed order across the 16 waves.  Waves that own
+  // no measurement (w*64 >= n) contribute exact zeros without shuffling.
+  if (w * 64 < n) {
 #pragma unroll
-  for (int k = 0; k < NACC; ++k) {
-    double v = acc[k];
+    for (int k = 0; k < NACC; ++k) {
+      double v = acc[k];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if (lane == 0) sh.red[w][k] = v;
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+      if (lane == 0) sh.red[w][k] = v;
+    }
+  } else if (lane < NACC) {
+    sh.red[w][lane] = 0.0;
   }
   __syncthreads();
-  if (tid == 0) {
-    double tot[NACC];
-    for (int k = 0; k < NACC; ++k) { double a = 0; for (int ww = 0; ww < VS_WG / 64; ++ww) a += sh.red[ww][k]; tot[k] = a; }
-    double H[36], bb[6];
-    int q = 0;
-    for (int r = 0; r < 6; ++r)
-      for (int cc = r; cc < 6; ++cc) { H[6 * r + cc] = tot[q]; H[6 * cc + r] = tot[q]; ++q; }
-    for (int r = 0; r < 6; ++r) bb[r] = tot[21 + r];
-    sh.E = tot[27];
-    sh.inl = (int)tot[28];
-    sh.outl = n - sh.inl;
-    // oneRound (stereouv_aligner.cpp:190-207)
-    for (int r = 0; r < 6; ++r) H[7 * r] += c.c.aligner_damping * n;
-    for (int k = 0; k < 36; ++k) sh.H[k] = H[k];
-    double nb[6], dx[6], D[12], Tn[12];
-    for (int r = 0; r < 6; ++r) nb[r] = -bb[r];
-    full_piv_solve<6>(H, nb, dx);
-    v2t(dx, D);
-    tf_mul(D, T, Tn);
-    double R[9], RtR[9];
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) R[3 * i + j] = Tn[4 * i + j];
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) {
-        RtR[3 * i + j] = (R[i] * R[j] + R[3 + i] * R[3 + j]) + R[6 + i] * R[6 + j];
-        if (i == j) RtR[3 * i + j] -= 1;
-      }
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j)
-        Tn[4 * i + j] = R[3 * i + j] - 0.5 * ((R[3 * i] * RtR[j] + R[3 * i + 1] * RtR[3 + j]) + R[3 * i + 2] * RtR[6 + j]);
-    for (int k = 0; k < 12; ++k) sh.T[k] = Tn[k];
-    ++sh.its;
+  if (w == 0) {
+    // lane k < 29 owns total k; the 6x6 system then lives one element per lane (column-major: lane = 6*col+row,
+    // right-hand side in lanes 36..41) and is solved by wave_solve6 without leaving registers.
+    double tot = 0;
+    if (lane < NACC) for (int ww = 0; ww < VS_WG / 64; ++ww) tot += sh.red[ww][lane];
+    const int j = lane / 6, i = lane - 6 * j;
+    int src = 0;
+    if (lane < 36) { const int r = min(i, j), cc = max(i, j); src = r * 6 - (r * (r - 1)) / 2 + (cc - r); }
+    else if (lane < 42) src = 21 + (lane - 36);
+    double a = __shfl(tot, src, 64);
+    if (lane < 36 && i == j) a += c.c.aligner_damping * n;   // oneRound (:196)
+    if (lane >= 36 && lane < 42) a = -a;
+    if (lane < 36) sh.H[6 * i + j] = a;
+    if (lane == 27) sh.E = tot;
+    if (lane == 28) { sh.inl = (int)tot; sh.outl = n - (int)tot; }
+    double dx[6];
+    wave_solve6(a, lane, dx);
+    if (lane == 0) {
+      double D[12], Tn[12];
+      v2t(dx, D);
+      tf_mul(D, T, Tn);
+      double R[9], RtR[9];
+#pragma unroll
+      for (int ii = 0; ii < 3; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) R[3 * ii + jj] = Tn[4 * ii + jj];
+#pragma unroll
+      for (int ii = 0; ii < 3; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {
+          RtR[3 * ii + jj] = (R[ii] * R[jj] + R[3 + ii] * R[3 + jj]) + R[6 + ii] * R[6 + jj];
+          if (ii == jj) RtR[3 * ii + jj] -= 1;
+        }
+#pragma unroll
+      for (int ii = 0; ii < 3; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj)
+          Tn[4 * ii + jj] = R[3 * ii + jj] - 0.5 * ((R[3 * ii] * RtR[jj] + R[3 * ii + 1] * RtR[3 + jj]) + R[3 * ii + 2] * RtR[6 + jj]);
+#pragma unroll
+      for (int k = 0; k < 12; ++k) sh.T[k] = Tn[k];
+      ++sh.its;
+    }
   }
   __syncthreads();
 }

@@ -348,20 +348,25 @@ __device__ void wg_stereo(const DevCfg& c, const DevBuf& b, int s, FrameShared& 
       atomicMax(bin_occ + rb * c.cols_bin + cb, j);
     }
     __syncthreads();
+    // bin id / disparity / distance of every candidate, once (match[] is free again: reuse it)
+    for (int q = tid; q < n_cand; q += VS_WG) {
+      const int i = sc[4 * q];
+      const int xl = kxyL[2 * i], yl = kxyL[2 * i + 1];
+      const int rb = min((int)rint((double)yl / bin), c.rows_bin - 1);
+      const int cb = min((int)rint((double)xl / bin), c.cols_bin - 1);
+      match[2 * q] = rb * c.cols_bin + cb;
+      match[2 * q + 1] = ((xl - kxyR[2 * sc[4 * q + 1]]) << 16) | (sc[4 * q + 2] & 0xFFFF);
+    }
+    __syncthreads();
     // one thread per bin replays its candidates in sweep order (the rule is not an argmax)
     for (int k = tid; k < nb; k += VS_WG) {
       int occ = ld_relaxed(bin_occ + k);
       if (occ >= 0) { bin_occ[k] = -2 - occ; continue; }  // tracked occupant: never replaced
       int win = -1, wdisp = 0, wdist = 0;
-      const int rbk = k / c.cols_bin, cbk = k - rbk * c.cols_bin;
       for (int q = 0; q < n_cand; ++q) {
-        const int i = sc[4 * q];
-        const int xl = kxyL[2 * i], yl = kxyL[2 * i + 1];
-        const int rb = min((int)rint((double)yl / bin), c.rows_bin - 1);
-        if (rb != rbk) continue;
-        const int cb = min((int)rint((double)xl / bin), c.cols_bin - 1);
-        if (cb != cbk) continue;
-        const int disp = xl - kxyR[2 * sc[4 * q + 1]], dist = sc[4 * q + 2];
+        if (match[2 * q] != k) continue;
+        const int pk = match[2 * q + 1];
+        const int disp = pk >> 16, dist = pk & 0xFFFF;
         if (win < 0 || (disp > wdisp && dist <= wdist)) { win = q; wdisp = disp; wdist = dist; }
       }
       bin_occ[k] = win;  // -1 empty, >= 0 candidate index
@@ -603,4 +608,114 @@ __global__ __launch_bounds__(VS_WG) void k_frame(const DevCfg c, const DevBuf b)
     for (int k = 0; k < 12; ++k) { info.camera_left_to_world[k] = c2w[k]; info.previous_to_current[k] = prior[k]; }
     if (f < VS_POSE_LOG) { double* pl = b.pose_log + ((size_t)s * VS_POSE_LOG + f) * 12; for (int k = 0; k < 12; ++k) pl[k] = c2w[k]; }
   }
+}
+
+// ==============================================================================================
+// Stage-granular entry points: the same device functions, one reference virtual per launch, with the
+// control flow left to the caller (shim/proslam_hip_plugin.h keeps the reference's PoseTracker3D logic).
+// ==============================================================================================
+enum { VS_STAGE_TRACK = 1, VS_STAGE_ALIGN = 2, VS_STAGE_PRUNE_RECOVER = 3, VS_STAGE_UPDATE = 4, VS_STAGE_STEREO = 5 };
+
+// WorldMap::createFrame + the bookkeeping PoseTracker3D::compute does before initialize() (:36-77)
+__global__ __launch_bounds__(256) void k_begin(const DevCfg c, const DevBuf b) {
+  const int s = blockIdx.x, tid = threadIdx.x;
+  StreamState& st = b.st[s];
+  const int f = st.frame_count;
+  if (st.has_prev) {
+    const PtView pv = pts_of(c, b, s, st.cur);
+    const int P = *pv.n;
+    for (int i = tid; i < P; i += blockDim.x) pv.meta[(size_t)i * META + M_NEXT] = 0;
+  }
+  if (tid == 0) {
+    set_pose(c, b, s, f, st.pose);
+    st.n_trk = 0; st.n_lost = 0; st.n_tracked_landmarks = 0; st.n_cur = 0; st.n_active = 0; st.al_n = 0;
+    st.aligner_valid = 0; st.n_after_prune = 0; st.n_recovered = 0; st.n_new = 0; st.track_calls = 0;
+    st.al_inliers = 0; st.al_outliers = 0; st.al_iterations = 0; st.al_converged = 0; st.al_total_error = 0;
+    vslam_frame_info& info = b.info[s];
+    info.status_at_start = st.status; info.fallback = 0; info.track_broken = 0;
+  }
+}
+
+__global__ __launch_bounds__(VS_WG) void k_stage(const DevCfg c, const DevBuf b, int stage, int arg) {
+  __shared__ FrameShared sh;
+  const int s = blockIdx.x, tid = threadIdx.x;
+  StreamState& st = b.st[s];
+  vslam_frame_info& info = b.info[s];
+  const int f = st.frame_count;
+  const int pb_prev = st.cur, pb_cur = st.cur ^ 1;
+  if (tid == 0) {
+    sh.n_trk = st.n_trk; sh.n_lost = st.n_lost; sh.n_lm = st.n_tracked_landmarks; sh.n_cur = st.n_cur; sh.n_cand = 0;
+    sh.E = st.al_total_error; sh.inl = st.al_inliers; sh.outl = st.al_outliers; sh.its = 0; sh.conv = 0; sh.flag = 0;
+  }
+  __syncthreads();
+  if (stage == VS_STAGE_TRACK) {
+    if (!st.has_prev) return;
+    double T[12];
+    for (int k = 0; k < 12; ++k) T[k] = st.prior[k];
+    const double tau = st.tau_track;
+    wg_track_resolve(c, b, s, sh, pb_prev, T, st.win, tau, st.tau_tri, arg);
+    if (tid == 0) {
+      st.n_trk = sh.n_trk; st.n_lost = sh.n_lost; st.n_tracked_landmarks = sh.n_lm; st.aligner_valid = 0; st.tau_gen = tau;
+      st.al_n = 0; st.track_calls += 1;
+      info.n_tracked = sh.n_trk; info.n_lost = sh.n_lost; info.n_tracked_landmarks = sh.n_lm; info.track_attempts = st.track_calls;
+      info.aligner_ran = 0;
+    }
+  } else if (stage == VS_STAGE_ALIGN) {
+    if (!st.has_prev) return;
+    double T0[12];
+    for (int k = 0; k < 12; ++k) T0[k] = st.prior[k];
+    wg_align(c, b, s, sh, pb_prev, arg != 0, T0);
+    if (tid == 0) {
+      st.al_n = sh.n_trk; st.al_inliers = sh.inl; st.al_outliers = sh.outl; st.al_iterations = sh.its; st.al_converged = sh.conv;
+      st.al_total_error = sh.E; st.aligner_valid = 1;
+      for (int k = 0; k < 12; ++k) st.al_T[k] = sh.T[k];
+      for (int k = 0; k < 36; ++k) st.al_H[k] = sh.H[k];
+      info.aligner_ran = 1; info.aligner_iterations = sh.its; info.aligner_converged = sh.conv; info.n_inliers = sh.inl;
+      info.n_outliers = sh.outl; info.total_error = sh.E;
+    }
+  } else if (stage == VS_STAGE_PRUNE_RECOVER) {
+    if (tid == 0) set_pose(c, b, s, f, st.pose);   // Frame::setRobotToWorld happened on the host side
+    __syncthreads();
+    if (!st.has_prev) return;
+    wg_prune(c, b, s, sh, pb_prev, pb_cur, st.aligner_valid != 0);
+    const int n_after = sh.n_cur;
+    int n_rec = 0;
+    if (arg) { wg_recover(c, b, s, sh, pb_prev, pb_cur, hpose_of(c, b, s, f) + 12, st.tau_gen, st.tau_tri); n_rec = sh.flag; }
+    if (tid == 0) {
+      st.n_cur = sh.n_cur; st.n_after_prune = n_after; st.n_recovered = n_rec;
+      info.n_after_prune = n_after; info.n_recovered = n_rec; info.n_points = sh.n_cur;
+    }
+  } else if (stage == VS_STAGE_UPDATE) {
+    wg_update_points(c, b, s, sh, pb_cur, f);
+    if (tid == 0) { st.n_active = sh.n_lm; info.n_active_landmarks = sh.n_lm; }
+  } else if (stage == VS_STAGE_STEREO) {
+    wg_stereo(c, b, s, sh, pb_cur, st.tau_tri, f);
+    if (tid == 0) {
+      const double* c2w = hpose_of(c, b, s, f);
+      *pts_of(c, b, s, pb_cur).n = sh.n_cur;
+      st.n_cur = sh.n_cur; st.n_new = sh.n_cand;
+      st.n_tracked_landmarks_prev = st.n_active;
+      st.frame_count = f + 1; st.has_prev = 1; st.cur = pb_cur;
+      info.frame_index = f + 1; info.status = st.status;
+      info.n_keypoints_left = b.n_kp[s * 2]; info.n_keypoints_right = b.n_kp[s * 2 + 1];
+      int rl = 0, rr = 0;
+      for (int r = 0; r < c.n_regions; ++r) { rl += st.raw_count[0][r]; rr += st.raw_count[1][r]; info.thresholds[r] = st.thr[r]; }
+      info.n_detected_left = rl; info.n_detected_right = rr;
+      info.n_new_stereo = sh.n_cand; info.n_points = sh.n_cur; info.window_pixels = st.win; info.error_flags = st.error_flags;
+      info.tau_track = st.tau_track; info.tau_triangulation = st.tau_tri;
+      for (int k = 0; k < 12; ++k) { info.camera_left_to_world[k] = c2w[k]; info.previous_to_current[k] = st.prior[k]; }
+      if (f < VS_POSE_LOG) { double* pl = b.pose_log + ((size_t)s * VS_POSE_LOG + f) * 12; for (int k = 0; k < 12; ++k) pl[k] = c2w[k]; }
+    }
+  }
+}
+
+// setters of the tracker-owned state (one thread)
+__global__ void k_set_tracker_state(const DevBuf b, int s, int status, int win, double tau, const double* prior) {
+  StreamState& st = b.st[s];
+  st.status = status; st.win = win; st.tau_track = tau;
+  for (int k = 0; k < 12; ++k) st.prior[k] = prior[k];
+}
+__global__ void k_set_pose(const DevBuf b, int s, const double* pose) {
+  StreamState& st = b.st[s];
+  for (int k = 0; k < 12; ++k) st.pose[k] = pose[k];
 }

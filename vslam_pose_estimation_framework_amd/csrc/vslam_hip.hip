@@ -289,7 +289,7 @@ static int launch_image_pipeline(vslam_ctx* c) {
 }
 static int launch_frame(vslam_ctx* c) {
   const int gx = std::max(4, std::min(128, 2048 / c->B));
-  { KernelTimer t(c, 3); hipLaunchKernelGGL(k_track_candidates, dim3(gx, c->B), dim3(256), 0, c->stream, c->cfg, c->buf); }
+  { KernelTimer t(c, 3); hipLaunchKernelGGL(k_track_candidates, dim3(gx, c->B), dim3(256), 0, c->stream, c->cfg, c->buf, -1); }
   { KernelTimer t(c, 4); hipLaunchKernelGGL(k_frame, dim3(c->B), dim3(VS_WG), 0, c->stream, c->cfg, c->buf); }
   HIP_TRY(c, hipGetLastError());
   return VSLAM_OK;
@@ -583,13 +583,25 @@ VS_API int vslam_align_points(vslam_ctx* c, int32_t n, const double* moving, con
   return rc;
 }
 
-// ---- stage entry points (driven by the shim's host-side PoseTracker3D) ------------------------------
-// Round 1: the stage-granular calls are served by the fused frame kernel; see DESIGN.md "Boundary".
+// ---- stage entry points (the reference's plug-in virtuals; control flow stays with the caller) ----------
+static int launch_begin(vslam_ctx* c) {
+  hipLaunchKernelGGL(k_begin, dim3(c->B), dim3(256), 0, c->stream, c->cfg, c->buf);
+  HIP_TRY(c, hipGetLastError());
+  return VSLAM_OK;
+}
+static int launch_stage(vslam_ctx* c, int stage, int arg) {
+  hipLaunchKernelGGL(k_stage, dim3(c->B), dim3(VS_WG), 0, c->stream, c->cfg, c->buf, stage, arg);
+  HIP_TRY(c, hipGetLastError());
+  return VSLAM_OK;
+}
 VS_API int vslam_frame_begin(vslam_ctx* c, const uint8_t* L, const uint8_t* R, int32_t row_stride, size_t image_stride, int on_device) {
   if (!c) return VSLAM_ERR_INVALID;
+  if (c->sticky != VSLAM_OK) return c->sticky;
+  HIP_TRY(c, hipSetDevice(c->device));
   int rc = on_device ? set_images_device(c, L, R, row_stride, image_stride) : upload_images(c, L, R, row_stride, image_stride);
   if (rc != VSLAM_OK) return rc;
   rc = launch_image_pipeline(c);
+  if (rc == VSLAM_OK) rc = launch_begin(c);
   c->frame_begun = rc == VSLAM_OK;
   return rc;
 }
@@ -599,14 +611,48 @@ VS_API int vslam_frame_finish(vslam_ctx* c) {
   c->frame_begun = false;
   return launch_frame(c);
 }
-
-// -- finer-grained stage calls: not wired yet (round-1 scope: fused frame kernel) ----------------------
-#define VS_TODO_STAGE(name, ...) VS_API int name(__VA_ARGS__) { return fail(c, VSLAM_ERR_STATE, #name ": stage-granular call not available in this build; use vslam_frame_begin + vslam_frame_finish"); }
-VS_TODO_STAGE(vslam_frame_restore, vslam_ctx* c)
-VS_TODO_STAGE(vslam_track, vslam_ctx* c, int)
-VS_TODO_STAGE(vslam_align, vslam_ctx* c, int)
-VS_TODO_STAGE(vslam_prune_recover, vslam_ctx* c)
-VS_TODO_STAGE(vslam_update_points, vslam_ctx* c)
-VS_TODO_STAGE(vslam_stereo_new, vslam_ctx* c)
-VS_TODO_STAGE(vslam_set_tracker_state, vslam_ctx* c, int, int, const double*, int, double)
-VS_TODO_STAGE(vslam_set_pose, vslam_ctx* c, int, const double*)
+#define NEED_FRAME(name) if (!c) return VSLAM_ERR_INVALID; if (!c->frame_begun) return fail(c, VSLAM_ERR_STATE, name " called before vslam_frame_begin")
+VS_API int vslam_frame_restore(vslam_ctx* c) {
+  // initialize(frame, false) only rebuilds the two feature stores; the device stores are rebuilt from the
+  // keypoint arrays by every vslam_track call (kill / used flags are recomputed), so nothing to launch.
+  NEED_FRAME("vslam_frame_restore");
+  return VSLAM_OK;
+}
+VS_API int vslam_track(vslam_ctx* c, int by_appearance) {
+  NEED_FRAME("vslam_track");
+  const int gx = std::max(4, std::min(128, 2048 / c->B));
+  hipLaunchKernelGGL(k_track_candidates, dim3(gx, c->B), dim3(256), 0, c->stream, c->cfg, c->buf, by_appearance ? 1 : 0);
+  return launch_stage(c, VS_STAGE_TRACK, by_appearance ? 1 : 0);
+}
+VS_API int vslam_align(vslam_ctx* c, int inverse_depth) { NEED_FRAME("vslam_align"); return launch_stage(c, VS_STAGE_ALIGN, inverse_depth); }
+VS_API int vslam_prune_recover(vslam_ctx* c) { NEED_FRAME("vslam_prune_recover"); return launch_stage(c, VS_STAGE_PRUNE_RECOVER, c->cfg.c.enable_landmark_recovery); }
+VS_API int vslam_update_points(vslam_ctx* c) { NEED_FRAME("vslam_update_points"); return launch_stage(c, VS_STAGE_UPDATE, 0); }
+VS_API int vslam_stereo_new(vslam_ctx* c) {
+  NEED_FRAME("vslam_stereo_new");
+  c->frame_begun = false;  // compute() is the last call PoseTracker3D::compute makes on a frame
+  return launch_stage(c, VS_STAGE_STEREO, 0);
+}
+VS_API int vslam_set_tracker_state(vslam_ctx* c, int s, int status, const double prior[12], int win, double tau) {
+  int rc = check_stream(c, s);
+  if (rc) return rc;
+  if (!prior) return fail(c, VSLAM_ERR_INVALID, "null prior");
+  double* d = nullptr;
+  HIP_TRY(c, hipMallocAsync((void**)&d, 12 * sizeof(double), c->stream));
+  HIP_TRY(c, hipMemcpyAsync(d, prior, 12 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_set_tracker_state, dim3(1), dim3(1), 0, c->stream, c->buf, s, status, win, tau, d);
+  HIP_TRY(c, hipFreeAsync(d, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // `prior` is caller memory
+  return VSLAM_OK;
+}
+VS_API int vslam_set_pose(vslam_ctx* c, int s, const double pose[12]) {
+  int rc = check_stream(c, s);
+  if (rc) return rc;
+  if (!pose) return fail(c, VSLAM_ERR_INVALID, "null pose");
+  double* d = nullptr;
+  HIP_TRY(c, hipMallocAsync((void**)&d, 12 * sizeof(double), c->stream));
+  HIP_TRY(c, hipMemcpyAsync(d, pose, 12 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(1), 0, c->stream, c->buf, s, d);
+  HIP_TRY(c, hipFreeAsync(d, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return VSLAM_OK;
+}
