@@ -52,6 +52,7 @@ def gather_poses(local_poses, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local_poses
     world = dist.get_world_size(group)
-    out = torch.empty((world,) + tuple(local_poses.shape), dtype=local_poses.dtype, device=local_poses.device)
+    out = torch.empty((world * local_poses.shape[0],) + tuple(local_poses.shape[1:]), dtype=local_poses.dtype,
+                      device=local_poses.device)
     dist.all_gather_into_tensor(out, local_poses.contiguous(), group=group)
-    return out.reshape((world * local_poses.shape[0],) + tuple(local_poses.shape[1:]))
+    return out
