@@ -42,7 +42,6 @@ struct DevCfg {
 // tracker + generator state carried from frame to frame (PoseTracker3D / BaseFramePointGenerator members)
 struct StreamState {
   int32_t thr[VSLAM_MAX_REGIONS];        // FastDetector thresholds in effect for the next detect
-  int32_t raw_count[2][VSLAM_MAX_REGIONS];
   int32_t status;                        // _status
   int32_t win;                           // _projection_tracking_distance_pixels
   int32_t frame_count;                   // frames processed
@@ -70,6 +69,13 @@ struct StreamState {
   int32_t n_cur, n_active, n_after_prune, n_recovered, n_new, track_calls;
 };
 
+// detector bookkeeping of one frame's image pipeline (double-buffered with the image products so that frame
+// t+1 can be detected/described while frame t is still being tracked)
+struct ImgInfo {
+  int32_t thr_after[VSLAM_MAX_REGIONS];   // thresholds after adjustDetectorThresholds of this frame
+  int32_t raw_count[2][VSLAM_MAX_REGIONS];
+};
+
 struct DevBuf {
   // current input images (device pointers)
   const uint8_t* img[2];
@@ -86,6 +92,7 @@ struct DevBuf {
   int32_t* rowcell;    // [B][2][rows][CW+1]
   uint8_t* used;       // [B][2][NMAX]
   int32_t* kill;       // [B][2][NMAX]
+  ImgInfo* iinfo;      // [B]
   // per-stream state
   StreamState* st;
   vslam_frame_info* info;

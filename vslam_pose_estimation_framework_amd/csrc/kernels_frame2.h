@@ -416,6 +416,13 @@ __device__ __forceinline__ void set_pose(const DevCfg& c, const DevBuf& b, int s
   tf_inverse(c2w, hp + 12);
 }
 
+// triangulation-distance rule of initialize() (stereo_framepoint_generator.cpp:109-125); frame status = tracker status
+__device__ __forceinline__ double tau_tri_rule(const DevCfg& c, int status, int n_left) {
+  if (status == VSLAM_LOCALIZING) return fmin(0.1 * 256, c.c.maximum_matching_distance_triangulation);
+  const double ratio = fmin((double)n_left / (double)c.target_kp, 1.0);
+  return fmax(ratio * c.c.maximum_matching_distance_triangulation, 0.1 * 256);
+}
+
 __global__ __launch_bounds__(VS_WG) void k_frame(const DevCfg c, const DevBuf b) {
   __shared__ FrameShared sh;
   __shared__ int wcnt[VS_WG / 64];
@@ -437,7 +444,7 @@ __global__ __launch_bounds__(VS_WG) void k_frame(const DevCfg c, const DevBuf b)
   }
   double prior[12];
   for (int k = 0; k < 12; ++k) prior[k] = st.prior[k];
-  const double tau_tri = st.tau_tri;
+  const double tau_tri = tau_tri_rule(c, status0, b.n_kp[s * 2]);
   int win = st.win;
   double tau_track = st.tau_track;          // tracker's _current_descriptor_distance_tracking
   double tau_gen = tau_track;               // generator's _maximum_descriptor_distance_tracking (last _track)
@@ -591,14 +598,14 @@ __global__ __launch_bounds__(VS_WG) void k_frame(const DevCfg c, const DevBuf b)
     st.ticks[4] += wall_clock64() - ts;
     const double* c2w = hpose_of(c, b, s, f);
     *pts_of(c, b, s, pb_cur).n = sh.n_cur;
-    st.status = status; st.win = win; st.tau_track = tau_track;
+    st.status = status; st.win = win; st.tau_track = tau_track; st.tau_tri = tau_tri;
     for (int k = 0; k < 12; ++k) { st.prior[k] = prior[k]; st.pose[k] = c2w[k]; }
     st.n_tracked_landmarks_prev = n_active;
     st.frame_count = f + 1; st.has_prev = 1; st.cur = pb_cur; st.aligner_valid = aligner_valid ? 1 : 0;
     info.frame_index = f + 1; info.status = status; info.status_at_start = status0;
     info.n_keypoints_left = b.n_kp[s * 2]; info.n_keypoints_right = b.n_kp[s * 2 + 1];
     int rl = 0, rr = 0;
-    for (int r = 0; r < c.n_regions; ++r) { rl += st.raw_count[0][r]; rr += st.raw_count[1][r]; info.thresholds[r] = st.thr[r]; }
+    for (int r = 0; r < c.n_regions; ++r) { rl += b.iinfo[s].raw_count[0][r]; rr += b.iinfo[s].raw_count[1][r]; info.thresholds[r] = b.iinfo[s].thr_after[r]; }
     for (int r = c.n_regions; r < VSLAM_MAX_REGIONS; ++r) info.thresholds[r] = 0;
     info.n_detected_left = rl; info.n_detected_right = rr;
     info.track_attempts = sh.attempts; info.n_after_prune = n_after_prune; info.n_recovered = n_recovered;
@@ -628,6 +635,7 @@ __global__ __launch_bounds__(256) void k_begin(const DevCfg c, const DevBuf b) {
   }
   if (tid == 0) {
     set_pose(c, b, s, f, st.pose);
+    st.tau_tri = tau_tri_rule(c, st.status, b.n_kp[s * 2]);
     st.n_trk = 0; st.n_lost = 0; st.n_tracked_landmarks = 0; st.n_cur = 0; st.n_active = 0; st.al_n = 0;
     st.aligner_valid = 0; st.n_after_prune = 0; st.n_recovered = 0; st.n_new = 0; st.track_calls = 0;
     st.al_inliers = 0; st.al_outliers = 0; st.al_iterations = 0; st.al_converged = 0; st.al_total_error = 0;
@@ -699,7 +707,7 @@ __global__ __launch_bounds__(VS_WG) void k_stage(const DevCfg c, const DevBuf b,
       info.frame_index = f + 1; info.status = st.status;
       info.n_keypoints_left = b.n_kp[s * 2]; info.n_keypoints_right = b.n_kp[s * 2 + 1];
       int rl = 0, rr = 0;
-      for (int r = 0; r < c.n_regions; ++r) { rl += st.raw_count[0][r]; rr += st.raw_count[1][r]; info.thresholds[r] = st.thr[r]; }
+      for (int r = 0; r < c.n_regions; ++r) { rl += b.iinfo[s].raw_count[0][r]; rr += b.iinfo[s].raw_count[1][r]; info.thresholds[r] = b.iinfo[s].thr_after[r]; }
       info.n_detected_left = rl; info.n_detected_right = rr;
       info.n_new_stereo = sh.n_cand; info.n_points = sh.n_cur; info.window_pixels = st.win; info.error_flags = st.error_flags;
       info.tau_track = st.tau_track; info.tau_triangulation = st.tau_tri;

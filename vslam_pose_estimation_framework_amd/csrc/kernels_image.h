@@ -73,26 +73,16 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* sh, int* total) 
 // tile with a 4 px halo (FAST ring 3 + NMS 1 == box radius 4) is staged once in LDS.
 // HBM traffic per pixel: 1 B read, 2 B box write, 1/8 B mask write.
 // ==============================================================================================
-__device__ __forceinline__ int fast_score_tile(const uint8_t (*t)[80], int ly, int lx, int thr) {
-  // (ly,lx) = centre in tile coordinates (tile origin = image (x0-4, y0-4))
+// v - ring pixel for the 16 positions of the Bresenham circle (OpenCV order) around tile position (ly,lx)
+__device__ __forceinline__ void fast_ring_diffs(const uint8_t (*t)[80], int ly, int lx, int* d) {
   const int v = t[ly][lx];
-  int d[16];
   d[0] = v - t[ly + 3][lx];      d[1] = v - t[ly + 3][lx + 1];  d[2] = v - t[ly + 2][lx + 2];  d[3] = v - t[ly + 1][lx + 3];
   d[4] = v - t[ly][lx + 3];      d[5] = v - t[ly - 1][lx + 3];  d[6] = v - t[ly - 2][lx + 2];  d[7] = v - t[ly - 3][lx + 1];
   d[8] = v - t[ly - 3][lx];      d[9] = v - t[ly - 3][lx - 1];  d[10] = v - t[ly - 2][lx - 2]; d[11] = v - t[ly - 1][lx - 3];
   d[12] = v - t[ly][lx - 3];     d[13] = v - t[ly + 1][lx - 3]; d[14] = v - t[ly + 2][lx - 2]; d[15] = v - t[ly + 3][lx - 1];
-  unsigned dark = 0, bright = 0;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    dark |= (d[k] > thr ? 1u : 0u) << k;
-    bright |= (d[k] < -thr ? 1u : 0u) << k;
-  }
-  unsigned m = dark | (dark << 16);
-  unsigned r = m & (m >> 1); r &= r >> 2; r &= r >> 4; r &= m >> 8;
-  unsigned m2 = bright | (bright << 16);
-  unsigned r2 = m2 & (m2 >> 1); r2 &= r2 >> 2; r2 &= r2 >> 4; r2 &= m2 >> 8;
-  if (((r | r2) & 0xFFFFu) == 0) return 0;
-  // cornerScore<16>: max over the 16 nine-arcs of the arc minimum (dark) / min of the arc maximum
+}
+// cornerScore<16> of a pixel known to be a corner: max(thr, max_arcs min d, -min_arcs max d) - 1
+__device__ __forceinline__ int fast_corner_score(const int* d, int thr) {
   int mn2[16], mx2[16], mn4[16], mx4[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
@@ -110,6 +100,21 @@ __device__ __forceinline__ int fast_score_tile(const uint8_t (*t)[80], int ly, i
   const int b0 = min(-a0, Bm);
   return -b0 - 1;
 }
+// 9-contiguous-of-16 test on wave-wide predicate masks: bit l of m[k] = "ring pixel k of lane l's pixel passes".
+// Pure 64-bit scalar logic (SALU), no per-lane bit assembly.
+__device__ __forceinline__ unsigned long long arc9_any(const unsigned long long* m) {
+  unsigned long long r1[16], r2[16], r4[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) r1[k] = m[k] & m[(k + 1) & 15];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) r2[k] = r1[k] & r1[(k + 2) & 15];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) r4[k] = r2[k] & r2[(k + 4) & 15];
+  unsigned long long any = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) any |= r4[k] & m[(k + 8) & 15];
+  return any;
+}
 
 // threshold of the detector region whose FAST-valid area (ROI minus 3 px) contains (x,y), or -1
 __device__ __forceinline__ int region_threshold(const DevCfg& c, const int32_t* thr, int x, int y) {
@@ -120,50 +125,100 @@ __device__ __forceinline__ int region_threshold(const DevCfg& c, const int32_t* 
   return -1;
 }
 
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 pk_min(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ s16x2 pk_max(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
+
+// FAST-9/16 without branches, two pixels per lane in packed i16 (v_pk_sub/min/max_i16): with
+// A = max over the 16 nine-arcs of min(d), Bm = min over arcs of max(d) (d = centre - ring pixel), the pixel is
+// a corner iff A > t or -Bm > t, and cornerScore = max(t, A, -Bm) - 1 — one sliding min/max table gives both.
+__device__ __forceinline__ void fast_pair_scores(const uint8_t (*t)[80], int ly0, int ly1, int lx, int thr0, int thr1,
+                                                 int* s0, int* s1) {
+  const int dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+  const int dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+  const s16x2 v = {(short)t[ly0][lx], (short)t[ly1][lx]};
+  s16x2 d[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const s16x2 p = {(short)t[ly0 + dy[k]][lx + dx[k]], (short)t[ly1 + dy[k]][lx + dx[k]]};
+    d[k] = v - p;
+  }
+  s16x2 mn2[16], mx2[16], mn4[16], mx4[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { mn2[k] = pk_min(d[k], d[(k + 1) & 15]); mx2[k] = pk_max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { mn4[k] = pk_min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = pk_max(mx2[k], mx2[(k + 2) & 15]); }
+  s16x2 A = {-1000, -1000}, Bm = {1000, 1000};
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    A = pk_max(A, pk_min(pk_min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]));
+    Bm = pk_min(Bm, pk_max(pk_max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]));
+  }
+  const int a0 = A.x, b0 = -Bm.x, a1 = A.y, b1 = -Bm.y;
+  *s0 = (thr0 >= 0 && (a0 > thr0 || b0 > thr0)) ? max(thr0, max(a0, b0)) - 1 : 0;
+  *s1 = (thr1 >= 0 && (a1 > thr1 || b1 > thr1)) ? max(thr1, max(a1, b1)) - 1 : 0;
+}
+
 __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b) {
-  __shared__ uint8_t tile[VS_TILE_H + 8][80];
-  __shared__ uint8_t sc[VS_TILE_H + 2][68];
-  __shared__ uint16_t hs[VS_TILE_H + 8][VS_TILE_W];
+  __shared__ __align__(16) uint8_t tile[VS_TILE_H + 8][80];
+  __shared__ __align__(4) uint8_t sc[VS_TILE_H + 2][68];
+  __shared__ __align__(8) uint16_t hs[VS_TILE_H + 8][VS_TILE_W];
   __shared__ int32_t s_thr[VSLAM_MAX_REGIONS];
   const int tx = blockIdx.x, ty = blockIdx.y, s = blockIdx.z >> 1, side = blockIdx.z & 1;
   const int x0 = tx * VS_TILE_W, y0 = ty * VS_TILE_H;
   const int rows = c.c.rows, cols = c.c.cols;
   const uint8_t* img = b.img[side] + (size_t)s * b.img_stream_stride;
   const int stride = b.img_row_stride;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (tid < c.n_regions) s_thr[tid] = min(max(b.st[s].thr[tid], 0), 255);
-  // stage the (64+8) x (16+8) tile, coordinates clamped (clamped pixels never reach a valid output)
-  for (int i = tid; i < (VS_TILE_H + 8) * 72; i += 256) {
-    const int r = i / 72, cc = i - r * 72;
-    const int gy = min(max(y0 - 4 + r, 0), rows - 1), gx = min(max(x0 - 4 + cc, 0), cols - 1);
-    tile[r][cc] = img[(size_t)gy * stride + gx];
-  }
-  __syncthreads();
-  // scores on the 66 x 18 neighbourhood (tile + 1 px NMS halo)
-  for (int i = tid; i < (VS_TILE_H + 2) * 66; i += 256) {
-    const int r = i / 66, cc = i - r * 66;
-    const int gx = x0 - 1 + cc, gy = y0 - 1 + r;
-    int sv = 0;
-    const int thr = region_threshold(c, s_thr, gx, gy);
-    if (thr >= 0) sv = fast_score_tile(tile, r + 3, cc + 3, thr);
-    sc[r][cc] = (uint8_t)sv;
-  }
-  // horizontal 9-sums for the box image
-  for (int i = tid; i < (VS_TILE_H + 8) * VS_TILE_W; i += 256) {
-    const int r = i >> 6, cc = i & 63;
-    int acc = 0;
+  // ---- stage the (64+8) x (16+8) u8 tile: aligned dwords in the interior, clamped bytes at the image border ----
+  const bool aligned = ((stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(img) & 3) == 0);
+  for (int i = tid; i < (VS_TILE_H + 8) * 18; i += 256) {
+    const int r = i / 18, q = i - r * 18;
+    const int gy = min(max(y0 - 4 + r, 0), rows - 1), gx0 = x0 - 4 + 4 * q;
+    uint32_t v;
+    if (aligned && gx0 >= 0 && gx0 + 3 < cols) {
+      v = *reinterpret_cast<const uint32_t*>(img + (size_t)gy * stride + gx0);
+    } else {
+      v = 0;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) acc += tile[r][cc + k];
-    hs[r][cc] = (uint16_t)acc;
+      for (int k = 0; k < 4; ++k) v |= (uint32_t)img[(size_t)gy * stride + min(max(gx0 + k, 0), cols - 1)] << (8 * k);
+    }
+    *reinterpret_cast<uint32_t*>(&tile[r][4 * q]) = v;
   }
   __syncthreads();
-  const int lane = tid & 63, w = tid >> 6;
+  // ---- FAST scores on the 66 x 18 region (tile + 1 px NMS halo): lane = column, two rows (r, r+9) per lane -----------
+  for (int i = tid; i < 9 * 66; i += 256) {
+    const int rp = i / 66, cc = i - rp * 66;
+    const int gx = x0 - 1 + cc, gy0 = y0 - 1 + rp, gy1 = gy0 + 9;
+    int sv0, sv1;
+    fast_pair_scores(tile, rp + 3, rp + 12, cc + 3, region_threshold(c, s_thr, gx, gy0), region_threshold(c, s_thr, gx, gy1), &sv0, &sv1);
+    sc[rp][cc] = (uint8_t)sv0;
+    sc[rp + 9][cc] = (uint8_t)sv1;
+  }
+  // ---- horizontal 9-sums, four outputs per thread from three aligned dwords -----------------------------------------
+  for (int i = tid; i < (VS_TILE_H + 8) * 16; i += 256) {
+    const int r = i >> 4, q = i & 15;
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(&tile[r][4 * q]);
+    const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+    const uint32_t s0 = __builtin_amdgcn_sad_u8(w0, 0u, __builtin_amdgcn_sad_u8(w1, 0u, w2 & 255u));
+    const uint32_t s1 = s0 - (w0 & 255u) + ((w2 >> 8) & 255u);
+    const uint32_t s2 = s1 - ((w0 >> 8) & 255u) + ((w2 >> 16) & 255u);
+    const uint32_t s3 = s2 - ((w0 >> 16) & 255u) + (w2 >> 24);
+    *reinterpret_cast<uint2*>(&hs[r][4 * q]) = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
+  }
+  __syncthreads();
+  // ---- strict 3x3 NMS -> 1 bit / pixel, sparse scores, vertical 9-sums (sliding) -> u16 box image ----------------------
   unsigned long long* mask = mask_of(c, b, s, side);
   uint8_t* score8 = score_of(c, b, s, side);
   uint16_t* box = box_of(c, b, s, side);
+  const int gx = x0 + lane;
+  int acc = 0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc += hs[w * 4 + k][lane];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int r = w * 4 + j, gy = y0 + r, gx = x0 + lane;
+    const int r = w * 4 + j, gy = y0 + r;
     const int v = sc[r + 1][lane + 1];
     bool keep = v > 0;
     if (keep) {
@@ -174,13 +229,9 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
     if (gy < rows) {
       if (lane == 0) mask[(size_t)gy * c.TX + tx] = m;
       if (keep) score8[(size_t)gy * c.bstride + gx] = (uint8_t)v;
-      if (gx < cols) {
-        int acc = 0;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) acc += hs[r + k][lane];
-        box[(size_t)gy * c.bstride + gx] = (uint16_t)acc;
-      }
+      if (gx < cols) box[(size_t)gy * c.bstride + gx] = (uint16_t)acc;
     }
+    if (j < 3) acc += (int)hs[r + 9][lane] - (int)hs[r][lane];
   }
 }
 
@@ -267,7 +318,7 @@ __global__ __launch_bounds__(1024) void k_emit(const DevCfg c, const DevBuf b, i
   }
   if (tid == 0) {
     for (int side = 0; side < 2; ++side)
-      for (int r = 0; r < c.n_regions; ++r) st.raw_count[side][r] = sh_cnt[side][r];
+      for (int r = 0; r < c.n_regions; ++r) b.iinfo[s].raw_count[side][r] = sh_cnt[side][r];
     if (run_controller) {
       // detectKeypoints controller (base_framepoint_generator.cpp:382-415) for L then R with the
       // thresholds that were in effect, then adjustDetectorThresholds (:440-459)
@@ -292,15 +343,8 @@ __global__ __launch_bounds__(1024) void k_emit(const DevCfg c, const DevBuf b, i
         }
         st.thr[r] = (int)rint(acc / 2);
       }
-      // triangulation distance (stereo_framepoint_generator.cpp:109-125); frame status = tracker status
-      const int n_left = b.n_kp[s * 2 + 0];
-      if (st.status == VSLAM_LOCALIZING) {
-        st.tau_tri = fmin(0.1 * 256, c.c.maximum_matching_distance_triangulation);
-      } else {
-        const double ratio = fmin((double)n_left / (double)c.target_kp, 1.0);
-        st.tau_tri = fmax(ratio * c.c.maximum_matching_distance_triangulation, 0.1 * 256);
-      }
     }
+    for (int r = 0; r < c.n_regions; ++r) b.iinfo[s].thr_after[r] = st.thr[r];
   }
 }
 

@@ -20,8 +20,15 @@ struct vslam_ctx {
   DevBuf buf;
   int device = 0;
   int B = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;       // tracker kernels (k_track_candidates, k_frame, stages) + read-back
+  hipStream_t stream_img = nullptr;   // image pipeline (k_fast_box, k_emit, k_brief) + uploads
   bool own_stream = false;
+  // image products are double-buffered: frame t+1 is detected/described while frame t is tracked
+  struct ImgSet { uint16_t* box; uint8_t* score8; unsigned long long* mask; int16_t* kp_xy; uint8_t* kp_score; uint8_t* desc;
+                  int32_t* n_kp; int32_t* rowcell; uint8_t* used; ImgInfo* iinfo; } sets[2];
+  int parity = 0, last_set = 0;
+  hipEvent_t ev_img[2] = {nullptr, nullptr}, ev_frm[2] = {nullptr, nullptr};
+  bool frm_pending[2] = {false, false};
   std::string err;
   std::vector<void*> allocs;
   uint8_t* upload[2] = {nullptr, nullptr};
@@ -66,11 +73,12 @@ static hipEvent_t ev_get(vslam_ctx* c) {
   return e;
 }
 struct KernelTimer {
-  vslam_ctx* c; int k; hipEvent_t a = nullptr;
-  KernelTimer(vslam_ctx* c_, int k_) : c(c_), k(k_) { if (c->timers) { a = ev_get(c); (void)hipEventRecord(a, c->stream); } }
-  ~KernelTimer() { if (a) { hipEvent_t b = ev_get(c); (void)hipEventRecord(b, c->stream); c->evrec.push_back({a, b, k}); } }
+  vslam_ctx* c; int k; hipStream_t st; hipEvent_t a = nullptr;
+  KernelTimer(vslam_ctx* c_, int k_, hipStream_t st_) : c(c_), k(k_), st(st_) { if (c->timers) { a = ev_get(c); (void)hipEventRecord(a, st); } }
+  ~KernelTimer() { if (a) { hipEvent_t b = ev_get(c); (void)hipEventRecord(b, st); c->evrec.push_back({a, b, k}); } }
 };
 static void harvest_events(vslam_ctx* c) {
+  (void)hipStreamSynchronize(c->stream_img);
   (void)hipStreamSynchronize(c->stream);
   for (auto& r : c->evrec) {
     float ms = 0;
@@ -80,6 +88,14 @@ static void harvest_events(vslam_ctx* c) {
   c->evrec.clear();
 }
 
+
+static DevBuf buf_set(const vslam_ctx* c, int set) {
+  DevBuf b = c->buf;
+  const vslam_ctx::ImgSet& q = c->sets[set];
+  b.box = q.box; b.score8 = q.score8; b.mask = q.mask; b.kp_xy = q.kp_xy; b.kp_score = q.kp_score; b.desc = q.desc;
+  b.n_kp = q.n_kp; b.rowcell = q.rowcell; b.used = q.used; b.iinfo = q.iinfo;
+  return b;
+}
 
 // ---- defaults (configurations/configuration_{kitti,euroc}.yaml, src/types/parameters.h) -----------
 static void common_defaults(vslam_config* c) {
@@ -177,8 +193,14 @@ static int init_state(vslam_ctx* c) {
   HIP_TRY(c, hipMemcpyAsync(c->buf.st, st.data(), sizeof(StreamState) * c->B, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemsetAsync(c->buf.info, 0, sizeof(vslam_frame_info) * c->B, c->stream));
   HIP_TRY(c, hipMemsetAsync(c->buf.n_points, 0, sizeof(int32_t) * c->B * 2, c->stream));
-  HIP_TRY(c, hipMemsetAsync(c->buf.n_kp, 0, sizeof(int32_t) * c->B * 2, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream_img));
+  for (int q = 0; q < 2; ++q) {
+    HIP_TRY(c, hipMemsetAsync(c->sets[q].n_kp, 0, sizeof(int32_t) * c->B * 2, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->sets[q].iinfo, 0, sizeof(ImgInfo) * c->B, c->stream));
+    c->frm_pending[q] = false;
+  }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->parity = 0; c->last_set = 0;
   c->frame_begun = false;
   return VSLAM_OK;
 }
@@ -201,8 +223,10 @@ static int create_internal(const vslam_config* cfg, int device, int n_streams, v
   c->device = device;
   c->B = n_streams;
   derive_cfg(*cfg, n_streams, &c->cfg);
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(nullptr, VSLAM_ERR_HIP, "hipStreamCreate failed"); }
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->stream_img, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(nullptr, VSLAM_ERR_HIP, "hipStreamCreate failed"); }
   c->own_stream = true;
+  for (int q = 0; q < 2; ++q) { (void)hipEventCreateWithFlags(&c->ev_img[q], hipEventDisableTiming); (void)hipEventCreateWithFlags(&c->ev_frm[q], hipEventDisableTiming); }
   const DevCfg& d = c->cfg;
   DevBuf& b = c->buf;
   std::memset(&b, 0, sizeof b);
@@ -222,6 +246,23 @@ static int create_internal(const vslam_config* cfg, int device, int n_streams, v
   A(st_match, B * N * 2); A(sc, B * N * 4); A(bin_occ, B * (size_t)d.rows_bin * d.cols_bin);
   A(h_pose, B * Hc * 24); A(h_cam, B * Hc * P * 3); A(h_prev, B * Hc * P);
 #undef A
+  for (int q = 0; q < 2 && e == hipSuccess; ++q) {
+    vslam_ctx::ImgSet& t = c->sets[q];
+    if (q == 0) { t = {b.box, b.score8, b.mask, b.kp_xy, b.kp_score, b.desc, b.n_kp, b.rowcell, b.used, nullptr}; }
+    else {
+      e = dalloc(c, &t.box, S2 * rows * d.bstride);
+      if (e == hipSuccess) e = dalloc(c, &t.score8, S2 * rows * d.bstride);
+      if (e == hipSuccess) e = dalloc(c, &t.mask, S2 * rows * d.TX);
+      if (e == hipSuccess) e = dalloc(c, &t.kp_xy, S2 * N * 2);
+      if (e == hipSuccess) e = dalloc(c, &t.kp_score, S2 * N);
+      if (e == hipSuccess) e = dalloc(c, &t.desc, S2 * N * 32);
+      if (e == hipSuccess) e = dalloc(c, &t.n_kp, S2);
+      if (e == hipSuccess) e = dalloc(c, &t.rowcell, S2 * rows * (d.CW + 1));
+      if (e == hipSuccess) e = dalloc(c, &t.used, S2 * N);
+    }
+    if (e == hipSuccess) e = dalloc(c, &t.iinfo, B);
+  }
+  if (e == hipSuccess) b.iinfo = c->sets[0].iinfo;
   c->up_stride = d.bstride;
   c->up_stream_stride = (size_t)rows * d.bstride;
   if (e == hipSuccess) e = dalloc(c, &c->upload[0], B * c->up_stream_stride);
@@ -248,12 +289,15 @@ VS_API int vslam_create(const vslam_config* cfg, int device, int n_streams, vsla
 VS_API void vslam_destroy(vslam_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream_img);
   (void)hipStreamSynchronize(c->stream);
   for (void* p : c->allocs) (void)hipFree(p);
   for (int i = 0; i < 6; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   harvest_events(c);
   for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
+  for (int q = 0; q < 2; ++q) { if (c->ev_img[q]) (void)hipEventDestroy(c->ev_img[q]); if (c->ev_frm[q]) (void)hipEventDestroy(c->ev_frm[q]); }
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->own_stream && c->stream_img) (void)hipStreamDestroy(c->stream_img);
   delete c;
 }
 VS_API int vslam_reset(vslam_ctx* c) {
@@ -263,14 +307,17 @@ VS_API int vslam_reset(vslam_ctx* c) {
 }
 VS_API int vslam_set_hip_stream(vslam_ctx* c, void* s) {
   if (!c) return VSLAM_ERR_INVALID;
+  (void)hipStreamSynchronize(c->stream_img);
   (void)hipStreamSynchronize(c->stream);
-  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
-  c->stream = (hipStream_t)s;
+  if (c->own_stream) { (void)hipStreamDestroy(c->stream); (void)hipStreamDestroy(c->stream_img); }
+  c->stream = (hipStream_t)s;       // one caller stream: image pipeline and tracker run back to back
+  c->stream_img = (hipStream_t)s;
   c->own_stream = false;
   return VSLAM_OK;
 }
 VS_API int vslam_synchronize(vslam_ctx* c) {
   if (!c) return VSLAM_ERR_INVALID;
+  HIP_TRY(c, hipStreamSynchronize(c->stream_img));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return c->sticky;
 }
@@ -279,20 +326,34 @@ VS_API int vslam_synchronize(vslam_ctx* c) {
 // ---- launches ------------------------------------------------------------------------------------
 static int launch_image_pipeline(vslam_ctx* c) {
   const DevCfg& d = c->cfg;
+  const int set = c->parity;
+  const DevBuf bs = buf_set(c, set);
+  hipStream_t st = c->stream_img;
+  // the image products of this set were last read by the frame kernel two steps ago
+  if (c->frm_pending[set] && st != c->stream) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_frm[set], 0));
   dim3 g1(d.TX, (d.c.rows + VS_TILE_H - 1) / VS_TILE_H, 2 * c->B);
-  { KernelTimer t(c, 0); hipLaunchKernelGGL(k_fast_box, g1, dim3(256), 0, c->stream, c->cfg, c->buf); }
-  { KernelTimer t(c, 1); hipLaunchKernelGGL(k_emit, dim3(c->B), dim3(1024), 0, c->stream, c->cfg, c->buf, (int)VSLAM_BRIEF_BORDER, 1); }
+  { KernelTimer t(c, 0, st); hipLaunchKernelGGL(k_fast_box, g1, dim3(256), 0, st, c->cfg, bs); }
+  { KernelTimer t(c, 1, st); hipLaunchKernelGGL(k_emit, dim3(c->B), dim3(1024), 0, st, c->cfg, bs, (int)VSLAM_BRIEF_BORDER, 1); }
   const int gx = std::max(4, std::min(64, 1024 / (2 * c->B)));
-  { KernelTimer t(c, 2); hipLaunchKernelGGL(k_brief, dim3(gx, 1, 2 * c->B), dim3(256), 0, c->stream, c->cfg, c->buf); }
+  { KernelTimer t(c, 2, st); hipLaunchKernelGGL(k_brief, dim3(gx, 1, 2 * c->B), dim3(256), 0, st, c->cfg, bs); }
   HIP_TRY(c, hipGetLastError());
+  if (st != c->stream) { HIP_TRY(c, hipEventRecord(c->ev_img[set], st)); HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_img[set], 0)); }
+  c->last_set = set;
+  return VSLAM_OK;
+}
+static int frame_done(vslam_ctx* c) {
+  const int set = c->last_set;
+  if (c->stream_img != c->stream) { HIP_TRY(c, hipEventRecord(c->ev_frm[set], c->stream)); c->frm_pending[set] = true; }
+  c->parity = set ^ 1;
   return VSLAM_OK;
 }
 static int launch_frame(vslam_ctx* c) {
+  const DevBuf bs = buf_set(c, c->last_set);
   const int gx = std::max(4, std::min(128, 2048 / c->B));
-  { KernelTimer t(c, 3); hipLaunchKernelGGL(k_track_candidates, dim3(gx, c->B), dim3(256), 0, c->stream, c->cfg, c->buf, -1); }
-  { KernelTimer t(c, 4); hipLaunchKernelGGL(k_frame, dim3(c->B), dim3(VS_WG), 0, c->stream, c->cfg, c->buf); }
+  { KernelTimer t(c, 3, c->stream); hipLaunchKernelGGL(k_track_candidates, dim3(gx, c->B), dim3(256), 0, c->stream, c->cfg, bs, -1); }
+  { KernelTimer t(c, 4, c->stream); hipLaunchKernelGGL(k_frame, dim3(c->B), dim3(VS_WG), 0, c->stream, c->cfg, bs); }
   HIP_TRY(c, hipGetLastError());
-  return VSLAM_OK;
+  return frame_done(c);
 }
 static int set_images_device(vslam_ctx* c, const uint8_t* L, const uint8_t* R, int32_t row_stride, size_t image_stride) {
   if (!L || !R) return fail(c, VSLAM_ERR_INVALID, "called with empty frame");  // stereo_framepoint_generator.cpp:75-78
@@ -307,9 +368,9 @@ static int upload_images(vslam_ctx* c, const uint8_t* L, const uint8_t* R, int32
   if (row_stride < c->cfg.c.cols) return fail(c, VSLAM_ERR_INVALID, "row stride smaller than image width");
   for (int s = 0; s < c->B; ++s) {
     HIP_TRY(c, hipMemcpy2DAsync(c->upload[0] + s * c->up_stream_stride, c->up_stride, L + s * image_stride, row_stride,
-                                c->cfg.c.cols, c->cfg.c.rows, hipMemcpyHostToDevice, c->stream));
+                                c->cfg.c.cols, c->cfg.c.rows, hipMemcpyHostToDevice, c->stream_img));
     HIP_TRY(c, hipMemcpy2DAsync(c->upload[1] + s * c->up_stream_stride, c->up_stride, R + s * image_stride, row_stride,
-                                c->cfg.c.cols, c->cfg.c.rows, hipMemcpyHostToDevice, c->stream));
+                                c->cfg.c.cols, c->cfg.c.rows, hipMemcpyHostToDevice, c->stream_img));
   }
   return set_images_device(c, c->upload[0], c->upload[1], c->up_stride, c->up_stream_stride);
 }
@@ -359,15 +420,17 @@ VS_API int vslam_get_keypoints(vslam_ctx* c, int s, int side, int32_t cap, int32
   if (rc) return rc;
   if (!n || side < 0 || side > 1) return fail(c, VSLAM_ERR_INVALID, "bad argument");
   int32_t cnt = 0;
-  HIP_TRY(c, d2h(c, &cnt, c->buf.n_kp + s * 2 + side, 1));
+  const vslam_ctx::ImgSet& iset = c->sets[c->last_set];
+  HIP_TRY(c, hipStreamSynchronize(c->stream_img));
+  HIP_TRY(c, d2h(c, &cnt, iset.n_kp + s * 2 + side, 1));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   *n = cnt;
   if (cnt > cap) return fail(c, VSLAM_ERR_CAPACITY, "keypoint output capacity too small");
   const size_t o = ((size_t)s * 2 + side) * c->cfg.NMAX;
   std::vector<uint8_t> sc(cnt);
-  HIP_TRY(c, d2h(c, xy, c->buf.kp_xy + o * 2, (size_t)cnt * 2));
-  HIP_TRY(c, d2h(c, sc.data(), c->buf.kp_score + o, (size_t)cnt));
-  HIP_TRY(c, d2h(c, desc, c->buf.desc + o * 32, (size_t)cnt * 32));
+  HIP_TRY(c, d2h(c, xy, iset.kp_xy + o * 2, (size_t)cnt * 2));
+  HIP_TRY(c, d2h(c, sc.data(), iset.kp_score + o, (size_t)cnt));
+  HIP_TRY(c, d2h(c, desc, iset.desc + o * 32, (size_t)cnt * 32));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (score) for (int i = 0; i < cnt; ++i) score[i] = sc[i];
   return VSLAM_OK;
@@ -490,8 +553,8 @@ VS_API int vslam_fast_detect(vslam_ctx* c, const uint8_t* img, int32_t rows, int
   rc = e == hipSuccess ? upload_images(t, img, img, stride, 0) : fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   if (rc == VSLAM_OK) {
     dim3 g1(t->cfg.TX, (rows + VS_TILE_H - 1) / VS_TILE_H, 2);
-    hipLaunchKernelGGL(k_fast_box, g1, dim3(256), 0, t->stream, t->cfg, t->buf);
-    hipLaunchKernelGGL(k_emit, dim3(1), dim3(1024), 0, t->stream, t->cfg, t->buf, 0, 0);
+    hipLaunchKernelGGL(k_fast_box, g1, dim3(256), 0, t->stream_img, t->cfg, t->buf);
+    hipLaunchKernelGGL(k_emit, dim3(1), dim3(1024), 0, t->stream_img, t->cfg, t->buf, 0, 0);
     int32_t cnt = 0;
     rc = vslam_get_keypoints(t, 0, 0, cap, &cnt, xy, score, nullptr);
     *n = cnt;
@@ -511,16 +574,16 @@ VS_API int vslam_brief_describe(vslam_ctx* c, const uint8_t* img, int32_t rows, 
   hipError_t e = dalloc(t, &dxy, (size_t)n * 2);
   if (e == hipSuccess) e = dalloc(t, &dkeep, (size_t)n);
   if (e == hipSuccess) e = dalloc(t, &ddesc, (size_t)n * 32);
-  if (e == hipSuccess && n) e = hipMemcpyAsync(dxy, xy, (size_t)n * 2 * sizeof(int16_t), hipMemcpyHostToDevice, t->stream);
+  if (e == hipSuccess && n) e = hipMemcpyAsync(dxy, xy, (size_t)n * 2 * sizeof(int16_t), hipMemcpyHostToDevice, t->stream_img);
   rc = e == hipSuccess ? upload_images(t, img, img, stride, 0) : fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   if (rc == VSLAM_OK && n) {
     dim3 g1(t->cfg.TX, (rows + VS_TILE_H - 1) / VS_TILE_H, 2);
-    hipLaunchKernelGGL(k_fast_box, g1, dim3(256), 0, t->stream, t->cfg, t->buf);
-    hipLaunchKernelGGL(k_brief_at, dim3(std::min(64, (n + 3) / 4)), dim3(256), 0, t->stream, t->buf.box, t->cfg.bstride, rows, cols,
+    hipLaunchKernelGGL(k_fast_box, g1, dim3(256), 0, t->stream_img, t->cfg, t->buf);
+    hipLaunchKernelGGL(k_brief_at, dim3(std::min(64, (n + 3) / 4)), dim3(256), 0, t->stream_img, t->buf.box, t->cfg.bstride, rows, cols,
                        n, dxy, dkeep, ddesc);
-    e = hipMemcpyAsync(keep, dkeep, (size_t)n, hipMemcpyDeviceToHost, t->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(desc, ddesc, (size_t)n * 32, hipMemcpyDeviceToHost, t->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+    e = hipMemcpyAsync(keep, dkeep, (size_t)n, hipMemcpyDeviceToHost, t->stream_img);
+    if (e == hipSuccess) e = hipMemcpyAsync(desc, ddesc, (size_t)n * 32, hipMemcpyDeviceToHost, t->stream_img);
+    if (e == hipSuccess) e = hipStreamSynchronize(t->stream_img);
     if (e != hipSuccess) rc = fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   }
   vslam_destroy(t);
@@ -585,12 +648,12 @@ VS_API int vslam_align_points(vslam_ctx* c, int32_t n, const double* moving, con
 
 // ---- stage entry points (the reference's plug-in virtuals; control flow stays with the caller) ----------
 static int launch_begin(vslam_ctx* c) {
-  hipLaunchKernelGGL(k_begin, dim3(c->B), dim3(256), 0, c->stream, c->cfg, c->buf);
+  hipLaunchKernelGGL(k_begin, dim3(c->B), dim3(256), 0, c->stream, c->cfg, buf_set(c, c->last_set));
   HIP_TRY(c, hipGetLastError());
   return VSLAM_OK;
 }
 static int launch_stage(vslam_ctx* c, int stage, int arg) {
-  hipLaunchKernelGGL(k_stage, dim3(c->B), dim3(VS_WG), 0, c->stream, c->cfg, c->buf, stage, arg);
+  hipLaunchKernelGGL(k_stage, dim3(c->B), dim3(VS_WG), 0, c->stream, c->cfg, buf_set(c, c->last_set), stage, arg);
   HIP_TRY(c, hipGetLastError());
   return VSLAM_OK;
 }
@@ -621,7 +684,7 @@ VS_API int vslam_frame_restore(vslam_ctx* c) {
 VS_API int vslam_track(vslam_ctx* c, int by_appearance) {
   NEED_FRAME("vslam_track");
   const int gx = std::max(4, std::min(128, 2048 / c->B));
-  hipLaunchKernelGGL(k_track_candidates, dim3(gx, c->B), dim3(256), 0, c->stream, c->cfg, c->buf, by_appearance ? 1 : 0);
+  hipLaunchKernelGGL(k_track_candidates, dim3(gx, c->B), dim3(256), 0, c->stream, c->cfg, buf_set(c, c->last_set), by_appearance ? 1 : 0);
   return launch_stage(c, VS_STAGE_TRACK, by_appearance ? 1 : 0);
 }
 VS_API int vslam_align(vslam_ctx* c, int inverse_depth) { NEED_FRAME("vslam_align"); return launch_stage(c, VS_STAGE_ALIGN, inverse_depth); }
@@ -630,7 +693,8 @@ VS_API int vslam_update_points(vslam_ctx* c) { NEED_FRAME("vslam_update_points")
 VS_API int vslam_stereo_new(vslam_ctx* c) {
   NEED_FRAME("vslam_stereo_new");
   c->frame_begun = false;  // compute() is the last call PoseTracker3D::compute makes on a frame
-  return launch_stage(c, VS_STAGE_STEREO, 0);
+  int rc = launch_stage(c, VS_STAGE_STEREO, 0);
+  return rc == VSLAM_OK ? frame_done(c) : rc;
 }
 VS_API int vslam_set_tracker_state(vslam_ctx* c, int s, int status, const double prior[12], int win, double tau) {
   int rc = check_stream(c, s);
