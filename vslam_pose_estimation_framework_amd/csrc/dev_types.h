@@ -64,6 +64,7 @@ struct StreamState {
   // in-kernel chronometers (wall_clock64 ticks, 100 MHz): tracking, pose_optimization, point_recovery,
   // landmark_optimization, track_creation (== point_triangulation)
   unsigned long long ticks[5];
+  unsigned long long dbg[12];              // fine-grained phase ticks (profiling builds of the bench)
   // stage-granular API (the shim's host-driven PoseTracker3D): values handed from one stage call to the next
   double tau_gen;                        // generator's _maximum_descriptor_distance_tracking (last track())
   int32_t n_cur, n_active, n_after_prune, n_recovered, n_new, track_calls;
@@ -127,6 +128,8 @@ struct DevBuf {
   int32_t* st_match;   // [B][NMAX][2]  matched right index / distance per left feature
   int32_t* sc;         // [B][NMAX][4]  fl, fr, dist, epi  (new candidates in sweep order)
   int32_t* bin_occ;    // [B][rows_bin*cols_bin]
+  uint8_t* sdist;      // [B][NMAX][16] precomputed L-R Hamming distances of the stereo sweep
+  int32_t* bin_aux;    // [B][2*(nb+1) + NMAX]  per-bin counts, starts, candidate lists
   // history ring for landmark refinement [B][HCAP]
   double* h_pose;      // [..][24]  cam_to_world, world_to_cam
   double* h_cam;       // [..][MAXP][3]

@@ -145,7 +145,8 @@ struct FrameShared {
   double bvec[6];
   double E, Eprev;
   int inl, outl, its, conv;
-  double red[16][32];
+  double red4[VS_WG / 64][4][32];
+  unsigned long long key;
 };
 
 __device__ __forceinline__ unsigned long long key3(unsigned a, int row, int col) {
@@ -333,11 +334,54 @@ __device__ void wg_track_resolve(const DevCfg& c, const DevBuf& b, int s, FrameS
 // ----------------------------------------------------------------------------------------------
 // StereoUVAligner
 // ----------------------------------------------------------------------------------------------
+// Symmetric elimination without pivoting (LDL^T) of the damped normal equations, every lane redundantly, all
+// indices static (registers only).  H is symmetric positive definite whenever the alignment is well posed, where
+// unpivoted elimination is backward stable, so the solution equals the reference's full-pivot LU up to rounding
+// (same class of difference as the H,b summation order).  Returns false when a pivot is not safely positive; the
+// caller then falls back to the exact full-pivot wave solver (rank-deficient systems keep reference semantics).
+__device__ __forceinline__ bool ldlt_solve6(const double* Hs, const double* rhs, double* x) {
+  double A[6][6], y[6];
+  double dmax = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) A[i][j] = Hs[6 * i + j];
+    y[i] = rhs[i];
+    dmax = fmax(dmax, fabs(A[i][i]));
+  }
+  bool ok = dmax > 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const double d = A[k][k];
+    if (!(d > 1e-12 * dmax)) ok = false;
+    const double inv = 1.0 / d;
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) {
+      const double f = A[i][k] * inv;
+#pragma unroll
+      for (int j = i; j < 6; ++j) A[i][j] -= f * A[k][j];   // trailing block stays symmetric: update the upper part
+      y[i] -= f * y[k];
+    }
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i)
+#pragma unroll
+      for (int j = i + 1; j < 6; ++j) A[j][i] = A[i][j];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    double sv = y[i];
+#pragma unroll
+    for (int j = i + 1; j < 6; ++j) sv -= A[i][j] * x[j];
+    x[i] = sv / A[i][i];
+  }
+  return ok;
+}
+
 // Eigen::FullPivLU<Matrix6>::solve on one wavefront.  Element (row i, col j) of the matrix sits in lane
 // 6*j+i (column-major, so "first strict maximum in column-major order" is the lowest set bit of a ballot),
 // the right-hand side in lanes 36..41.  Arithmetic per element is the serial algorithm's (same operands,
 // same order), so the result is bit-identical to dev_math.h full_piv_solve<6> / the CPU oracle.
-__device__ __forceinline__ void wave_solve6(double a, int lane, double* x) {
+__device__ __forceinline__ void wave_solve6(double a, int lane, double* x, unsigned long long* lds_key) {
   const int j = lane / 6, i = lane - 6 * j;
   const int row = lane < 36 ? i : (lane < 42 ? lane - 36 : -1);
   unsigned perm = 0x543210u;
@@ -347,9 +391,13 @@ __device__ __forceinline__ void wave_solve6(double a, int lane, double* x) {
     if (rank == 6) {
       const bool elig = lane < 36 && i >= k && j >= k;
       const double v = elig ? fabs(a) : -1.0;
-      double m = v;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+      // maximum of |a| over the remaining corner: the bit pattern of a non-negative double orders like an integer
+      if (lane == 0) *lds_key = 0ull;
+      __builtin_amdgcn_wave_barrier();
+      if (elig) atomicMax(lds_key, (unsigned long long)__double_as_longlong(v));
+      __builtin_amdgcn_wave_barrier();
+      const double m = __longlong_as_double((long long)__hip_atomic_load(lds_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      __builtin_amdgcn_wave_barrier();
       if (!(m > 0)) {
         rank = k;
       } else {
@@ -401,103 +449,136 @@ __device__ __forceinline__ void wave_solve6(double a, int lane, double* x) {
   }
 }
 
-#define NACC 29  // 21 upper-triangular H + 6 b + E + inlier count
-__device__ void wg_one_round(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int n, bool ignore_outliers) {
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+#define NACC 29   // 21 upper-triangular H + 6 b + E + inlier count
+#define VS_ALCACHE 1   // measurements per thread kept in registers across rounds (covers M <= 3*VS_WG)
+
+struct AlignPoint { double m[3], f[4], om, wt; };
+
+// row-wise (16-lane) inclusive add by DPP row_shr 1,2,4,8: lanes 15,31,47,63 end up with their row's sum
+__device__ __forceinline__ double dpp_row_sum(double v) {
+#define VS_DPP_STEP(ctrl)                                                                      \
+  {                                                                                            \
+    const long long bits = __double_as_longlong(v);                                           \
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xFFFFFFFFll), ctrl, 0xF, 0xF, true); \
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), ctrl, 0xF, 0xF, true);   \
+    v += __longlong_as_double(((long long)hi << 32) | (unsigned)lo);                           \
+  }
+  VS_DPP_STEP(0x111) VS_DPP_STEP(0x112) VS_DPP_STEP(0x114) VS_DPP_STEP(0x118)
+#undef VS_DPP_STEP
+  return v;
+}
+
+// contribution of one measurement to H, b, E (linearize body, stereouv_aligner.cpp:81-185)
+__device__ __forceinline__ void align_point(const DevCfg& c, const double* T, const AlignPoint& P, bool ignore_outliers,
+                                            double* acc, double* chi_out, uint8_t* inl_out) {
+  const double* K = c.c.K;
+  double chi_w = -1;
+  uint8_t inl_w = 0;
+  double omega = P.om;
+  double p[3];
+  tf_apply(T, P.m, p);
+  bool skip = p[2] < c.c.minimum_depth_meters;
+  double aL[3], aR[3];
+  mat3_mul_vec(K, p, aL);
+  for (int k = 0; k < 3; ++k) aR[k] = aL[k] + c.c.baseline_h[k];
+  const double cL = aL[2], cR = aR[2];
+  const double uL = aL[0] / cL, vL = aL[1] / cL, uR = aR[0] / cR, vR = aR[1] / cR;
+  if (!skip) {
+    if (uL < 0 || uL > c.c.cols || vL < 0 || vL > c.c.rows) skip = true;
+    if (uR < 0 || uR > c.c.cols || vR < 0 || vR > c.c.rows) skip = true;
+  }
+  if (!skip) {
+    const double e[4] = {uL - P.f[0], vL - P.f[1], uR - P.f[2], vR - P.f[3]};
+    const double chi = omega * (((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]) + e[3] * e[3]);
+    chi_w = chi;
+    bool use = true;
+    if (chi > c.c.aligner_maximum_error_kernel) {
+      if (ignore_outliers) use = false;
+      else omega *= c.c.aligner_maximum_error_kernel / chi;
+    } else {
+      inl_w = 1;
+      acc[28] += 1.0;
+    }
+    if (use) {
+      acc[27] += chi;
+      const double wt = P.wt;
+      // K * [w*I3 | -2*skew(p)]
+      const double Jt[3][6] = {{wt, 0, 0, 0, 2 * p[2], -2 * p[1]}, {0, wt, 0, -2 * p[2], 0, 2 * p[0]}, {0, 0, wt, 2 * p[1], -2 * p[0], 0}};
+      double KJ[3][6];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) KJ[i][j] = (K[3 * i] * Jt[0][j] + K[3 * i + 1] * Jt[1][j]) + K[3 * i + 2] * Jt[2][j];
+      const double icL = 1 / cL, icR = 1 / cR, icL2 = icL * icL, icR2 = icR * icR;
+      const double jl0 = -aL[0] * icL2, jl1 = -aL[1] * icL2, jr0 = -aR[0] * icR2, jr1 = -aR[1] * icR2;
+      double J[4][6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        J[0][j] = (icL * KJ[0][j] + 0 * KJ[1][j]) + jl0 * KJ[2][j];
+        J[1][j] = (0 * KJ[0][j] + icL * KJ[1][j]) + jl1 * KJ[2][j];
+        J[2][j] = (icR * KJ[0][j] + 0 * KJ[1][j]) + jr0 * KJ[2][j];
+        J[3][j] = (0 * KJ[0][j] + icR * KJ[1][j]) + jr1 * KJ[2][j];
+      }
+      int q = 0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+#pragma unroll
+        for (int cc = r; cc < 6; ++cc)
+          acc[q++] += omega * (((J[0][r] * J[0][cc] + J[1][r] * J[1][cc]) + J[2][r] * J[2][cc]) + J[3][r] * J[3][cc]);
+      }
+#pragma unroll
+      for (int r = 0; r < 6; ++r) acc[21 + r] += omega * (((J[0][r] * e[0] + J[1][r] * e[1]) + J[2][r] * e[2]) + J[3][r] * e[3]);
+    }
+  }
+  *chi_out = chi_w;
+  *inl_out = inl_w;
+}
+
+__device__ __forceinline__ void load_align_point(const DevCfg& c, const DevBuf& b, int s, int u, AlignPoint& P) {
   const double* moving = b.al_moving + (size_t)s * c.MAXP * 3;
   const double* fixed = b.al_fixed + (size_t)s * c.MAXP * 4;
-  const double* omega_v = b.al_omega + (size_t)s * c.MAXP;
-  const double* weight = b.al_weight + (size_t)s * c.MAXP;
+  for (int k = 0; k < 3; ++k) P.m[k] = moving[3 * (size_t)u + k];
+  for (int k = 0; k < 4; ++k) P.f[k] = fixed[4 * (size_t)u + k];
+  P.om = (b.al_omega + (size_t)s * c.MAXP)[u];
+  P.wt = (b.al_weight + (size_t)s * c.MAXP)[u];
+}
+
+__device__ __forceinline__ void wg_one_round(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int n, bool ignore_outliers,
+                             const AlignPoint* cache) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   double* chi_o = b.al_chi + (size_t)s * c.MAXP;
   uint8_t* inl_o = b.al_inl + (size_t)s * c.MAXP;
   double T[12];
   for (int k = 0; k < 12; ++k) T[k] = sh.T[k];
-  const double* K = c.c.K;
   double acc[NACC];
 #pragma unroll
   for (int k = 0; k < NACC; ++k) acc[k] = 0;
-  for (int u = tid; u < n; u += VS_WG) {
-    double chi_w = -1;
-    uint8_t inl_w = 0;
-    double omega = omega_v[u];
-    double p[3];
-    tf_apply(T, moving + 3 * (size_t)u, p);
-    bool skip = p[2] < c.c.minimum_depth_meters;
-    double aL[3], aR[3];
-    mat3_mul_vec(K, p, aL);
-    for (int k = 0; k < 3; ++k) aR[k] = aL[k] + c.c.baseline_h[k];
-    const double cL = aL[2], cR = aR[2];
-    const double uL = aL[0] / cL, vL = aL[1] / cL, uR = aR[0] / cR, vR = aR[1] / cR;
-    if (!skip) {
-      if (uL < 0 || uL > c.c.cols || vL < 0 || vL > c.c.rows) skip = true;
-      if (uR < 0 || uR > c.c.cols || vR < 0 || vR > c.c.rows) skip = true;
-    }
-    if (!skip) {
-      const double e[4] = {uL - fixed[4 * (size_t)u], vL - fixed[4 * (size_t)u + 1], uR - fixed[4 * (size_t)u + 2],
-                           vR - fixed[4 * (size_t)u + 3]};
-      const double chi = omega * (((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]) + e[3] * e[3]);
-      chi_w = chi;
-      bool use = true;
-      if (chi > c.c.aligner_maximum_error_kernel) {
-        if (ignore_outliers) use = false;
-        else omega *= c.c.aligner_maximum_error_kernel / chi;
-      } else {
-        inl_w = 1;
-        acc[28] += 1.0;
-      }
-      if (use) {
-        acc[27] += chi;
-        const double wt = weight[u];
-        // K * [w*I3 | -2*skew(p)]
-        const double Jt[3][6] = {{wt, 0, 0, 0, 2 * p[2], -2 * p[1]}, {0, wt, 0, -2 * p[2], 0, 2 * p[0]}, {0, 0, wt, 2 * p[1], -2 * p[0], 0}};
-        double KJ[3][6];
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int j = 0; j < 6; ++j) KJ[i][j] = (K[3 * i] * Jt[0][j] + K[3 * i + 1] * Jt[1][j]) + K[3 * i + 2] * Jt[2][j];
-        const double icL = 1 / cL, icR = 1 / cR, icL2 = icL * icL, icR2 = icR * icR;
-        const double jl0 = -aL[0] * icL2, jl1 = -aL[1] * icL2, jr0 = -aR[0] * icR2, jr1 = -aR[1] * icR2;
-        double J[4][6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          J[0][j] = (icL * KJ[0][j] + 0 * KJ[1][j]) + jl0 * KJ[2][j];
-          J[1][j] = (0 * KJ[0][j] + icL * KJ[1][j]) + jl1 * KJ[2][j];
-          J[2][j] = (icR * KJ[0][j] + 0 * KJ[1][j]) + jr0 * KJ[2][j];
-          J[3][j] = (0 * KJ[0][j] + icR * KJ[1][j]) + jr1 * KJ[2][j];
-        }
-        int q = 0;
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-#pragma unroll
-          for (int cc = r; cc < 6; ++cc)
-            acc[q++] += omega * (((J[0][r] * J[0][cc] + J[1][r] * J[1][cc]) + J[2][r] * J[2][cc]) + J[3][r] * J[3][cc]);
-        }
-#pragma unroll
-        for (int r = 0; r < 6; ++r) acc[21 + r] += omega * (((J[0][r] * e[0] + J[1][r] * e[1]) + J[2][r] * e[2]) + J[3][r] * e[3]);
-      }
-    }
-    chi_o[u] = chi_w;
-    inl_o[u] = inl_w;
+  for (int q = 0; q < VS_ALCACHE; ++q) {
+    const int u = tid + q * VS_WG;
+    if (u < n) align_point(c, T, cache[q], ignore_outliers, acc, chi_o + u, inl_o + u);
   }
-  // deterministic reduction: butterfly inside the wave, fixed order across the 16 waves.  Waves that own
-  // no measurement (w*64 >= n) contribute exact zeros without shuffling.
+  for (int u = tid + VS_ALCACHE * VS_WG; u < n; u += VS_WG) {
+    AlignPoint P;
+    load_align_point(c, b, s, u, P);
+    align_point(c, T, P, ignore_outliers, acc, chi_o + u, inl_o + u);
+  }
+  // deterministic reduction: DPP sums inside each 16-lane row, then a fixed-order sum of the 4 row totals of
+  // every wave that owns measurements (w*64 < n); the other waves contribute exact zeros.
   if (w * 64 < n) {
 #pragma unroll
     for (int k = 0; k < NACC; ++k) {
-      double v = acc[k];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-      if (lane == 0) sh.red[w][k] = v;
+      const double v = dpp_row_sum(acc[k]);
+      if ((lane & 15) == 15) sh.red4[w][lane >> 4][k] = v;
     }
-  } else if (lane < NACC) {
-    sh.red[w][lane] = 0.0;
   }
   __syncthreads();
   if (w == 0) {
     // lane k < 29 owns total k; the 6x6 system then lives one element per lane (column-major: lane = 6*col+row,
     // right-hand side in lanes 36..41) and is solved by wave_solve6 without leaving registers.
     double tot = 0;
-    if (lane < NACC) for (int ww = 0; ww < VS_WG / 64; ++ww) tot += sh.red[ww][lane];
+    const int nw = min((n + 63) >> 6, VS_WG / 64);
+    if (lane < NACC) for (int ww = 0; ww < nw; ++ww) tot += ((sh.red4[ww][0][lane] + sh.red4[ww][1][lane]) + sh.red4[ww][2][lane]) + sh.red4[ww][3][lane];
     const int j = lane / 6, i = lane - 6 * j;
     int src = 0;
     if (lane < 36) { const int r = min(i, j), cc = max(i, j); src = r * 6 - (r * (r - 1)) / 2 + (cc - r); }
@@ -508,8 +589,11 @@ __device__ void wg_one_round(const DevCfg& c, const DevBuf& b, int s, FrameShare
     if (lane < 36) sh.H[6 * i + j] = a;
     if (lane == 27) sh.E = tot;
     if (lane == 28) { sh.inl = (int)tot; sh.outl = n - (int)tot; }
+    if (lane >= 36 && lane < 42) sh.bvec[lane - 36] = a;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     double dx[6];
-    wave_solve6(a, lane, dx);
+    if (!ldlt_solve6(sh.H, sh.bvec, dx)) wave_solve6(a, lane, dx, &sh.key);
     if (lane == 0) {
       double D[12], Tn[12];
       v2t(dx, D);
@@ -540,7 +624,7 @@ __device__ void wg_one_round(const DevCfg& c, const DevBuf& b, int s, FrameShare
 }
 
 // converge (:210-264) on the aligner SoA of stream s (n measurements), starting from T_init
-__device__ void wg_align_converge(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int n, const double* T_init) {
+__device__ __forceinline__ void wg_align_converge(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int n, const double* T_init) {
   const int tid = threadIdx.x;
   __syncthreads();
   if (tid == 0) {
@@ -551,26 +635,35 @@ __device__ void wg_align_converge(const DevCfg& c, const DevBuf& b, int s, Frame
   __syncthreads();
   const int max_it = c.c.aligner_maximum_number_of_iterations;
   const double delta = c.c.aligner_error_delta_for_convergence;
+  AlignPoint cache[VS_ALCACHE];
+#pragma unroll
+  for (int q = 0; q < VS_ALCACHE; ++q) {
+    const int u = tid + q * VS_WG;
+    if (u < n) load_align_point(c, b, s, u, cache[q]);
+  }
+  // converge() as one loop (single inlined copy of the round): outer rounds use the saturated kernel, after the
+  // first convergence inlier-only rounds follow while they keep changing the error (:216-255)
   double e_prev = 0;
-  for (int it = 0; it < max_it; ++it) {
-    wg_one_round(c, b, s, sh, n, false);
+  int it = 0, it2 = 0;
+  bool refine = false;
+  while (true) {
+    wg_one_round(c, b, s, sh, n, refine, cache);
     const double E = sh.E;
-    const int inl = sh.inl, outl = sh.outl;
-    if (delta > fabs(e_prev - E)) {
-      e_prev = E;
-      if (inl > c.c.aligner_minimum_number_of_inliers && inl > outl) {
-        for (int it2 = 0; it2 < max_it; ++it2) {
-          wg_one_round(c, b, s, sh, n, true);
-          const double E2 = sh.E;
-          const bool done = fabs(e_prev - E2) < delta;
-          e_prev = E2;
-          if (done) break;
-        }
+    if (!refine) {
+      ++it;
+      if (delta > fabs(e_prev - E)) {
+        e_prev = E;
+        if (sh.inl > c.c.aligner_minimum_number_of_inliers && sh.inl > sh.outl && max_it > 0) { refine = true; continue; }
+        if (tid == 0) sh.conv = 1;
+        break;
       }
-      if (tid == 0) sh.conv = 1;
-      break;
-    } else {
       e_prev = E;
+      if (it >= max_it) break;
+    } else {
+      ++it2;
+      const bool done = fabs(e_prev - E) < delta;
+      e_prev = E;
+      if (done || it2 >= max_it) { if (tid == 0) sh.conv = 1; break; }
     }
   }
   __syncthreads();

@@ -284,9 +284,27 @@ __device__ void wg_stereo(const DevCfg& c, const DevBuf& b, int s, FrameShared& 
   int32_t* bin_occ = b.bin_occ + (size_t)s * c.rows_bin * c.cols_bin;
   const int n_tracked = sh.n_cur;
   int n_cand = 0;
+  unsigned long long tq = wall_clock64();
+#define DBG_STAMP(k) do { __syncthreads(); if (tid == 0) { const unsigned long long tn = wall_clock64(); b.st[s].dbg[k] += tn - tq; tq = tn; } } while (0)
   for (int oi = 0; oi < c.n_offsets; ++oi) {
     const int o = c.offsets[oi];
-    for (int i = tid; i < nL; i += VS_WG) match[2 * i] = -1;
+    // distances of every left feature to the right features of its row that lie at or left of it (a prefix of
+    // the row in x order), all features in parallel; the sequential cursor logic below only reads them
+    uint8_t* sdist = b.sdist + (size_t)s * c.NMAX * 16;
+    for (int i = tid; i < nL; i += VS_WG) {
+      match[2 * i] = -1;
+      if (usedL[i]) continue;
+      const int r = kxyL[2 * i + 1], rr = r - o;
+      if (rr < 0 || rr >= rows) continue;
+      const int g0 = rcR[(size_t)rr * CW1], g1 = rcR[(size_t)rr * CW1 + c.CW];
+      const int xl = kxyL[2 * i];
+      uint32_t ld[8];
+      for (int k = 0; k < 8; ++k) ld[k] = reinterpret_cast<const uint32_t*>(descL + (size_t)32 * i)[k];
+      for (int g = g0, j = 0; g < g1 && j < 16; ++g, ++j) {
+        if (xl - kxyR[2 * g] < 0) break;
+        sdist[(size_t)i * 16 + j] = (uint8_t)hamming32(ld, reinterpret_cast<const uint32_t*>(descR + (size_t)32 * g));
+      }
+    }
     __syncthreads();
     for (int r = tid; r < rows; r += VS_WG) {
       const int rr = r - o;  // right row: L.row == R.row + o
@@ -296,17 +314,21 @@ __device__ void wg_stereo(const DevCfg& c, const DevBuf& b, int s, FrameShared& 
       int cur = g0;
       for (int i = l0; i < l1; ++i) {
         if (usedL[i]) continue;
-        while (cur < g1 && usedR[cur]) ++cur;  // pruned features are not in the vector
         if (cur >= g1) break;
         const int xl = kxyL[2 * i];
-        uint32_t ld[8];
-        for (int k = 0; k < 8; ++k) ld[k] = reinterpret_cast<const uint32_t*>(descL + (size_t)32 * i)[k];
         double best = tau_tri;
         int bg = -1;
         for (int g = cur; g < g1; ++g) {
           if (usedR[g]) continue;
           if (xl - kxyR[2 * g] < 0) break;
-          const double h = (double)hamming32(ld, reinterpret_cast<const uint32_t*>(descR + (size_t)32 * g));
+          double h;
+          if (g - g0 < 16) {
+            h = (double)sdist[(size_t)i * 16 + (g - g0)];
+          } else {
+            uint32_t ld[8];
+            for (int k = 0; k < 8; ++k) ld[k] = reinterpret_cast<const uint32_t*>(descL + (size_t)32 * i)[k];
+            h = (double)hamming32(ld, reinterpret_cast<const uint32_t*>(descR + (size_t)32 * g));
+          }
           if (h < best) { best = h; bg = g; }
         }
         if (bg >= 0) {
@@ -316,7 +338,7 @@ __device__ void wg_stereo(const DevCfg& c, const DevBuf& b, int s, FrameShared& 
         }
       }
     }
-    __syncthreads();
+    DBG_STAMP(0);
     // append the matches of this offset in sorted-left order; mark both features used (prune)
     const int per = (nL + VS_WG - 1) / VS_WG;
     const int i0 = tid * per, i1 = min(i0 + per, nL);
@@ -332,7 +354,7 @@ __device__ void wg_stereo(const DevCfg& c, const DevBuf& b, int s, FrameShared& 
       ++off;
     }
     n_cand += total;
-    __syncthreads();
+    DBG_STAMP(1);
   }
   // ---- binning (:147-155, :371-394, :435-456) ---------------------------------------------------
   const int nb = c.rows_bin * c.cols_bin;
@@ -358,20 +380,49 @@ __device__ void wg_stereo(const DevCfg& c, const DevBuf& b, int s, FrameShared& 
       match[2 * q + 1] = ((xl - kxyR[2 * sc[4 * q + 1]]) << 16) | (sc[4 * q + 2] & 0xFFFF);
     }
     __syncthreads();
+    DBG_STAMP(2);
+    // per-bin candidate lists by counting sort (arrival order inside a bin is arbitrary, restored by a tiny sort)
+    int32_t* bcnt = b.bin_aux + (size_t)s * (2 * ((size_t)nb + 1) + c.NMAX);
+    int32_t* bstart = bcnt + (nb + 1);
+    int32_t* bitems = bstart + (nb + 1);
+    for (int k = tid; k < nb; k += VS_WG) __hip_atomic_store(bcnt + k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    for (int q = tid; q < n_cand; q += VS_WG) atomicAdd(bcnt + match[2 * q], 1);
+    __syncthreads();
+    {
+      const int perb = (nb + VS_WG - 1) / VS_WG;
+      const int k0 = tid * perb, k1 = min(k0 + perb, nb);
+      int cnt = 0;
+      for (int k = k0; k < k1; ++k) cnt += ld_relaxed(bcnt + k);
+      int total;
+      int off = block_exclusive_scan(cnt, sh.scan, &total);
+      for (int k = k0; k < k1; ++k) { const int m = ld_relaxed(bcnt + k); bstart[k] = off; off += m; __hip_atomic_store(bcnt + k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      if (tid == 0) bstart[nb] = total;
+    }
+    __syncthreads();
+    for (int q = tid; q < n_cand; q += VS_WG) {
+      const int k = match[2 * q];
+      bitems[bstart[k] + atomicAdd(bcnt + k, 1)] = q;
+    }
+    __syncthreads();
     // one thread per bin replays its candidates in sweep order (the rule is not an argmax)
     for (int k = tid; k < nb; k += VS_WG) {
       int occ = ld_relaxed(bin_occ + k);
       if (occ >= 0) { bin_occ[k] = -2 - occ; continue; }  // tracked occupant: never replaced
-      int win = -1, wdisp = 0, wdist = 0;
-      for (int q = 0; q < n_cand; ++q) {
-        if (match[2 * q] != k) continue;
+      const int i0 = bstart[k], m = bstart[k + 1] - i0;
+      int win = -1, wdisp = 0, wdist = 0, last = -1;
+      for (int t = 0; t < m; ++t) {
+        // next candidate in ascending sweep order: smallest q greater than the last one taken
+        int q = 0x7FFFFFFF;
+        for (int u = 0; u < m; ++u) { const int v = ld_relaxed(bitems + i0 + u); if (v > last && v < q) q = v; }
+        last = q;
         const int pk = match[2 * q + 1];
         const int disp = pk >> 16, dist = pk & 0xFFFF;
         if (win < 0 || (disp > wdisp && dist <= wdist)) { win = q; wdisp = disp; wdist = dist; }
       }
       bin_occ[k] = win;  // -1 empty, >= 0 candidate index
     }
-    __syncthreads();
+    DBG_STAMP(3);
     const int per = (nb + VS_WG - 1) / VS_WG;
     const int k0 = tid * per, k1 = min(k0 + per, nb);
     int cnt = 0;
@@ -395,6 +446,7 @@ __device__ void wg_stereo(const DevCfg& c, const DevBuf& b, int s, FrameShared& 
     added = n_cand;
   }
   __syncthreads();
+  DBG_STAMP(4);
   const int n_final = min(n_tracked + added, c.MAXP);
   // history of the appended points
   double* hc = hcam_of(c, b, s, f);
@@ -718,12 +770,13 @@ __global__ __launch_bounds__(VS_WG) void k_stage(const DevCfg c, const DevBuf b,
 }
 
 // setters of the tracker-owned state (one thread)
-__global__ void k_set_tracker_state(const DevBuf b, int s, int status, int win, double tau, const double* prior) {
+struct D12 { double v[12]; };   // a transform passed by value as a kernel argument (no staging buffer)
+__global__ void k_set_tracker_state(const DevBuf b, int s, int status, int win, double tau, const D12 prior) {
   StreamState& st = b.st[s];
   st.status = status; st.win = win; st.tau_track = tau;
-  for (int k = 0; k < 12; ++k) st.prior[k] = prior[k];
+  for (int k = 0; k < 12; ++k) st.prior[k] = prior.v[k];
 }
-__global__ void k_set_pose(const DevBuf b, int s, const double* pose) {
+__global__ void k_set_pose(const DevBuf b, int s, const D12 pose) {
   StreamState& st = b.st[s];
-  for (int k = 0; k < 12; ++k) st.pose[k] = pose[k];
+  for (int k = 0; k < 12; ++k) st.pose[k] = pose.v[k];
 }

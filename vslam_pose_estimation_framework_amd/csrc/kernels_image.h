@@ -366,16 +366,68 @@ __device__ __forceinline__ void brief_wave(const uint16_t* box, int bstride, int
   }
 }
 
+// Tiled form: one workgroup owns the keypoints of a 128 x 32 pixel tile (found through the row/cell CSR), stages
+// the (128+48) x (32+48) u16 box region once in LDS with coalesced loads and evaluates the 256 tests from LDS,
+// one wavefront per keypoint.  Replaces 512 scattered 2-byte global gathers per keypoint.
+#define VS_BT_W 128
+#define VS_BT_H 32
+#define VS_BT_RW (VS_BT_W + 2 * VSLAM_BRIEF_PATCH_HALF)   // 176
+#define VS_BT_RH (VS_BT_H + 2 * VSLAM_BRIEF_PATCH_HALF)   // 80
 __global__ __launch_bounds__(256) void k_brief(const DevCfg c, const DevBuf b) {
+  __shared__ __align__(16) uint16_t reg[VS_BT_RH][VS_BT_RW];
+  __shared__ int row_lo[VS_BT_H], row_off[VS_BT_H + 1];
   const int s = blockIdx.z >> 1, side = blockIdx.z & 1;
-  const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int nwaves = gridDim.x * (blockDim.x >> 6);
-  const int n = b.n_kp[s * 2 + side];
+  const int tx = blockIdx.x, ty = blockIdx.y;
+  const int x0 = tx * VS_BT_W, y0 = ty * VS_BT_H;
+  const int rows = c.c.rows, cols = c.c.cols;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int32_t* rowcell = rowcell_of(c, b, s, side);
+  // keypoints of the tile: per row the CSR range of cells [8*tx, 8*tx+8)
+  if (tid < VS_BT_H) {
+    const int r = y0 + tid;
+    int lo = 0, n = 0;
+    if (r < rows) {
+      const int c0 = min(8 * tx, c.CW), c1 = min(8 * tx + 8, c.CW);
+      lo = rowcell[(size_t)r * (c.CW + 1) + c0];
+      n = rowcell[(size_t)r * (c.CW + 1) + c1] - lo;
+    }
+    row_lo[tid] = lo;
+    int inc = n;
+#pragma unroll
+    for (int o = 1; o < VS_BT_H; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (tid >= o) inc += t; }
+    row_off[tid + 1] = inc;
+    if (tid == 0) row_off[0] = 0;
+  }
+  __syncthreads();
+  const int K = row_off[VS_BT_H];
+  if (K == 0) return;
+  const uint16_t* box = box_of(c, b, s, side);
+  // stage the box region, two pixels per 32-bit load (x0 - 24 is even, the row stride is a multiple of 64)
+  for (int i = tid; i < VS_BT_RH * (VS_BT_RW / 2); i += 256) {
+    const int r = i / (VS_BT_RW / 2), q = i - r * (VS_BT_RW / 2);
+    const int gy = min(max(y0 - VSLAM_BRIEF_PATCH_HALF + r, 0), rows - 1);
+    const int gx = min(max(x0 - VSLAM_BRIEF_PATCH_HALF + 2 * q, 0), c.bstride - 2);
+    *reinterpret_cast<uint32_t*>(&reg[r][2 * q]) = *reinterpret_cast<const uint32_t*>(box + (size_t)gy * c.bstride + gx);
+  }
+  __syncthreads();
   const int16_t* kxy = kpxy_of(c, b, s, side);
   uint8_t* desc = desc_of(c, b, s, side);
-  const uint16_t* box = box_of(c, b, s, side);
-  for (int i = wave; i < n; i += nwaves) brief_wave(box, c.bstride, kxy[2 * i], kxy[2 * i + 1], lane, desc + (size_t)32 * i);
+  for (int k = w; k < K; k += 4) {
+    // locate keypoint k: row with row_off[r] <= k < row_off[r+1]
+    int r = 0;
+#pragma unroll
+    for (int step = VS_BT_H / 2; step > 0; step >>= 1) if (row_off[r + step] <= k) r += step;
+    const int idx = row_lo[r] + (k - row_off[r]);
+    const int lx = kxy[2 * idx] - x0 + VSLAM_BRIEF_PATCH_HALF, ly = r + VSLAM_BRIEF_PATCH_HALF;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = j * 64 + lane;
+      const int a = reg[ly + c_brief[i][0]][lx + c_brief[i][1]];
+      const int bb = reg[ly + c_brief[i][2]][lx + c_brief[i][3]];
+      const unsigned long long m = __ballot(a < bb);
+      if (lane == 0) reinterpret_cast<unsigned long long*>(desc + (size_t)32 * idx)[j] = __builtin_bswap64(__brevll(m));
+    }
+  }
 }
 
 // stand-alone BRIEF at caller keypoints (vslam_brief_describe): keep[] = inside the 28 px border

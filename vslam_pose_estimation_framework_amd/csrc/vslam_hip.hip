@@ -243,7 +243,7 @@ static int create_internal(const vslam_config* cfg, int device, int n_streams, v
   A(res, B * P * 4); A(trk, B * P * 4); A(lost, B * P);
   A(al_moving, B * P * 3); A(al_fixed, B * P * 4); A(al_omega, B * P); A(al_weight, B * P); A(al_chi, B * P); A(al_inl, B * P);
   A(rec, B * P * 6); A(rec_desc, B * P * 64);
-  A(st_match, B * N * 2); A(sc, B * N * 4); A(bin_occ, B * (size_t)d.rows_bin * d.cols_bin);
+  A(st_match, B * N * 2); A(sc, B * N * 4); A(bin_occ, B * (size_t)d.rows_bin * d.cols_bin); A(sdist, B * N * 16); A(bin_aux, B * (2 * ((size_t)d.rows_bin * d.cols_bin + 1) + N));
   A(h_pose, B * Hc * 24); A(h_cam, B * Hc * P * 3); A(h_prev, B * Hc * P);
 #undef A
   for (int q = 0; q < 2 && e == hipSuccess; ++q) {
@@ -334,8 +334,8 @@ static int launch_image_pipeline(vslam_ctx* c) {
   dim3 g1(d.TX, (d.c.rows + VS_TILE_H - 1) / VS_TILE_H, 2 * c->B);
   { KernelTimer t(c, 0, st); hipLaunchKernelGGL(k_fast_box, g1, dim3(256), 0, st, c->cfg, bs); }
   { KernelTimer t(c, 1, st); hipLaunchKernelGGL(k_emit, dim3(c->B), dim3(1024), 0, st, c->cfg, bs, (int)VSLAM_BRIEF_BORDER, 1); }
-  const int gx = std::max(4, std::min(64, 1024 / (2 * c->B)));
-  { KernelTimer t(c, 2, st); hipLaunchKernelGGL(k_brief, dim3(gx, 1, 2 * c->B), dim3(256), 0, st, c->cfg, bs); }
+  dim3 g3((d.c.cols + VS_BT_W - 1) / VS_BT_W, (d.c.rows + VS_BT_H - 1) / VS_BT_H, 2 * c->B);
+  { KernelTimer t(c, 2, st); hipLaunchKernelGGL(k_brief, g3, dim3(256), 0, st, c->cfg, bs); }
   HIP_TRY(c, hipGetLastError());
   if (st != c->stream) { HIP_TRY(c, hipEventRecord(c->ev_img[set], st)); HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_img[set], 0)); }
   c->last_set = set;
@@ -700,23 +700,29 @@ VS_API int vslam_set_tracker_state(vslam_ctx* c, int s, int status, const double
   int rc = check_stream(c, s);
   if (rc) return rc;
   if (!prior) return fail(c, VSLAM_ERR_INVALID, "null prior");
-  double* d = nullptr;
-  HIP_TRY(c, hipMallocAsync((void**)&d, 12 * sizeof(double), c->stream));
-  HIP_TRY(c, hipMemcpyAsync(d, prior, 12 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_set_tracker_state, dim3(1), dim3(1), 0, c->stream, c->buf, s, status, win, tau, d);
-  HIP_TRY(c, hipFreeAsync(d, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));  // `prior` is caller memory
+  D12 p;
+  std::memcpy(p.v, prior, sizeof p.v);
+  hipLaunchKernelGGL(k_set_tracker_state, dim3(1), dim3(1), 0, c->stream, c->buf, s, status, win, tau, p);
+  HIP_TRY(c, hipGetLastError());
   return VSLAM_OK;
 }
 VS_API int vslam_set_pose(vslam_ctx* c, int s, const double pose[12]) {
   int rc = check_stream(c, s);
   if (rc) return rc;
   if (!pose) return fail(c, VSLAM_ERR_INVALID, "null pose");
-  double* d = nullptr;
-  HIP_TRY(c, hipMallocAsync((void**)&d, 12 * sizeof(double), c->stream));
-  HIP_TRY(c, hipMemcpyAsync(d, pose, 12 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(1), 0, c->stream, c->buf, s, d);
-  HIP_TRY(c, hipFreeAsync(d, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  D12 p;
+  std::memcpy(p.v, pose, sizeof p.v);
+  hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(1), 0, c->stream, c->buf, s, p);
+  HIP_TRY(c, hipGetLastError());
+  return VSLAM_OK;
+}
+
+// profiling aid (not part of the ABI): mean per-stream ticks of the fine-grained phase stamps, in microseconds
+VS_API int vslam_debug_ticks(vslam_ctx* c, double us[12]) {
+  if (!c || !us) return VSLAM_ERR_INVALID;
+  harvest_events(c);
+  std::vector<StreamState> st(c->B);
+  HIP_TRY(c, hipMemcpy(st.data(), c->buf.st, sizeof(StreamState) * c->B, hipMemcpyDeviceToHost));
+  for (int k = 0; k < 12; ++k) { double a = 0; for (int s = 0; s < c->B; ++s) a += (double)st[s].dbg[k]; us[k] = a * 1e-2 / c->B; }
   return VSLAM_OK;
 }
