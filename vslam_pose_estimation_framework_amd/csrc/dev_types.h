@@ -19,7 +19,7 @@
 #include "../../include/vslam_hip.h"
 
 #define VS_TILE_W 64
-#define VS_TILE_H 16
+#define VS_TILE_H 32
 #define VS_CELL 16
 #define VS_MAXCAND 16        // candidate list length per previous point (overflow -> exact rescan)
 #define VS_WG 512            // threads of the per-stream frame kernel

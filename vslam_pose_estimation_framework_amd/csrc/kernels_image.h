@@ -132,15 +132,15 @@ __device__ __forceinline__ s16x2 pk_max(s16x2 a, s16x2 b) { return __builtin_ele
 // FAST-9/16 without branches, two pixels per lane in packed i16 (v_pk_sub/min/max_i16): with
 // A = max over the 16 nine-arcs of min(d), Bm = min over arcs of max(d) (d = centre - ring pixel), the pixel is
 // a corner iff A > t or -Bm > t, and cornerScore = max(t, A, -Bm) - 1 — one sliding min/max table gives both.
-__device__ __forceinline__ void fast_pair_scores(const uint8_t (*t)[80], int ly0, int ly1, int lx, int thr0, int thr1,
+__device__ __forceinline__ void fast_pair_scores(const uint8_t (*t)[80], int ly0, int lx0, int ly1, int lx1, int thr0, int thr1,
                                                  int* s0, int* s1) {
   const int dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
   const int dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
-  const s16x2 v = {(short)t[ly0][lx], (short)t[ly1][lx]};
+  const s16x2 v = {(short)t[ly0][lx0], (short)t[ly1][lx1]};
   s16x2 d[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    const s16x2 p = {(short)t[ly0 + dy[k]][lx + dx[k]], (short)t[ly1 + dy[k]][lx + dx[k]]};
+    const s16x2 p = {(short)t[ly0 + dy[k]][lx0 + dx[k]], (short)t[ly1 + dy[k]][lx1 + dx[k]]};
     d[k] = v - p;
   }
   s16x2 mn2[16], mx2[16], mn4[16], mx4[16];
@@ -164,6 +164,8 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
   __shared__ __align__(4) uint8_t sc[VS_TILE_H + 2][68];
   __shared__ __align__(8) uint16_t hs[VS_TILE_H + 8][VS_TILE_W];
   __shared__ int32_t s_thr[VSLAM_MAX_REGIONS];
+  __shared__ uint16_t queue[(VS_TILE_H + 2) * 66];
+  __shared__ int qn;
   const int tx = blockIdx.x, ty = blockIdx.y, s = blockIdx.z >> 1, side = blockIdx.z & 1;
   const int x0 = tx * VS_TILE_W, y0 = ty * VS_TILE_H;
   const int rows = c.c.rows, cols = c.c.cols;
@@ -171,6 +173,7 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
   const int stride = b.img_row_stride;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (tid < c.n_regions) s_thr[tid] = min(max(b.st[s].thr[tid], 0), 255);
+  if (tid == 0) qn = 0;
   // ---- stage the (64+8) x (16+8) u8 tile: aligned dwords in the interior, clamped bytes at the image border ----
   const bool aligned = ((stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(img) & 3) == 0);
   for (int i = tid; i < (VS_TILE_H + 8) * 18; i += 256) {
@@ -187,14 +190,24 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
     *reinterpret_cast<uint32_t*>(&tile[r][4 * q]) = v;
   }
   __syncthreads();
-  // ---- FAST scores on the 66 x 18 region (tile + 1 px NMS halo): lane = column, two rows (r, r+9) per lane -----------
-  for (int i = tid; i < 9 * 66; i += 256) {
-    const int rp = i / 66, cc = i - rp * 66;
-    const int gx = x0 - 1 + cc, gy0 = y0 - 1 + rp, gy1 = gy0 + 9;
-    int sv0, sv1;
-    fast_pair_scores(tile, rp + 3, rp + 12, cc + 3, region_threshold(c, s_thr, gx, gy0), region_threshold(c, s_thr, gx, gy1), &sv0, &sv1);
-    sc[rp][cc] = (uint8_t)sv0;
-    sc[rp + 9][cc] = (uint8_t)sv1;
+  // ---- FAST on the 66 x (H+2) score region (tile + 1 px NMS halo), two passes:
+  //  A) every pixel: the high-speed test (a 9-arc of 16 contains two ADJACENT compass points, so one of the four
+  //     adjacent compass pairs must pass on the dark or on the bright side) -> ~1 pixel in 8 survives, queued in LDS
+  //  B) queued pixels only, two per lane in packed i16: exact corner test + cornerScore
+  for (int i = tid; i < (VS_TILE_H + 2) * 66; i += 256) {
+    const int r = i / 66, cc = i - r * 66;
+    const int thr = region_threshold(c, s_thr, x0 - 1 + cc, y0 - 1 + r);
+    bool cand = false;
+    if (thr >= 0) {
+      const int ly = r + 3, lx = cc + 3;
+      const int v = tile[ly][lx];
+      const int d0 = v - tile[ly + 3][lx], d4 = v - tile[ly][lx + 3], d8 = v - tile[ly - 3][lx], d12 = v - tile[ly][lx - 3];
+      const int dk = max(max(min(d0, d4), min(d4, d8)), max(min(d8, d12), min(d12, d0)));
+      const int br = min(min(max(d0, d4), max(d4, d8)), min(max(d8, d12), max(d12, d0)));
+      cand = dk > thr || br < -thr;
+    }
+    if (cand) queue[atomicAdd(&qn, 1)] = (uint16_t)((r << 8) | cc);
+    else sc[r][cc] = 0;
   }
   // ---- horizontal 9-sums, four outputs per thread from three aligned dwords -----------------------------------------
   for (int i = tid; i < (VS_TILE_H + 8) * 16; i += 256) {
@@ -208,17 +221,31 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
     *reinterpret_cast<uint2*>(&hs[r][4 * q]) = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
   }
   __syncthreads();
+  {
+    const int nq = qn;
+    for (int q = tid; 2 * q < nq; q += 256) {
+      const int e0 = queue[2 * q], e1 = (2 * q + 1 < nq) ? queue[2 * q + 1] : e0;
+      const int r0 = e0 >> 8, c0 = e0 & 255, r1 = e1 >> 8, c1 = e1 & 255;
+      int sv0, sv1;
+      fast_pair_scores(tile, r0 + 3, c0 + 3, r1 + 3, c1 + 3, region_threshold(c, s_thr, x0 - 1 + c0, y0 - 1 + r0),
+                       region_threshold(c, s_thr, x0 - 1 + c1, y0 - 1 + r1), &sv0, &sv1);
+      sc[r0][c0] = (uint8_t)sv0;
+      if (2 * q + 1 < nq) sc[r1][c1] = (uint8_t)sv1;
+    }
+  }
+  __syncthreads();
   // ---- strict 3x3 NMS -> 1 bit / pixel, sparse scores, vertical 9-sums (sliding) -> u16 box image ----------------------
   unsigned long long* mask = mask_of(c, b, s, side);
   uint8_t* score8 = score_of(c, b, s, side);
   uint16_t* box = box_of(c, b, s, side);
   const int gx = x0 + lane;
   int acc = 0;
+  constexpr int RW = VS_TILE_H / 4;   // output rows per wave
 #pragma unroll
-  for (int k = 0; k < 9; ++k) acc += hs[w * 4 + k][lane];
+  for (int k = 0; k < 9; ++k) acc += hs[w * RW + k][lane];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int r = w * 4 + j, gy = y0 + r;
+  for (int j = 0; j < RW; ++j) {
+    const int r = w * RW + j, gy = y0 + r;
     const int v = sc[r + 1][lane + 1];
     bool keep = v > 0;
     if (keep) {
@@ -231,7 +258,7 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
       if (keep) score8[(size_t)gy * c.bstride + gx] = (uint8_t)v;
       if (gx < cols) box[(size_t)gy * c.bstride + gx] = (uint16_t)acc;
     }
-    if (j < 3) acc += (int)hs[r + 9][lane] - (int)hs[r][lane];
+    if (j < RW - 1) acc += (int)hs[r + 9][lane] - (int)hs[r][lane];
   }
 }
 
