@@ -73,6 +73,21 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* sh, int* total) 
 // tile with a 4 px halo (FAST ring 3 + NMS 1 == box radius 4) is staged once in LDS.
 // HBM traffic per pixel: 1 B read, 2 B box write, 1/8 B mask write.
 // ==============================================================================================
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (block b and b+8 share an L2), so the
+// linear block id is re-labelled such that CONSECUTIVE tiles (x fastest, then y, then image) run on the same XCD
+// and the halo lines neighbouring tiles share are fetched into one L2 only.  Speed only, never correctness.
+__device__ __forceinline__ void xcd_tile(int* tx, int* ty, int* tz) {
+  const int gx = gridDim.x, gy = gridDim.y;
+  const int total = gx * gy * gridDim.z;
+  int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  const int per = total >> 3;
+  if (lin < (per << 3)) lin = (lin & 7) * per + (lin >> 3);
+  *tx = lin % gx;
+  const int r = lin / gx;
+  *ty = r % gy;
+  *tz = r / gy;
+}
+
 // v - ring pixel for the 16 positions of the Bresenham circle (OpenCV order) around tile position (ly,lx)
 __device__ __forceinline__ void fast_ring_diffs(const uint8_t (*t)[80], int ly, int lx, int* d) {
   const int v = t[ly][lx];
@@ -166,7 +181,9 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
   __shared__ int32_t s_thr[VSLAM_MAX_REGIONS];
   __shared__ uint16_t queue[(VS_TILE_H + 2) * 66];
   __shared__ int qn;
-  const int tx = blockIdx.x, ty = blockIdx.y, s = blockIdx.z >> 1, side = blockIdx.z & 1;
+  int tx, ty, tz;
+  xcd_tile(&tx, &ty, &tz);
+  const int s = tz >> 1, side = tz & 1;
   const int x0 = tx * VS_TILE_W, y0 = ty * VS_TILE_H;
   const int rows = c.c.rows, cols = c.c.cols;
   const uint8_t* img = b.img[side] + (size_t)s * b.img_stream_stride;
@@ -403,8 +420,9 @@ __device__ __forceinline__ void brief_wave(const uint16_t* box, int bstride, int
 __global__ __launch_bounds__(256) void k_brief(const DevCfg c, const DevBuf b) {
   __shared__ __align__(16) uint16_t reg[VS_BT_RH][VS_BT_RW];
   __shared__ int row_lo[VS_BT_H], row_off[VS_BT_H + 1];
-  const int s = blockIdx.z >> 1, side = blockIdx.z & 1;
-  const int tx = blockIdx.x, ty = blockIdx.y;
+  int tx, ty, tz;
+  xcd_tile(&tx, &ty, &tz);
+  const int s = tz >> 1, side = tz & 1;
   const int x0 = tx * VS_BT_W, y0 = ty * VS_BT_H;
   const int rows = c.c.rows, cols = c.c.cols;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
