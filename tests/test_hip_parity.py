@@ -200,3 +200,85 @@ def test_stage_call_before_frame_begin_is_an_error():
         assert rc == -1 and "empty frame" in api.last_error(api.ctx)   # the reference throws "called with empty frame"
     finally:
         api.destroy()
+
+
+def _pair_compare(o, g, L, R, k, tag):
+    o.process_host(L, R)
+    g.process_host(L, R)
+    compare_frame(o, g, 0, k, tag)
+
+
+def test_degenerate_inputs_blank_noise_and_scene_cut():
+    """Edge cases the reference would meet in the wild: featureless frames (no keypoints, no points), pure noise
+    (keypoints everywhere, no stereo matches), a scene cut (nothing tracks -> recursive registration -> breakTrack),
+    then recovery on normal frames.  Everything must stay identical to the oracle and raise no capacity flags."""
+    from _oracle import Oracle
+    o = Oracle()
+    sc = o.scene_kitti(scale=0.4, seed=9)
+    sc2 = o.scene_kitti(scale=0.4, seed=1234)
+    cfg = o.config_for_scene(sc)
+    o.create(cfg, 0, 1)
+    g = hip.load()
+    g.create(cfg, 0, 1)
+    rng = np.random.default_rng(5)
+    try:
+        blank = np.full((cfg.rows, cfg.cols), 77, np.uint8)
+        k = 0
+        for _ in range(2):
+            _pair_compare(o, g, blank, blank, k, "blank"); k += 1
+        for f in range(4):
+            _pair_compare(o, g, *o.render(sc, f), k, "normal"); k += 1
+        noise = rng.integers(0, 256, (cfg.rows, cfg.cols), dtype=np.uint8)
+        noise2 = rng.integers(0, 256, (cfg.rows, cfg.cols), dtype=np.uint8)
+        _pair_compare(o, g, noise, noise2, k, "noise"); k += 1
+        for f in range(3):
+            _pair_compare(o, g, *o.render(sc2, 40 + f), k, "cut"); k += 1     # different world: track is lost
+        _pair_compare(o, g, blank, blank, k, "blank-again"); k += 1
+        for f in range(3):
+            _pair_compare(o, g, *o.render(sc, 10 + f), k, "resume"); k += 1
+        assert g.frame_info(0).error_flags == 0
+    finally:
+        g.destroy()
+        o.destroy()
+
+
+def test_keypoint_capacity_overflow_is_flagged_not_fatal():
+    """A device buffer that is too small sets error_flags bit 0 and truncates; nothing is written out of bounds."""
+    from _oracle import Oracle
+    o = Oracle()
+    sc = o.scene_kitti(scale=0.4, seed=3)
+    cfg = o.config_for_scene(sc)
+    cfg.max_keypoints = 128
+    cfg.max_points = 64
+    g = hip.load()
+    g.create(cfg, 0, 1)
+    try:
+        for f in range(4):
+            g.process_host(*o.render(sc, f))
+        fi = g.frame_info(0)
+        assert fi.error_flags & 1
+        assert fi.n_keypoints_left <= 128 and fi.n_points <= 64
+        xy, score, desc = g.keypoints(0, 0)
+        assert len(xy) == fi.n_keypoints_left
+    finally:
+        g.destroy()
+
+
+def test_odd_image_geometry():
+    """Image sizes that are not multiples of the 64x32 / 128x32 tiles, with a row stride larger than the width."""
+    from _oracle import Oracle
+    o = Oracle()
+    sc = o.scene_kitti(scale=0.37, seed=17)          # 139 x 459
+    cfg = o.config_for_scene(sc)
+    o.create(cfg, 0, 1)
+    g = hip.load()
+    g.create(cfg, 0, 1)
+    try:
+        for k in range(6):
+            L, R = o.render(sc, k, stride=sc.cols + 13)
+            o.process_host(L, R)
+            g.process_host(L, R)
+            compare_frame(o, g, 0, k, "odd")
+    finally:
+        g.destroy()
+        o.destroy()
