@@ -163,7 +163,9 @@ def main():
         frames_per_step = B * world
         eff = L / float(L + overlap)
         value = frames_per_step * K / elapsed * eff
-        abytes = algorithmic_bytes(cfg, B, stats)
+        # the context processes its streams in G independent groups: one launch covers B/G streams
+        groups = max(1, ktimes["k_frame"][1] // max(K, 1))
+        abytes = algorithmic_bytes(cfg, B / groups, stats)
         kern = {}
         for name, (ms, n) in ktimes.items():
             avg_ms = ms / max(n, 1)
@@ -180,7 +182,8 @@ def main():
             "config": {"workload": "KITTI-00-shaped synthetic stereo (1241x376, 4541 frames), configuration_kitti.yaml "
                                    "values, bin 15 (target 2158 kp/image), FAST+BRIEF-32, open loop",
                        "streams_per_gpu": B, "chunk_frames": L, "chunk_overlap": overlap,
-                       "frames_per_step": frames_per_step, "unique_frame_fraction": round(eff, 4),
+                       "frames_per_step": frames_per_step, "stream_groups": groups, "streams_per_launch": B // groups,
+                       "unique_frame_fraction": round(eff, 4),
                        "parallelism": "frame-sharded chunks, %d per GPU x %d GPU" % (B, world),
                        "mean_keypoints_per_image": round(stats["N"], 1), "mean_points_per_frame": round(stats["P"], 1),
                        "mean_tracked": round(stats["M"], 1), "mean_aligner_iterations": round(stats["I"], 1),

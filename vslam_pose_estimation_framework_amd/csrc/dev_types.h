@@ -78,6 +78,7 @@ struct ImgInfo {
 };
 
 struct DevBuf {
+  int32_t s0;          // first stream of the launch (streams are processed in independent groups)
   // current input images (device pointers)
   const uint8_t* img[2];
   int32_t img_row_stride;

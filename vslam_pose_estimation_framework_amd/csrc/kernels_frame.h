@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void k_track_candidates(const DevCfg c, const 
   // mode < 0: fused path (appearance iff the tracker is Localizing, window forced to max in that case);
   // mode 0/1: stage path, window and distance exactly as set through vslam_set_tracker_state
   __shared__ int wcnt[4];
-  const int s = blockIdx.y;
+  const int s = b.s0 + blockIdx.y;
   const StreamState& st = b.st[s];
   if (!st.has_prev) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;

@@ -478,7 +478,7 @@ __device__ __forceinline__ double tau_tri_rule(const DevCfg& c, int status, int 
 __global__ __launch_bounds__(VS_WG) void k_frame(const DevCfg c, const DevBuf b) {
   __shared__ FrameShared sh;
   __shared__ int wcnt[VS_WG / 64];
-  const int s = blockIdx.x, tid = threadIdx.x;
+  const int s = b.s0 + blockIdx.x, tid = threadIdx.x;
   StreamState& st = b.st[s];
   vslam_frame_info& info = b.info[s];
   const int f = st.frame_count;             // index of the frame being processed
@@ -494,6 +494,7 @@ __global__ __launch_bounds__(VS_WG) void k_frame(const DevCfg c, const DevBuf b)
     for (int k = 0; k < 36; ++k) sh.H[k] = 0;
     set_pose(c, b, s, f, st.pose);          // frame created at WorldMap::robot_to_world
   }
+  const unsigned long long tK0 = wall_clock64();
   double prior[12];
   for (int k = 0; k < 12; ++k) prior[k] = st.prior[k];
   const double tau_tri = tau_tri_rule(c, status0, b.n_kp[s * 2]);
@@ -625,7 +626,9 @@ __global__ __launch_bounds__(VS_WG) void k_frame(const DevCfg c, const DevBuf b)
       for (int k = 0; k < 12; ++k) st.al_T[k] = sh.T[k];
       for (int k = 0; k < 36; ++k) st.al_H[k] = sh.H[k];
     }
+    const unsigned long long tP = wall_clock64();
     wg_prune(c, b, s, sh, pb_prev, pb_cur, aligner_valid);
+    if (tid == 0) st.dbg[6] += wall_clock64() - tP;
     n_after_prune = sh.n_cur;
     if (c.c.enable_landmark_recovery) {
       const unsigned long long tr = wall_clock64();
@@ -666,6 +669,7 @@ __global__ __launch_bounds__(VS_WG) void k_frame(const DevCfg c, const DevBuf b)
     info.error_flags = st.error_flags; info.tau_track = tau_track; info.tau_triangulation = tau_tri;
     for (int k = 0; k < 12; ++k) { info.camera_left_to_world[k] = c2w[k]; info.previous_to_current[k] = prior[k]; }
     if (f < VS_POSE_LOG) { double* pl = b.pose_log + ((size_t)s * VS_POSE_LOG + f) * 12; for (int k = 0; k < 12; ++k) pl[k] = c2w[k]; }
+    st.dbg[8] += wall_clock64() - tK0;
   }
 }
 
@@ -677,7 +681,7 @@ enum { VS_STAGE_TRACK = 1, VS_STAGE_ALIGN = 2, VS_STAGE_PRUNE_RECOVER = 3, VS_ST
 
 // WorldMap::createFrame + the bookkeeping PoseTracker3D::compute does before initialize() (:36-77)
 __global__ __launch_bounds__(256) void k_begin(const DevCfg c, const DevBuf b) {
-  const int s = blockIdx.x, tid = threadIdx.x;
+  const int s = b.s0 + blockIdx.x, tid = threadIdx.x;
   StreamState& st = b.st[s];
   const int f = st.frame_count;
   if (st.has_prev) {
@@ -698,7 +702,7 @@ __global__ __launch_bounds__(256) void k_begin(const DevCfg c, const DevBuf b) {
 
 __global__ __launch_bounds__(VS_WG) void k_stage(const DevCfg c, const DevBuf b, int stage, int arg) {
   __shared__ FrameShared sh;
-  const int s = blockIdx.x, tid = threadIdx.x;
+  const int s = b.s0 + blockIdx.x, tid = threadIdx.x;
   StreamState& st = b.st[s];
   vslam_frame_info& info = b.info[s];
   const int f = st.frame_count;

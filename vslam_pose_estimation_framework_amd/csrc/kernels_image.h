@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
   __shared__ int qn;
   int tx, ty, tz;
   xcd_tile(&tx, &ty, &tz);
-  const int s = tz >> 1, side = tz & 1;
+  const int s = b.s0 + (tz >> 1), side = tz & 1;
   const int x0 = tx * VS_TILE_W, y0 = ty * VS_TILE_H;
   const int rows = c.c.rows, cols = c.c.cols;
   const uint8_t* img = b.img[side] + (size_t)s * b.img_stream_stride;
@@ -297,7 +297,7 @@ __device__ __forceinline__ unsigned long long col_mask(int lo, int hi, int wx0) 
 __global__ __launch_bounds__(1024) void k_emit(const DevCfg c, const DevBuf b, int border, int run_controller) {
   __shared__ int sh_scan[17];
   __shared__ int sh_cnt[2][VSLAM_MAX_REGIONS];
-  const int s = blockIdx.x, tid = threadIdx.x;
+  const int s = b.s0 + blockIdx.x, tid = threadIdx.x;
   const int rows = c.c.rows, cols = c.c.cols, TX = c.TX, CW = c.CW;
   StreamState& st = b.st[s];
   if (tid < 2 * VSLAM_MAX_REGIONS) sh_cnt[tid / VSLAM_MAX_REGIONS][tid % VSLAM_MAX_REGIONS] = 0;
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void k_brief(const DevCfg c, const DevBuf b) {
   __shared__ int row_lo[VS_BT_H], row_off[VS_BT_H + 1];
   int tx, ty, tz;
   xcd_tile(&tx, &ty, &tz);
-  const int s = tz >> 1, side = tz & 1;
+  const int s = b.s0 + (tz >> 1), side = tz & 1;
   const int x0 = tx * VS_BT_W, y0 = ty * VS_BT_H;
   const int rows = c.c.rows, cols = c.c.cols;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;

@@ -27,8 +27,10 @@ struct vslam_ctx {
   struct ImgSet { uint16_t* box; uint8_t* score8; unsigned long long* mask; int16_t* kp_xy; uint8_t* kp_score; uint8_t* desc;
                   int32_t* n_kp; int32_t* rowcell; uint8_t* used; ImgInfo* iinfo; } sets[2];
   int parity = 0, last_set = 0;
-  hipEvent_t ev_img[2] = {nullptr, nullptr}, ev_frm[2] = {nullptr, nullptr};
-  bool frm_pending[2] = {false, false};
+  // streams are processed in G independent groups, each with its own pair of HIP streams: a slow stream only
+  // delays its own group, the other groups' kernels fill the idle CUs
+  struct Group { int s0, n; hipStream_t st_frm, st_img; hipEvent_t ev_img[2], ev_frm[2]; bool frm_pending[2]; };
+  std::vector<Group> groups;
   std::string err;
   std::vector<void*> allocs;
   uint8_t* upload[2] = {nullptr, nullptr};
@@ -77,9 +79,9 @@ struct KernelTimer {
   KernelTimer(vslam_ctx* c_, int k_, hipStream_t st_) : c(c_), k(k_), st(st_) { if (c->timers) { a = ev_get(c); (void)hipEventRecord(a, st); } }
   ~KernelTimer() { if (a) { hipEvent_t b = ev_get(c); (void)hipEventRecord(b, st); c->evrec.push_back({a, b, k}); } }
 };
+static void sync_all(vslam_ctx* c);
 static void harvest_events(vslam_ctx* c) {
-  (void)hipStreamSynchronize(c->stream_img);
-  (void)hipStreamSynchronize(c->stream);
+  sync_all(c);
   for (auto& r : c->evrec) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { c->kern_ms[r.k] += ms; c->kern_n[r.k] += 1; }
@@ -89,8 +91,16 @@ static void harvest_events(vslam_ctx* c) {
 }
 
 
-static DevBuf buf_set(const vslam_ctx* c, int set) {
+static void sync_all(vslam_ctx* c) {
+  for (auto& g : c->groups) { (void)hipStreamSynchronize(g.st_img); (void)hipStreamSynchronize(g.st_frm); }
+}
+static int group_of(const vslam_ctx* c, int s) {
+  for (size_t i = 0; i < c->groups.size(); ++i) if (s >= c->groups[i].s0 && s < c->groups[i].s0 + c->groups[i].n) return (int)i;
+  return 0;
+}
+static DevBuf buf_set(const vslam_ctx* c, int set, int s0 = 0) {
   DevBuf b = c->buf;
+  b.s0 = s0;
   const vslam_ctx::ImgSet& q = c->sets[set];
   b.box = q.box; b.score8 = q.score8; b.mask = q.mask; b.kp_xy = q.kp_xy; b.kp_score = q.kp_score; b.desc = q.desc;
   b.n_kp = q.n_kp; b.rowcell = q.rowcell; b.used = q.used; b.iinfo = q.iinfo;
@@ -193,11 +203,11 @@ static int init_state(vslam_ctx* c) {
   HIP_TRY(c, hipMemcpyAsync(c->buf.st, st.data(), sizeof(StreamState) * c->B, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemsetAsync(c->buf.info, 0, sizeof(vslam_frame_info) * c->B, c->stream));
   HIP_TRY(c, hipMemsetAsync(c->buf.n_points, 0, sizeof(int32_t) * c->B * 2, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream_img));
+  sync_all(c);
   for (int q = 0; q < 2; ++q) {
     HIP_TRY(c, hipMemsetAsync(c->sets[q].n_kp, 0, sizeof(int32_t) * c->B * 2, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->sets[q].iinfo, 0, sizeof(ImgInfo) * c->B, c->stream));
-    c->frm_pending[q] = false;
+    for (auto& g : c->groups) g.frm_pending[q] = false;
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->parity = 0; c->last_set = 0;
@@ -223,10 +233,27 @@ static int create_internal(const vslam_config* cfg, int device, int n_streams, v
   c->device = device;
   c->B = n_streams;
   derive_cfg(*cfg, n_streams, &c->cfg);
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->stream_img, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(nullptr, VSLAM_ERR_HIP, "hipStreamCreate failed"); }
-  c->own_stream = true;
-  for (int q = 0; q < 2; ++q) { (void)hipEventCreateWithFlags(&c->ev_img[q], hipEventDisableTiming); (void)hipEventCreateWithFlags(&c->ev_frm[q], hipEventDisableTiming); }
+  {
+    int G = 1;   // measured on MI355X: concurrent HIP streams did not overlap the per-group kernels (1 group is fastest)
+    if (const char* e = getenv("VSLAM_GROUPS")) G = atoi(e);
+    G = std::max(1, std::min(std::min(G, 16), n_streams));
+    for (int g = 0; g < G; ++g) {
+      vslam_ctx::Group q;
+      q.s0 = (int)((long long)n_streams * g / G);
+      q.n = (int)((long long)n_streams * (g + 1) / G) - q.s0;
+      bool ok = hipStreamCreateWithFlags(&q.st_frm, hipStreamNonBlocking) == hipSuccess &&
+                hipStreamCreateWithFlags(&q.st_img, hipStreamNonBlocking) == hipSuccess;
+      for (int k = 0; k < 2 && ok; ++k)
+        ok = hipEventCreateWithFlags(&q.ev_img[k], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&q.ev_frm[k], hipEventDisableTiming) == hipSuccess;
+      q.frm_pending[0] = q.frm_pending[1] = false;
+      if (!ok) { delete c; return fail(nullptr, VSLAM_ERR_HIP, "hipStreamCreate failed"); }
+      c->groups.push_back(q);
+    }
+    c->stream = c->groups[0].st_frm;
+    c->stream_img = c->groups[0].st_img;
+    c->own_stream = true;
+  }
   const DevCfg& d = c->cfg;
   DevBuf& b = c->buf;
   std::memset(&b, 0, sizeof b);
@@ -289,15 +316,15 @@ VS_API int vslam_create(const vslam_config* cfg, int device, int n_streams, vsla
 VS_API void vslam_destroy(vslam_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream_img);
-  (void)hipStreamSynchronize(c->stream);
+  sync_all(c);
   for (void* p : c->allocs) (void)hipFree(p);
   for (int i = 0; i < 6; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   harvest_events(c);
   for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
-  for (int q = 0; q < 2; ++q) { if (c->ev_img[q]) (void)hipEventDestroy(c->ev_img[q]); if (c->ev_frm[q]) (void)hipEventDestroy(c->ev_frm[q]); }
-  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
-  if (c->own_stream && c->stream_img) (void)hipStreamDestroy(c->stream_img);
+  for (auto& g : c->groups) {
+    for (int q = 0; q < 2; ++q) { (void)hipEventDestroy(g.ev_img[q]); (void)hipEventDestroy(g.ev_frm[q]); }
+    if (c->own_stream) { (void)hipStreamDestroy(g.st_frm); (void)hipStreamDestroy(g.st_img); }
+  }
   delete c;
 }
 VS_API int vslam_reset(vslam_ctx* c) {
@@ -307,18 +334,25 @@ VS_API int vslam_reset(vslam_ctx* c) {
 }
 VS_API int vslam_set_hip_stream(vslam_ctx* c, void* s) {
   if (!c) return VSLAM_ERR_INVALID;
-  (void)hipStreamSynchronize(c->stream_img);
-  (void)hipStreamSynchronize(c->stream);
-  if (c->own_stream) { (void)hipStreamDestroy(c->stream); (void)hipStreamDestroy(c->stream_img); }
-  c->stream = (hipStream_t)s;       // one caller stream: image pipeline and tracker run back to back
-  c->stream_img = (hipStream_t)s;
+  sync_all(c);
+  for (auto& g : c->groups) {
+    for (int q = 0; q < 2; ++q) { (void)hipEventDestroy(g.ev_img[q]); (void)hipEventDestroy(g.ev_frm[q]); }
+    if (c->own_stream) { (void)hipStreamDestroy(g.st_frm); (void)hipStreamDestroy(g.st_img); }
+  }
+  c->groups.clear();
+  // one caller stream: a single group, image pipeline and tracker run back to back on it
+  vslam_ctx::Group q;
+  q.s0 = 0; q.n = c->B; q.st_frm = (hipStream_t)s; q.st_img = (hipStream_t)s;
+  for (int k = 0; k < 2; ++k) { (void)hipEventCreateWithFlags(&q.ev_img[k], hipEventDisableTiming); (void)hipEventCreateWithFlags(&q.ev_frm[k], hipEventDisableTiming); }
+  q.frm_pending[0] = q.frm_pending[1] = false;
+  c->groups.push_back(q);
+  c->stream = q.st_frm; c->stream_img = q.st_img;
   c->own_stream = false;
   return VSLAM_OK;
 }
 VS_API int vslam_synchronize(vslam_ctx* c) {
   if (!c) return VSLAM_ERR_INVALID;
-  HIP_TRY(c, hipStreamSynchronize(c->stream_img));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (auto& g : c->groups) { HIP_TRY(c, hipStreamSynchronize(g.st_img)); HIP_TRY(c, hipStreamSynchronize(g.st_frm)); }
   return c->sticky;
 }
 
@@ -327,31 +361,36 @@ VS_API int vslam_synchronize(vslam_ctx* c) {
 static int launch_image_pipeline(vslam_ctx* c) {
   const DevCfg& d = c->cfg;
   const int set = c->parity;
-  const DevBuf bs = buf_set(c, set);
-  hipStream_t st = c->stream_img;
-  // the image products of this set were last read by the frame kernel two steps ago
-  if (c->frm_pending[set] && st != c->stream) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_frm[set], 0));
-  dim3 g1(d.TX, (d.c.rows + VS_TILE_H - 1) / VS_TILE_H, 2 * c->B);
-  { KernelTimer t(c, 0, st); hipLaunchKernelGGL(k_fast_box, g1, dim3(256), 0, st, c->cfg, bs); }
-  { KernelTimer t(c, 1, st); hipLaunchKernelGGL(k_emit, dim3(c->B), dim3(1024), 0, st, c->cfg, bs, (int)VSLAM_BRIEF_BORDER, 1); }
-  dim3 g3((d.c.cols + VS_BT_W - 1) / VS_BT_W, (d.c.rows + VS_BT_H - 1) / VS_BT_H, 2 * c->B);
-  { KernelTimer t(c, 2, st); hipLaunchKernelGGL(k_brief, g3, dim3(256), 0, st, c->cfg, bs); }
-  HIP_TRY(c, hipGetLastError());
-  if (st != c->stream) { HIP_TRY(c, hipEventRecord(c->ev_img[set], st)); HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_img[set], 0)); }
+  for (auto& g : c->groups) {
+    const DevBuf bs = buf_set(c, set, g.s0);
+    hipStream_t st = g.st_img;
+    // the image products of this set were last read by the frame kernel two steps ago
+    if (g.frm_pending[set] && st != g.st_frm) HIP_TRY(c, hipStreamWaitEvent(st, g.ev_frm[set], 0));
+    dim3 g1(d.TX, (d.c.rows + VS_TILE_H - 1) / VS_TILE_H, 2 * g.n);
+    { KernelTimer t(c, 0, st); hipLaunchKernelGGL(k_fast_box, g1, dim3(256), 0, st, c->cfg, bs); }
+    { KernelTimer t(c, 1, st); hipLaunchKernelGGL(k_emit, dim3(g.n), dim3(1024), 0, st, c->cfg, bs, (int)VSLAM_BRIEF_BORDER, 1); }
+    dim3 g3((d.c.cols + VS_BT_W - 1) / VS_BT_W, (d.c.rows + VS_BT_H - 1) / VS_BT_H, 2 * g.n);
+    { KernelTimer t(c, 2, st); hipLaunchKernelGGL(k_brief, g3, dim3(256), 0, st, c->cfg, bs); }
+    HIP_TRY(c, hipGetLastError());
+    if (st != g.st_frm) { HIP_TRY(c, hipEventRecord(g.ev_img[set], st)); HIP_TRY(c, hipStreamWaitEvent(g.st_frm, g.ev_img[set], 0)); }
+  }
   c->last_set = set;
   return VSLAM_OK;
 }
 static int frame_done(vslam_ctx* c) {
   const int set = c->last_set;
-  if (c->stream_img != c->stream) { HIP_TRY(c, hipEventRecord(c->ev_frm[set], c->stream)); c->frm_pending[set] = true; }
+  for (auto& g : c->groups)
+    if (g.st_img != g.st_frm) { HIP_TRY(c, hipEventRecord(g.ev_frm[set], g.st_frm)); g.frm_pending[set] = true; }
   c->parity = set ^ 1;
   return VSLAM_OK;
 }
 static int launch_frame(vslam_ctx* c) {
-  const DevBuf bs = buf_set(c, c->last_set);
-  const int gx = std::max(4, std::min(128, 2048 / c->B));
-  { KernelTimer t(c, 3, c->stream); hipLaunchKernelGGL(k_track_candidates, dim3(gx, c->B), dim3(256), 0, c->stream, c->cfg, bs, -1); }
-  { KernelTimer t(c, 4, c->stream); hipLaunchKernelGGL(k_frame, dim3(c->B), dim3(VS_WG), 0, c->stream, c->cfg, bs); }
+  for (auto& g : c->groups) {
+    const DevBuf bs = buf_set(c, c->last_set, g.s0);
+    const int gx = std::max(4, std::min(128, 2048 / std::max(g.n, 1)));
+    { KernelTimer t(c, 3, g.st_frm); hipLaunchKernelGGL(k_track_candidates, dim3(gx, g.n), dim3(256), 0, g.st_frm, c->cfg, bs, -1); }
+    { KernelTimer t(c, 4, g.st_frm); hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, c->cfg, bs); }
+  }
   HIP_TRY(c, hipGetLastError());
   return frame_done(c);
 }
@@ -367,10 +406,11 @@ static int upload_images(vslam_ctx* c, const uint8_t* L, const uint8_t* R, int32
   if (!L || !R) return fail(c, VSLAM_ERR_INVALID, "called with empty frame");
   if (row_stride < c->cfg.c.cols) return fail(c, VSLAM_ERR_INVALID, "row stride smaller than image width");
   for (int s = 0; s < c->B; ++s) {
+    hipStream_t st = c->groups[group_of(c, s)].st_img;
     HIP_TRY(c, hipMemcpy2DAsync(c->upload[0] + s * c->up_stream_stride, c->up_stride, L + s * image_stride, row_stride,
-                                c->cfg.c.cols, c->cfg.c.rows, hipMemcpyHostToDevice, c->stream_img));
+                                c->cfg.c.cols, c->cfg.c.rows, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpy2DAsync(c->upload[1] + s * c->up_stream_stride, c->up_stride, R + s * image_stride, row_stride,
-                                c->cfg.c.cols, c->cfg.c.rows, hipMemcpyHostToDevice, c->stream_img));
+                                c->cfg.c.cols, c->cfg.c.rows, hipMemcpyHostToDevice, st));
   }
   return set_images_device(c, c->upload[0], c->upload[1], c->up_stride, c->up_stream_stride);
 }
@@ -399,6 +439,7 @@ VS_API int vslam_process_host(vslam_ctx* c, const uint8_t* L, const uint8_t* R, 
 static int check_stream(vslam_ctx* c, int s) {
   if (!c) return VSLAM_ERR_INVALID;
   if (s < 0 || s >= c->B) return fail(c, VSLAM_ERR_INVALID, "stream index out of range");
+  sync_all(c);   // read-back: every group's queued work must have finished
   return VSLAM_OK;
 }
 template <typename T>
@@ -492,6 +533,7 @@ VS_API int vslam_get_poses(vslam_ctx* c, int s, int32_t first, int32_t nf, doubl
 }
 VS_API int vslam_copy_poses_device(vslam_ctx* c, int32_t first, int32_t nf, double* dst) {
   if (!c || !dst || first < 0 || nf < 0 || first + nf > VS_POSE_LOG) return VSLAM_ERR_INVALID;
+  sync_all(c);
   HIP_TRY(c, hipMemcpy2DAsync(dst, (size_t)nf * 12 * sizeof(double), c->buf.pose_log + (size_t)first * 12,
                               (size_t)VS_POSE_LOG * 12 * sizeof(double), (size_t)nf * 12 * sizeof(double), c->B,
                               hipMemcpyDeviceToDevice, c->stream));
@@ -648,12 +690,12 @@ VS_API int vslam_align_points(vslam_ctx* c, int32_t n, const double* moving, con
 
 // ---- stage entry points (the reference's plug-in virtuals; control flow stays with the caller) ----------
 static int launch_begin(vslam_ctx* c) {
-  hipLaunchKernelGGL(k_begin, dim3(c->B), dim3(256), 0, c->stream, c->cfg, buf_set(c, c->last_set));
+  for (auto& g : c->groups) hipLaunchKernelGGL(k_begin, dim3(g.n), dim3(256), 0, g.st_frm, c->cfg, buf_set(c, c->last_set, g.s0));
   HIP_TRY(c, hipGetLastError());
   return VSLAM_OK;
 }
 static int launch_stage(vslam_ctx* c, int stage, int arg) {
-  hipLaunchKernelGGL(k_stage, dim3(c->B), dim3(VS_WG), 0, c->stream, c->cfg, buf_set(c, c->last_set), stage, arg);
+  for (auto& g : c->groups) hipLaunchKernelGGL(k_stage, dim3(g.n), dim3(VS_WG), 0, g.st_frm, c->cfg, buf_set(c, c->last_set, g.s0), stage, arg);
   HIP_TRY(c, hipGetLastError());
   return VSLAM_OK;
 }
@@ -683,8 +725,10 @@ VS_API int vslam_frame_restore(vslam_ctx* c) {
 }
 VS_API int vslam_track(vslam_ctx* c, int by_appearance) {
   NEED_FRAME("vslam_track");
-  const int gx = std::max(4, std::min(128, 2048 / c->B));
-  hipLaunchKernelGGL(k_track_candidates, dim3(gx, c->B), dim3(256), 0, c->stream, c->cfg, buf_set(c, c->last_set), by_appearance ? 1 : 0);
+  for (auto& g : c->groups) {
+    const int gx = std::max(4, std::min(128, 2048 / std::max(g.n, 1)));
+    hipLaunchKernelGGL(k_track_candidates, dim3(gx, g.n), dim3(256), 0, g.st_frm, c->cfg, buf_set(c, c->last_set, g.s0), by_appearance ? 1 : 0);
+  }
   return launch_stage(c, VS_STAGE_TRACK, by_appearance ? 1 : 0);
 }
 VS_API int vslam_align(vslam_ctx* c, int inverse_depth) { NEED_FRAME("vslam_align"); return launch_stage(c, VS_STAGE_ALIGN, inverse_depth); }
@@ -702,7 +746,7 @@ VS_API int vslam_set_tracker_state(vslam_ctx* c, int s, int status, const double
   if (!prior) return fail(c, VSLAM_ERR_INVALID, "null prior");
   D12 p;
   std::memcpy(p.v, prior, sizeof p.v);
-  hipLaunchKernelGGL(k_set_tracker_state, dim3(1), dim3(1), 0, c->stream, c->buf, s, status, win, tau, p);
+  hipLaunchKernelGGL(k_set_tracker_state, dim3(1), dim3(1), 0, c->groups[group_of(c, s)].st_frm, c->buf, s, status, win, tau, p);
   HIP_TRY(c, hipGetLastError());
   return VSLAM_OK;
 }
@@ -712,7 +756,7 @@ VS_API int vslam_set_pose(vslam_ctx* c, int s, const double pose[12]) {
   if (!pose) return fail(c, VSLAM_ERR_INVALID, "null pose");
   D12 p;
   std::memcpy(p.v, pose, sizeof p.v);
-  hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(1), 0, c->stream, c->buf, s, p);
+  hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(1), 0, c->groups[group_of(c, s)].st_frm, c->buf, s, p);
   HIP_TRY(c, hipGetLastError());
   return VSLAM_OK;
 }
