@@ -23,6 +23,7 @@
 #define VS_CELL 16
 #define VS_MAXCAND 16        // candidate list length per previous point (overflow -> exact rescan)
 #define VS_WG 512            // threads of the per-stream frame kernel
+#define VS_ARENA (64 * 1024) // bytes of LDS scratch the frame kernel stages hot index arrays in
 #define VS_POSE_LOG 32768    // frames of trajectory kept per stream
 
 struct DevRegion { int32_t x, y, w, h; };

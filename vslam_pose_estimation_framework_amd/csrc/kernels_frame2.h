@@ -100,24 +100,36 @@ __device__ void wg_recover(const DevCfg& c, const DevBuf& b, int s, FrameShared&
     }
     int dist = 0;
     if (ok) {  // wave-uniform
-      uint8_t* dl = rdesc + (size_t)64 * q;
-      brief_wave(boxL, c.bstride, xL, yL, lane, dl);
-      brief_wave(boxR, c.bstride, xR, yR, lane, dl + 32);
-      __builtin_amdgcn_wave_barrier();
-      __threadfence_block();
-      const uint32_t* nl32 = reinterpret_cast<const uint32_t*>(dl);
-      const uint32_t* pl32 = reinterpret_cast<const uint32_t*>(pv.desc + (size_t)64 * ip);
-      uint32_t a[8], bb[8], pa[8], pb[8];
-      for (int k = 0; k < 8; ++k) {
-        a[k] = __hip_atomic_load(nl32 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bb[k] = __hip_atomic_load(nl32 + 8 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        pa[k] = pl32[k]; pb[k] = pl32[8 + k];
+      // both descriptors in (uniform) registers: the 16 box gathers of a lane are issued together, then 8 ballots
+      int aL[4], bL[4], aR[4], bR[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = j * 64 + lane;
+        aL[j] = boxL[(size_t)(yL + c_brief[i][0]) * c.bstride + (xL + c_brief[i][1])];
+        bL[j] = boxL[(size_t)(yL + c_brief[i][2]) * c.bstride + (xL + c_brief[i][3])];
+        aR[j] = boxR[(size_t)(yR + c_brief[i][0]) * c.bstride + (xR + c_brief[i][1])];
+        bR[j] = boxR[(size_t)(yR + c_brief[i][2]) * c.bstride + (xR + c_brief[i][3])];
       }
-      if ((double)hamming32(pa, a) > tau_track) ok = 0;
+      unsigned long long dL[4], dR[4];
+      const unsigned long long* pd = reinterpret_cast<const unsigned long long*>(pv.desc + (size_t)64 * ip);
+      int hL = 0, hR = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        dL[j] = __builtin_bswap64(__brevll(__ballot(aL[j] < bL[j])));
+        dR[j] = __builtin_bswap64(__brevll(__ballot(aR[j] < bR[j])));
+        hL += __popcll(dL[j] ^ pd[j]);
+        hR += __popcll(dR[j] ^ pd[4 + j]);
+        dist += __popcll(dL[j] ^ dR[j]);
+      }
+      if ((double)hL > tau_track) ok = 0;
       if (ok && (double)(pLx - pRx) < c.c.minimum_disparity_pixels) ok = 0;
-      if (ok && (double)hamming32(pb, bb) > tau_track) ok = 0;
-      dist = hamming32(a, bb);
+      if (ok && (double)hR > tau_track) ok = 0;
       if (ok && (double)dist > tau_tri) ok = 0;
+      if (ok && lane == 0) {
+        unsigned long long* dl = reinterpret_cast<unsigned long long*>(rdesc + (size_t)64 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dl[j] = dL[j]; dl[4 + j] = dR[j]; }
+      }
     }
     if (lane == 0) {
       rec[6 * q] = ok; rec[6 * q + 1] = xL; rec[6 * q + 2] = yL; rec[6 * q + 3] = xR; rec[6 * q + 4] = yR; rec[6 * q + 5] = dist;
@@ -266,7 +278,8 @@ __device__ void wg_update_points(const DevCfg& c, const DevBuf& b, int s, FrameS
 // compute() (stereo_framepoint_generator.cpp:135-462): stereo sweep with one thread per image row (rows are
 // independent: the right cursor only moves inside a row), then the order-dependent bin competition with
 // one thread per bin, then emission in bin-grid row-major order.
-__device__ void wg_stereo(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_cur, double tau_tri, int f) {
+__device__ void wg_stereo(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_cur, double tau_tri, int f,
+                          unsigned char* arena, int arena_bytes) {
   const int tid = threadIdx.x;
   const PtView cv = pts_of(c, b, s, pb_cur);
   const int rows = c.c.rows, CW1 = c.CW + 1;
@@ -283,6 +296,17 @@ __device__ void wg_stereo(const DevCfg& c, const DevBuf& b, int s, FrameShared& 
   int32_t* sc = b.sc + (size_t)s * c.NMAX * 4;
   int32_t* bin_occ = b.bin_occ + (size_t)s * c.rows_bin * c.cols_bin;
   const int n_tracked = sh.n_cur;
+  const int nR = b.n_kp[s * 2 + 1];
+  // LDS staging of what the sequential row sweep touches (x coordinates, used flags, row starts): the sweep is a
+  // chain of dependent loads, ~100 ns each from LDS instead of ~1 us from HBM
+  const int nLp = (nL + 7) & ~7, nRp = (nR + 7) & ~7;
+  const bool staged = (size_t)4 * 2 * (rows + 1) + (size_t)3 * (nLp + nRp) <= (size_t)arena_bytes;
+  int32_t* srL = reinterpret_cast<int32_t*>(arena);
+  int32_t* srR = srL + (rows + 1);
+  int16_t* sxL = reinterpret_cast<int16_t*>(srR + (rows + 1));
+  int16_t* sxR = sxL + nLp;
+  uint8_t* suL = reinterpret_cast<uint8_t*>(sxR + nRp);
+  uint8_t* suR = suL + nLp;
   int n_cand = 0;
   unsigned long long tq = wall_clock64();
 #define DBG_STAMP(k) do { __syncthreads(); if (tid == 0) { const unsigned long long tn = wall_clock64(); b.st[s].dbg[k] += tn - tq; tq = tn; } } while (0)
@@ -291,21 +315,88 @@ __device__ void wg_stereo(const DevCfg& c, const DevBuf& b, int s, FrameShared& 
     // distances of every left feature to the right features of its row that lie at or left of it (a prefix of
     // the row in x order), all features in parallel; the sequential cursor logic below only reads them
     uint8_t* sdist = b.sdist + (size_t)s * c.NMAX * 16;
-    for (int i = tid; i < nL; i += VS_WG) {
-      match[2 * i] = -1;
-      if (usedL[i]) continue;
-      const int r = kxyL[2 * i + 1], rr = r - o;
-      if (rr < 0 || rr >= rows) continue;
-      const int g0 = rcR[(size_t)rr * CW1], g1 = rcR[(size_t)rr * CW1 + c.CW];
-      const int xl = kxyL[2 * i];
-      uint32_t ld[8];
-      for (int k = 0; k < 8; ++k) ld[k] = reinterpret_cast<const uint32_t*>(descL + (size_t)32 * i)[k];
-      for (int g = g0, j = 0; g < g1 && j < 16; ++g, ++j) {
-        if (xl - kxyR[2 * g] < 0) break;
-        sdist[(size_t)i * 16 + j] = (uint8_t)hamming32(ld, reinterpret_cast<const uint32_t*>(descR + (size_t)32 * g));
+    if (staged) {
+      for (int r = tid; r <= rows; r += VS_WG) {
+        srL[r] = r < rows ? rcL[(size_t)r * CW1] : rcL[(size_t)(rows - 1) * CW1 + c.CW];
+        srR[r] = r < rows ? rcR[(size_t)r * CW1] : rcR[(size_t)(rows - 1) * CW1 + c.CW];
+      }
+      for (int i = tid; i < nL; i += VS_WG) { sxL[i] = kxyL[2 * i]; suL[i] = usedL[i]; }
+      for (int g = tid; g < nR; g += VS_WG) { sxR[g] = kxyR[2 * g]; suR[g] = usedR[g]; }
+      __syncthreads();
+      for (int i = tid; i < nL; i += VS_WG) {
+        match[2 * i] = -1;
+        if (suL[i]) continue;
+        const int r = kxyL[2 * i + 1], rr = r - o;
+        if (rr < 0 || rr >= rows) continue;
+        const int g0 = srR[rr], g1 = srR[rr + 1];
+        const int xl = sxL[i];
+        int m = 0;
+        while (g0 + m < g1 && m < 16 && xl - sxR[g0 + m] >= 0) ++m;
+        if (m == 0) continue;
+        const uint4 la = reinterpret_cast<const uint4*>(descL + (size_t)32 * i)[0], lb = reinterpret_cast<const uint4*>(descL + (size_t)32 * i)[1];
+        uint32_t pk[4] = {0, 0, 0, 0};
+        for (int j = 0; j < m; ++j) {
+          const uint4 ra = reinterpret_cast<const uint4*>(descR + (size_t)32 * (g0 + j))[0], rb = reinterpret_cast<const uint4*>(descR + (size_t)32 * (g0 + j))[1];
+          const int h = __popc(la.x ^ ra.x) + __popc(la.y ^ ra.y) + __popc(la.z ^ ra.z) + __popc(la.w ^ ra.w) +
+                        __popc(lb.x ^ rb.x) + __popc(lb.y ^ rb.y) + __popc(lb.z ^ rb.z) + __popc(lb.w ^ rb.w);
+          pk[j >> 2] |= (uint32_t)(h > 255 ? 255 : h) << (8 * (j & 3));
+        }
+        *reinterpret_cast<uint4*>(sdist + (size_t)i * 16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+      }
+    } else {
+      for (int i = tid; i < nL; i += VS_WG) {
+        match[2 * i] = -1;
+        if (usedL[i]) continue;
+        const int r = kxyL[2 * i + 1], rr = r - o;
+        if (rr < 0 || rr >= rows) continue;
+        const int g0 = rcR[(size_t)rr * CW1], g1 = rcR[(size_t)rr * CW1 + c.CW];
+        const int xl = kxyL[2 * i];
+        uint32_t ld[8];
+        for (int k = 0; k < 8; ++k) ld[k] = reinterpret_cast<const uint32_t*>(descL + (size_t)32 * i)[k];
+        for (int g = g0, j = 0; g < g1 && j < 16; ++g, ++j) {
+          if (xl - kxyR[2 * g] < 0) break;
+          sdist[(size_t)i * 16 + j] = (uint8_t)hamming32(ld, reinterpret_cast<const uint32_t*>(descR + (size_t)32 * g));
+        }
       }
     }
     __syncthreads();
+    if (staged) {
+      for (int r = tid; r < rows; r += VS_WG) {
+        const int rr = r - o;  // right row: L.row == R.row + o
+        if (rr < 0 || rr >= rows) continue;
+        const int l0 = srL[r], l1 = srL[r + 1];
+        const int g0 = srR[rr], g1 = srR[rr + 1];
+        int cur = g0;
+        for (int i = l0; i < l1; ++i) {
+          if (suL[i]) continue;
+          if (cur >= g1) break;
+          const int xl = sxL[i];
+          const uint4 dq = *reinterpret_cast<const uint4*>(sdist + (size_t)i * 16);
+          const uint32_t dw[4] = {dq.x, dq.y, dq.z, dq.w};
+          double best = tau_tri;
+          int bg = -1;
+          for (int g = cur; g < g1; ++g) {
+            if (suR[g]) continue;
+            if (xl - sxR[g] < 0) break;
+            const int j = g - g0;
+            double h;
+            if (j < 16) {
+              h = (double)((dw[j >> 2] >> (8 * (j & 3))) & 255u);
+            } else {
+              uint32_t ld[8];
+              for (int k = 0; k < 8; ++k) ld[k] = reinterpret_cast<const uint32_t*>(descL + (size_t)32 * i)[k];
+              h = (double)hamming32(ld, reinterpret_cast<const uint32_t*>(descR + (size_t)32 * g));
+            }
+            if (h < best) { best = h; bg = g; }
+          }
+          if (bg >= 0) {
+            if ((double)(xl - sxR[bg]) < c.c.minimum_disparity_pixels) continue;
+            match[2 * i] = bg; match[2 * i + 1] = (int)best;
+            cur = bg + 1;
+          }
+        }
+      }
+    } else
     for (int r = tid; r < rows; r += VS_WG) {
       const int rr = r - o;  // right row: L.row == R.row + o
       if (rr < 0 || rr >= rows) continue;
@@ -477,6 +568,7 @@ __device__ __forceinline__ double tau_tri_rule(const DevCfg& c, int status, int 
 
 __global__ __launch_bounds__(VS_WG) void k_frame(const DevCfg c, const DevBuf b) {
   __shared__ FrameShared sh;
+  __shared__ __align__(16) unsigned char arena[VS_ARENA];
   __shared__ int wcnt[VS_WG / 64];
   const int s = b.s0 + blockIdx.x, tid = threadIdx.x;
   StreamState& st = b.st[s];
@@ -648,7 +740,7 @@ __global__ __launch_bounds__(VS_WG) void k_frame(const DevCfg c, const DevBuf b)
   int status = sh.status;
   if (n_active > c.c.minimum_number_of_landmarks_to_track) status = VSLAM_TRACKING;
   const unsigned long long ts = wall_clock64();
-  wg_stereo(c, b, s, sh, pb_cur, tau_tri, f);
+  wg_stereo(c, b, s, sh, pb_cur, tau_tri, f, arena, VS_ARENA);
   if (tid == 0) {
     st.ticks[4] += wall_clock64() - ts;
     const double* c2w = hpose_of(c, b, s, f);
@@ -702,6 +794,7 @@ __global__ __launch_bounds__(256) void k_begin(const DevCfg c, const DevBuf b) {
 
 __global__ __launch_bounds__(VS_WG) void k_stage(const DevCfg c, const DevBuf b, int stage, int arg) {
   __shared__ FrameShared sh;
+  __shared__ __align__(16) unsigned char arena[VS_ARENA];
   const int s = b.s0 + blockIdx.x, tid = threadIdx.x;
   StreamState& st = b.st[s];
   vslam_frame_info& info = b.info[s];
@@ -753,7 +846,7 @@ __global__ __launch_bounds__(VS_WG) void k_stage(const DevCfg c, const DevBuf b,
     wg_update_points(c, b, s, sh, pb_cur, f);
     if (tid == 0) { st.n_active = sh.n_lm; info.n_active_landmarks = sh.n_lm; }
   } else if (stage == VS_STAGE_STEREO) {
-    wg_stereo(c, b, s, sh, pb_cur, st.tau_tri, f);
+    wg_stereo(c, b, s, sh, pb_cur, st.tau_tri, f, arena, VS_ARENA);
     if (tid == 0) {
       const double* c2w = hpose_of(c, b, s, f);
       *pts_of(c, b, s, pb_cur).n = sh.n_cur;
