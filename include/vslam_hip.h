@@ -230,10 +230,11 @@ int vslam_get_aligner_result(vslam_ctx* ctx, int stream, int32_t cap, int32_t* n
 int vslam_get_timers(vslam_ctx* ctx, double seconds[8]);
 int vslam_enable_timers(vslam_ctx* ctx, int on);
 /* Per-kernel device time (HIP events on the context stream, recorded while timers are enabled):
- * accumulated milliseconds and launch counts of k_fast_box, k_emit, k_brief, k_track_candidates, k_frame.
+ * accumulated milliseconds and launch counts of k_fast_box, k_emit, k_brief, k_track_candidates, k_frame (its
+ * three phase launches together, counted once), k_recover_brief, k_update_landmarks, k_stereo_dist.
  * Used by bench.py for the roofline of the dominant kernel.  Synchronises; vslam_enable_timers(ctx,1)
  * clears the accumulators. */
-int vslam_get_kernel_times(vslam_ctx* ctx, double ms[5], int32_t launches[5]);
+int vslam_get_kernel_times(vslam_ctx* ctx, double ms[8], int32_t launches[8]);
 
 /* ---- stand-alone kernels (unit parity, and the reference's optional knnMatch block) -------- */
 /* cv::FastFeatureDetector::detect on one ROI (base_framepoint_generator.cpp:12-25,367):

@@ -280,11 +280,12 @@ def _extra_methods():
         self.check(self.fn("enable_timers")(self.ctx, C.c_int(1 if on else 0)))
 
     def kernel_times(self):
-        ms = (C.c_double * 5)()
-        n = (C.c_int32 * 5)()
+        ms = (C.c_double * 8)()
+        n = (C.c_int32 * 8)()
         self.check(self.fn("get_kernel_times")(self.ctx, ms, n))
-        names = ["k_fast_box", "k_emit", "k_brief", "k_track_candidates", "k_frame"]
-        return {names[i]: (ms[i], n[i]) for i in range(5)}
+        names = ["k_fast_box", "k_emit", "k_brief", "k_track_candidates", "k_frame", "k_recover_brief",
+                 "k_update_landmarks", "k_stereo_dist"]
+        return {names[i]: (ms[i], n[i]) for i in range(8)}
 
     def timers(self):
         sec = (C.c_double * 8)()

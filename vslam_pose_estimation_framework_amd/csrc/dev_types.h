@@ -40,6 +40,15 @@ struct DevCfg {
   int32_t n_streams;
 };
 
+// scalars of the frame in flight, handed from one phase kernel of the frame to the next
+struct FrameCarry {
+  int32_t status, status0, win, attempts, broken, fallback, n_after_prune, aligner_valid, n_tracked_landmarks;
+  int32_t n_cur, n_lost, n_recovered, n_active, pad;
+  double tau_track, tau_gen, tau_tri;
+  double prior[12];
+  unsigned long long t0;
+};
+
 // tracker + generator state carried from frame to frame (PoseTracker3D / BaseFramePointGenerator members)
 struct StreamState {
   int32_t thr[VSLAM_MAX_REGIONS];        // FastDetector thresholds in effect for the next detect
@@ -69,6 +78,7 @@ struct StreamState {
   // stage-granular API (the shim's host-driven PoseTracker3D): values handed from one stage call to the next
   double tau_gen;                        // generator's _maximum_descriptor_distance_tracking (last track())
   int32_t n_cur, n_active, n_after_prune, n_recovered, n_new, track_calls;
+  FrameCarry fc;
 };
 
 // detector bookkeeping of one frame's image pipeline (double-buffered with the image products so that frame

@@ -64,24 +64,21 @@ __device__ void wg_prune(const DevCfg& c, const DevBuf& b, int s, FrameShared& s
   __syncthreads();
 }
 
-// recoverPoints (stereo_framepoint_generator.cpp:683-869): one wavefront per lost point evaluates BRIEF
-// at the landmark's projection in both box images; survivors are appended in lost-list order.
-__device__ void wg_recover(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_prev, int pb_cur, const double* w2c,
-                           double tau_track, double tau_tri) {
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+// recoverPoints (stereo_framepoint_generator.cpp:683-869) in three steps:
+//   project : one thread per lost point: landmark -> both image planes, depth and border gates (:704-764)
+//   brief   : one wavefront per surviving point: BRIEF at both projections from the box images, the three
+//             descriptor gates and the disparity gate (:773-842).  Runs inside the workgroup (stage path) or as
+//             the wide kernel k_recover_brief over all streams (fused path).
+//   append  : survivors are appended in lost-list order (:844-864)
+// rec[6q] : 0 = rejected, 2 = projected (needs BRIEF), 1 = recovered; then xL, yL, xR, yR, Hamming L-R
+__device__ void wg_recover_project(const DevCfg& c, const DevBuf& b, int s, int n_lost, int pb_prev, const double* w2c) {
   const PtView pv = pts_of(c, b, s, pb_prev);
-  const PtView cv = pts_of(c, b, s, pb_cur);
   const int32_t* lost = b.lost + (size_t)s * c.MAXP;
   int32_t* rec = b.rec + (size_t)s * c.MAXP * 6;
-  uint8_t* rdesc = b.rec_desc + (size_t)s * c.MAXP * 64;
-  const int nl = sh.n_lost;
-  const uint16_t* boxL = box_of(c, b, s, 0);
-  const uint16_t* boxR = box_of(c, b, s, 1);
-  for (int q = w; q < nl; q += VS_WG / 64) {
+  for (int q = threadIdx.x; q < n_lost; q += blockDim.x) {
     const int ip = lost[q];
-    int ok = pv.meta[(size_t)ip * META + M_LMUP] > 0;
+    int ok = pv.meta[(size_t)ip * META + M_LMUP] > 0 ? 2 : 0;
     int xL = 0, yL = 0, xR = 0, yR = 0;
-    float pLx = 0, pRx = 0;
     if (ok) {
       double pc[3], uL[3], uR[3];
       tf_apply(w2c, pv.lm + 3 * (size_t)ip, pc);
@@ -90,60 +87,79 @@ __device__ void wg_recover(const DevCfg& c, const DevBuf& b, int s, FrameShared&
       if (uL[2] < c.c.minimum_depth_meters || uL[2] > c.c.maximum_depth_meters || uR[2] < c.c.minimum_depth_meters ||
           uR[2] > c.c.maximum_depth_meters) ok = 0;
       if (ok) {
-        pLx = (float)rint(uL[0] / uL[2]); const float pLy = (float)rint(uL[1] / uL[2]);
-        pRx = (float)rint(uR[0] / uR[2]); const float pRy = (float)rint(uR[1] / uR[2]);
+        const float pLx = (float)rint(uL[0] / uL[2]), pLy = (float)rint(uL[1] / uL[2]);
+        const float pRx = (float)rint(uR[0] / uR[2]), pRy = (float)rint(uR[1] / uR[2]);
         const float border = 35.f;  // 5 * keypoint.size (FAST: 7)
         if (pLx < border + 1 || pLx > c.c.cols - border - 1 || pRx < border + 1 || pRx > c.c.cols - border - 1 ||
             pLy < border + 1 || pLy > c.c.rows - border - 1 || pRy < border + 1 || pRy > c.c.rows - border - 1) ok = 0;
         xL = (int)pLx; yL = (int)pLy; xR = (int)pRx; yR = (int)pRy;
       }
     }
-    int dist = 0;
-    if (ok) {  // wave-uniform
-      // both descriptors in (uniform) registers: the 16 box gathers of a lane are issued together, then 8 ballots
-      int aL[4], bL[4], aR[4], bR[4];
+    rec[6 * q] = ok; rec[6 * q + 1] = xL; rec[6 * q + 2] = yL; rec[6 * q + 3] = xR; rec[6 * q + 4] = yR; rec[6 * q + 5] = 0;
+  }
+}
+
+__device__ __forceinline__ void recover_brief_wave(const DevCfg& c, const DevBuf& b, int s, int pb_prev, int q, int lane,
+                                                   double tau_track, double tau_tri) {
+  int32_t* rec = b.rec + (size_t)s * c.MAXP * 6;
+  if (rec[6 * q] != 2) return;   // wave-uniform
+  const PtView pv = pts_of(c, b, s, pb_prev);
+  const int ip = (b.lost + (size_t)s * c.MAXP)[q];
+  const int xL = rec[6 * q + 1], yL = rec[6 * q + 2], xR = rec[6 * q + 3], yR = rec[6 * q + 4];
+  const uint16_t* boxL = box_of(c, b, s, 0);
+  const uint16_t* boxR = box_of(c, b, s, 1);
+  // both descriptors in (uniform) registers: the 16 box gathers of a lane are issued together, then 8 ballots
+  int aL[4], bL[4], aR[4], bR[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int i = j * 64 + lane;
-        aL[j] = boxL[(size_t)(yL + c_brief[i][0]) * c.bstride + (xL + c_brief[i][1])];
-        bL[j] = boxL[(size_t)(yL + c_brief[i][2]) * c.bstride + (xL + c_brief[i][3])];
-        aR[j] = boxR[(size_t)(yR + c_brief[i][0]) * c.bstride + (xR + c_brief[i][1])];
-        bR[j] = boxR[(size_t)(yR + c_brief[i][2]) * c.bstride + (xR + c_brief[i][3])];
-      }
-      unsigned long long dL[4], dR[4];
-      const unsigned long long* pd = reinterpret_cast<const unsigned long long*>(pv.desc + (size_t)64 * ip);
-      int hL = 0, hR = 0;
+  for (int j = 0; j < 4; ++j) {
+    const int i = j * 64 + lane;
+    aL[j] = boxL[(size_t)(yL + c_brief[i][0]) * c.bstride + (xL + c_brief[i][1])];
+    bL[j] = boxL[(size_t)(yL + c_brief[i][2]) * c.bstride + (xL + c_brief[i][3])];
+    aR[j] = boxR[(size_t)(yR + c_brief[i][0]) * c.bstride + (xR + c_brief[i][1])];
+    bR[j] = boxR[(size_t)(yR + c_brief[i][2]) * c.bstride + (xR + c_brief[i][3])];
+  }
+  unsigned long long dL[4], dR[4];
+  const unsigned long long* pd = reinterpret_cast<const unsigned long long*>(pv.desc + (size_t)64 * ip);
+  int hL = 0, hR = 0, dist = 0;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        dL[j] = __builtin_bswap64(__brevll(__ballot(aL[j] < bL[j])));
-        dR[j] = __builtin_bswap64(__brevll(__ballot(aR[j] < bR[j])));
-        hL += __popcll(dL[j] ^ pd[j]);
-        hR += __popcll(dR[j] ^ pd[4 + j]);
-        dist += __popcll(dL[j] ^ dR[j]);
-      }
-      if ((double)hL > tau_track) ok = 0;
-      if (ok && (double)(pLx - pRx) < c.c.minimum_disparity_pixels) ok = 0;
-      if (ok && (double)hR > tau_track) ok = 0;
-      if (ok && (double)dist > tau_tri) ok = 0;
-      if (ok && lane == 0) {
-        unsigned long long* dl = reinterpret_cast<unsigned long long*>(rdesc + (size_t)64 * q);
+  for (int j = 0; j < 4; ++j) {
+    dL[j] = __builtin_bswap64(__brevll(__ballot(aL[j] < bL[j])));
+    dR[j] = __builtin_bswap64(__brevll(__ballot(aR[j] < bR[j])));
+    hL += __popcll(dL[j] ^ pd[j]);
+    hR += __popcll(dR[j] ^ pd[4 + j]);
+    dist += __popcll(dL[j] ^ dR[j]);
+  }
+  int ok = 1;
+  if ((double)hL > tau_track) ok = 0;
+  if (ok && (double)((float)xL - (float)xR) < c.c.minimum_disparity_pixels) ok = 0;
+  if (ok && (double)hR > tau_track) ok = 0;
+  if (ok && (double)dist > tau_tri) ok = 0;
+  if (lane == 0) {
+    rec[6 * q] = ok; rec[6 * q + 5] = dist;
+    if (ok) {
+      unsigned long long* dl = reinterpret_cast<unsigned long long*>(b.rec_desc + ((size_t)s * c.MAXP + q) * 64);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { dl[j] = dL[j]; dl[4 + j] = dR[j]; }
-      }
-    }
-    if (lane == 0) {
-      rec[6 * q] = ok; rec[6 * q + 1] = xL; rec[6 * q + 2] = yL; rec[6 * q + 3] = xR; rec[6 * q + 4] = yR; rec[6 * q + 5] = dist;
+      for (int j = 0; j < 4; ++j) { dl[j] = dL[j]; dl[4 + j] = dR[j]; }
     }
   }
-  __syncthreads();
+}
+
+__device__ void wg_recover_append(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_prev, int pb_cur) {
+  const int tid = threadIdx.x;
+  const PtView pv = pts_of(c, b, s, pb_prev);
+  const PtView cv = pts_of(c, b, s, pb_cur);
+  const int32_t* lost = b.lost + (size_t)s * c.MAXP;
+  const int32_t* rec = b.rec + (size_t)s * c.MAXP * 6;
+  const uint8_t* rdesc = b.rec_desc + (size_t)s * c.MAXP * 64;
+  const int nl = sh.n_lost;
   const int per = (nl + VS_WG - 1) / VS_WG;
   const int q0 = tid * per, q1 = min(q0 + per, nl);
   int cnt = 0;
-  for (int q = q0; q < q1; ++q) cnt += rec[6 * q] ? 1 : 0;
+  for (int q = q0; q < q1; ++q) cnt += rec[6 * q] == 1 ? 1 : 0;
   int total;
   int off = sh.n_cur + block_exclusive_scan(cnt, sh.scan, &total);
   for (int q = q0; q < q1; ++q) {
-    if (!rec[6 * q]) continue;
+    if (rec[6 * q] != 1) continue;
     if (off < c.MAXP) {
       const int ip = lost[q], j = off;
       const int xL = rec[6 * q + 1], yL = rec[6 * q + 2], xR = rec[6 * q + 3], yR = rec[6 * q + 4];
@@ -167,28 +183,40 @@ __device__ void wg_recover(const DevCfg& c, const DevBuf& b, int s, FrameShared&
   __syncthreads();
 }
 
+// whole recovery inside one workgroup (stage path)
+__device__ void wg_recover(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_prev, int pb_cur, const double* w2c,
+                           double tau_track, double tau_tri) {
+  wg_recover_project(c, b, s, sh.n_lost, pb_prev, w2c);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int q = w; q < sh.n_lost; q += VS_WG / 64) recover_brief_wave(c, b, s, pb_prev, q, lane, tau_track, tau_tri);
+  __syncthreads();
+  wg_recover_append(c, b, s, sh, pb_prev, pb_cur);
+}
+
+// fused path: BRIEF of the projected lost points of ALL streams, one wavefront each
+__global__ __launch_bounds__(256) void k_recover_brief(const DevCfg c, const DevBuf b) {
+  const int s = b.s0 + blockIdx.y;
+  const StreamState& st = b.st[s];
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  const int nl = st.fc.n_lost;
+  for (int q = wave; q < nl; q += nwaves) recover_brief_wave(c, b, s, st.cur, q, lane, st.fc.tau_gen, st.fc.tau_tri);
+}
+
 // _updatePoints (pose_tracker_3d.cpp:475-520): one thread per framepoint; landmark creation = mean of the
 // track's world coordinates (landmark.cpp:19-31), update = Gauss-Newton over all measurements of the
 // track (landmark.cpp:66-167).  Measurements are reached by walking the per-frame `prev` links of the
 // history ring (frame f, index i) -> (f-1, prev[i]).
-__device__ void wg_update_points(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_cur, int f) {
-  const int tid = threadIdx.x;
-  const PtView cv = pts_of(c, b, s, pb_cur);
-  const int n = sh.n_cur;
-  // publish the current frame's cam/prev to the history ring first (chains start here)
-  double* hc = hcam_of(c, b, s, f);
-  int32_t* hp = hprev_of(c, b, s, f);
-  for (int i = tid; i < n; i += VS_WG) {
-    for (int k = 0; k < 3; ++k) hc[3 * (size_t)i + k] = cv.cam[3 * (size_t)i + k];
-    hp[i] = cv.meta[(size_t)i * META + M_PREV];
-  }
-  __syncthreads();
+// landmark of framepoint i of the current frame: creation = mean of the track's world coordinates
+// (Landmark::Landmark, landmark.cpp:19-31), otherwise Gauss-Newton refinement over all measurements of the track
+// (Landmark::update, :66-167).  Returns true when the point carries an active landmark afterwards.
+__device__ bool landmark_point(const DevCfg& c, const DevBuf& b, int s, const PtView& cv, int f, int i) {
   const double* w2c_cur = hpose_of(c, b, s, f) + 12;
-  int active = 0;
-  for (int i = tid; i < n; i += VS_WG) {
+  {
     int32_t* m = cv.meta + (size_t)i * META;
     const int tlen = m[M_TLEN];
-    if (tlen < c.c.minimum_track_length_for_landmark_creation) continue;
+    if (tlen < c.c.minimum_track_length_for_landmark_creation) return false;
     int len = tlen + 1;
     if (len > c.HCAP) { len = c.HCAP; atomicOr(&b.st[s].error_flags, 4); }
     double wpos[3];
@@ -267,19 +295,53 @@ __device__ void wg_update_points(const DevCfg& c, const DevBuf& b, int s, FrameS
     }
     for (int q = 0; q < 3; ++q) cv.lm[3 * (size_t)i + q] = wpos[q];
     tf_apply(w2c_cur, wpos, cv.camlm + 3 * (size_t)i);
-    ++active;
   }
+  return true;
+}
+
+__device__ void wg_publish_history(const DevCfg& c, const DevBuf& b, int s, int n, int pb_cur, int f) {
+  const PtView cv = pts_of(c, b, s, pb_cur);
+  double* hc = hcam_of(c, b, s, f);
+  int32_t* hp = hprev_of(c, b, s, f);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    for (int k = 0; k < 3; ++k) hc[3 * (size_t)i + k] = cv.cam[3 * (size_t)i + k];
+    hp[i] = cv.meta[(size_t)i * META + M_PREV];
+  }
+}
+
+__device__ void wg_update_points(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_cur, int f) {
+  const int tid = threadIdx.x;
+  const PtView cv = pts_of(c, b, s, pb_cur);
+  const int n = sh.n_cur;
+  // publish the current frame's cam/prev to the history ring first (chains start here)
+  wg_publish_history(c, b, s, n, pb_cur, f);
+  __syncthreads();
+  int active = 0;
+  for (int i = tid; i < n; i += VS_WG) active += landmark_point(c, b, s, cv, f, i) ? 1 : 0;
   int total;
   block_exclusive_scan(active, sh.scan, &total);
   if (tid == 0) sh.n_lm = total;  // _number_of_active_landmarks
   __syncthreads();
 }
 
+// fused path: one thread per framepoint of every stream
+__global__ __launch_bounds__(256) void k_update_landmarks(const DevCfg c, const DevBuf b) {
+  const int s = b.s0 + blockIdx.y;
+  StreamState& st = b.st[s];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = st.fc.n_cur;
+  if (blockIdx.x * blockDim.x >= n) return;
+  const PtView cv = pts_of(c, b, s, st.cur ^ 1);
+  const bool act = i < n && landmark_point(c, b, s, cv, st.frame_count, i);
+  const int cnt = __popcll(__ballot(act));
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&st.fc.n_active, cnt);
+}
+
 // compute() (stereo_framepoint_generator.cpp:135-462): stereo sweep with one thread per image row (rows are
 // independent: the right cursor only moves inside a row), then the order-dependent bin competition with
 // one thread per bin, then emission in bin-grid row-major order.
 __device__ void wg_stereo(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_cur, double tau_tri, int f,
-                          unsigned char* arena, int arena_bytes) {
+                          unsigned char* arena, int arena_bytes, bool dist_ready) {
   const int tid = threadIdx.x;
   const PtView cv = pts_of(c, b, s, pb_cur);
   const int rows = c.c.rows, CW1 = c.CW + 1;
@@ -325,6 +387,7 @@ __device__ void wg_stereo(const DevCfg& c, const DevBuf& b, int s, FrameShared& 
       __syncthreads();
       for (int i = tid; i < nL; i += VS_WG) {
         match[2 * i] = -1;
+        if (dist_ready && oi == 0) continue;   // distances of the first pass came from k_stereo_dist
         if (suL[i]) continue;
         const int r = kxyL[2 * i + 1], rr = r - o;
         if (rr < 0 || rr >= rows) continue;
@@ -550,6 +613,38 @@ __device__ void wg_stereo(const DevCfg& c, const DevBuf& b, int s, FrameShared& 
   __syncthreads();
 }
 
+// fused path: L-R Hamming distances of the first epipolar pass for every left feature of every stream
+// (same bytes as the in-workgroup precompute of wg_stereo: position j = j-th right feature of the row)
+__global__ __launch_bounds__(256) void k_stereo_dist(const DevCfg c, const DevBuf b) {
+  const int s = b.s0 + blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nL = b.n_kp[s * 2];
+  if (i >= nL) return;
+  if (used_of(c, b, s, 0)[i]) return;
+  const int16_t* kxyL = kpxy_of(c, b, s, 0);
+  const int16_t* kxyR = kpxy_of(c, b, s, 1);
+  const int rows = c.c.rows, CW1 = c.CW + 1, o = c.offsets[0];
+  const int rr = kxyL[2 * i + 1] - o;
+  if (rr < 0 || rr >= rows) return;
+  const int32_t* rcR = rowcell_of(c, b, s, 1);
+  const int g0 = rcR[(size_t)rr * CW1], g1 = rcR[(size_t)rr * CW1 + c.CW];
+  const int xl = kxyL[2 * i];
+  int m = 0;
+  while (g0 + m < g1 && m < 16 && xl - kxyR[2 * (g0 + m)] >= 0) ++m;
+  if (m == 0) return;
+  const uint8_t* descL = desc_of(c, b, s, 0);
+  const uint8_t* descR = desc_of(c, b, s, 1);
+  const uint4 la = reinterpret_cast<const uint4*>(descL + (size_t)32 * i)[0], lb = reinterpret_cast<const uint4*>(descL + (size_t)32 * i)[1];
+  uint32_t pk[4] = {0, 0, 0, 0};
+  for (int j = 0; j < m; ++j) {
+    const uint4 ra = reinterpret_cast<const uint4*>(descR + (size_t)32 * (g0 + j))[0], rb = reinterpret_cast<const uint4*>(descR + (size_t)32 * (g0 + j))[1];
+    const int h = __popc(la.x ^ ra.x) + __popc(la.y ^ ra.y) + __popc(la.z ^ ra.z) + __popc(la.w ^ ra.w) +
+                  __popc(lb.x ^ rb.x) + __popc(lb.y ^ rb.y) + __popc(lb.z ^ rb.z) + __popc(lb.w ^ rb.w);
+    pk[j >> 2] |= (uint32_t)(h > 255 ? 255 : h) << (8 * (j & 3));
+  }
+  *reinterpret_cast<uint4*>(b.sdist + ((size_t)s * c.NMAX + i) * 16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+}
+
 // ==============================================================================================
 // K5: PoseTracker3D::compute for one stream (pose_tracker_3d.cpp:32-222)
 // ==============================================================================================
@@ -566,7 +661,14 @@ __device__ __forceinline__ double tau_tri_rule(const DevCfg& c, int status, int 
   return fmax(ratio * c.c.maximum_matching_distance_triangulation, 0.1 * 256);
 }
 
-__global__ __launch_bounds__(VS_WG) void k_frame(const DevCfg c, const DevBuf b) {
+// The frame is processed by three phase launches of this kernel with wide kernels in between (fused path):
+//   phase 0  track resolution, registration (aligner, recursion, fallback / break), prune, recovery projection
+//   [k_recover_brief]   BRIEF of the projected lost points, all streams, one wavefront each
+//   phase 1  recovery append, history publication
+//   [k_update_landmarks] landmark creation / refinement, one thread per framepoint; [k_stereo_dist] L-R distances
+//   phase 2  status switch, stereo sweep + binning + emission, report
+// phase < 0 runs everything in one launch (the wide steps inside the workgroup).
+__global__ __launch_bounds__(VS_WG) void k_frame(const DevCfg c, const DevBuf b, int phase) {
   __shared__ FrameShared sh;
   __shared__ __align__(16) unsigned char arena[VS_ARENA];
   __shared__ int wcnt[VS_WG / 64];
@@ -578,6 +680,8 @@ __global__ __launch_bounds__(VS_WG) void k_frame(const DevCfg c, const DevBuf b)
   const int pb_prev = st.cur, pb_cur = st.cur ^ 1;
   const int status0 = st.status;
   const int n_lm_prev = st.n_tracked_landmarks_prev;
+  FrameCarry& fc = st.fc;
+  if (phase <= 0) {   // ======================================= phase 0 =======================================
   if (tid == 0) {
     sh.status = status0; sh.win = st.win; sh.tau_track = st.tau_track; sh.attempts = 0; sh.broken = 0; sh.fallback = 0;
     sh.aligner_ran = 0; sh.n_trk = 0; sh.n_lost = 0; sh.n_lm = 0; sh.n_cur = 0; sh.n_cand = 0; sh.its = 0; sh.conv = 0;
@@ -587,6 +691,7 @@ __global__ __launch_bounds__(VS_WG) void k_frame(const DevCfg c, const DevBuf b)
     set_pose(c, b, s, f, st.pose);          // frame created at WorldMap::robot_to_world
   }
   const unsigned long long tK0 = wall_clock64();
+  (void)tK0;
   double prior[12];
   for (int k = 0; k < 12; ++k) prior[k] = st.prior[k];
   const double tau_tri = tau_tri_rule(c, status0, b.n_kp[s * 2]);
@@ -722,46 +827,82 @@ __global__ __launch_bounds__(VS_WG) void k_frame(const DevCfg c, const DevBuf b)
     wg_prune(c, b, s, sh, pb_prev, pb_cur, aligner_valid);
     if (tid == 0) st.dbg[6] += wall_clock64() - tP;
     n_after_prune = sh.n_cur;
-    if (c.c.enable_landmark_recovery) {
-      const unsigned long long tr = wall_clock64();
-      wg_recover(c, b, s, sh, pb_prev, pb_cur, hpose_of(c, b, s, f) + 12, tau_gen, tau_tri);
-      n_recovered = sh.flag;
-      if (tid == 0) st.ticks[2] += wall_clock64() - tr;
-    }
+    if (c.c.enable_landmark_recovery) wg_recover_project(c, b, s, sh.n_lost, pb_prev, hpose_of(c, b, s, f) + 12);
   } else if (tid == 0) {
     info.n_tracked = 0; info.n_lost = 0; info.n_tracked_landmarks = 0; info.aligner_ran = 0; info.aligner_iterations = 0;
     info.aligner_converged = 0; info.n_inliers = 0; info.n_outliers = 0; info.total_error = 0; st.al_n = 0;
   }
   __syncthreads();
-  const unsigned long long tu = wall_clock64();
-  wg_update_points(c, b, s, sh, pb_cur, f);
-  if (tid == 0) st.ticks[3] += wall_clock64() - tu;
-  const int n_active = sh.n_lm;
-  int status = sh.status;
+  if (tid == 0) {
+    fc.status = sh.status; fc.status0 = status0; fc.win = win; fc.attempts = sh.attempts; fc.broken = sh.broken; fc.fallback = sh.fallback;
+    fc.n_after_prune = n_after_prune; fc.aligner_valid = aligner_valid ? 1 : 0; fc.n_tracked_landmarks = n_tracked_landmarks;
+    fc.n_cur = sh.n_cur; fc.n_lost = (has_prev && c.c.enable_landmark_recovery) ? sh.n_lost : 0; fc.n_recovered = 0; fc.n_active = 0;
+    fc.tau_track = tau_track; fc.tau_gen = tau_gen; fc.tau_tri = tau_tri; fc.t0 = tK0;
+    for (int k = 0; k < 12; ++k) fc.prior[k] = prior[k];
+  }
+  __syncthreads();
+  if (phase == 0) return;
+  }  // phase 0
+
+  if (phase == 1 || phase < 0) {   // ========================== phase 1 ==========================
+    if (tid == 0) { sh.n_cur = fc.n_cur; sh.n_lost = fc.n_lost; sh.flag = 0; }
+    __syncthreads();
+    if (has_prev && c.c.enable_landmark_recovery) {
+      const unsigned long long tr = wall_clock64();
+      if (phase < 0) {
+        const int lane = tid & 63, w = tid >> 6;
+        for (int q = w; q < sh.n_lost; q += VS_WG / 64) recover_brief_wave(c, b, s, pb_prev, q, lane, fc.tau_gen, fc.tau_tri);
+        __syncthreads();
+      }
+      wg_recover_append(c, b, s, sh, pb_prev, pb_cur);
+      if (tid == 0) { st.ticks[2] += wall_clock64() - tr; fc.n_recovered = sh.flag; }
+    }
+    wg_publish_history(c, b, s, sh.n_cur, pb_cur, f);
+    if (tid == 0) { fc.n_cur = sh.n_cur; fc.n_active = 0; }
+    __syncthreads();
+    if (phase == 1) return;
+  }
+
+  // ============================================== phase 2 ==============================================
+  if (tid == 0) { sh.n_cur = fc.n_cur; sh.n_cand = 0; }
+  __syncthreads();
+  if (phase < 0) {
+    const unsigned long long tu = wall_clock64();
+    const PtView cvu = pts_of(c, b, s, pb_cur);
+    int active = 0;
+    for (int i = tid; i < sh.n_cur; i += VS_WG) active += landmark_point(c, b, s, cvu, f, i) ? 1 : 0;
+    int total;
+    block_exclusive_scan(active, sh.scan, &total);
+    if (tid == 0) { fc.n_active = total; st.ticks[3] += wall_clock64() - tu; }
+    __syncthreads();
+  }
+  const int n_active = fc.n_active;
+  int status = fc.status;
   if (n_active > c.c.minimum_number_of_landmarks_to_track) status = VSLAM_TRACKING;
+  const double tau_tri2 = fc.tau_tri;
   const unsigned long long ts = wall_clock64();
-  wg_stereo(c, b, s, sh, pb_cur, tau_tri, f, arena, VS_ARENA);
+  wg_stereo(c, b, s, sh, pb_cur, tau_tri2, f, arena, VS_ARENA, phase >= 0 && c.n_offsets == 1);
   if (tid == 0) {
     st.ticks[4] += wall_clock64() - ts;
     const double* c2w = hpose_of(c, b, s, f);
     *pts_of(c, b, s, pb_cur).n = sh.n_cur;
-    st.status = status; st.win = win; st.tau_track = tau_track; st.tau_tri = tau_tri;
-    for (int k = 0; k < 12; ++k) { st.prior[k] = prior[k]; st.pose[k] = c2w[k]; }
+    st.status = status; st.win = fc.win; st.tau_track = fc.tau_track; st.tau_tri = tau_tri2;
+    for (int k = 0; k < 12; ++k) { st.prior[k] = fc.prior[k]; st.pose[k] = c2w[k]; }
     st.n_tracked_landmarks_prev = n_active;
-    st.frame_count = f + 1; st.has_prev = 1; st.cur = pb_cur; st.aligner_valid = aligner_valid ? 1 : 0;
-    info.frame_index = f + 1; info.status = status; info.status_at_start = status0;
+    st.frame_count = f + 1; st.has_prev = 1; st.cur = pb_cur; st.aligner_valid = fc.aligner_valid;
+    info.frame_index = f + 1; info.status = status; info.status_at_start = fc.status0;
     info.n_keypoints_left = b.n_kp[s * 2]; info.n_keypoints_right = b.n_kp[s * 2 + 1];
     int rl = 0, rr = 0;
     for (int r = 0; r < c.n_regions; ++r) { rl += b.iinfo[s].raw_count[0][r]; rr += b.iinfo[s].raw_count[1][r]; info.thresholds[r] = b.iinfo[s].thr_after[r]; }
     for (int r = c.n_regions; r < VSLAM_MAX_REGIONS; ++r) info.thresholds[r] = 0;
     info.n_detected_left = rl; info.n_detected_right = rr;
-    info.track_attempts = sh.attempts; info.n_after_prune = n_after_prune; info.n_recovered = n_recovered;
+    info.track_attempts = fc.attempts; info.n_after_prune = fc.n_after_prune; info.n_recovered = fc.n_recovered;
     info.n_active_landmarks = n_active; info.n_new_stereo = sh.n_cand; info.n_points = sh.n_cur;
-    info.track_broken = sh.broken; info.fallback = sh.fallback; info.window_pixels = win;
-    info.error_flags = st.error_flags; info.tau_track = tau_track; info.tau_triangulation = tau_tri;
-    for (int k = 0; k < 12; ++k) { info.camera_left_to_world[k] = c2w[k]; info.previous_to_current[k] = prior[k]; }
+    info.track_broken = fc.broken; info.fallback = fc.fallback; info.window_pixels = fc.win;
+    info.error_flags = st.error_flags; info.tau_track = fc.tau_track; info.tau_triangulation = tau_tri2;
+    for (int k = 0; k < 12; ++k) { info.camera_left_to_world[k] = c2w[k]; info.previous_to_current[k] = fc.prior[k]; }
     if (f < VS_POSE_LOG) { double* pl = b.pose_log + ((size_t)s * VS_POSE_LOG + f) * 12; for (int k = 0; k < 12; ++k) pl[k] = c2w[k]; }
-    st.dbg[8] += wall_clock64() - tK0;
+    st.dbg[8] += wall_clock64() - fc.t0;
   }
 }
 
@@ -846,7 +987,7 @@ __global__ __launch_bounds__(VS_WG) void k_stage(const DevCfg c, const DevBuf b,
     wg_update_points(c, b, s, sh, pb_cur, f);
     if (tid == 0) { st.n_active = sh.n_lm; info.n_active_landmarks = sh.n_lm; }
   } else if (stage == VS_STAGE_STEREO) {
-    wg_stereo(c, b, s, sh, pb_cur, st.tau_tri, f, arena, VS_ARENA);
+    wg_stereo(c, b, s, sh, pb_cur, st.tau_tri, f, arena, VS_ARENA, false);
     if (tid == 0) {
       const double* c2w = hpose_of(c, b, s, f);
       *pts_of(c, b, s, pb_cur).n = sh.n_cur;

@@ -29,22 +29,25 @@ struct vslam_ctx {
   int parity = 0, last_set = 0;
   // streams are processed in G independent groups, each with its own pair of HIP streams: a slow stream only
   // delays its own group, the other groups' kernels fill the idle CUs
-  struct Group { int s0, n; hipStream_t st_frm, st_img; hipEvent_t ev_img[2], ev_frm[2]; bool frm_pending[2]; };
+  // st_img: image pipeline of even steps (and uploads), st_img2: image pipeline of odd steps, so that BRIEF of step t
+  // overlaps FAST of step t+1 (FAST(t+1) only waits for the threshold controller in k_emit(t))
+  struct Group { int s0, n; hipStream_t st_frm, st_img, st_img2; hipEvent_t ev_img[2], ev_frm[2], ev_emit[2]; bool frm_pending[2], emit_pending[2]; };
   std::vector<Group> groups;
   std::string err;
   std::vector<void*> allocs;
-  uint8_t* upload[2] = {nullptr, nullptr};
+  uint8_t* upload[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [step parity][left/right]
   int up_stride = 0;
   size_t up_stream_stride = 0;
   bool frame_begun = false;
   bool timers = false;
   double timer_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  struct EvRec { hipEvent_t a, b; int k; };
+  struct EvRec { hipEvent_t a, b; int k; bool count; };
   std::vector<EvRec> evrec;
   std::vector<hipEvent_t> evpool;
-  double kern_ms[5] = {0, 0, 0, 0, 0};
-  int kern_n[5] = {0, 0, 0, 0, 0};
+  double kern_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int kern_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int split = 0;   // 1: frame processed by phase launches with wide kernels in between (measured slower); 0: one launch
   int sticky = VSLAM_OK;
 };
 
@@ -75,16 +78,16 @@ static hipEvent_t ev_get(vslam_ctx* c) {
   return e;
 }
 struct KernelTimer {
-  vslam_ctx* c; int k; hipStream_t st; hipEvent_t a = nullptr;
-  KernelTimer(vslam_ctx* c_, int k_, hipStream_t st_) : c(c_), k(k_), st(st_) { if (c->timers) { a = ev_get(c); (void)hipEventRecord(a, st); } }
-  ~KernelTimer() { if (a) { hipEvent_t b = ev_get(c); (void)hipEventRecord(b, st); c->evrec.push_back({a, b, k}); } }
+  vslam_ctx* c; int k; hipStream_t st; bool count; hipEvent_t a = nullptr;
+  KernelTimer(vslam_ctx* c_, int k_, hipStream_t st_, bool count_ = true) : c(c_), k(k_), st(st_), count(count_) { if (c->timers) { a = ev_get(c); (void)hipEventRecord(a, st); } }
+  ~KernelTimer() { if (a) { hipEvent_t b = ev_get(c); (void)hipEventRecord(b, st); c->evrec.push_back({a, b, k, count}); } }
 };
 static void sync_all(vslam_ctx* c);
 static void harvest_events(vslam_ctx* c) {
   sync_all(c);
   for (auto& r : c->evrec) {
     float ms = 0;
-    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { c->kern_ms[r.k] += ms; c->kern_n[r.k] += 1; }
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { c->kern_ms[r.k] += ms; if (r.count) c->kern_n[r.k] += 1; }
     c->evpool.push_back(r.a); c->evpool.push_back(r.b);
   }
   c->evrec.clear();
@@ -92,7 +95,7 @@ static void harvest_events(vslam_ctx* c) {
 
 
 static void sync_all(vslam_ctx* c) {
-  for (auto& g : c->groups) { (void)hipStreamSynchronize(g.st_img); (void)hipStreamSynchronize(g.st_frm); }
+  for (auto& g : c->groups) { (void)hipStreamSynchronize(g.st_img); (void)hipStreamSynchronize(g.st_img2); (void)hipStreamSynchronize(g.st_frm); }
 }
 static int group_of(const vslam_ctx* c, int s) {
   for (size_t i = 0; i < c->groups.size(); ++i) if (s >= c->groups[i].s0 && s < c->groups[i].s0 + c->groups[i].n) return (int)i;
@@ -207,7 +210,7 @@ static int init_state(vslam_ctx* c) {
   for (int q = 0; q < 2; ++q) {
     HIP_TRY(c, hipMemsetAsync(c->sets[q].n_kp, 0, sizeof(int32_t) * c->B * 2, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->sets[q].iinfo, 0, sizeof(ImgInfo) * c->B, c->stream));
-    for (auto& g : c->groups) g.frm_pending[q] = false;
+    for (auto& g : c->groups) { g.frm_pending[q] = false; g.emit_pending[q] = false; }
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->parity = 0; c->last_set = 0;
@@ -242,17 +245,23 @@ static int create_internal(const vslam_config* cfg, int device, int n_streams, v
       q.s0 = (int)((long long)n_streams * g / G);
       q.n = (int)((long long)n_streams * (g + 1) / G) - q.s0;
       bool ok = hipStreamCreateWithFlags(&q.st_frm, hipStreamNonBlocking) == hipSuccess &&
-                hipStreamCreateWithFlags(&q.st_img, hipStreamNonBlocking) == hipSuccess;
+                hipStreamCreateWithFlags(&q.st_img, hipStreamNonBlocking) == hipSuccess &&
+                hipStreamCreateWithFlags(&q.st_img2, hipStreamNonBlocking) == hipSuccess;
+      // a second image stream (BRIEF(t) overlapping FAST(t+1)) measured slower on MI355X: opt-in only
+      if (ok && !(getenv("VSLAM_IMG_STREAMS") && atoi(getenv("VSLAM_IMG_STREAMS")) == 2)) { (void)hipStreamDestroy(q.st_img2); q.st_img2 = q.st_img; }
       for (int k = 0; k < 2 && ok; ++k)
         ok = hipEventCreateWithFlags(&q.ev_img[k], hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&q.ev_frm[k], hipEventDisableTiming) == hipSuccess;
+             hipEventCreateWithFlags(&q.ev_frm[k], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&q.ev_emit[k], hipEventDisableTiming) == hipSuccess;
       q.frm_pending[0] = q.frm_pending[1] = false;
+      q.emit_pending[0] = q.emit_pending[1] = false;
       if (!ok) { delete c; return fail(nullptr, VSLAM_ERR_HIP, "hipStreamCreate failed"); }
       c->groups.push_back(q);
     }
     c->stream = c->groups[0].st_frm;
     c->stream_img = c->groups[0].st_img;
     c->own_stream = true;
+    if (const char* e = getenv("VSLAM_SPLIT")) c->split = atoi(e) != 0;
   }
   const DevCfg& d = c->cfg;
   DevBuf& b = c->buf;
@@ -292,8 +301,9 @@ static int create_internal(const vslam_config* cfg, int device, int n_streams, v
   if (e == hipSuccess) b.iinfo = c->sets[0].iinfo;
   c->up_stride = d.bstride;
   c->up_stream_stride = (size_t)rows * d.bstride;
-  if (e == hipSuccess) e = dalloc(c, &c->upload[0], B * c->up_stream_stride);
-  if (e == hipSuccess) e = dalloc(c, &c->upload[1], B * c->up_stream_stride);
+  for (int q = 0; q < 2; ++q)
+    for (int d2 = 0; d2 < 2; ++d2)
+      if (e == hipSuccess) e = dalloc(c, &c->upload[q][d2], B * c->up_stream_stride);
   if (e != hipSuccess) {
     std::string msg = std::string("vslam_create: hipMalloc failed: ") + hipGetErrorString(e);
     for (void* p : c->allocs) (void)hipFree(p);
@@ -322,8 +332,8 @@ VS_API void vslam_destroy(vslam_ctx* c) {
   harvest_events(c);
   for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
   for (auto& g : c->groups) {
-    for (int q = 0; q < 2; ++q) { (void)hipEventDestroy(g.ev_img[q]); (void)hipEventDestroy(g.ev_frm[q]); }
-    if (c->own_stream) { (void)hipStreamDestroy(g.st_frm); (void)hipStreamDestroy(g.st_img); }
+    for (int q = 0; q < 2; ++q) { (void)hipEventDestroy(g.ev_img[q]); (void)hipEventDestroy(g.ev_frm[q]); (void)hipEventDestroy(g.ev_emit[q]); }
+    if (c->own_stream) { (void)hipStreamDestroy(g.st_frm); (void)hipStreamDestroy(g.st_img); if (g.st_img2 != g.st_img) (void)hipStreamDestroy(g.st_img2); }
   }
   delete c;
 }
@@ -336,15 +346,16 @@ VS_API int vslam_set_hip_stream(vslam_ctx* c, void* s) {
   if (!c) return VSLAM_ERR_INVALID;
   sync_all(c);
   for (auto& g : c->groups) {
-    for (int q = 0; q < 2; ++q) { (void)hipEventDestroy(g.ev_img[q]); (void)hipEventDestroy(g.ev_frm[q]); }
-    if (c->own_stream) { (void)hipStreamDestroy(g.st_frm); (void)hipStreamDestroy(g.st_img); }
+    for (int q = 0; q < 2; ++q) { (void)hipEventDestroy(g.ev_img[q]); (void)hipEventDestroy(g.ev_frm[q]); (void)hipEventDestroy(g.ev_emit[q]); }
+    if (c->own_stream) { (void)hipStreamDestroy(g.st_frm); (void)hipStreamDestroy(g.st_img); if (g.st_img2 != g.st_img) (void)hipStreamDestroy(g.st_img2); }
   }
   c->groups.clear();
   // one caller stream: a single group, image pipeline and tracker run back to back on it
   vslam_ctx::Group q;
-  q.s0 = 0; q.n = c->B; q.st_frm = (hipStream_t)s; q.st_img = (hipStream_t)s;
-  for (int k = 0; k < 2; ++k) { (void)hipEventCreateWithFlags(&q.ev_img[k], hipEventDisableTiming); (void)hipEventCreateWithFlags(&q.ev_frm[k], hipEventDisableTiming); }
+  q.s0 = 0; q.n = c->B; q.st_frm = (hipStream_t)s; q.st_img = (hipStream_t)s; q.st_img2 = (hipStream_t)s;
+  for (int k = 0; k < 2; ++k) { (void)hipEventCreateWithFlags(&q.ev_img[k], hipEventDisableTiming); (void)hipEventCreateWithFlags(&q.ev_frm[k], hipEventDisableTiming); (void)hipEventCreateWithFlags(&q.ev_emit[k], hipEventDisableTiming); }
   q.frm_pending[0] = q.frm_pending[1] = false;
+  q.emit_pending[0] = q.emit_pending[1] = false;
   c->groups.push_back(q);
   c->stream = q.st_frm; c->stream_img = q.st_img;
   c->own_stream = false;
@@ -352,7 +363,7 @@ VS_API int vslam_set_hip_stream(vslam_ctx* c, void* s) {
 }
 VS_API int vslam_synchronize(vslam_ctx* c) {
   if (!c) return VSLAM_ERR_INVALID;
-  for (auto& g : c->groups) { HIP_TRY(c, hipStreamSynchronize(g.st_img)); HIP_TRY(c, hipStreamSynchronize(g.st_frm)); }
+  for (auto& g : c->groups) { HIP_TRY(c, hipStreamSynchronize(g.st_img)); HIP_TRY(c, hipStreamSynchronize(g.st_img2)); HIP_TRY(c, hipStreamSynchronize(g.st_frm)); }
   return c->sticky;
 }
 
@@ -363,12 +374,15 @@ static int launch_image_pipeline(vslam_ctx* c) {
   const int set = c->parity;
   for (auto& g : c->groups) {
     const DevBuf bs = buf_set(c, set, g.s0);
-    hipStream_t st = g.st_img;
-    // the image products of this set were last read by the frame kernel two steps ago
+    hipStream_t st = set ? g.st_img2 : g.st_img;
+    // the image products of this set were last read by the frame kernel two steps ago; the detector thresholds come
+    // from the controller in k_emit of the previous step (other image stream)
     if (g.frm_pending[set] && st != g.st_frm) HIP_TRY(c, hipStreamWaitEvent(st, g.ev_frm[set], 0));
+    if (g.emit_pending[set ^ 1] && g.st_img != g.st_img2) HIP_TRY(c, hipStreamWaitEvent(st, g.ev_emit[set ^ 1], 0));
     dim3 g1(d.TX, (d.c.rows + VS_TILE_H - 1) / VS_TILE_H, 2 * g.n);
     { KernelTimer t(c, 0, st); hipLaunchKernelGGL(k_fast_box, g1, dim3(256), 0, st, c->cfg, bs); }
     { KernelTimer t(c, 1, st); hipLaunchKernelGGL(k_emit, dim3(g.n), dim3(1024), 0, st, c->cfg, bs, (int)VSLAM_BRIEF_BORDER, 1); }
+    if (g.st_img != g.st_img2) { HIP_TRY(c, hipEventRecord(g.ev_emit[set], st)); g.emit_pending[set] = true; }
     dim3 g3((d.c.cols + VS_BT_W - 1) / VS_BT_W, (d.c.rows + VS_BT_H - 1) / VS_BT_H, 2 * g.n);
     { KernelTimer t(c, 2, st); hipLaunchKernelGGL(k_brief, g3, dim3(256), 0, st, c->cfg, bs); }
     HIP_TRY(c, hipGetLastError());
@@ -389,7 +403,17 @@ static int launch_frame(vslam_ctx* c) {
     const DevBuf bs = buf_set(c, c->last_set, g.s0);
     const int gx = std::max(4, std::min(128, 2048 / std::max(g.n, 1)));
     { KernelTimer t(c, 3, g.st_frm); hipLaunchKernelGGL(k_track_candidates, dim3(gx, g.n), dim3(256), 0, g.st_frm, c->cfg, bs, -1); }
-    { KernelTimer t(c, 4, g.st_frm); hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, c->cfg, bs); }
+    if (!c->split) {
+      KernelTimer t(c, 4, g.st_frm);
+      hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, c->cfg, bs, -1);
+    } else {
+      { KernelTimer t(c, 4, g.st_frm, false); hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, c->cfg, bs, 0); }
+      if (c->cfg.c.enable_landmark_recovery) { KernelTimer t(c, 5, g.st_frm); hipLaunchKernelGGL(k_recover_brief, dim3(std::max(4, std::min(64, 1024 / std::max(g.n, 1))), g.n), dim3(256), 0, g.st_frm, c->cfg, bs); }
+      { KernelTimer t(c, 4, g.st_frm, false); hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, c->cfg, bs, 1); }
+      { KernelTimer t(c, 6, g.st_frm); hipLaunchKernelGGL(k_update_landmarks, dim3((c->cfg.MAXP + 255) / 256, g.n), dim3(256), 0, g.st_frm, c->cfg, bs); }
+      if (c->cfg.n_offsets == 1) { KernelTimer t(c, 7, g.st_frm); hipLaunchKernelGGL(k_stereo_dist, dim3((c->cfg.NMAX + 255) / 256, g.n), dim3(256), 0, g.st_frm, c->cfg, bs); }
+      { KernelTimer t(c, 4, g.st_frm); hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, c->cfg, bs, 2); }
+    }
   }
   HIP_TRY(c, hipGetLastError());
   return frame_done(c);
@@ -406,13 +430,14 @@ static int upload_images(vslam_ctx* c, const uint8_t* L, const uint8_t* R, int32
   if (!L || !R) return fail(c, VSLAM_ERR_INVALID, "called with empty frame");
   if (row_stride < c->cfg.c.cols) return fail(c, VSLAM_ERR_INVALID, "row stride smaller than image width");
   for (int s = 0; s < c->B; ++s) {
-    hipStream_t st = c->groups[group_of(c, s)].st_img;
-    HIP_TRY(c, hipMemcpy2DAsync(c->upload[0] + s * c->up_stream_stride, c->up_stride, L + s * image_stride, row_stride,
+    const vslam_ctx::Group& gg = c->groups[group_of(c, s)];
+    hipStream_t st = c->parity ? gg.st_img2 : gg.st_img;
+    HIP_TRY(c, hipMemcpy2DAsync(c->upload[c->parity][0] + s * c->up_stream_stride, c->up_stride, L + s * image_stride, row_stride,
                                 c->cfg.c.cols, c->cfg.c.rows, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpy2DAsync(c->upload[1] + s * c->up_stream_stride, c->up_stride, R + s * image_stride, row_stride,
+    HIP_TRY(c, hipMemcpy2DAsync(c->upload[c->parity][1] + s * c->up_stream_stride, c->up_stride, R + s * image_stride, row_stride,
                                 c->cfg.c.cols, c->cfg.c.rows, hipMemcpyHostToDevice, st));
   }
-  return set_images_device(c, c->upload[0], c->upload[1], c->up_stride, c->up_stream_stride);
+  return set_images_device(c, c->upload[c->parity][0], c->upload[c->parity][1], c->up_stride, c->up_stream_stride);
 }
 
 VS_API int vslam_process_device(vslam_ctx* c, const uint8_t* L, const uint8_t* R, int32_t row_stride, size_t image_stride) {
@@ -552,20 +577,20 @@ VS_API int vslam_get_timers(vslam_ctx* c, double seconds[8]) {
   seconds[3] = c->kern_ms[3] * 1e-3 + ph[0];            // tracking: candidate search + resolution
   seconds[4] = ph[4];                                   // track_creation (tracker's timer around compute())
   seconds[5] = ph[1];                                   // pose_optimization
-  seconds[6] = ph[3];                                   // landmark_optimization
-  seconds[7] = ph[2];                                   // point_recovery
+  seconds[6] = ph[3] + c->kern_ms[6] * 1e-3;            // landmark_optimization (in-kernel part + wide kernel)
+  seconds[7] = ph[2] + c->kern_ms[5] * 1e-3;            // point_recovery
   return VSLAM_OK;
 }
-VS_API int vslam_get_kernel_times(vslam_ctx* c, double ms[5], int32_t launches[5]) {
+VS_API int vslam_get_kernel_times(vslam_ctx* c, double ms[8], int32_t launches[8]) {
   if (!c || !ms || !launches) return VSLAM_ERR_INVALID;
   harvest_events(c);
-  for (int k = 0; k < 5; ++k) { ms[k] = c->kern_ms[k]; launches[k] = c->kern_n[k]; }
+  for (int k = 0; k < 8; ++k) { ms[k] = c->kern_ms[k]; launches[k] = c->kern_n[k]; }
   return VSLAM_OK;
 }
 VS_API int vslam_enable_timers(vslam_ctx* c, int on) {
   if (!c) return VSLAM_ERR_INVALID;
   harvest_events(c);
-  if (on && !c->timers) { for (int k = 0; k < 5; ++k) { c->kern_ms[k] = 0; c->kern_n[k] = 0; } }
+  if (on && !c->timers) { for (int k = 0; k < 8; ++k) { c->kern_ms[k] = 0; c->kern_n[k] = 0; } }
   c->timers = on != 0;
   return VSLAM_OK;
 }
