@@ -294,8 +294,31 @@ __device__ __forceinline__ unsigned long long col_mask(int lo, int hi, int wx0) 
   return hi_m & ~((1ull << a) - 1ull);
 }
 
+// exclusive scan inside each half of a 1024-thread block (threads 0-511 / 512-1023 scan independently);
+// sh must hold 18 ints, *total receives the sum of the caller's half
+__device__ __forceinline__ int half_block_exclusive_scan(int v, int* sh, int* total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, half = w >> 3;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  __syncthreads();
+  if (lane == 63) sh[w] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0 || threadIdx.x == 512) {
+    int acc = 0;
+    for (int i = half * 8; i < half * 8 + 8; ++i) { const int t = sh[i]; sh[i] = acc; acc += t; }
+    sh[16 + half] = acc;
+  }
+  __syncthreads();
+  *total = sh[16 + half];
+  return sh[w] + inc - v;
+}
+
 __global__ __launch_bounds__(1024) void k_emit(const DevCfg c, const DevBuf b, int border, int run_controller) {
-  __shared__ int sh_scan[17];
+  __shared__ int sh_scan[18];
   __shared__ int sh_cnt[2][VSLAM_MAX_REGIONS];
   const int s = b.s0 + blockIdx.x, tid = threadIdx.x;
   const int rows = c.c.rows, cols = c.c.cols, TX = c.TX, CW = c.CW;
@@ -303,15 +326,17 @@ __global__ __launch_bounds__(1024) void k_emit(const DevCfg c, const DevBuf b, i
   if (tid < 2 * VSLAM_MAX_REGIONS) sh_cnt[tid / VSLAM_MAX_REGIONS][tid % VSLAM_MAX_REGIONS] = 0;
   __syncthreads();
   const int nwords = rows * TX;
-  const int chunk = (nwords + blockDim.x - 1) / blockDim.x;
-  for (int side = 0; side < 2; ++side) {
+  // the two images are scanned concurrently: threads 0-511 own the left, 512-1023 the right image
+  const int side = tid >> 9, ht = tid & 511;
+  const int chunk = (nwords + 511) / 512;
+  {
     const unsigned long long* mask = mask_of(c, b, s, side);
     const uint8_t* score8 = score_of(c, b, s, side);
     int16_t* kxy = kpxy_of(c, b, s, side);
     uint8_t* ksc = kpscore_of(c, b, s, side);
     int32_t* rowcell = rowcell_of(c, b, s, side);
     uint8_t* used = used_of(c, b, s, side);
-    const int w0 = tid * chunk, w1 = min(w0 + chunk, nwords);
+    const int w0 = min(ht * chunk, nwords), w1 = min(w0 + chunk, nwords);
     int local = 0;
     for (int w = w0; w < w1; ++w) {
       const int row = w / TX, t = w - row * TX;
@@ -331,8 +356,8 @@ __global__ __launch_bounds__(1024) void k_emit(const DevCfg c, const DevBuf b, i
       local += __popcll(f);
     }
     int total;
-    int off = block_exclusive_scan(local, sh_scan, &total);
-    if (total > c.NMAX) { if (tid == 0) atomicOr(&st.error_flags, 1); }
+    int off = half_block_exclusive_scan(local, sh_scan, &total);
+    if (total > c.NMAX) { if (ht == 0) atomicOr(&st.error_flags, 1); }
     for (int w = w0; w < w1; ++w) {
       const int row = w / TX, t = w - row * TX;
       const unsigned long long m = mask[w];
@@ -357,7 +382,7 @@ __global__ __launch_bounds__(1024) void k_emit(const DevCfg c, const DevBuf b, i
         ++off;
       }
     }
-    if (tid == 0) b.n_kp[s * 2 + side] = min(total, c.NMAX);
+    if (ht == 0) b.n_kp[s * 2 + side] = min(total, c.NMAX);
     __syncthreads();
   }
   if (tid == 0) {
