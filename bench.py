@@ -176,6 +176,15 @@ def main():
                           "achieved_GBs": round(abytes[name] / (avg_ms * 1e-3) / 1e9, 2) if avg_ms > 0 else None}
         kern = {k_: v_ for k_, v_ in kern.items() if v_["launches"] > 0}
         dom = max(ktimes.items(), key=lambda kv: kv[1][0])[0]
+        # HBM traffic of the dominant kernel: PMC counters cannot be read in-process; taken from the committed
+        # rocprofv3 --pmc summary (separate FETCH_SIZE / WRITE_SIZE passes of this same command) when it matches B
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_d_pmc_traffic_final.json")))
+            if B == 160 and groups == 1 and dom in pm["per_launch_KB"]:
+                traffic = int((pm["per_launch_KB"][dom]["FETCH_SIZE"] + pm["per_launch_KB"][dom]["WRITE_SIZE"]) * 1024)
+        except (OSError, KeyError, ValueError):
+            pass
         dom_avg_s = ktimes[dom][0] / max(ktimes[dom][1], 1) * 1e-3
         achieved = abytes[dom] / dom_avg_s / 1e9
         out = {
@@ -193,7 +202,7 @@ def main():
                        "mean_tracked": round(stats["M"], 1), "mean_aligner_iterations": round(stats["I"], 1),
                        "error_flags": flags},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(abytes[dom]), "avg_launch_ms": round(dom_avg_s * 1e3, 4)},
             "kernels": kern,
             "chronometers_s": {k: round(v, 4) for k, v in chrono.items()},
