@@ -191,40 +191,72 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (tid < c.n_regions) s_thr[tid] = min(max(b.st[s].thr[tid], 0), 255);
   if (tid == 0) qn = 0;
-  // ---- stage the (64+8) x (16+8) u8 tile: aligned dwords in the interior, clamped bytes at the image border ----
+  // ---- stage the (64+8) x (H+8) u8 tile.  Interior tiles: aligned dwords, all of a thread's loads in flight before
+  // the first LDS store; tiles touching the left/right image border: clamped bytes. ------------------------------------
   const bool aligned = ((stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(img) & 3) == 0);
-  for (int i = tid; i < (VS_TILE_H + 8) * 18; i += 256) {
-    const int r = i / 18, q = i - r * 18;
-    const int gy = min(max(y0 - 4 + r, 0), rows - 1), gx0 = x0 - 4 + 4 * q;
-    uint32_t v;
-    if (aligned && gx0 >= 0 && gx0 + 3 < cols) {
-      v = *reinterpret_cast<const uint32_t*>(img + (size_t)gy * stride + gx0);
-    } else {
-      v = 0;
+  constexpr int NST = ((VS_TILE_H + 8) * 18 + 255) / 256;
+  if (aligned && x0 >= 4 && x0 + 68 <= cols) {
+    uint32_t v[NST];
+#pragma unroll
+    for (int u = 0; u < NST; ++u) {
+      const int i = tid + 256 * u;
+      const int r = i / 18, q = i - r * 18;
+      const int gy = min(max(y0 - 4 + r, 0), rows - 1);
+      v[u] = 0;
+      if (i < (VS_TILE_H + 8) * 18) v[u] = *reinterpret_cast<const uint32_t*>(img + (size_t)gy * stride + (x0 - 4 + 4 * q));
+    }
+#pragma unroll
+    for (int u = 0; u < NST; ++u) {
+      const int i = tid + 256 * u;
+      const int r = i / 18, q = i - r * 18;
+      if (i < (VS_TILE_H + 8) * 18) *reinterpret_cast<uint32_t*>(&tile[r][4 * q]) = v[u];
+    }
+  } else {
+    for (int i = tid; i < (VS_TILE_H + 8) * 18; i += 256) {
+      const int r = i / 18, q = i - r * 18;
+      const int gy = min(max(y0 - 4 + r, 0), rows - 1), gx0 = x0 - 4 + 4 * q;
+      uint32_t v = 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) v |= (uint32_t)img[(size_t)gy * stride + min(max(gx0 + k, 0), cols - 1)] << (8 * k);
+      *reinterpret_cast<uint32_t*>(&tile[r][4 * q]) = v;
     }
-    *reinterpret_cast<uint32_t*>(&tile[r][4 * q]) = v;
   }
+  // one detector region covers the whole 66 x (H+2) score region of most tiles: its threshold is then tile-uniform
   __syncthreads();
+  int uni_thr = -2;
+  {
+    const int ta = region_threshold(c, s_thr, x0 - 1, y0 - 1), tb = region_threshold(c, s_thr, x0 + 64, y0 + VS_TILE_H);
+    if (c.n_regions == 1 && ta >= 0 && tb >= 0) uni_thr = ta;
+  }
   // ---- FAST on the 66 x (H+2) score region (tile + 1 px NMS halo), two passes:
-  //  A) every pixel: the high-speed test (a 9-arc of 16 contains two ADJACENT compass points, so one of the four
-  //     adjacent compass pairs must pass on the dark or on the bright side) -> ~1 pixel in 8 survives, queued in LDS
+  //  A) every pixel: the high-speed test (a 9-arc of 16 contains two ADJACENT compass points, i.e. one of {N,S} and one
+  //     of {E,W}, on the dark or on the bright side) -> ~1 pixel in 8 survives, queued in LDS (one atomic per wave-row)
   //  B) queued pixels only, two per lane in packed i16: exact corner test + cornerScore
-  for (int i = tid; i < (VS_TILE_H + 2) * 66; i += 256) {
-    const int r = i / 66, cc = i - r * 66;
-    const int thr = region_threshold(c, s_thr, x0 - 1 + cc, y0 - 1 + r);
+  auto pretest = [&](int r, int cc) {
+    const int thr = uni_thr != -2 ? uni_thr : region_threshold(c, s_thr, x0 - 1 + cc, y0 - 1 + r);
     bool cand = false;
     if (thr >= 0) {
       const int ly = r + 3, lx = cc + 3;
       const int v = tile[ly][lx];
       const int d0 = v - tile[ly + 3][lx], d4 = v - tile[ly][lx + 3], d8 = v - tile[ly - 3][lx], d12 = v - tile[ly][lx - 3];
-      const int dk = max(max(min(d0, d4), min(d4, d8)), max(min(d8, d12), min(d12, d0)));
-      const int br = min(min(max(d0, d4), max(d4, d8)), min(max(d8, d12), max(d12, d0)));
+      const int dk = min(max(d0, d8), max(d4, d12));
+      const int br = max(min(d0, d8), min(d4, d12));
       cand = dk > thr || br < -thr;
     }
-    if (cand) queue[atomicAdd(&qn, 1)] = (uint16_t)((r << 8) | cc);
-    else sc[r][cc] = 0;
+    const unsigned long long m = __ballot(cand);
+    if (m) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&qn, __popcll(m));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (cand) queue[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)((r << 8) | cc);
+    }
+    if (!cand) sc[r][cc] = 0;
+  };
+  for (int r = w; r < VS_TILE_H + 2; r += 4) pretest(r, lane);
+  // the two halo columns 64, 65 of every row: (H+2)*2 pixels, waves 0-1
+  if (tid < 128) {
+    const int i = tid;
+    if (i < (VS_TILE_H + 2) * 2) pretest(i >> 1, 64 + (i & 1));
   }
   // ---- horizontal 9-sums, four outputs per thread from three aligned dwords -----------------------------------------
   for (int i = tid; i < (VS_TILE_H + 8) * 16; i += 256) {
@@ -317,6 +349,7 @@ __device__ __forceinline__ int half_block_exclusive_scan(int v, int* sh, int* to
   return sh[w] + inc - v;
 }
 
+#define VS_EMIT_WPT 16   // mask words a thread keeps in registers (16 * 512 words = 524288 px per image; more -> reload)
 __global__ __launch_bounds__(1024) void k_emit(const DevCfg c, const DevBuf b, int border, int run_controller) {
   __shared__ int sh_scan[18];
   __shared__ int sh_cnt[2][VSLAM_MAX_REGIONS];
@@ -327,8 +360,9 @@ __global__ __launch_bounds__(1024) void k_emit(const DevCfg c, const DevBuf b, i
   __syncthreads();
   const int nwords = rows * TX;
   // the two images are scanned concurrently: threads 0-511 own the left, 512-1023 the right image
-  const int side = tid >> 9, ht = tid & 511;
+  const int side = tid >> 9, ht = tid & 511, lane = tid & 63;
   const int chunk = (nwords + 511) / 512;
+  const bool cached = chunk <= VS_EMIT_WPT;
   {
     const unsigned long long* mask = mask_of(c, b, s, side);
     const uint8_t* score8 = score_of(c, b, s, side);
@@ -337,32 +371,54 @@ __global__ __launch_bounds__(1024) void k_emit(const DevCfg c, const DevBuf b, i
     int32_t* rowcell = rowcell_of(c, b, s, side);
     uint8_t* used = used_of(c, b, s, side);
     const int w0 = min(ht * chunk, nwords), w1 = min(w0 + chunk, nwords);
+    // all mask words of the thread in flight at once (the scan is otherwise a chain of dependent L2 round trips)
+    unsigned long long mw[VS_EMIT_WPT];
+#pragma unroll
+    for (int j = 0; j < VS_EMIT_WPT; ++j) mw[j] = (cached && w0 + j < w1) ? mask[w0 + j] : 0ull;
+    const int row0 = w0 / TX, t0 = w0 - row0 * TX;
+    auto filtered = [&](unsigned long long m, int row, int t) -> unsigned long long {
+      const bool row_ok = row >= border && row < rows - border;
+      return row_ok ? (m & col_mask(border, cols - border, t * 64)) : 0ull;
+    };
     int local = 0;
-    for (int w = w0; w < w1; ++w) {
-      const int row = w / TX, t = w - row * TX;
-      const unsigned long long m = mask[w];
-      if (m) {
-        // raw detections per region (controller input): every corner bit lies in exactly one region
-        for (int r = 0; r < c.n_regions; ++r) {
-          const DevRegion& R = c.regions[r];
-          if (row >= R.y + 3 && row < R.y + R.h - 3) {
-            const int n = __popcll(m & col_mask(R.x + 3, R.x + R.w - 3, t * 64));
-            if (n) atomicAdd(&sh_cnt[side][r], n);
-          }
+    if (cached) {
+      int row = row0, t = t0;
+#pragma unroll
+      for (int j = 0; j < VS_EMIT_WPT; ++j) {
+        local += __popcll(filtered(mw[j], row, t));
+        if (++t == TX) { t = 0; ++row; }
+      }
+    } else {
+      for (int w = w0; w < w1; ++w) { const int row = w / TX; local += __popcll(filtered(mask[w], row, w - row * TX)); }
+    }
+    // raw detections per region (controller input): every corner bit lies in exactly one region; one LDS atomic
+    // per wavefront and region
+    for (int r = 0; r < c.n_regions; ++r) {
+      const DevRegion& R = c.regions[r];
+      int n = 0;
+      if (cached) {
+        int row = row0, t = t0;
+#pragma unroll
+        for (int j = 0; j < VS_EMIT_WPT; ++j) {
+          if (row >= R.y + 3 && row < R.y + R.h - 3) n += __popcll(mw[j] & col_mask(R.x + 3, R.x + R.w - 3, t * 64));
+          if (++t == TX) { t = 0; ++row; }
+        }
+      } else {
+        for (int w = w0; w < w1; ++w) {
+          const int row = w / TX;
+          if (row >= R.y + 3 && row < R.y + R.h - 3) n += __popcll(mask[w] & col_mask(R.x + 3, R.x + R.w - 3, (w - row * TX) * 64));
         }
       }
-      const bool row_ok = row >= border && row < rows - border;
-      const unsigned long long f = row_ok ? (m & col_mask(border, cols - border, t * 64)) : 0ull;
-      local += __popcll(f);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+      if (lane == 0 && n) atomicAdd(&sh_cnt[side][r], n);
     }
     int total;
     int off = half_block_exclusive_scan(local, sh_scan, &total);
     if (total > c.NMAX) { if (ht == 0) atomicOr(&st.error_flags, 1); }
-    for (int w = w0; w < w1; ++w) {
-      const int row = w / TX, t = w - row * TX;
-      const unsigned long long m = mask[w];
-      const bool row_ok = row >= border && row < rows - border;
-      unsigned long long f = row_ok ? (m & col_mask(border, cols - border, t * 64)) : 0ull;
+    // keypoints (x, row) in row-major order + the row/cell CSR: stores only
+    auto emit_word = [&](unsigned long long m, int row, int t) {
+      unsigned long long f = filtered(m, row, t);
       int32_t* rc = rowcell + (size_t)row * (CW + 1) + t * 4;
       rc[0] = min(off, c.NMAX);
       rc[1] = min(off + __popcll(f & 0xFFFFull), c.NMAX);
@@ -373,16 +429,40 @@ __global__ __launch_bounds__(1024) void k_emit(const DevCfg c, const DevBuf b, i
         const int bit = __ffsll((long long)f) - 1;
         f &= f - 1;
         if (off < c.NMAX) {
-          const int x = t * 64 + bit;
-          kxy[2 * off] = (int16_t)x;
+          kxy[2 * off] = (int16_t)(t * 64 + bit);
           kxy[2 * off + 1] = (int16_t)row;
-          ksc[off] = score8[(size_t)row * c.bstride + x];
           used[off] = 0;
         }
         ++off;
       }
+    };
+    if (cached) {
+      int row = row0, t = t0;
+#pragma unroll
+      for (int j = 0; j < VS_EMIT_WPT; ++j) {
+        if (w0 + j < w1) emit_word(mw[j], row, t);
+        if (++t == TX) { t = 0; ++row; }
+      }
+    } else {
+      for (int w = w0; w < w1; ++w) { const int row = w / TX; emit_word(mask[w], row, w - row * TX); }
     }
     if (ht == 0) b.n_kp[s * 2 + side] = min(total, c.NMAX);
+    __syncthreads();   // the workgroup's keypoint stores are visible to its own loads below
+    // scores: one keypoint per thread, four gathers in flight
+    const int nk = min(total, c.NMAX);
+    for (int i0 = ht; i0 < nk; i0 += 4 * 512) {
+      int px[4];
+      uint8_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 512 * u;
+        px[u] = (i < nk) ? *reinterpret_cast<const int32_t*>(kxy + 2 * i) : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = (i0 + 512 * u < nk) ? score8[(size_t)(px[u] >> 16) * c.bstride + (px[u] & 0xFFFF)] : 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (i0 + 512 * u < nk) ksc[i0 + 512 * u] = v[u];
+    }
     __syncthreads();
   }
   if (tid == 0) {
@@ -443,13 +523,13 @@ __device__ __forceinline__ void brief_wave(const uint16_t* box, int bstride, int
 #define VS_BT_RW (VS_BT_W + 2 * VSLAM_BRIEF_PATCH_HALF)   // 176
 #define VS_BT_RH (VS_BT_H + 2 * VSLAM_BRIEF_PATCH_HALF)   // 80
 __global__ __launch_bounds__(256) void k_brief(const DevCfg c, const DevBuf b) {
-  __shared__ __align__(16) uint16_t reg[VS_BT_RH][VS_BT_RW];
+  __shared__ __align__(16) uint16_t reg[VS_BT_RH * VS_BT_RW];
   __shared__ int row_lo[VS_BT_H], row_off[VS_BT_H + 1];
   int tx, ty, tz;
   xcd_tile(&tx, &ty, &tz);
   const int s = b.s0 + (tz >> 1), side = tz & 1;
   const int x0 = tx * VS_BT_W, y0 = ty * VS_BT_H;
-  const int rows = c.c.rows, cols = c.c.cols;
+  const int rows = c.c.rows;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int32_t* rowcell = rowcell_of(c, b, s, side);
   // keypoints of the tile: per row the CSR range of cells [8*tx, 8*tx+8)
@@ -472,30 +552,65 @@ __global__ __launch_bounds__(256) void k_brief(const DevCfg c, const DevBuf b) {
   const int K = row_off[VS_BT_H];
   if (K == 0) return;
   const uint16_t* box = box_of(c, b, s, side);
-  // stage the box region, two pixels per 32-bit load (x0 - 24 is even, the row stride is a multiple of 64)
-  for (int i = tid; i < VS_BT_RH * (VS_BT_RW / 2); i += 256) {
-    const int r = i / (VS_BT_RW / 2), q = i - r * (VS_BT_RW / 2);
+  // stage the box region with 16-byte loads, ALL of a thread's loads in flight before the first LDS store (the loop
+  // is otherwise a chain of dependent L2 round trips).  x0 - 24 is a multiple of 8 pixels and the row stride a multiple
+  // of 64, so a chunk lies entirely inside or outside the padded row; outside chunks (never sampled by a keypoint that
+  // passed the 28 px border filter) are zero.
+  constexpr int CPR = VS_BT_RW / 8;                              // 16-byte chunks per region row (22)
+  constexpr int NLD = (VS_BT_RH * CPR + 255) / 256;              // loads per thread (7)
+  uint4 stage[NLD];
+#pragma unroll
+  for (int u = 0; u < NLD; ++u) {
+    const int i = tid + 256 * u;
+    const int r = i / CPR, q = i - r * CPR;
     const int gy = min(max(y0 - VSLAM_BRIEF_PATCH_HALF + r, 0), rows - 1);
-    const int gx = min(max(x0 - VSLAM_BRIEF_PATCH_HALF + 2 * q, 0), c.bstride - 2);
-    *reinterpret_cast<uint32_t*>(&reg[r][2 * q]) = *reinterpret_cast<const uint32_t*>(box + (size_t)gy * c.bstride + gx);
+    const int gx = x0 - VSLAM_BRIEF_PATCH_HALF + 8 * q;
+    stage[u] = make_uint4(0u, 0u, 0u, 0u);
+    if (i < VS_BT_RH * CPR && gx >= 0 && gx + 8 <= c.bstride) stage[u] = *reinterpret_cast<const uint4*>(box + (size_t)gy * c.bstride + gx);
+  }
+  // lane l of wave w looks up keypoint w + 4*l of the tile (row by binary search in the CSR prefix, x from the keypoint
+  // array) while the staging loads are in flight
+  const int16_t* kxy = kpxy_of(c, b, s, side);
+  auto lookup = [&](int k, int* base, int* idx) {
+    *base = 0; *idx = -1;
+    if (k < K) {
+      int r = 0;
+#pragma unroll
+      for (int step = VS_BT_H / 2; step > 0; step >>= 1) if (row_off[r + step] <= k) r += step;
+      const int id = row_lo[r] + (k - row_off[r]);
+      *idx = id;
+      *base = (r + VSLAM_BRIEF_PATCH_HALF) * VS_BT_RW + (kxy[2 * id] - x0 + VSLAM_BRIEF_PATCH_HALF);
+    }
+  };
+  int my_base, my_idx;
+  lookup(w + 4 * lane, &my_base, &my_idx);
+  // the 4 test pairs of this lane as offsets inside the LDS region
+  int off_a[4], off_b[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = j * 64 + lane;
+    off_a[j] = c_brief[i][0] * VS_BT_RW + c_brief[i][1];
+    off_b[j] = c_brief[i][2] * VS_BT_RW + c_brief[i][3];
+  }
+#pragma unroll
+  for (int u = 0; u < NLD; ++u) {
+    const int i = tid + 256 * u;
+    if (i < VS_BT_RH * CPR) *reinterpret_cast<uint4*>(&reg[8 * i]) = stage[u];
   }
   __syncthreads();
-  const int16_t* kxy = kpxy_of(c, b, s, side);
   uint8_t* desc = desc_of(c, b, s, side);
-  for (int k = w; k < K; k += 4) {
-    // locate keypoint k: row with row_off[r] <= k < row_off[r+1]
-    int r = 0;
+  for (int k0 = 0; k0 < K; k0 += 256) {
+    if (k0 > 0) lookup(k0 + w + 4 * lane, &my_base, &my_idx);
+    const int n_here = (min(K - k0, 256) - w + 3) >> 2;          // keypoints of this wave in the chunk
+    for (int i = 0; i < n_here; ++i) {
+      const int base = __builtin_amdgcn_readlane(my_base, i), idx = __builtin_amdgcn_readlane(my_idx, i);
+      unsigned long long word = 0;
 #pragma unroll
-    for (int step = VS_BT_H / 2; step > 0; step >>= 1) if (row_off[r + step] <= k) r += step;
-    const int idx = row_lo[r] + (k - row_off[r]);
-    const int lx = kxy[2 * idx] - x0 + VSLAM_BRIEF_PATCH_HALF, ly = r + VSLAM_BRIEF_PATCH_HALF;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int i = j * 64 + lane;
-      const int a = reg[ly + c_brief[i][0]][lx + c_brief[i][1]];
-      const int bb = reg[ly + c_brief[i][2]][lx + c_brief[i][3]];
-      const unsigned long long m = __ballot(a < bb);
-      if (lane == 0) reinterpret_cast<unsigned long long*>(desc + (size_t)32 * idx)[j] = __builtin_bswap64(__brevll(m));
+      for (int j = 0; j < 4; ++j) {
+        const unsigned long long m = __ballot(reg[base + off_a[j]] < reg[base + off_b[j]]);
+        if (lane == j) word = m;
+      }
+      if (lane < 4) reinterpret_cast<unsigned long long*>(desc + (size_t)32 * idx)[lane] = __builtin_bswap64(__brevll(word));
     }
   }
 }
