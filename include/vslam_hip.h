@@ -99,7 +99,7 @@ typedef struct vslam_config {
   int32_t landmark_maximum_number_of_iterations;
 
   /* capacities of the device-resident buffers (no reference counterpart: std::vector grows) */
-  int32_t max_keypoints;       /* per image                                                   */
+  int32_t max_keypoints;       /* per image, 64..65535                                        */
   int32_t max_points;          /* framepoints per frame                                       */
   int32_t max_history_frames;  /* frames of per-point history kept for landmark refinement     */
 } vslam_config;

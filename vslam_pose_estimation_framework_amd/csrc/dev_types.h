@@ -22,8 +22,15 @@
 #define VS_TILE_H 32
 #define VS_CELL 16
 #define VS_MAXCAND 16        // candidate list length per previous point (overflow -> exact rescan)
+#ifndef VS_WG
 #define VS_WG 512            // threads of the per-stream frame kernel
-#define VS_ARENA (64 * 1024) // bytes of LDS scratch the frame kernel stages hot index arrays in
+#endif
+#ifdef VS_FRAME_WAVES_PER_EU       // optional register budget of the frame kernel: 512 / this VGPRs per lane
+#define VS_FRAME_BOUNDS __launch_bounds__(VS_WG, VS_FRAME_WAVES_PER_EU)
+#else
+#define VS_FRAME_BOUNDS __launch_bounds__(VS_WG)
+#endif
+#define VS_ARENA (128 * 1024) // bytes of LDS scratch the frame kernel stages hot index arrays in (one frame workgroup per CU)
 #define VS_POSE_LOG 32768    // frames of trajectory kept per stream
 
 struct DevRegion { int32_t x, y, w, h; };
@@ -86,6 +93,7 @@ struct StreamState {
 struct ImgInfo {
   int32_t thr_after[VSLAM_MAX_REGIONS];   // thresholds after adjustDetectorThresholds of this frame
   int32_t raw_count[2][VSLAM_MAX_REGIONS];
+  int32_t ticket;                         // k_emit: arrival counter of the stream's two per-image workgroups
 };
 
 struct DevBuf {
@@ -119,11 +127,10 @@ struct DevBuf {
   double* p_lm;        // [..][3]
   int32_t* n_points;   // [B][2]
   // track candidates / resolution  [B][MAXP]
-  int32_t* proj;       // [..][4] row, col, flag(1=in image), pad
-  int32_t* cand_cnt;
-  int32_t* cand_idx;   // [..][VS_MAXCAND]
-  int32_t* cand_h;     // [..][VS_MAXCAND]
-  int32_t* res;        // [..][4] fl, fr, dist, flag (bit0 success, bit1 lost-eligible)
+  int32_t* proj;       // [..][4] row, col, candidate count (-1 = projection outside the image), |epipolar offset|
+  double* proj_q;      // [..][2] right-image projection u/w, v/w of the previous point under the prior
+  uint32_t* cand_key;  // [..][VS_MAXCAND] sorted (primary << 16 | left feature index)
+  int32_t* res;        // [..][8] fl, fr, dist, flag (bit0 success, bit1 lost-eligible), x of fl, row of fr, pad
   int32_t* trk;        // [..][4] prev, fl, fr, dist  (compacted, order of previous points)
   int32_t* lost;       // [..]
   // aligner SoA [B][MAXP]
@@ -137,7 +144,7 @@ struct DevBuf {
   int32_t* rec;        // [..][6] flag, xL, yL, xR, yR, dist
   uint8_t* rec_desc;   // [..][64]
   // stereo scratch
-  int32_t* st_match;   // [B][NMAX][2]  matched right index / distance per left feature
+  int32_t* st_match;   // [B][NMAX][3]  matched right index / distance per left feature; [2*NMAX..) winners of the bin grid
   int32_t* sc;         // [B][NMAX][4]  fl, fr, dist, epi  (new candidates in sweep order)
   int32_t* bin_occ;    // [B][rows_bin*cols_bin]
   uint8_t* sdist;      // [B][NMAX][16] precomputed L-R Hamming distances of the stereo sweep

@@ -69,22 +69,29 @@ __device__ __forceinline__ bool project_prev(const DevCfg& c, const double* T, c
   return true;
 }
 
-// One wavefront gathers, for previous point i, every left feature inside the search window whose
-// Hamming distance to the point's left descriptor is below tau (the only features
-// getMatchingFeatureInRectangularRegion can return, in either mode).  Lanes split the window rows;
-// the row/cell CSR bounds each row to the 16-px cells the window overlaps.
-__device__ void candidates_wave(const DevCfg& c, const DevBuf& b, int s, int pb_prev, int i, int lane, int* wcnt,
-                                const double* T, int d, double tau) {
+// Per previous point i the wide candidate kernel leaves everything of track() that depends only on the motion prior:
+//   proj[i]    = {row, col, n_candidates (-1: projection outside the image), |epipolar offset|}
+//   proj_q[i]  = right-image projection (u/w, v/w) before the left-match correction (:541-556)
+//   cand_key[i][0..15] = the left features inside the search window below the descriptor distance, as sorted keys
+//                (primary << 16 | feature index): primary = Hamming distance (appearance mode) or squared pixel distance
+//                (projection mode, < 10000 only).  Features are stored row-major, so ordering by index is the reference's
+//                (row, col) tie-break and the first key whose feature is still present IS the reference's match.
+// One wavefront per point: lanes split the window rows; the row/cell CSR bounds each row to the 16-px cells the window
+// overlaps; a rank sort through LDS orders the (at most 16) keys.
+struct CandWave { int cnt; uint32_t keys[VS_MAXCAND]; };
+
+__device__ __forceinline__ void candidates_wave(const DevCfg& c, const DevBuf& b, int s, int pb_prev, int i, int lane, CandWave* cw,
+                                const double* T, int d, double tau, int by_app) {
   const PtView pv = pts_of(c, b, s, pb_prev);
   const size_t gi = (size_t)s * c.MAXP + i;
   double uvw[3];
   int row, col;
   const bool ok = project_prev(c, T, pv.cam + 3 * (size_t)i, uvw, &row, &col);
-  if (lane == 0) {
-    b.proj[gi * 4 + 0] = row; b.proj[gi * 4 + 1] = col; b.proj[gi * 4 + 2] = ok ? 1 : 0;
-    *wcnt = 0;
+  if (lane == 0) cw->cnt = 0;
+  if (!ok) {
+    if (lane == 0) { b.proj[gi * 4 + 0] = row; b.proj[gi * 4 + 1] = col; b.proj[gi * 4 + 2] = -1; b.proj[gi * 4 + 3] = 0; }
+    return;
   }
-  if (!ok) { if (lane == 0) b.cand_cnt[gi] = 0; return; }
   const int rows = c.c.rows, cols = c.c.cols;
   const int r0 = max(row - d, 0), r1 = min(row + d + 1, rows);
   const int c0 = max(col - d, 0), c1 = min(col + d + 1, cols);
@@ -102,21 +109,37 @@ __device__ void candidates_wave(const DevCfg& c, const DevBuf& b, int s, int pb_
         const int x = kxy[2 * k];
         if (x < c0 || x >= c1) continue;
         const int h = hamming32(pd, reinterpret_cast<const uint32_t*>(desc + (size_t)32 * k));
-        if ((double)h < tau) {
-          const int slot = atomicAdd(wcnt, 1);
-          if (slot < VS_MAXCAND) { b.cand_idx[gi * VS_MAXCAND + slot] = k; b.cand_h[gi * VS_MAXCAND + slot] = h; }
-        }
+        if (!((double)h < tau)) continue;
+        unsigned prim;
+        if (by_app) prim = (unsigned)h;
+        else { const int dr = row - r, dc = col - x; prim = (unsigned)(dr * dr + dc * dc); if (prim >= 10000u) continue; }
+        const int slot = atomicAdd(&cw->cnt, 1);
+        if (slot < VS_MAXCAND) cw->keys[slot] = (prim << 16) | (unsigned)k;
       }
     }
   }
   __builtin_amdgcn_wave_barrier();
-  if (lane == 0) b.cand_cnt[gi] = __hip_atomic_load(wcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  const int cnt = __hip_atomic_load(&cw->cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (cnt <= VS_MAXCAND && lane < cnt) {
+    const uint32_t mine = __hip_atomic_load(&cw->keys[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    int rank = 0;
+    for (int j = 0; j < cnt; ++j) rank += __hip_atomic_load(&cw->keys[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < mine ? 1 : 0;
+    b.cand_key[gi * VS_MAXCAND + rank] = mine;
+  }
+  if (lane == 0) {
+    double uR[3];
+    for (int k = 0; k < 3; ++k) uR[k] = uvw[k] + c.c.baseline_h[k];
+    b.proj[gi * 4 + 0] = row; b.proj[gi * 4 + 1] = col; b.proj[gi * 4 + 2] = cnt;
+    b.proj[gi * 4 + 3] = (int)fabs((double)pv.meta[(size_t)i * META + M_EPI]);
+    b.proj_q[gi * 2] = uR[0] / uR[2]; b.proj_q[gi * 2 + 1] = uR[1] / uR[2];
+  }
+  __builtin_amdgcn_wave_barrier();
 }
 
 __global__ __launch_bounds__(256) void k_track_candidates(const DevCfg c, const DevBuf b, int mode) {
   // mode < 0: fused path (appearance iff the tracker is Localizing, window forced to max in that case);
   // mode 0/1: stage path, window and distance exactly as set through vslam_set_tracker_state
-  __shared__ int wcnt[4];
+  __shared__ CandWave cw[4];
   const int s = b.s0 + blockIdx.y;
   const StreamState& st = b.st[s];
   if (!st.has_prev) return;
@@ -128,11 +151,11 @@ __global__ __launch_bounds__(256) void k_track_candidates(const DevCfg c, const 
   const int d = (mode < 0 && by_app) ? c.c.maximum_projection_tracking_distance_pixels : st.win;
   double T[12];
   for (int k = 0; k < 12; ++k) T[k] = st.prior[k];
-  for (int i = wave; i < P; i += nwaves) candidates_wave(c, b, s, pb_prev, i, lane, &wcnt[w], T, d, st.tau_track);
+  for (int i = wave; i < P; i += nwaves) candidates_wave(c, b, s, pb_prev, i, lane, &cw[w], T, d, st.tau_track, by_app);
 }
 
 // ==============================================================================================
-// frame kernel pieces (all called by the whole 1024-thread workgroup of stream s)
+// frame kernel pieces (all called by the whole workgroup of stream s)
 // ==============================================================================================
 struct FrameShared {
   int scan[17];
@@ -147,45 +170,57 @@ struct FrameShared {
   int inl, outl, its, conv;
   double red4[VS_WG / 64][4][32];
   unsigned long long key;
+  CandWave cw[VS_WG / 64];
 };
 
 __device__ __forceinline__ unsigned long long key3(unsigned a, int row, int col) {
   return ((unsigned long long)a << 32) | ((unsigned long long)(unsigned)row << 16) | (unsigned)col;
 }
 
+// "who removed which feature" + the right keypoint coordinates of the stream: in LDS when they fit the arena (the
+// usual case), in HBM otherwise; same code through flat pointers
+struct TrackTables {
+  int32_t* killL; int32_t* killR;
+  const uint16_t* xyR;     // [nR][2] x, y
+};
+__device__ __forceinline__ int ld_kill(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
 // evaluation of one previous point against the current kill state: what the sequential loop body
 // of track() would do if all earlier points had the outcomes recorded in `kill`.
-__device__ void evaluate_point(const DevCfg& c, const DevBuf& b, int s, int pb_prev, int i, const double* T, int d,
-                               double tau_track, double tau_tri, int by_app, int* out /*fl,fr,dist,flag*/) {
+// out = fl, fr, dist, flag (bit0 success, bit1 lost-eligible), x of fl, y of fr (for the parallax clearing)
+__device__ __forceinline__ void evaluate_point(const DevCfg& c, const DevBuf& b, int s, int pb_prev, int i, const TrackTables& tt, int d,
+                               double tau_track, double tau_tri, int by_app, int* out) {
   const size_t gi = (size_t)s * c.MAXP + i;
-  out[0] = -1; out[1] = -1; out[2] = 0; out[3] = 0;
-  if (!b.proj[gi * 4 + 2]) return;  // not in image: neither tracked nor lost (:508-513)
-  const int row = b.proj[gi * 4 + 0], col = b.proj[gi * 4 + 1];
+  out[0] = -1; out[1] = -1; out[2] = 0; out[3] = 0; out[4] = 0; out[5] = 0;
+  // everything whose address is known up front, in flight together
+  const int4 pr = *reinterpret_cast<const int4*>(b.proj + gi * 4);
+  const double2 q = *reinterpret_cast<const double2*>(b.proj_q + gi * 2);
+  uint4 kv[VS_MAXCAND / 4];
+#pragma unroll
+  for (int k = 0; k < VS_MAXCAND / 4; ++k) kv[k] = reinterpret_cast<const uint4*>(b.cand_key + gi * VS_MAXCAND)[k];
   const PtView pv = pts_of(c, b, s, pb_prev);
-  const int32_t* killL = kill_of(c, b, s, 0);
-  const int32_t* killR = kill_of(c, b, s, 1);
+  uint32_t prd[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) prd[k] = reinterpret_cast<const uint32_t*>(pv.desc + (size_t)64 * i + 32)[k];
+  const int cnt = pr.z;
+  if (cnt < 0) return;  // not in image: neither tracked nor lost (:508-513)
+  const int row = pr.x, col = pr.y;
   const int16_t* kxyL = kpxy_of(c, b, s, 0);
-  const int16_t* kxyR = kpxy_of(c, b, s, 1);
   const uint8_t* descL = desc_of(c, b, s, 0);
   const uint8_t* descR = desc_of(c, b, s, 1);
   const int rows = c.c.rows, cols = c.c.cols, CW1 = c.CW + 1;
-  // ---- left search -------------------------------------------------------------------------
-  unsigned long long best = ~0ull;
+  // ---- left search: first surviving key -------------------------------------------------------
   int fl = -1;
-  const int cnt = b.cand_cnt[gi];
   if (cnt <= VS_MAXCAND) {
-    for (int k = 0; k < cnt; ++k) {
-      const int f = b.cand_idx[gi * VS_MAXCAND + k];
-      if (ld_relaxed(killL + f) < i) continue;
-      const int fx = kxyL[2 * f], fy = kxyL[2 * f + 1];
-      unsigned prim;
-      if (by_app) prim = (unsigned)b.cand_h[gi * VS_MAXCAND + k];
-      else { const int dr = row - fy, dc = col - fx; prim = (unsigned)(dr * dr + dc * dc); if (prim >= 10000u) continue; }
-      const unsigned long long key = key3(prim, fy, fx);
-      if (key < best) { best = key; fl = f; }
+    const uint32_t* keys = reinterpret_cast<const uint32_t*>(kv);
+#pragma unroll
+    for (int k = 0; k < VS_MAXCAND; ++k) {
+      const int f = (int)(keys[k] & 0xFFFFu);
+      if (fl < 0 && k < cnt && ld_kill(tt.killL + f) >= i) fl = f;
     }
   } else {
     // candidate list overflowed: exact serial rescan of the window
+    unsigned long long best = ~0ull;
     uint32_t pd[8];
     for (int k = 0; k < 8; ++k) pd[k] = reinterpret_cast<const uint32_t*>(pv.desc + (size_t)64 * i)[k];
     const int r0 = max(row - d, 0), r1 = min(row + d + 1, rows), c0 = max(col - d, 0), c1 = min(col + d + 1, cols);
@@ -196,7 +231,7 @@ __device__ void evaluate_point(const DevCfg& c, const DevBuf& b, int s, int pb_p
         for (int f = lo; f < hi; ++f) {
           const int fx = kxyL[2 * f];
           if (fx < c0 || fx >= c1) continue;
-          if (ld_relaxed(killL + f) < i) continue;
+          if (ld_kill(tt.killL + f) < i) continue;
           const int h = hamming32(pd, reinterpret_cast<const uint32_t*>(descL + (size_t)32 * f));
           if (!((double)h < tau_track)) continue;
           unsigned prim;
@@ -209,99 +244,114 @@ __device__ void evaluate_point(const DevCfg& c, const DevBuf& b, int s, int pb_p
   }
   if (fl < 0) { out[3] = 2; return; }  // no left match: lost-eligible
   // ---- right search (:541-590) --------------------------------------------------------------
-  const int flx = kxyL[2 * fl], fly = kxyL[2 * fl + 1];
-  double uvw[3];
-  {
-    double q[3];
-    tf_apply(T, pv.cam + 3 * (size_t)i, q);
-    mat3_mul_vec(c.c.K, q, uvw);
-  }
+  const int fxy = *reinterpret_cast<const int32_t*>(kxyL + 2 * fl);
+  uint32_t ld[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) ld[k] = reinterpret_cast<const uint32_t*>(descL + (size_t)32 * fl)[k];
+  const int flx = (int16_t)(fxy & 0xFFFF), fly = fxy >> 16;
   const float ex = (float)col - (float)flx, ey = (float)row - (float)fly;
-  double uR[3];
-  for (int k = 0; k < 3; ++k) uR[k] = uvw[k] + c.c.baseline_h[k];
   int colR, rowR;
-  if (!to_int32(uR[0] / uR[2] - ex, &colR) || !to_int32(uR[1] / uR[2] - ey, &rowR)) return;
+  if (!to_int32(q.x - ex, &colR) || !to_int32(q.y - ey, &rowR)) return;
   if (colR < 0 || colR > cols || rowR < 0 || rowR > rows) return;
-  const int kk = (int)fabs((double)pv.meta[(size_t)i * META + M_EPI]);
+  const int kk = pr.w;
   const int rr0 = max(rowR - kk, 0), rr1 = min(rowR + kk + 1, rows);
   const int rc0 = max(colR - d, 0), rc1 = min(colR + d + 1, flx);
-  uint32_t ld[8];
-  for (int k = 0; k < 8; ++k) ld[k] = reinterpret_cast<const uint32_t*>(descL + (size_t)32 * fl)[k];
   double dbest = tau_tri;
   int fr = -1;
+  uint32_t rd[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) rd[k] = 0;
   if (rc1 > rc0) {
     const int32_t* rowcellR = rowcell_of(c, b, s, 1);
     for (int r = rr0; r < rr1; ++r) {
       const int lo = rowcellR[(size_t)r * CW1 + (rc0 >> 4)], hi = rowcellR[(size_t)r * CW1 + ((rc1 - 1) >> 4) + 1];
       for (int g = lo; g < hi; ++g) {
-        const int gx = kxyR[2 * g];
+        const int gx = tt.xyR[2 * g];
         if (gx < rc0 || gx >= rc1) continue;
-        if (ld_relaxed(killR + g) < i) continue;
-        const double h = (double)hamming32(ld, reinterpret_cast<const uint32_t*>(descR + (size_t)32 * g));
-        if (h < dbest) { dbest = h; fr = g; }
+        if (ld_kill(tt.killR + g) < i) continue;
+        uint32_t gd[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gd[k] = reinterpret_cast<const uint32_t*>(descR + (size_t)32 * g)[k];
+        const double h = (double)hamming32(ld, gd);
+        if (h < dbest) {
+          dbest = h; fr = g;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) rd[k] = gd[k];
+        }
       }
     }
   }
   if (fr < 0) { out[3] = 2; return; }  // no right match: lost-eligible
-  const int frx = kxyR[2 * fr];
+  const int frx = tt.xyR[2 * fr];
   if ((double)(flx - frx) < c.c.minimum_disparity_pixels) return;  // continue: not lost (:597-600)
-  uint32_t rd[8], prd[8];
-  for (int k = 0; k < 8; ++k) {
-    rd[k] = reinterpret_cast<const uint32_t*>(descR + (size_t)32 * fr)[k];
-    prd[k] = reinterpret_cast<const uint32_t*>(pv.desc + (size_t)64 * i + 32)[k];
-  }
   if ((double)hamming32(rd, prd) > tau_track) return;               // continue (:603-608)
-  out[0] = fl; out[1] = fr; out[2] = (int)dbest; out[3] = 1;
+  out[0] = fl; out[1] = fr; out[2] = (int)dbest; out[3] = 1; out[4] = flx; out[5] = tt.xyR[2 * fr + 1];
 }
 
 // Order-exact resolution of track(): Jacobi iteration on "who removed which lattice cell".
 // kill[f] = smallest index of a previous point whose (tentative) success removes feature f; point i
 // sees f as present iff kill[f] >= i.  A fixed point equals the sequential result (induction on i:
 // point 0 never depends on others; if all j < i are final, the kills i sees are final).
-__device__ void wg_track_resolve(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_prev, const double* T,
+__device__ __forceinline__ void wg_track_resolve(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_prev, unsigned char* arena,
                                  int d, double tau_track, double tau_tri, int by_app) {
   const int tid = threadIdx.x;
   const PtView pv = pts_of(c, b, s, pb_prev);
   const int P = *pv.n;
   const int nL = b.n_kp[s * 2], nR = b.n_kp[s * 2 + 1];
-  int32_t* killL = kill_of(c, b, s, 0);
-  int32_t* killR = kill_of(c, b, s, 1);
-  int32_t* res = b.res + (size_t)s * c.MAXP * 4;
-  const int16_t* kxyL = kpxy_of(c, b, s, 0);
   const int16_t* kxyR = kpxy_of(c, b, s, 1);
-  const int32_t* rowcellR = rowcell_of(c, b, s, 1);
-  for (int i = tid; i < P; i += VS_WG) { res[4 * i] = -1; res[4 * i + 1] = -1; res[4 * i + 2] = 0; res[4 * i + 3] = 0; }
+  TrackTables tt;
+  const bool in_lds = (size_t)nL * 4 + (size_t)nR * 8 <= VS_ARENA;
+  if (in_lds) {
+    tt.killL = reinterpret_cast<int32_t*>(arena);
+    tt.killR = tt.killL + nL;
+    uint32_t* xy = reinterpret_cast<uint32_t*>(tt.killR + nR);
+    for (int g = tid; g < nR; g += VS_WG) xy[g] = reinterpret_cast<const uint32_t*>(kxyR)[g];
+    tt.xyR = reinterpret_cast<const uint16_t*>(xy);
+  } else {
+    tt.killL = kill_of(c, b, s, 0);
+    tt.killR = kill_of(c, b, s, 1);
+    tt.xyR = reinterpret_cast<const uint16_t*>(kxyR);
+  }
+  int32_t* res = b.res + (size_t)s * c.MAXP * 8;
+  for (int i = tid; i < P; i += VS_WG) { res[8 * i] = -1; res[8 * i + 1] = -1; res[8 * i + 2] = 0; res[8 * i + 3] = 0; }
   __syncthreads();
+  unsigned long long tq = wall_clock64();
   for (int iter = 0; iter <= P + 1; ++iter) {
-    for (int f = tid; f < nL; f += VS_WG) __hip_atomic_store(killL + f, 0x7FFFFFFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int f = tid; f < nR; f += VS_WG) __hip_atomic_store(killR + f, 0x7FFFFFFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) b.st[s].dbg[7] += 1;
+    for (int f = tid; f < nL; f += VS_WG) __hip_atomic_store(tt.killL + f, 0x7FFFFFFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (int f = tid; f < nR; f += VS_WG) __hip_atomic_store(tt.killR + f, 0x7FFFFFFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __syncthreads();
-    for (int i = tid; i < P; i += VS_WG) {
-      if (res[4 * i + 3] & 1) {
-        const int fl = res[4 * i], fr = res[4 * i + 1];
-        atomicMin(killL + fl, i);
-        atomicMin(killR + fr, i);
-        // parallax clearing (:612-621): right features strictly between fR.col and fL.col on fR.row
-        const int rowR = kxyR[2 * fr + 1], lim = kxyL[2 * fl];
-        const int rend = rowcellR[(size_t)rowR * (c.CW + 1) + c.CW];
-        for (int g = fr + 1; g < rend && kxyR[2 * g] < lim; ++g) atomicMin(killR + g, i);
+    if (iter > 0) {
+      for (int i = tid; i < P; i += VS_WG) {
+        const int4 r4 = *reinterpret_cast<const int4*>(res + 8 * i);
+        if (r4.w & 1) {
+          const int fl = r4.x, fr = r4.y;
+          const int lim = res[8 * i + 4], rowR = res[8 * i + 5];
+          atomicMin(tt.killL + fl, i);
+          atomicMin(tt.killR + fr, i);
+          // parallax clearing (:612-621): right features strictly between fR.col and fL.col on fR.row
+          for (int g = fr + 1; g < nR && tt.xyR[2 * g + 1] == rowR && tt.xyR[2 * g] < lim; ++g) atomicMin(tt.killR + g, i);
+        }
       }
+      __syncthreads();
     }
-    __syncthreads();
     int changed = 0;
     for (int i = tid; i < P; i += VS_WG) {
-      int o[4];
-      evaluate_point(c, b, s, pb_prev, i, T, d, tau_track, tau_tri, by_app, o);
-      if (o[0] != res[4 * i] || o[1] != res[4 * i + 1] || o[3] != res[4 * i + 3]) changed = 1;
-      res[4 * i] = o[0]; res[4 * i + 1] = o[1]; res[4 * i + 2] = o[2]; res[4 * i + 3] = o[3];
+      int o[6];
+      evaluate_point(c, b, s, pb_prev, i, tt, d, tau_track, tau_tri, by_app, o);
+      const int4 old = *reinterpret_cast<const int4*>(res + 8 * i);
+      if (o[0] != old.x || o[1] != old.y || o[3] != old.w) changed = 1;
+      *reinterpret_cast<int4*>(res + 8 * i) = make_int4(o[0], o[1], o[2], o[3]);
+      res[8 * i + 4] = o[4]; res[8 * i + 5] = o[5];
     }
     if (!__syncthreads_or(changed)) break;
   }
+  if (tid == 0) { const unsigned long long tn = wall_clock64(); b.st[s].dbg[9] += tn - tq; tq = tn; }
   // used flags == every feature some final success removed (matched_indices_* + prune, :646-672)
   uint8_t* usedL = used_of(c, b, s, 0);
   uint8_t* usedR = used_of(c, b, s, 1);
-  for (int f = tid; f < nL; f += VS_WG) usedL[f] = ld_relaxed(killL + f) != 0x7FFFFFFF;
-  for (int f = tid; f < nR; f += VS_WG) usedR[f] = ld_relaxed(killR + f) != 0x7FFFFFFF;
+  for (int f = tid; f < nL; f += VS_WG) usedL[f] = ld_kill(tt.killL + f) != 0x7FFFFFFF;
+  for (int f = tid; f < nR; f += VS_WG) usedR[f] = ld_kill(tt.killR + f) != 0x7FFFFFFF;
   // compaction in previous-point order: tracked list, lost list, landmark count
   int32_t* trk = b.trk + (size_t)s * c.MAXP * 4;
   int32_t* lost = b.lost + (size_t)s * c.MAXP;
@@ -309,7 +359,7 @@ __device__ void wg_track_resolve(const DevCfg& c, const DevBuf& b, int s, FrameS
   const int i0 = tid * per, i1 = min(i0 + per, P);
   int nt = 0, nl = 0, nlm = 0;
   for (int i = i0; i < i1; ++i) {
-    const int fl = res[4 * i + 3];
+    const int fl = res[8 * i + 3];
     if (fl & 1) { ++nt; if (pv.meta[(size_t)i * META + M_LMUP] > 0) ++nlm; }
     else if ((fl & 2) && !pv.meta[(size_t)i * META + M_NEXT]) ++nl;
   }
@@ -318,16 +368,16 @@ __device__ void wg_track_resolve(const DevCfg& c, const DevBuf& b, int s, FrameS
   int ol = block_exclusive_scan(nl, sh.scan, &tot_l);
   block_exclusive_scan(nlm, sh.scan, &tot_lm);
   for (int i = i0; i < i1; ++i) {
-    const int fl = res[4 * i + 3];
+    const int fl = res[8 * i + 3];
     if (fl & 1) {
-      trk[4 * ot] = i; trk[4 * ot + 1] = res[4 * i]; trk[4 * ot + 2] = res[4 * i + 1]; trk[4 * ot + 3] = res[4 * i + 2];
+      trk[4 * ot] = i; trk[4 * ot + 1] = res[8 * i]; trk[4 * ot + 2] = res[8 * i + 1]; trk[4 * ot + 3] = res[8 * i + 2];
       ++ot;
       pv.meta[(size_t)i * META + M_NEXT] = 1;
     } else if ((fl & 2) && !pv.meta[(size_t)i * META + M_NEXT]) {
       lost[ol++] = i;
     }
   }
-  if (tid == 0) { sh.n_trk = tot_t; sh.n_lost = tot_l; sh.n_lm = tot_lm; }
+  if (tid == 0) { sh.n_trk = tot_t; sh.n_lost = tot_l; sh.n_lm = tot_lm; b.st[s].dbg[10] += wall_clock64() - tq; }
   __syncthreads();
 }
 
@@ -340,7 +390,7 @@ __device__ void wg_track_resolve(const DevCfg& c, const DevBuf& b, int s, FrameS
 // (same class of difference as the H,b summation order).  Returns false when a pivot is not safely positive; the
 // caller then falls back to the exact full-pivot wave solver (rank-deficient systems keep reference semantics).
 __device__ __forceinline__ bool ldlt_solve6(const double* Hs, const double* rhs, double* x) {
-  double A[6][6], y[6];
+  double A[6][6], y[6], invd[6];
   double dmax = 0;
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
@@ -355,6 +405,7 @@ __device__ __forceinline__ bool ldlt_solve6(const double* Hs, const double* rhs,
     const double d = A[k][k];
     if (!(d > 1e-12 * dmax)) ok = false;
     const double inv = 1.0 / d;
+    invd[k] = inv;
 #pragma unroll
     for (int i = k + 1; i < 6; ++i) {
       const double f = A[i][k] * inv;
@@ -372,7 +423,7 @@ __device__ __forceinline__ bool ldlt_solve6(const double* Hs, const double* rhs,
     double sv = y[i];
 #pragma unroll
     for (int j = i + 1; j < 6; ++j) sv -= A[i][j] * x[j];
-    x[i] = sv / A[i][i];
+    x[i] = sv * invd[i];
   }
   return ok;
 }
@@ -544,7 +595,7 @@ __device__ __forceinline__ void load_align_point(const DevCfg& c, const DevBuf& 
 }
 
 __device__ __forceinline__ void wg_one_round(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int n, bool ignore_outliers,
-                             const AlignPoint* cache) {
+                             const AlignPoint* cache, double* chi_reg, uint8_t* inl_reg) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   double* chi_o = b.al_chi + (size_t)s * c.MAXP;
   uint8_t* inl_o = b.al_inl + (size_t)s * c.MAXP;
@@ -556,7 +607,7 @@ __device__ __forceinline__ void wg_one_round(const DevCfg& c, const DevBuf& b, i
 #pragma unroll
   for (int q = 0; q < VS_ALCACHE; ++q) {
     const int u = tid + q * VS_WG;
-    if (u < n) align_point(c, T, cache[q], ignore_outliers, acc, chi_o + u, inl_o + u);
+    if (u < n) align_point(c, T, cache[q], ignore_outliers, acc, &chi_reg[q], &inl_reg[q]);   // stored after the last round
   }
   for (int u = tid + VS_ALCACHE * VS_WG; u < n; u += VS_WG) {
     AlignPoint P;
@@ -636,9 +687,12 @@ __device__ __forceinline__ void wg_align_converge(const DevCfg& c, const DevBuf&
   const int max_it = c.c.aligner_maximum_number_of_iterations;
   const double delta = c.c.aligner_error_delta_for_convergence;
   AlignPoint cache[VS_ALCACHE];
+  double chi_reg[VS_ALCACHE];
+  uint8_t inl_reg[VS_ALCACHE];
 #pragma unroll
   for (int q = 0; q < VS_ALCACHE; ++q) {
     const int u = tid + q * VS_WG;
+    chi_reg[q] = -1; inl_reg[q] = 0;
     if (u < n) load_align_point(c, b, s, u, cache[q]);
   }
   // converge() as one loop (single inlined copy of the round): outer rounds use the saturated kernel, after the
@@ -647,7 +701,7 @@ __device__ __forceinline__ void wg_align_converge(const DevCfg& c, const DevBuf&
   int it = 0, it2 = 0;
   bool refine = false;
   while (true) {
-    wg_one_round(c, b, s, sh, n, refine, cache);
+    wg_one_round(c, b, s, sh, n, refine, cache, chi_reg, inl_reg);
     const double E = sh.E;
     if (!refine) {
       ++it;
@@ -666,11 +720,18 @@ __device__ __forceinline__ void wg_align_converge(const DevCfg& c, const DevBuf&
       if (done || it2 >= max_it) { if (tid == 0) sh.conv = 1; break; }
     }
   }
+  // errors / inlier flags of the last linearization (the rounds themselves keep them in registers: a global store per
+  // round would put an HBM round trip on every barrier)
+#pragma unroll
+  for (int q = 0; q < VS_ALCACHE; ++q) {
+    const int u = tid + q * VS_WG;
+    if (u < n) { (b.al_chi + (size_t)s * c.MAXP)[u] = chi_reg[q]; (b.al_inl + (size_t)s * c.MAXP)[u] = inl_reg[q]; }
+  }
   __syncthreads();
 }
 
 // initialize (:10-69) on the tracked list, then converge
-__device__ void wg_align(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_prev, bool inverse_depth,
+__device__ __forceinline__ void wg_align(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_prev, bool inverse_depth,
                          const double* T_init) {
   const int tid = threadIdx.x;
   const int n = sh.n_trk;

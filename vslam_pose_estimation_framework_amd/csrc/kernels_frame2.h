@@ -2,6 +2,7 @@
 // stereo sweep + binning, and the PoseTracker3D control flow that strings the stages together.
 #pragma once
 #include "kernels_frame.h"
+#include <type_traits>
 
 // write one framepoint (Frame::createFramepoint, types/frame.cpp:61-84) from a left/right feature pair
 __device__ __forceinline__ void materialize_point(const DevCfg& c, const DevBuf& b, int s, const PtView& cv, int j, int fl,
@@ -23,7 +24,7 @@ __device__ __forceinline__ void materialize_point(const DevCfg& c, const DevBuf&
 
 // _prunePoints (pose_tracker_3d.cpp:437-472) fused with the materialisation of the surviving tracked
 // points into the current frame's point arrays.  Quirk B.3: aligner not run on these points -> drop all.
-__device__ void wg_prune(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_prev, int pb_cur, bool aligner_valid) {
+__device__ __forceinline__ void wg_prune(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_prev, int pb_cur, bool aligner_valid) {
   const int tid = threadIdx.x;
   const int n = sh.n_trk;
   const PtView pv = pts_of(c, b, s, pb_prev);
@@ -71,7 +72,7 @@ __device__ void wg_prune(const DevCfg& c, const DevBuf& b, int s, FrameShared& s
 //             the wide kernel k_recover_brief over all streams (fused path).
 //   append  : survivors are appended in lost-list order (:844-864)
 // rec[6q] : 0 = rejected, 2 = projected (needs BRIEF), 1 = recovered; then xL, yL, xR, yR, Hamming L-R
-__device__ void wg_recover_project(const DevCfg& c, const DevBuf& b, int s, int n_lost, int pb_prev, const double* w2c) {
+__device__ __forceinline__ void wg_recover_project(const DevCfg& c, const DevBuf& b, int s, int n_lost, int pb_prev, const double* w2c) {
   const PtView pv = pts_of(c, b, s, pb_prev);
   const int32_t* lost = b.lost + (size_t)s * c.MAXP;
   int32_t* rec = b.rec + (size_t)s * c.MAXP * 6;
@@ -144,7 +145,7 @@ __device__ __forceinline__ void recover_brief_wave(const DevCfg& c, const DevBuf
   }
 }
 
-__device__ void wg_recover_append(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_prev, int pb_cur) {
+__device__ __forceinline__ void wg_recover_append(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_prev, int pb_cur) {
   const int tid = threadIdx.x;
   const PtView pv = pts_of(c, b, s, pb_prev);
   const PtView cv = pts_of(c, b, s, pb_cur);
@@ -184,7 +185,7 @@ __device__ void wg_recover_append(const DevCfg& c, const DevBuf& b, int s, Frame
 }
 
 // whole recovery inside one workgroup (stage path)
-__device__ void wg_recover(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_prev, int pb_cur, const double* w2c,
+__device__ __forceinline__ void wg_recover(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_prev, int pb_cur, const double* w2c,
                            double tau_track, double tau_tri) {
   wg_recover_project(c, b, s, sh.n_lost, pb_prev, w2c);
   __syncthreads();
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256) void k_recover_brief(const DevCfg c, const Dev
 // landmark of framepoint i of the current frame: creation = mean of the track's world coordinates
 // (Landmark::Landmark, landmark.cpp:19-31), otherwise Gauss-Newton refinement over all measurements of the track
 // (Landmark::update, :66-167).  Returns true when the point carries an active landmark afterwards.
-__device__ bool landmark_point(const DevCfg& c, const DevBuf& b, int s, const PtView& cv, int f, int i) {
+__device__ __forceinline__ bool landmark_point(const DevCfg& c, const DevBuf& b, int s, const PtView& cv, int f, int i) {
   const double* w2c_cur = hpose_of(c, b, s, f) + 12;
   {
     int32_t* m = cv.meta + (size_t)i * META;
@@ -299,7 +300,7 @@ __device__ bool landmark_point(const DevCfg& c, const DevBuf& b, int s, const Pt
   return true;
 }
 
-__device__ void wg_publish_history(const DevCfg& c, const DevBuf& b, int s, int n, int pb_cur, int f) {
+__device__ __forceinline__ void wg_publish_history(const DevCfg& c, const DevBuf& b, int s, int n, int pb_cur, int f) {
   const PtView cv = pts_of(c, b, s, pb_cur);
   double* hc = hcam_of(c, b, s, f);
   int32_t* hp = hprev_of(c, b, s, f);
@@ -309,7 +310,7 @@ __device__ void wg_publish_history(const DevCfg& c, const DevBuf& b, int s, int 
   }
 }
 
-__device__ void wg_update_points(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_cur, int f) {
+__device__ __forceinline__ void wg_update_points(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_cur, int f) {
   const int tid = threadIdx.x;
   const PtView cv = pts_of(c, b, s, pb_cur);
   const int n = sh.n_cur;
@@ -337,11 +338,33 @@ __global__ __launch_bounds__(256) void k_update_landmarks(const DevCfg c, const 
   if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&st.fc.n_active, cnt);
 }
 
+// sdist[i][k], k < 16: Hamming distance of left feature i to right feature g0 + w0 + k of its row [g0, g1), where the
+// window [w0, m) holds the (up to 16) nearest right features at or left of the left feature: m = number of right
+// features of the row with x <= xl, w0 = max(m - 16, 0).  Nothing is written for m = 0 or m >= 255.
+template <class XR>
+__device__ __forceinline__ void stereo_dist_row(const uint8_t* descL, const uint8_t* descR, int i, int g0, int g1, int xl, XR xr,
+                                                uint8_t* sdist) {
+  int m = 0;
+  while (g0 + m < g1 && m < 255 && xl - xr(g0 + m) >= 0) ++m;
+  if (m == 0 || m >= 255) return;
+  const int w0 = max(m - 16, 0), mw = m - w0;
+  const uint4 la = reinterpret_cast<const uint4*>(descL + (size_t)32 * i)[0], lb = reinterpret_cast<const uint4*>(descL + (size_t)32 * i)[1];
+  uint32_t pk[4] = {0, 0, 0, 0};
+  for (int k = 0; k < mw; ++k) {
+    const uint4* rp = reinterpret_cast<const uint4*>(descR + (size_t)32 * (g0 + w0 + k));
+    const uint4 ra = rp[0], rb = rp[1];
+    const int h = __popc(la.x ^ ra.x) + __popc(la.y ^ ra.y) + __popc(la.z ^ ra.z) + __popc(la.w ^ ra.w) +
+                  __popc(lb.x ^ rb.x) + __popc(lb.y ^ rb.y) + __popc(lb.z ^ rb.z) + __popc(lb.w ^ rb.w);
+    pk[k >> 2] |= (uint32_t)(h > 255 ? 255 : h) << (8 * (k & 3));
+  }
+  *reinterpret_cast<uint4*>(sdist + (size_t)i * 16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+}
+
 // compute() (stereo_framepoint_generator.cpp:135-462): stereo sweep with one thread per image row (rows are
 // independent: the right cursor only moves inside a row), then the order-dependent bin competition with
 // one thread per bin, then emission in bin-grid row-major order.
-__device__ void wg_stereo(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_cur, double tau_tri, int f,
-                          unsigned char* arena, int arena_bytes, bool dist_ready) {
+__device__ __forceinline__ void wg_stereo(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_cur, double tau_tri, int f,
+                          unsigned char* arena, int arena_bytes) {
   const int tid = threadIdx.x;
   const PtView cv = pts_of(c, b, s, pb_cur);
   const int rows = c.c.rows, CW1 = c.CW + 1;
@@ -354,141 +377,174 @@ __device__ void wg_stereo(const DevCfg& c, const DevBuf& b, int s, FrameShared& 
   const uint8_t* descR = desc_of(c, b, s, 1);
   uint8_t* usedL = used_of(c, b, s, 0);
   uint8_t* usedR = used_of(c, b, s, 1);
-  int32_t* match = b.st_match + (size_t)s * c.NMAX * 2;
+  int32_t* match = b.st_match + (size_t)s * c.NMAX * 3;
   int32_t* sc = b.sc + (size_t)s * c.NMAX * 4;
   int32_t* bin_occ = b.bin_occ + (size_t)s * c.rows_bin * c.cols_bin;
   const int n_tracked = sh.n_cur;
   const int nR = b.n_kp[s * 2 + 1];
-  // LDS staging of what the sequential row sweep touches (x coordinates, used flags, row starts): the sweep is a
-  // chain of dependent loads, ~100 ns each from LDS instead of ~1 us from HBM
-  const int nLp = (nL + 7) & ~7, nRp = (nR + 7) & ~7;
-  const bool staged = (size_t)4 * 2 * (rows + 1) + (size_t)3 * (nLp + nRp) <= (size_t)arena_bytes;
-  int32_t* srL = reinterpret_cast<int32_t*>(arena);
-  int32_t* srR = srL + (rows + 1);
-  int16_t* sxL = reinterpret_cast<int16_t*>(srR + (rows + 1));
-  int16_t* sxR = sxL + nLp;
-  uint8_t* suL = reinterpret_cast<uint8_t*>(sxR + nRp);
+  // The sweep (:235-360) is sequential per image row only through the right cursor (a match at right feature g forbids
+  // g and everything left of it to later left features of the row).  It runs in two steps on LDS copies of what it
+  // touches:
+  //  (A) every left feature, in parallel: over the window of its (up to 16) nearest right features at or left of it —
+  //      whose descriptor distances k_stereo_dist precomputed — the first-minimum right feature for EVERY possible
+  //      cursor position (a suffix-argmin table, 16 nibbles);
+  //  (B) one thread per row replays the cursor with one table lookup per left feature.  Only a cursor left of the
+  //      window (more than 16 unconsumed right features behind the left feature) needs the reference's explicit scan.
+  const int nLp = (nL + 7) & ~7, nRp = (nR + 7) & ~7, rowsp = (rows + 8) & ~7;
+  const size_t stage_bytes = (size_t)4 * 2 * rowsp + (size_t)(8 + 4 + 4 + 2 + 1 + 1) * nLp + (size_t)(2 + 1) * nRp;
+  const bool staged = stage_bytes <= (size_t)arena_bytes;
+  // the distance rows of the first pass (from k_stereo_dist of the image pipeline) ride along when they fit
+  const bool sd_lds = staged && ((stage_bytes + 15) & ~(size_t)15) + (size_t)16 * nL <= (size_t)arena_bytes;
+  unsigned long long* ssuf = reinterpret_cast<unsigned long long*>(arena);   // step A: suffix-argmin nibbles
+  int32_t* srL = reinterpret_cast<int32_t*>(ssuf + nLp);     // row starts, left / right
+  int32_t* srR = srL + rowsp;
+  uint32_t* sxyL = reinterpret_cast<uint32_t*>(srR + rowsp); // x | y << 16
+  int32_t* smatch = reinterpret_cast<int32_t*>(sxyL + nLp);  // sweep result per left feature: -1 or distance << 16 | right index
+  uint16_t* sval = reinterpret_cast<uint16_t*>(smatch + nLp);// step A: bit c = a candidate exists at window position >= c
+  int16_t* sxR = reinterpret_cast<int16_t*>(sval + nLp);
+  uint8_t* suL = reinterpret_cast<uint8_t*>(sxR + nRp);      // used flags
   uint8_t* suR = suL + nLp;
+  uint8_t* smL = suR + nRp;                                  // right features of the row at or left of the left feature (<= 255)
+  uint4* sd4 = reinterpret_cast<uint4*>(arena + ((stage_bytes + 15) & ~(size_t)15));
+  const int itau = (int)ceil(tau_tri);   // integer h < tau_tri  <=>  h < ceil(tau_tri)
   int n_cand = 0;
   unsigned long long tq = wall_clock64();
 #define DBG_STAMP(k) do { __syncthreads(); if (tid == 0) { const unsigned long long tn = wall_clock64(); b.st[s].dbg[k] += tn - tq; tq = tn; } } while (0)
   for (int oi = 0; oi < c.n_offsets; ++oi) {
     const int o = c.offsets[oi];
-    // distances of every left feature to the right features of its row that lie at or left of it (a prefix of
-    // the row in x order), all features in parallel; the sequential cursor logic below only reads them
     uint8_t* sdist = b.sdist + (size_t)s * c.NMAX * 16;
     if (staged) {
       for (int r = tid; r <= rows; r += VS_WG) {
         srL[r] = r < rows ? rcL[(size_t)r * CW1] : rcL[(size_t)(rows - 1) * CW1 + c.CW];
         srR[r] = r < rows ? rcR[(size_t)r * CW1] : rcR[(size_t)(rows - 1) * CW1 + c.CW];
       }
-      for (int i = tid; i < nL; i += VS_WG) { sxL[i] = kxyL[2 * i]; suL[i] = usedL[i]; }
+#pragma unroll 4
+      for (int i = tid; i < nL; i += VS_WG) { sxyL[i] = reinterpret_cast<const uint32_t*>(kxyL)[i]; suL[i] = usedL[i]; }
+#pragma unroll 4
       for (int g = tid; g < nR; g += VS_WG) { sxR[g] = kxyR[2 * g]; suR[g] = usedR[g]; }
+      if (oi == 0 && sd_lds) {
+#pragma unroll 4
+        for (int i = tid; i < nL; i += VS_WG) sd4[i] = reinterpret_cast<const uint4*>(sdist)[i];
+      }
       __syncthreads();
-      for (int i = tid; i < nL; i += VS_WG) {
-        match[2 * i] = -1;
-        if (dist_ready && oi == 0) continue;   // distances of the first pass came from k_stereo_dist
-        if (suL[i]) continue;
-        const int r = kxyL[2 * i + 1], rr = r - o;
-        if (rr < 0 || rr >= rows) continue;
-        const int g0 = srR[rr], g1 = srR[rr + 1];
-        const int xl = sxL[i];
-        int m = 0;
-        while (g0 + m < g1 && m < 16 && xl - sxR[g0 + m] >= 0) ++m;
-        if (m == 0) continue;
-        const uint4 la = reinterpret_cast<const uint4*>(descL + (size_t)32 * i)[0], lb = reinterpret_cast<const uint4*>(descL + (size_t)32 * i)[1];
-        uint32_t pk[4] = {0, 0, 0, 0};
-        for (int j = 0; j < m; ++j) {
-          const uint4 ra = reinterpret_cast<const uint4*>(descR + (size_t)32 * (g0 + j))[0], rb = reinterpret_cast<const uint4*>(descR + (size_t)32 * (g0 + j))[1];
-          const int h = __popc(la.x ^ ra.x) + __popc(la.y ^ ra.y) + __popc(la.z ^ ra.z) + __popc(la.w ^ ra.w) +
-                        __popc(lb.x ^ rb.x) + __popc(lb.y ^ rb.y) + __popc(lb.z ^ rb.z) + __popc(lb.w ^ rb.w);
-          pk[j >> 2] |= (uint32_t)(h > 255 ? 255 : h) << (8 * (j & 3));
+      if (tid == 0) { const unsigned long long tn = wall_clock64(); b.st[s].dbg[11] += tn - tq; }
+      // distances of the first pass came from k_stereo_dist (image pipeline); later offsets recompute them here
+      if (oi > 0) {
+        for (int i = tid; i < nL; i += VS_WG) {
+          if (suL[i]) continue;
+          const int rr = (int)(sxyL[i] >> 16) - o;
+          if (rr < 0 || rr >= rows) continue;
+          stereo_dist_row(descL, descR, i, srR[rr], srR[rr + 1], (int)(sxyL[i] & 0xFFFFu), [&](int g) { return (int)sxR[g]; }, sdist);
         }
-        *reinterpret_cast<uint4*>(sdist + (size_t)i * 16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        __syncthreads();
       }
+      // (instantiated twice: distance rows in LDS or in HBM — a run-time pointer select would turn every access into a
+      // FLAT instruction, which waits on both the LDS and the HBM counters)
+      auto steps_ab = [&](auto sd_tag) {
+        constexpr bool SD = decltype(sd_tag)::value;
+        // ---- step A ---------------------------------------------------------------------------------------------------
+        for (int i = tid; i < nL; i += VS_WG) {
+          unsigned long long suf = 0;
+          unsigned val = 0;
+          int m = 0;
+          const uint32_t xy = sxyL[i];
+          const int rr = (int)(xy >> 16) - o;
+          if (!suL[i] && rr >= 0 && rr < rows) {
+            const int g0 = srR[rr], g1 = srR[rr + 1];
+            const int xl = (int)(xy & 0xFFFFu);
+            {  // m = right features of the row with x <= xl (x-sorted): binary search
+              int lo = g0, hi = g1;
+              while (lo < hi) { const int mid = (lo + hi) >> 1; if (xl - sxR[mid] >= 0) lo = mid + 1; else hi = mid; }
+              m = min(lo - g0, 255);
+            }
+            if (m > 0 && m < 255) {
+              const int w0 = max(m - 16, 0), mw = m - w0;
+              uint4 dq;
+              if constexpr (SD) dq = sd4[i]; else dq = *reinterpret_cast<const uint4*>(sdist + (size_t)i * 16);
+              const unsigned long long d01 = ((unsigned long long)dq.y << 32) | dq.x, d23 = ((unsigned long long)dq.w << 32) | dq.z;
+              int bh = 0, bj = -1;
+              for (int k = mw - 1; k >= 0; --k) {
+                const int h = (int)(((k < 8 ? d01 : d23) >> (8 * (k & 7))) & 255ull);
+                if (!suR[g0 + w0 + k] && h < itau && (bj < 0 || h <= bh)) { bh = h; bj = k; }
+                if (bj >= 0) { suf |= (unsigned long long)bj << (4 * k); val |= 1u << k; }
+              }
+            }
+          }
+          ssuf[i] = suf; sval[i] = (uint16_t)val; smL[i] = (uint8_t)m;
+        }
+        __syncthreads();
+        if (tid == 0) { const unsigned long long tn = wall_clock64(); b.st[s].dbg[1] += tn - tq; }
+        // ---- step B ---------------------------------------------------------------------------------------------------
+        for (int r = tid; r < rows; r += VS_WG) {
+          const int rr = r - o;  // right row: L.row == R.row + o
+          const bool rv = rr >= 0 && rr < rows;
+          const int l0 = srL[r], l1 = srL[r + 1];
+          const int g0 = rv ? srR[rr] : 0, g1 = rv ? srR[rr + 1] : 0;
+          int cur = g0;
+          for (int i = l0; i < l1; ++i) {
+            const int m = smL[i];
+            int bg = -1, best = 0;
+            if (m > 0 && cur < g0 + m) {
+              const int w0 = max(m - 16, 0), cpos = cur - g0 - w0;
+              if (m < 255 && cpos >= 0) {
+                const unsigned val = sval[i];
+                if ((val >> cpos) & 1u) {
+                  const int k = (int)((ssuf[i] >> (4 * cpos)) & 15ull);
+                  bg = g0 + w0 + k;
+                  if constexpr (SD) best = reinterpret_cast<const uint8_t*>(sd4 + i)[k]; else best = sdist[(size_t)i * 16 + k];
+                }
+              } else {
+                // cursor left of the window: the reference's explicit scan from the cursor
+                const int xl = (int)(sxyL[i] & 0xFFFFu);
+                uint32_t ld[8];
+                for (int q = 0; q < 8; ++q) ld[q] = reinterpret_cast<const uint32_t*>(descL + (size_t)32 * i)[q];
+                best = itau;
+                for (int g = cur; g < g1; ++g) {
+                  if (suR[g]) continue;
+                  if (xl - sxR[g] < 0) break;
+                  const int h = hamming32(ld, reinterpret_cast<const uint32_t*>(descR + (size_t)32 * g));
+                  if (h < best) { best = h; bg = g; }
+                }
+              }
+            }
+            int res = -1;
+            if (bg >= 0 && !((double)((int)(sxyL[i] & 0xFFFFu) - sxR[bg]) < c.c.minimum_disparity_pixels)) {
+              res = (best << 16) | bg;
+              cur = bg + 1;
+            }
+            smatch[i] = res;   // LDS: a global store here would put an HBM round trip into every step of the replay
+          }
+        }
+      };
+      if (oi == 0 && sd_lds) steps_ab(std::true_type{}); else steps_ab(std::false_type{});
     } else {
-      for (int i = tid; i < nL; i += VS_WG) {
-        match[2 * i] = -1;
-        if (usedL[i]) continue;
-        const int r = kxyL[2 * i + 1], rr = r - o;
-        if (rr < 0 || rr >= rows) continue;
-        const int g0 = rcR[(size_t)rr * CW1], g1 = rcR[(size_t)rr * CW1 + c.CW];
-        const int xl = kxyL[2 * i];
-        uint32_t ld[8];
-        for (int k = 0; k < 8; ++k) ld[k] = reinterpret_cast<const uint32_t*>(descL + (size_t)32 * i)[k];
-        for (int g = g0, j = 0; g < g1 && j < 16; ++g, ++j) {
-          if (xl - kxyR[2 * g] < 0) break;
-          sdist[(size_t)i * 16 + j] = (uint8_t)hamming32(ld, reinterpret_cast<const uint32_t*>(descR + (size_t)32 * g));
-        }
-      }
-    }
-    __syncthreads();
-    if (staged) {
+      // capacities beyond the LDS arena: the reference's loop on HBM, one thread per row
+      for (int i = tid; i < nL; i += VS_WG) match[2 * i] = -1;
+      __syncthreads();
       for (int r = tid; r < rows; r += VS_WG) {
         const int rr = r - o;  // right row: L.row == R.row + o
         if (rr < 0 || rr >= rows) continue;
-        const int l0 = srL[r], l1 = srL[r + 1];
-        const int g0 = srR[rr], g1 = srR[rr + 1];
+        const int l0 = rcL[(size_t)r * CW1], l1 = rcL[(size_t)r * CW1 + c.CW];
+        const int g0 = rcR[(size_t)rr * CW1], g1 = rcR[(size_t)rr * CW1 + c.CW];
         int cur = g0;
         for (int i = l0; i < l1; ++i) {
-          if (suL[i]) continue;
+          if (usedL[i]) continue;
           if (cur >= g1) break;
-          const int xl = sxL[i];
-          const uint4 dq = *reinterpret_cast<const uint4*>(sdist + (size_t)i * 16);
-          const uint32_t dw[4] = {dq.x, dq.y, dq.z, dq.w};
-          double best = tau_tri;
-          int bg = -1;
+          const int xl = kxyL[2 * i];
+          uint32_t ld[8];
+          for (int q = 0; q < 8; ++q) ld[q] = reinterpret_cast<const uint32_t*>(descL + (size_t)32 * i)[q];
+          int best = itau, bg = -1;
           for (int g = cur; g < g1; ++g) {
-            if (suR[g]) continue;
-            if (xl - sxR[g] < 0) break;
-            const int j = g - g0;
-            double h;
-            if (j < 16) {
-              h = (double)((dw[j >> 2] >> (8 * (j & 3))) & 255u);
-            } else {
-              uint32_t ld[8];
-              for (int k = 0; k < 8; ++k) ld[k] = reinterpret_cast<const uint32_t*>(descL + (size_t)32 * i)[k];
-              h = (double)hamming32(ld, reinterpret_cast<const uint32_t*>(descR + (size_t)32 * g));
-            }
+            if (usedR[g]) continue;
+            if (xl - kxyR[2 * g] < 0) break;
+            const int h = hamming32(ld, reinterpret_cast<const uint32_t*>(descR + (size_t)32 * g));
             if (h < best) { best = h; bg = g; }
           }
           if (bg >= 0) {
-            if ((double)(xl - sxR[bg]) < c.c.minimum_disparity_pixels) continue;
-            match[2 * i] = bg; match[2 * i + 1] = (int)best;
+            if ((double)(xl - kxyR[2 * bg]) < c.c.minimum_disparity_pixels) continue;
+            match[2 * i] = bg; match[2 * i + 1] = best;
             cur = bg + 1;
           }
-        }
-      }
-    } else
-    for (int r = tid; r < rows; r += VS_WG) {
-      const int rr = r - o;  // right row: L.row == R.row + o
-      if (rr < 0 || rr >= rows) continue;
-      const int l0 = rcL[(size_t)r * CW1], l1 = rcL[(size_t)r * CW1 + c.CW];
-      const int g0 = rcR[(size_t)rr * CW1], g1 = rcR[(size_t)rr * CW1 + c.CW];
-      int cur = g0;
-      for (int i = l0; i < l1; ++i) {
-        if (usedL[i]) continue;
-        if (cur >= g1) break;
-        const int xl = kxyL[2 * i];
-        double best = tau_tri;
-        int bg = -1;
-        for (int g = cur; g < g1; ++g) {
-          if (usedR[g]) continue;
-          if (xl - kxyR[2 * g] < 0) break;
-          double h;
-          if (g - g0 < 16) {
-            h = (double)sdist[(size_t)i * 16 + (g - g0)];
-          } else {
-            uint32_t ld[8];
-            for (int k = 0; k < 8; ++k) ld[k] = reinterpret_cast<const uint32_t*>(descL + (size_t)32 * i)[k];
-            h = (double)hamming32(ld, reinterpret_cast<const uint32_t*>(descR + (size_t)32 * g));
-          }
-          if (h < best) { best = h; bg = g; }
-        }
-        if (bg >= 0) {
-          if ((double)(xl - kxyR[2 * bg]) < c.c.minimum_disparity_pixels) continue;
-          match[2 * i] = bg; match[2 * i + 1] = (int)best;
-          cur = bg + 1;
         }
       }
     }
@@ -497,13 +553,15 @@ __device__ void wg_stereo(const DevCfg& c, const DevBuf& b, int s, FrameShared& 
     const int per = (nL + VS_WG - 1) / VS_WG;
     const int i0 = tid * per, i1 = min(i0 + per, nL);
     int cnt = 0;
-    for (int i = i0; i < i1; ++i) cnt += match[2 * i] >= 0 ? 1 : 0;
+    for (int i = i0; i < i1; ++i) cnt += (staged ? smatch[i] : match[2 * i]) >= 0 ? 1 : 0;
     int total;
     int off = n_cand + block_exclusive_scan(cnt, sh.scan, &total);
     for (int i = i0; i < i1; ++i) {
-      const int g = match[2 * i];
+      int g, dist;
+      if (staged) { const int sm = smatch[i]; g = sm < 0 ? -1 : (sm & 0xFFFF); dist = sm >> 16; }
+      else { g = match[2 * i]; dist = g >= 0 ? match[2 * i + 1] : 0; }
       if (g < 0) continue;
-      sc[4 * off] = i; sc[4 * off + 1] = g; sc[4 * off + 2] = match[2 * i + 1]; sc[4 * off + 3] = o;
+      sc[4 * off] = i; sc[4 * off + 1] = g; sc[4 * off + 2] = dist; sc[4 * off + 3] = o;
       usedL[i] = 1; usedR[g] = 1;
       ++off;
     }
@@ -515,39 +573,43 @@ __device__ void wg_stereo(const DevCfg& c, const DevBuf& b, int s, FrameShared& 
   const double bin = (double)c.c.bin_size_pixels;
   int added = 0;
   if (c.c.enable_keypoint_binning) {
-    for (int k = tid; k < nb; k += VS_WG) bin_occ[k] = -1;
+    // working arrays of the bin competition: in LDS (the sweep's staging is dead by now) when they fit, else in HBM
+    const bool bl = ((size_t)3 * (nb + 1) + (size_t)4 * n_cand) * 4 <= (size_t)arena_bytes;
+    int32_t* occ = bl ? reinterpret_cast<int32_t*>(arena) : bin_occ;
+    int32_t* bcnt = bl ? occ + (nb + 1) : b.bin_aux + (size_t)s * (2 * ((size_t)nb + 1) + c.NMAX);
+    int32_t* bstart = bcnt + (nb + 1);
+    int32_t* bitems = bstart + (nb + 1);                       // [n_cand]
+    int32_t* cbin = bl ? bitems + n_cand : match;              // [n_cand][2]: bin id, (disparity << 16 | distance)
+    int32_t* emit_q = bl ? cbin + 2 * n_cand : match + 2 * (size_t)c.NMAX;   // [<= n_cand] winners in bin order
+    __syncthreads();
+    for (int k = tid; k < nb; k += VS_WG) { occ[k] = -1; bcnt[k] = 0; }
     __syncthreads();
     // tracked points seed the grid; later points overwrite earlier ones -> keep the largest index
     for (int j = tid; j < n_tracked; j += VS_WG) {
       const int rb = min((int)rint((double)cv.kp[4 * (size_t)j + 1] / bin), c.rows_bin - 1);
       const int cb = min((int)rint((double)cv.kp[4 * (size_t)j] / bin), c.cols_bin - 1);
-      atomicMax(bin_occ + rb * c.cols_bin + cb, j);
+      atomicMax(occ + rb * c.cols_bin + cb, j);
     }
-    __syncthreads();
-    // bin id / disparity / distance of every candidate, once (match[] is free again: reuse it)
+    // bin id / disparity / distance of every candidate, once; per-bin counts
     for (int q = tid; q < n_cand; q += VS_WG) {
-      const int i = sc[4 * q];
-      const int xl = kxyL[2 * i], yl = kxyL[2 * i + 1];
+      const int4 e = *reinterpret_cast<const int4*>(sc + 4 * q);
+      const int lxy = *reinterpret_cast<const int32_t*>(kxyL + 2 * e.x);
+      const int xl = (int16_t)(lxy & 0xFFFF), yl = lxy >> 16;
       const int rb = min((int)rint((double)yl / bin), c.rows_bin - 1);
       const int cb = min((int)rint((double)xl / bin), c.cols_bin - 1);
-      match[2 * q] = rb * c.cols_bin + cb;
-      match[2 * q + 1] = ((xl - kxyR[2 * sc[4 * q + 1]]) << 16) | (sc[4 * q + 2] & 0xFFFF);
+      const int k = rb * c.cols_bin + cb;
+      cbin[2 * q] = k;
+      cbin[2 * q + 1] = ((xl - kxyR[2 * e.y]) << 16) | (e.z & 0xFFFF);
+      atomicAdd(bcnt + k, 1);
     }
     __syncthreads();
     DBG_STAMP(2);
     // per-bin candidate lists by counting sort (arrival order inside a bin is arbitrary, restored by a tiny sort)
-    int32_t* bcnt = b.bin_aux + (size_t)s * (2 * ((size_t)nb + 1) + c.NMAX);
-    int32_t* bstart = bcnt + (nb + 1);
-    int32_t* bitems = bstart + (nb + 1);
-    for (int k = tid; k < nb; k += VS_WG) __hip_atomic_store(bcnt + k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    for (int q = tid; q < n_cand; q += VS_WG) atomicAdd(bcnt + match[2 * q], 1);
-    __syncthreads();
     {
       const int perb = (nb + VS_WG - 1) / VS_WG;
       const int k0 = tid * perb, k1 = min(k0 + perb, nb);
       int cnt = 0;
-      for (int k = k0; k < k1; ++k) cnt += ld_relaxed(bcnt + k);
+      for (int k = k0; k < k1; ++k) cnt += ld_relaxed(bcnt + k);   // written by atomics: read past the vector L1
       int total;
       int off = block_exclusive_scan(cnt, sh.scan, &total);
       for (int k = k0; k < k1; ++k) { const int m = ld_relaxed(bcnt + k); bstart[k] = off; off += m; __hip_atomic_store(bcnt + k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -555,14 +617,14 @@ __device__ void wg_stereo(const DevCfg& c, const DevBuf& b, int s, FrameShared& 
     }
     __syncthreads();
     for (int q = tid; q < n_cand; q += VS_WG) {
-      const int k = match[2 * q];
+      const int k = cbin[2 * q];
       bitems[bstart[k] + atomicAdd(bcnt + k, 1)] = q;
     }
     __syncthreads();
     // one thread per bin replays its candidates in sweep order (the rule is not an argmax)
     for (int k = tid; k < nb; k += VS_WG) {
-      int occ = ld_relaxed(bin_occ + k);
-      if (occ >= 0) { bin_occ[k] = -2 - occ; continue; }  // tracked occupant: never replaced
+      const int o0 = ld_relaxed(occ + k);
+      if (o0 >= 0) { occ[k] = -2 - o0; continue; }  // tracked occupant: never replaced
       const int i0 = bstart[k], m = bstart[k + 1] - i0;
       int win = -1, wdisp = 0, wdist = 0, last = -1;
       for (int t = 0; t < m; ++t) {
@@ -570,25 +632,27 @@ __device__ void wg_stereo(const DevCfg& c, const DevBuf& b, int s, FrameShared& 
         int q = 0x7FFFFFFF;
         for (int u = 0; u < m; ++u) { const int v = ld_relaxed(bitems + i0 + u); if (v > last && v < q) q = v; }
         last = q;
-        const int pk = match[2 * q + 1];
+        const int pk = cbin[2 * q + 1];
         const int disp = pk >> 16, dist = pk & 0xFFFF;
         if (win < 0 || (disp > wdisp && dist <= wdist)) { win = q; wdisp = disp; wdist = dist; }
       }
-      bin_occ[k] = win;  // -1 empty, >= 0 candidate index
+      occ[k] = win;  // -1 empty, >= 0 candidate index
     }
+    __syncthreads();
     DBG_STAMP(3);
+    // winners in bin-grid row-major order, then one thread per new point
     const int per = (nb + VS_WG - 1) / VS_WG;
     const int k0 = tid * per, k1 = min(k0 + per, nb);
     int cnt = 0;
-    for (int k = k0; k < k1; ++k) cnt += bin_occ[k] >= 0 ? 1 : 0;
+    for (int k = k0; k < k1; ++k) cnt += occ[k] >= 0 ? 1 : 0;
     int total;
-    int off = n_tracked + block_exclusive_scan(cnt, sh.scan, &total);
-    for (int k = k0; k < k1; ++k) {
-      const int q = bin_occ[k];
-      if (q < 0) continue;
-      if (off < c.MAXP) materialize_point(c, b, s, cv, off, sc[4 * q], sc[4 * q + 1], sc[4 * q + 2], sc[4 * q + 3], -1, 0);
-      else atomicOr(&b.st[s].error_flags, 2);
-      ++off;
+    int off = block_exclusive_scan(cnt, sh.scan, &total);
+    for (int k = k0; k < k1; ++k) { const int q = occ[k]; if (q >= 0) emit_q[off++] = q; }
+    __syncthreads();
+    if (n_tracked + total > c.MAXP && tid == 0) atomicOr(&b.st[s].error_flags, 2);
+    for (int t = tid; t < total && n_tracked + t < c.MAXP; t += VS_WG) {
+      const int4 e = *reinterpret_cast<const int4*>(sc + 4 * emit_q[t]);
+      materialize_point(c, b, s, cv, n_tracked + t, e.x, e.y, e.z, e.w, -1, 0);
     }
     added = total;
   } else {
@@ -613,36 +677,21 @@ __device__ void wg_stereo(const DevCfg& c, const DevBuf& b, int s, FrameShared& 
   __syncthreads();
 }
 
-// fused path: L-R Hamming distances of the first epipolar pass for every left feature of every stream
-// (same bytes as the in-workgroup precompute of wg_stereo: position j = j-th right feature of the row)
+// L-R Hamming distances of the first epipolar pass for every left feature of every stream (image pipeline): the window
+// wg_stereo's step A reads.  One thread per left feature.
 __global__ __launch_bounds__(256) void k_stereo_dist(const DevCfg c, const DevBuf b) {
   const int s = b.s0 + blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int nL = b.n_kp[s * 2];
   if (i >= nL) return;
-  if (used_of(c, b, s, 0)[i]) return;
   const int16_t* kxyL = kpxy_of(c, b, s, 0);
   const int16_t* kxyR = kpxy_of(c, b, s, 1);
   const int rows = c.c.rows, CW1 = c.CW + 1, o = c.offsets[0];
   const int rr = kxyL[2 * i + 1] - o;
   if (rr < 0 || rr >= rows) return;
   const int32_t* rcR = rowcell_of(c, b, s, 1);
-  const int g0 = rcR[(size_t)rr * CW1], g1 = rcR[(size_t)rr * CW1 + c.CW];
-  const int xl = kxyL[2 * i];
-  int m = 0;
-  while (g0 + m < g1 && m < 16 && xl - kxyR[2 * (g0 + m)] >= 0) ++m;
-  if (m == 0) return;
-  const uint8_t* descL = desc_of(c, b, s, 0);
-  const uint8_t* descR = desc_of(c, b, s, 1);
-  const uint4 la = reinterpret_cast<const uint4*>(descL + (size_t)32 * i)[0], lb = reinterpret_cast<const uint4*>(descL + (size_t)32 * i)[1];
-  uint32_t pk[4] = {0, 0, 0, 0};
-  for (int j = 0; j < m; ++j) {
-    const uint4 ra = reinterpret_cast<const uint4*>(descR + (size_t)32 * (g0 + j))[0], rb = reinterpret_cast<const uint4*>(descR + (size_t)32 * (g0 + j))[1];
-    const int h = __popc(la.x ^ ra.x) + __popc(la.y ^ ra.y) + __popc(la.z ^ ra.z) + __popc(la.w ^ ra.w) +
-                  __popc(lb.x ^ rb.x) + __popc(lb.y ^ rb.y) + __popc(lb.z ^ rb.z) + __popc(lb.w ^ rb.w);
-    pk[j >> 2] |= (uint32_t)(h > 255 ? 255 : h) << (8 * (j & 3));
-  }
-  *reinterpret_cast<uint4*>(b.sdist + ((size_t)s * c.NMAX + i) * 16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+  stereo_dist_row(desc_of(c, b, s, 0), desc_of(c, b, s, 1), i, rcR[(size_t)rr * CW1], rcR[(size_t)rr * CW1 + c.CW], kxyL[2 * i],
+                  [&](int g) { return (int)kxyR[2 * g]; }, b.sdist + (size_t)s * c.NMAX * 16);
 }
 
 // ==============================================================================================
@@ -668,10 +717,9 @@ __device__ __forceinline__ double tau_tri_rule(const DevCfg& c, int status, int 
 //   [k_update_landmarks] landmark creation / refinement, one thread per framepoint; [k_stereo_dist] L-R distances
 //   phase 2  status switch, stereo sweep + binning + emission, report
 // phase < 0 runs everything in one launch (the wide steps inside the workgroup).
-__global__ __launch_bounds__(VS_WG) void k_frame(const DevCfg c, const DevBuf b, int phase) {
+__global__ VS_FRAME_BOUNDS void k_frame(const DevCfg c, const DevBuf b, int phase) {
   __shared__ FrameShared sh;
   __shared__ __align__(16) unsigned char arena[VS_ARENA];
-  __shared__ int wcnt[VS_WG / 64];
   const int s = b.s0 + blockIdx.x, tid = threadIdx.x;
   StreamState& st = b.st[s];
   vslam_frame_info& info = b.info[s];
@@ -719,13 +767,13 @@ __global__ __launch_bounds__(VS_WG) void k_frame(const DevCfg c, const DevBuf b,
         const unsigned long long tc = wall_clock64();
         // initialize(frame, false): fresh feature stores; candidates for the new prior / window / mode
         const int lane = tid & 63, w = tid >> 6;
-        for (int i = w; i < P; i += VS_WG / 64) candidates_wave(c, b, s, pb_prev, i, lane, &wcnt[w], prior, win, tau_gen);
+        for (int i = w; i < P; i += VS_WG / 64) candidates_wave(c, b, s, pb_prev, i, lane, &sh.cw[w], prior, win, tau_gen, by_app);
         __syncthreads();
         if (tid == 0) st.ticks[0] += wall_clock64() - tc;
       }
       aligner_valid = false;
       unsigned long long t0 = wall_clock64();
-      wg_track_resolve(c, b, s, sh, pb_prev, prior, win, tau_gen, tau_tri, by_app);
+      wg_track_resolve(c, b, s, sh, pb_prev, arena, win, tau_gen, tau_tri, by_app);
       if (tid == 0) st.ticks[0] += wall_clock64() - t0;
       const int n_trk = sh.n_trk;
       n_tracked_landmarks = sh.n_lm;
@@ -881,7 +929,7 @@ __global__ __launch_bounds__(VS_WG) void k_frame(const DevCfg c, const DevBuf b,
   if (n_active > c.c.minimum_number_of_landmarks_to_track) status = VSLAM_TRACKING;
   const double tau_tri2 = fc.tau_tri;
   const unsigned long long ts = wall_clock64();
-  wg_stereo(c, b, s, sh, pb_cur, tau_tri2, f, arena, VS_ARENA, phase >= 0 && c.n_offsets == 1);
+  wg_stereo(c, b, s, sh, pb_cur, tau_tri2, f, arena, VS_ARENA);
   if (tid == 0) {
     st.ticks[4] += wall_clock64() - ts;
     const double* c2w = hpose_of(c, b, s, f);
@@ -948,10 +996,8 @@ __global__ __launch_bounds__(VS_WG) void k_stage(const DevCfg c, const DevBuf b,
   __syncthreads();
   if (stage == VS_STAGE_TRACK) {
     if (!st.has_prev) return;
-    double T[12];
-    for (int k = 0; k < 12; ++k) T[k] = st.prior[k];
     const double tau = st.tau_track;
-    wg_track_resolve(c, b, s, sh, pb_prev, T, st.win, tau, st.tau_tri, arg);
+    wg_track_resolve(c, b, s, sh, pb_prev, arena, st.win, tau, st.tau_tri, arg);
     if (tid == 0) {
       st.n_trk = sh.n_trk; st.n_lost = sh.n_lost; st.n_tracked_landmarks = sh.n_lm; st.aligner_valid = 0; st.tau_gen = tau;
       st.al_n = 0; st.track_calls += 1;
@@ -987,7 +1033,7 @@ __global__ __launch_bounds__(VS_WG) void k_stage(const DevCfg c, const DevBuf b,
     wg_update_points(c, b, s, sh, pb_cur, f);
     if (tid == 0) { st.n_active = sh.n_lm; info.n_active_landmarks = sh.n_lm; }
   } else if (stage == VS_STAGE_STEREO) {
-    wg_stereo(c, b, s, sh, pb_cur, st.tau_tri, f, arena, VS_ARENA, false);
+    wg_stereo(c, b, s, sh, pb_cur, st.tau_tri, f, arena, VS_ARENA);
     if (tid == 0) {
       const double* c2w = hpose_of(c, b, s, f);
       *pts_of(c, b, s, pb_cur).n = sh.n_cur;

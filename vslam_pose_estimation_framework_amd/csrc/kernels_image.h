@@ -326,41 +326,19 @@ __device__ __forceinline__ unsigned long long col_mask(int lo, int hi, int wx0) 
   return hi_m & ~((1ull << a) - 1ull);
 }
 
-// exclusive scan inside each half of a 1024-thread block (threads 0-511 / 512-1023 scan independently);
-// sh must hold 18 ints, *total receives the sum of the caller's half
-__device__ __forceinline__ int half_block_exclusive_scan(int v, int* sh, int* total) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, half = w >> 3;
-  int inc = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += t;
-  }
-  __syncthreads();
-  if (lane == 63) sh[w] = inc;
-  __syncthreads();
-  if (threadIdx.x == 0 || threadIdx.x == 512) {
-    int acc = 0;
-    for (int i = half * 8; i < half * 8 + 8; ++i) { const int t = sh[i]; sh[i] = acc; acc += t; }
-    sh[16 + half] = acc;
-  }
-  __syncthreads();
-  *total = sh[16 + half];
-  return sh[w] + inc - v;
-}
-
 #define VS_EMIT_WPT 16   // mask words a thread keeps in registers (16 * 512 words = 524288 px per image; more -> reload)
-__global__ __launch_bounds__(1024) void k_emit(const DevCfg c, const DevBuf b, int border, int run_controller) {
+__global__ __launch_bounds__(512, 4) void k_emit(const DevCfg c, const DevBuf b, int border, int run_controller) {
   __shared__ int sh_scan[18];
-  __shared__ int sh_cnt[2][VSLAM_MAX_REGIONS];
+  __shared__ int sh_cnt[VSLAM_MAX_REGIONS];
+  __shared__ int sh_last;
   const int s = b.s0 + blockIdx.x, tid = threadIdx.x;
   const int rows = c.c.rows, cols = c.c.cols, TX = c.TX, CW = c.CW;
   StreamState& st = b.st[s];
-  if (tid < 2 * VSLAM_MAX_REGIONS) sh_cnt[tid / VSLAM_MAX_REGIONS][tid % VSLAM_MAX_REGIONS] = 0;
+  if (tid < VSLAM_MAX_REGIONS) sh_cnt[tid] = 0;
   __syncthreads();
   const int nwords = rows * TX;
-  // the two images are scanned concurrently: threads 0-511 own the left, 512-1023 the right image
-  const int side = tid >> 9, ht = tid & 511, lane = tid & 63;
+  // one 512-thread workgroup per image (blockIdx.y = side): at most 128 VGPRs, so it shares a CU with a frame workgroup
+  const int side = blockIdx.y, ht = tid, lane = tid & 63;
   const int chunk = (nwords + 511) / 512;
   const bool cached = chunk <= VS_EMIT_WPT;
   {
@@ -411,10 +389,10 @@ __global__ __launch_bounds__(1024) void k_emit(const DevCfg c, const DevBuf b, i
       }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
-      if (lane == 0 && n) atomicAdd(&sh_cnt[side][r], n);
+      if (lane == 0 && n) atomicAdd(&sh_cnt[r], n);
     }
     int total;
-    int off = half_block_exclusive_scan(local, sh_scan, &total);
+    int off = block_exclusive_scan(local, sh_scan, &total);
     if (total > c.NMAX) { if (ht == 0) atomicOr(&st.error_flags, 1); }
     // keypoints (x, row) in row-major order + the row/cell CSR: stores only
     auto emit_word = [&](unsigned long long m, int row, int t) {
@@ -465,9 +443,17 @@ __global__ __launch_bounds__(1024) void k_emit(const DevCfg c, const DevBuf b, i
     }
     __syncthreads();
   }
+  // the second of the stream's two workgroups to get here runs the controller on both images' counts
   if (tid == 0) {
-    for (int side = 0; side < 2; ++side)
-      for (int r = 0; r < c.n_regions; ++r) b.iinfo[s].raw_count[side][r] = sh_cnt[side][r];
+    for (int r = 0; r < c.n_regions; ++r) b.iinfo[s].raw_count[side][r] = sh_cnt[r];
+    __threadfence();
+    const int ticket = atomicAdd(&b.iinfo[s].ticket, 1);
+    sh_last = ticket == 1;
+    if (ticket == 1) { __threadfence(); b.iinfo[s].ticket = 0; }
+  }
+  __syncthreads();
+  if (tid == 0 && sh_last) {
+    const int (*cnt)[VSLAM_MAX_REGIONS] = b.iinfo[s].raw_count;
     if (run_controller) {
       // detectKeypoints controller (base_framepoint_generator.cpp:382-415) for L then R with the
       // thresholds that were in effect, then adjustDetectorThresholds (:440-459)
@@ -476,9 +462,9 @@ __global__ __launch_bounds__(1024) void k_emit(const DevCfg c, const DevBuf b, i
       const double target = (double)c.target_per_detector;
       for (int r = 0; r < c.n_regions; ++r) {
         double acc = 0;
-        for (int side = 0; side < 2; ++side) {
+        for (int sd = 0; sd < 2; ++sd) {
           double t = (double)st.thr[r];
-          const double delta = ((double)sh_cnt[side][r] - target) / target;
+          const double delta = ((double)__hip_atomic_load(&cnt[sd][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) / target;
           if (delta < -tol) {
             const double change = fmax(delta, -maxchg);
             t = t + fmin(change * t, -1.0);
@@ -519,7 +505,7 @@ __device__ __forceinline__ void brief_wave(const uint16_t* box, int bstride, int
 // the (128+48) x (32+48) u16 box region once in LDS with coalesced loads and evaluates the 256 tests from LDS,
 // one wavefront per keypoint.  Replaces 512 scattered 2-byte global gathers per keypoint.
 #define VS_BT_W 128
-#define VS_BT_H 32
+#define VS_BT_H 64
 #define VS_BT_RW (VS_BT_W + 2 * VSLAM_BRIEF_PATCH_HALF)   // 176
 #define VS_BT_RH (VS_BT_H + 2 * VSLAM_BRIEF_PATCH_HALF)   // 80
 __global__ __launch_bounds__(256) void k_brief(const DevCfg c, const DevBuf b) {

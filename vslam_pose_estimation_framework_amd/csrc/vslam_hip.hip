@@ -25,7 +25,7 @@ struct vslam_ctx {
   bool own_stream = false;
   // image products are double-buffered: frame t+1 is detected/described while frame t is tracked
   struct ImgSet { uint16_t* box; uint8_t* score8; unsigned long long* mask; int16_t* kp_xy; uint8_t* kp_score; uint8_t* desc;
-                  int32_t* n_kp; int32_t* rowcell; uint8_t* used; ImgInfo* iinfo; } sets[2];
+                  int32_t* n_kp; int32_t* rowcell; uint8_t* used; uint8_t* sdist; ImgInfo* iinfo; } sets[2];
   int parity = 0, last_set = 0;
   // streams are processed in G independent groups, each with its own pair of HIP streams: a slow stream only
   // delays its own group, the other groups' kernels fill the idle CUs
@@ -106,7 +106,7 @@ static DevBuf buf_set(const vslam_ctx* c, int set, int s0 = 0) {
   b.s0 = s0;
   const vslam_ctx::ImgSet& q = c->sets[set];
   b.box = q.box; b.score8 = q.score8; b.mask = q.mask; b.kp_xy = q.kp_xy; b.kp_score = q.kp_score; b.desc = q.desc;
-  b.n_kp = q.n_kp; b.rowcell = q.rowcell; b.used = q.used; b.iinfo = q.iinfo;
+  b.n_kp = q.n_kp; b.rowcell = q.rowcell; b.used = q.used; b.sdist = q.sdist; b.iinfo = q.iinfo;
   return b;
 }
 
@@ -224,7 +224,7 @@ static int create_internal(const vslam_config* cfg, int device, int n_streams, v
   if (cfg->det_rows < 1 || cfg->det_cols < 1 || cfg->det_rows * cfg->det_cols > VSLAM_MAX_REGIONS) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: invalid detector grid");
   if (!(-cfg->baseline_h[0] / cfg->K[0] > 0)) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: invalid baseline (m), verify intrinsic camera parameters");
   if (cfg->maximum_epipolar_search_offset_pixels < 0 || cfg->maximum_epipolar_search_offset_pixels > VSLAM_MAX_EPI) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: epipolar offset out of range");
-  if (cfg->max_keypoints < 64 || cfg->max_points < 64 || cfg->max_history_frames < 2 || cfg->bin_size_pixels < 1) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: invalid capacities");
+  if (cfg->max_keypoints < 64 || cfg->max_keypoints > 65535 || cfg->max_points < 64 || cfg->max_history_frames < 2 || cfg->bin_size_pixels < 1) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: invalid capacities");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, VSLAM_ERR_NO_DEVICE, "vslam_create: no HIP device available (the HIP path has no CPU fallback)");
   if (device < 0 || device >= ndev) return fail(nullptr, VSLAM_ERR_NO_DEVICE, "vslam_create: device ordinal out of range");
@@ -249,6 +249,8 @@ static int create_internal(const vslam_config* cfg, int device, int n_streams, v
                 hipStreamCreateWithFlags(&q.st_img2, hipStreamNonBlocking) == hipSuccess;
       // a second image stream (BRIEF(t) overlapping FAST(t+1)) measured slower on MI355X: opt-in only
       if (ok && !(getenv("VSLAM_IMG_STREAMS") && atoi(getenv("VSLAM_IMG_STREAMS")) == 2)) { (void)hipStreamDestroy(q.st_img2); q.st_img2 = q.st_img; }
+      // VSLAM_IMG_STREAMS=0: everything on one HIP stream (no overlap) — measurement aid for stand-alone kernel times
+      if (ok && getenv("VSLAM_IMG_STREAMS") && atoi(getenv("VSLAM_IMG_STREAMS")) == 0) { (void)hipStreamDestroy(q.st_img); q.st_img = q.st_img2 = q.st_frm; }
       for (int k = 0; k < 2 && ok; ++k)
         ok = hipEventCreateWithFlags(&q.ev_img[k], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&q.ev_frm[k], hipEventDisableTiming) == hipSuccess &&
@@ -275,16 +277,16 @@ static int create_internal(const vslam_config* cfg, int device, int n_streams, v
   A(st, B); A(info, B); A(pose_log, B * VS_POSE_LOG * 12);
   A(p_kp, S2 * P * 4); A(p_desc, S2 * P * 64); A(p_meta, S2 * P * META); A(p_cam, S2 * P * 3); A(p_camlm, S2 * P * 3);
   A(p_lm, S2 * P * 3); A(n_points, S2);
-  A(proj, B * P * 4); A(cand_cnt, B * P); A(cand_idx, B * P * VS_MAXCAND); A(cand_h, B * P * VS_MAXCAND);
-  A(res, B * P * 4); A(trk, B * P * 4); A(lost, B * P);
+  A(proj, B * P * 4); A(proj_q, B * P * 2); A(cand_key, B * P * VS_MAXCAND);
+  A(res, B * P * 8); A(trk, B * P * 4); A(lost, B * P);
   A(al_moving, B * P * 3); A(al_fixed, B * P * 4); A(al_omega, B * P); A(al_weight, B * P); A(al_chi, B * P); A(al_inl, B * P);
   A(rec, B * P * 6); A(rec_desc, B * P * 64);
-  A(st_match, B * N * 2); A(sc, B * N * 4); A(bin_occ, B * (size_t)d.rows_bin * d.cols_bin); A(sdist, B * N * 16); A(bin_aux, B * (2 * ((size_t)d.rows_bin * d.cols_bin + 1) + N));
+  A(st_match, B * N * 3); A(sc, B * N * 4); A(bin_occ, B * (size_t)d.rows_bin * d.cols_bin); A(sdist, B * N * 16); A(bin_aux, B * (2 * ((size_t)d.rows_bin * d.cols_bin + 1) + N));
   A(h_pose, B * Hc * 24); A(h_cam, B * Hc * P * 3); A(h_prev, B * Hc * P);
 #undef A
   for (int q = 0; q < 2 && e == hipSuccess; ++q) {
     vslam_ctx::ImgSet& t = c->sets[q];
-    if (q == 0) { t = {b.box, b.score8, b.mask, b.kp_xy, b.kp_score, b.desc, b.n_kp, b.rowcell, b.used, nullptr}; }
+    if (q == 0) { t = {b.box, b.score8, b.mask, b.kp_xy, b.kp_score, b.desc, b.n_kp, b.rowcell, b.used, b.sdist, nullptr}; }
     else {
       e = dalloc(c, &t.box, S2 * rows * d.bstride);
       if (e == hipSuccess) e = dalloc(c, &t.score8, S2 * rows * d.bstride);
@@ -295,6 +297,7 @@ static int create_internal(const vslam_config* cfg, int device, int n_streams, v
       if (e == hipSuccess) e = dalloc(c, &t.n_kp, S2);
       if (e == hipSuccess) e = dalloc(c, &t.rowcell, S2 * rows * (d.CW + 1));
       if (e == hipSuccess) e = dalloc(c, &t.used, S2 * N);
+      if (e == hipSuccess) e = dalloc(c, &t.sdist, B * N * 16);
     }
     if (e == hipSuccess) e = dalloc(c, &t.iinfo, B);
   }
@@ -333,7 +336,7 @@ VS_API void vslam_destroy(vslam_ctx* c) {
   for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
   for (auto& g : c->groups) {
     for (int q = 0; q < 2; ++q) { (void)hipEventDestroy(g.ev_img[q]); (void)hipEventDestroy(g.ev_frm[q]); (void)hipEventDestroy(g.ev_emit[q]); }
-    if (c->own_stream) { (void)hipStreamDestroy(g.st_frm); (void)hipStreamDestroy(g.st_img); if (g.st_img2 != g.st_img) (void)hipStreamDestroy(g.st_img2); }
+    if (c->own_stream) { if (g.st_img != g.st_frm) (void)hipStreamDestroy(g.st_img); if (g.st_img2 != g.st_img) (void)hipStreamDestroy(g.st_img2); (void)hipStreamDestroy(g.st_frm); }
   }
   delete c;
 }
@@ -347,7 +350,7 @@ VS_API int vslam_set_hip_stream(vslam_ctx* c, void* s) {
   sync_all(c);
   for (auto& g : c->groups) {
     for (int q = 0; q < 2; ++q) { (void)hipEventDestroy(g.ev_img[q]); (void)hipEventDestroy(g.ev_frm[q]); (void)hipEventDestroy(g.ev_emit[q]); }
-    if (c->own_stream) { (void)hipStreamDestroy(g.st_frm); (void)hipStreamDestroy(g.st_img); if (g.st_img2 != g.st_img) (void)hipStreamDestroy(g.st_img2); }
+    if (c->own_stream) { if (g.st_img != g.st_frm) (void)hipStreamDestroy(g.st_img); if (g.st_img2 != g.st_img) (void)hipStreamDestroy(g.st_img2); (void)hipStreamDestroy(g.st_frm); }
   }
   c->groups.clear();
   // one caller stream: a single group, image pipeline and tracker run back to back on it
@@ -381,10 +384,13 @@ static int launch_image_pipeline(vslam_ctx* c) {
     if (g.emit_pending[set ^ 1] && g.st_img != g.st_img2) HIP_TRY(c, hipStreamWaitEvent(st, g.ev_emit[set ^ 1], 0));
     dim3 g1(d.TX, (d.c.rows + VS_TILE_H - 1) / VS_TILE_H, 2 * g.n);
     { KernelTimer t(c, 0, st); hipLaunchKernelGGL(k_fast_box, g1, dim3(256), 0, st, c->cfg, bs); }
-    { KernelTimer t(c, 1, st); hipLaunchKernelGGL(k_emit, dim3(g.n), dim3(1024), 0, st, c->cfg, bs, (int)VSLAM_BRIEF_BORDER, 1); }
+    { KernelTimer t(c, 1, st); hipLaunchKernelGGL(k_emit, dim3(g.n, 2), dim3(512), 0, st, c->cfg, bs, (int)VSLAM_BRIEF_BORDER, 1); }
     if (g.st_img != g.st_img2) { HIP_TRY(c, hipEventRecord(g.ev_emit[set], st)); g.emit_pending[set] = true; }
     dim3 g3((d.c.cols + VS_BT_W - 1) / VS_BT_W, (d.c.rows + VS_BT_H - 1) / VS_BT_H, 2 * g.n);
     { KernelTimer t(c, 2, st); hipLaunchKernelGGL(k_brief, g3, dim3(256), 0, st, c->cfg, bs); }
+    // left-right descriptor distances of the first epipolar pass: a product of the images alone, so it is computed
+    // here, wide, instead of inside the per-stream frame workgroup
+    { KernelTimer t(c, 7, st); hipLaunchKernelGGL(k_stereo_dist, dim3((d.NMAX + 255) / 256, g.n), dim3(256), 0, st, c->cfg, bs); }
     HIP_TRY(c, hipGetLastError());
     if (st != g.st_frm) { HIP_TRY(c, hipEventRecord(g.ev_img[set], st)); HIP_TRY(c, hipStreamWaitEvent(g.st_frm, g.ev_img[set], 0)); }
   }
@@ -411,7 +417,6 @@ static int launch_frame(vslam_ctx* c) {
       if (c->cfg.c.enable_landmark_recovery) { KernelTimer t(c, 5, g.st_frm); hipLaunchKernelGGL(k_recover_brief, dim3(std::max(4, std::min(64, 1024 / std::max(g.n, 1))), g.n), dim3(256), 0, g.st_frm, c->cfg, bs); }
       { KernelTimer t(c, 4, g.st_frm, false); hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, c->cfg, bs, 1); }
       { KernelTimer t(c, 6, g.st_frm); hipLaunchKernelGGL(k_update_landmarks, dim3((c->cfg.MAXP + 255) / 256, g.n), dim3(256), 0, g.st_frm, c->cfg, bs); }
-      if (c->cfg.n_offsets == 1) { KernelTimer t(c, 7, g.st_frm); hipLaunchKernelGGL(k_stereo_dist, dim3((c->cfg.NMAX + 255) / 256, g.n), dim3(256), 0, g.st_frm, c->cfg, bs); }
       { KernelTimer t(c, 4, g.st_frm); hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, c->cfg, bs, 2); }
     }
   }
@@ -621,7 +626,7 @@ VS_API int vslam_fast_detect(vslam_ctx* c, const uint8_t* img, int32_t rows, int
   if (rc == VSLAM_OK) {
     dim3 g1(t->cfg.TX, (rows + VS_TILE_H - 1) / VS_TILE_H, 2);
     hipLaunchKernelGGL(k_fast_box, g1, dim3(256), 0, t->stream_img, t->cfg, t->buf);
-    hipLaunchKernelGGL(k_emit, dim3(1), dim3(1024), 0, t->stream_img, t->cfg, t->buf, 0, 0);
+    hipLaunchKernelGGL(k_emit, dim3(1, 2), dim3(512), 0, t->stream_img, t->cfg, t->buf, 0, 0);
     int32_t cnt = 0;
     rc = vslam_get_keypoints(t, 0, 0, cap, &cnt, xy, score, nullptr);
     *n = cnt;
@@ -793,5 +798,17 @@ VS_API int vslam_debug_ticks(vslam_ctx* c, double us[12]) {
   std::vector<StreamState> st(c->B);
   HIP_TRY(c, hipMemcpy(st.data(), c->buf.st, sizeof(StreamState) * c->B, hipMemcpyDeviceToHost));
   for (int k = 0; k < 12; ++k) { double a = 0; for (int s = 0; s < c->B; ++s) a += (double)st[s].dbg[k]; us[k] = a * 1e-2 / c->B; }
+  return VSLAM_OK;
+}
+// profiling aid (not part of the ABI): per stream, the 5 chronometer tick counters followed by the 12 phase stamps
+// (cumulative, 100 MHz ticks)
+VS_API int vslam_debug_stream_ticks(vslam_ctx* c, unsigned long long* out /* [B][17] */) {
+  if (!c || !out) return VSLAM_ERR_INVALID;
+  std::vector<StreamState> st(c->B);
+  HIP_TRY(c, hipMemcpy(st.data(), c->buf.st, sizeof(StreamState) * c->B, hipMemcpyDeviceToHost));
+  for (int s = 0; s < c->B; ++s) {
+    for (int k = 0; k < 5; ++k) out[17 * s + k] = st[s].ticks[k];
+    for (int k = 0; k < 12; ++k) out[17 * s + 5 + k] = st[s].dbg[k];
+  }
   return VSLAM_OK;
 }
