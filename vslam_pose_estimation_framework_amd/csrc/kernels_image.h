@@ -180,6 +180,7 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
   __shared__ __align__(8) uint16_t hs[VS_TILE_H + 8][VS_TILE_W];
   __shared__ int32_t s_thr[VSLAM_MAX_REGIONS];
   __shared__ uint16_t queue[(VS_TILE_H + 2) * 66];
+  __shared__ unsigned long long lmask[VS_TILE_H];
   __shared__ int qn;
   int tx, ty, tz;
   xcd_tile(&tx, &ty, &tz);
@@ -191,6 +192,9 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (tid < c.n_regions) s_thr[tid] = min(max(b.st[s].thr[tid], 0), 255);
   if (tid == 0) qn = 0;
+  if (tid < VS_TILE_H) lmask[tid] = 0ull;
+  // scores of non-candidates are zero: clear the whole score tile with dword stores, candidates overwrite theirs
+  for (int i = tid; i < (VS_TILE_H + 2) * 17; i += 256) reinterpret_cast<uint32_t*>(&sc[0][0])[i] = 0u;
   // ---- stage the (64+8) x (H+8) u8 tile.  Interior tiles: aligned dwords, all of a thread's loads in flight before
   // the first LDS store; tiles touching the left/right image border: clamped bytes. ------------------------------------
   const bool aligned = ((stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(img) & 3) == 0);
@@ -250,7 +254,6 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
       base = __builtin_amdgcn_readfirstlane(base);
       if (cand) queue[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)((r << 8) | cc);
     }
-    if (!cand) sc[r][cc] = 0;
   };
   for (int r = w; r < VS_TILE_H + 2; r += 4) pretest(r, lane);
   // the two halo columns 64, 65 of every row: (H+2)*2 pixels, waves 0-1
@@ -283,32 +286,47 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
     }
   }
   __syncthreads();
-  // ---- strict 3x3 NMS -> 1 bit / pixel, sparse scores, vertical 9-sums (sliding) -> u16 box image ----------------------
+  // ---- strict 3x3 NMS, candidate-driven: only scored pixels look at their 8 neighbours; survivors set their bit in the
+  // LDS row masks and write their (sparse) score ---------------------------------------------------------------------
   unsigned long long* mask = mask_of(c, b, s, side);
   uint8_t* score8 = score_of(c, b, s, side);
   uint16_t* box = box_of(c, b, s, side);
-  const int gx = x0 + lane;
-  int acc = 0;
-  constexpr int RW = VS_TILE_H / 4;   // output rows per wave
-#pragma unroll
-  for (int k = 0; k < 9; ++k) acc += hs[w * RW + k][lane];
-#pragma unroll
-  for (int j = 0; j < RW; ++j) {
-    const int r = w * RW + j, gy = y0 + r;
-    const int v = sc[r + 1][lane + 1];
-    bool keep = v > 0;
-    if (keep) {
-      keep = v > sc[r][lane] && v > sc[r][lane + 1] && v > sc[r][lane + 2] && v > sc[r + 1][lane] &&
-             v > sc[r + 1][lane + 2] && v > sc[r + 2][lane] && v > sc[r + 2][lane + 1] && v > sc[r + 2][lane + 2];
+  {
+    const int nq = qn;
+    for (int q = tid; q < nq; q += 256) {
+      const int e0 = queue[q];
+      const int r = e0 >> 8, cc = e0 & 255;
+      if (r < 1 || r > VS_TILE_H || cc < 1 || cc > 64) continue;      // halo pixels only serve as neighbours
+      const int v = sc[r][cc];
+      if (v == 0) continue;
+      const bool keep = v > sc[r - 1][cc - 1] && v > sc[r - 1][cc] && v > sc[r - 1][cc + 1] && v > sc[r][cc - 1] &&
+                        v > sc[r][cc + 1] && v > sc[r + 1][cc - 1] && v > sc[r + 1][cc] && v > sc[r + 1][cc + 1];
+      if (keep) {
+        atomicOr(&lmask[r - 1], 1ull << (cc - 1));
+        const int gy = y0 + r - 1;
+        if (gy < rows) score8[(size_t)gy * c.bstride + (x0 + cc - 1)] = (uint8_t)v;
+      }
     }
-    const unsigned long long m = __ballot(keep);
-    if (gy < rows) {
-      if (lane == 0) mask[(size_t)gy * c.TX + tx] = m;
-      if (keep) score8[(size_t)gy * c.bstride + gx] = (uint8_t)v;
-      if (gx < cols) box[(size_t)gy * c.bstride + gx] = (uint16_t)acc;
-    }
-    if (j < RW - 1) acc += (int)hs[r + 9][lane] - (int)hs[r][lane];
   }
+  // ---- vertical 9-sums (sliding), two pixels per lane in packed u16 -> u16 box image: lanes 0-31 own the upper half of
+  // the wave's rows, lanes 32-63 the lower half --------------------------------------------------------------------------
+  {
+    constexpr int RW = VS_TILE_H / 8;   // output rows per half-wave
+    const int half = lane >> 5, px = 2 * (lane & 31);
+    const int rbase = (w * 2 + half) * RW;
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    u16x2 acc = {0, 0};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc += *reinterpret_cast<const u16x2*>(&hs[rbase + k][px]);
+#pragma unroll
+    for (int j = 0; j < RW; ++j) {
+      const int r = rbase + j, gy = y0 + r;
+      if (gy < rows && x0 + px < c.bstride) *reinterpret_cast<u16x2*>(box + (size_t)gy * c.bstride + x0 + px) = acc;
+      if (j < RW - 1) acc += *reinterpret_cast<const u16x2*>(&hs[r + 9][px]) - *reinterpret_cast<const u16x2*>(&hs[r][px]);
+    }
+  }
+  __syncthreads();
+  if (tid < VS_TILE_H && y0 + tid < rows) mask[(size_t)(y0 + tid) * c.TX + tx] = lmask[tid];
 }
 
 // ==============================================================================================
