@@ -76,8 +76,10 @@ __device__ __forceinline__ bool project_prev(const DevCfg& c, const double* T, c
 //                (primary << 16 | feature index): primary = Hamming distance (appearance mode) or squared pixel distance
 //                (projection mode, < 10000 only).  Features are stored row-major, so ordering by index is the reference's
 //                (row, col) tie-break and the first key whose feature is still present IS the reference's match.
-// One wavefront per point: lanes split the window rows; the row/cell CSR bounds each row to the 16-px cells the window
-// overlaps; a rank sort through LDS orders the (at most 16) keys.
+// One group of 16 lanes per point (four points per wavefront: in Tracking state the window is ~21 rows): the lanes split
+// the window rows; the row/cell CSR bounds each row to the 16-px cells the window overlaps; a rank sort through LDS
+// orders the (at most 16) keys.  `lane` is the lane inside the group, `cw` the group's LDS slot.
+#define VS_CGL 16
 struct CandWave { int cnt; uint32_t keys[VS_MAXCAND]; };
 
 __device__ __forceinline__ void candidates_wave(const DevCfg& c, const DevBuf& b, int s, int pb_prev, int i, int lane, CandWave* cw,
@@ -103,7 +105,7 @@ __device__ __forceinline__ void candidates_wave(const DevCfg& c, const DevBuf& b
   const uint8_t* desc = desc_of(c, b, s, 0);
   if (c1 > c0) {
     const int cl = c0 >> 4, ch = ((c1 - 1) >> 4) + 1;
-    for (int r = r0 + lane; r < r1; r += 64) {
+    for (int r = r0 + lane; r < r1; r += VS_CGL) {
       const int lo = rowcell[(size_t)r * (c.CW + 1) + cl], hi = rowcell[(size_t)r * (c.CW + 1) + ch];
       for (int k = lo; k < hi; ++k) {
         const int x = kxy[2 * k];
@@ -139,12 +141,12 @@ __device__ __forceinline__ void candidates_wave(const DevCfg& c, const DevBuf& b
 __global__ __launch_bounds__(256) void k_track_candidates(const DevCfg c, const DevBuf b, int mode) {
   // mode < 0: fused path (appearance iff the tracker is Localizing, window forced to max in that case);
   // mode 0/1: stage path, window and distance exactly as set through vslam_set_tracker_state
-  __shared__ CandWave cw[4];
+  __shared__ CandWave cw[256 / VS_CGL];
   const int s = b.s0 + blockIdx.y;
   const StreamState& st = b.st[s];
   if (!st.has_prev) return;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int wave = blockIdx.x * 4 + w, nwaves = gridDim.x * 4;
+  const int lane = threadIdx.x % VS_CGL, w = threadIdx.x / VS_CGL;
+  const int wave = blockIdx.x * (256 / VS_CGL) + w, nwaves = gridDim.x * (256 / VS_CGL);
   const int pb_prev = st.cur;  // the previous frame's points: buffer that was current last frame
   const int P = b.n_points[s * 2 + pb_prev];
   const int by_app = mode < 0 ? (st.status == VSLAM_LOCALIZING) : mode;
@@ -170,7 +172,7 @@ struct FrameShared {
   int inl, outl, its, conv;
   double red4[VS_WG / 64][4][32];
   unsigned long long key;
-  CandWave cw[VS_WG / 64];
+  CandWave cw[VS_WG / VS_CGL];
 };
 
 __device__ __forceinline__ unsigned long long key3(unsigned a, int row, int col) {
