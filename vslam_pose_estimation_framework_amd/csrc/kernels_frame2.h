@@ -766,8 +766,8 @@ __global__ VS_FRAME_BOUNDS void k_frame(const DevCfg c, const DevBuf b, int phas
       if (attempt > 0) {
         const unsigned long long tc = wall_clock64();
         // initialize(frame, false): fresh feature stores; candidates for the new prior / window / mode
-        const int lane = tid & 63, w = tid >> 6;
-        for (int i = w; i < P; i += VS_WG / 64) candidates_wave(c, b, s, pb_prev, i, lane, &sh.cw[w], prior, win, tau_gen, by_app);
+        const int lane = tid % VS_CGL, w = tid / VS_CGL;
+        for (int i = w; i < P; i += VS_WG / VS_CGL) candidates_wave(c, b, s, pb_prev, i, lane, &sh.cw[w], prior, win, tau_gen, by_app);
         __syncthreads();
         if (tid == 0) st.ticks[0] += wall_clock64() - tc;
       }
