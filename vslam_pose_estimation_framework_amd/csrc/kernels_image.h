@@ -255,11 +255,59 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
       if (cand) queue[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)((r << 8) | cc);
     }
   };
-  for (int r = w; r < VS_TILE_H + 2; r += 4) pretest(r, lane);
-  // the two halo columns 64, 65 of every row: (H+2)*2 pixels, waves 0-1
-  if (tid < 128) {
-    const int i = tid;
-    if (i < (VS_TILE_H + 2) * 2) pretest(i >> 1, 64 + (i & 1));
+  if (uni_thr != -2) {
+    // uniform threshold (the usual tile): four pixels per lane from aligned dwords, the compass differences in packed
+    // i16 (v_perm_b32 unpacks, v_pk_sub/min/max_i16), one queue reservation per wave-pass
+    const s16x2 thr2 = {(short)uni_thr, (short)uni_thr};
+    constexpr int NT = (VS_TILE_H + 2) * 18;
+    for (int t0 = 0; t0 < NT; t0 += 256) {
+      const int t = t0 + tid;
+      unsigned bits4 = 0;
+      int r = 0, q = 0;
+      if (t < NT) {
+        r = t / 18; q = t - 18 * r;
+        const uint32_t* rowp = reinterpret_cast<const uint32_t*>(&tile[r + 3][0]);
+        const uint32_t C = rowp[q], C0 = q > 0 ? rowp[q - 1] : 0u, C2 = rowp[q + 1];
+        const uint32_t N = reinterpret_cast<const uint32_t*>(&tile[r][0])[q], S = reinterpret_cast<const uint32_t*>(&tile[r + 6][0])[q];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const uint32_t sel = half ? 0x0c030c02u : 0x0c010c00u;
+          const uint32_t vv = __builtin_amdgcn_perm(0u, C, sel), nn = __builtin_amdgcn_perm(0u, N, sel), ss = __builtin_amdgcn_perm(0u, S, sel);
+          const uint32_t ee = __builtin_amdgcn_perm(C2, C, half ? 0x0c060c05u : 0x0c040c03u);
+          const uint32_t ww = __builtin_amdgcn_perm(C, C0, half ? 0x0c040c03u : 0x0c020c01u);
+          const s16x2 v = __builtin_bit_cast(s16x2, vv);
+          const s16x2 d0 = v - __builtin_bit_cast(s16x2, ss), d8 = v - __builtin_bit_cast(s16x2, nn);
+          const s16x2 d4 = v - __builtin_bit_cast(s16x2, ee), d12 = v - __builtin_bit_cast(s16x2, ww);
+          const s16x2 dk = pk_min(pk_max(d0, d8), pk_max(d4, d12));
+          const s16x2 br = pk_max(pk_min(d0, d8), pk_min(d4, d12));
+          // dk > thr  <=>  thr - dk < 0 ;  br < -thr  <=>  br + thr < 0   (|values| <= 510: no i16 overflow)
+          const uint32_t neg = (__builtin_bit_cast(uint32_t, thr2 - dk) | __builtin_bit_cast(uint32_t, br + thr2)) & 0x80008000u;
+          bits4 |= (((neg >> 15) & 1u) | ((neg >> 30) & 2u)) << (2 * half);
+        }
+        if (q == 0) bits4 &= 8u;     // region columns -3..0: only column 0 exists
+        if (q == 17) bits4 &= 1u;    // region columns 65..68: only column 65 exists
+      }
+      const unsigned long long m0 = __ballot(bits4 & 1u), m1 = __ballot(bits4 & 2u), m2 = __ballot(bits4 & 4u), m3 = __ballot(bits4 & 8u);
+      const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
+      if (n0 + n1 + n2 + n3) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&qn, n0 + n1 + n2 + n3);
+        base = __builtin_amdgcn_readfirstlane(base);
+        const int cc0 = 4 * q - 3, e = r << 8;
+        auto below = [&](unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
+        if (bits4 & 1u) queue[base + below(m0)] = (uint16_t)(e | cc0);
+        if (bits4 & 2u) queue[base + n0 + below(m1)] = (uint16_t)(e | (cc0 + 1));
+        if (bits4 & 4u) queue[base + n0 + n1 + below(m2)] = (uint16_t)(e | (cc0 + 2));
+        if (bits4 & 8u) queue[base + n0 + n1 + n2 + below(m3)] = (uint16_t)(e | (cc0 + 3));
+      }
+    }
+  } else {
+    for (int r = w; r < VS_TILE_H + 2; r += 4) pretest(r, lane);
+    // the two halo columns 64, 65 of every row: (H+2)*2 pixels, waves 0-1
+    if (tid < 128) {
+      const int i = tid;
+      if (i < (VS_TILE_H + 2) * 2) pretest(i >> 1, 64 + (i & 1));
+    }
   }
   // ---- horizontal 9-sums, four outputs per thread from three aligned dwords -----------------------------------------
   for (int i = tid; i < (VS_TILE_H + 8) * 16; i += 256) {
