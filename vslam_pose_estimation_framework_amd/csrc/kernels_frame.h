@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void k_track_candidates(const DevCfg c, const 
 struct FrameShared {
   int scan[17];
   int flag;
-  int n_trk, n_lost, n_lm, n_cur, n_cand;
+  int n_trk, n_lost, n_lm, n_cur, n_cand, n_proj;
   int status, win, attempts, broken, fallback, aligner_ran;
   double tau_track;
   double T[12];          // aligner estimate

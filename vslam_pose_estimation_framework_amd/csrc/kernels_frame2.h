@@ -72,7 +72,10 @@ __device__ __forceinline__ void wg_prune(const DevCfg& c, const DevBuf& b, int s
 //             the wide kernel k_recover_brief over all streams (fused path).
 //   append  : survivors are appended in lost-list order (:844-864)
 // rec[6q] : 0 = rejected, 2 = projected (needs BRIEF), 1 = recovered; then xL, yL, xR, yR, Hamming L-R
-__device__ __forceinline__ void wg_recover_project(const DevCfg& c, const DevBuf& b, int s, int n_lost, int pb_prev, const double* w2c) {
+// `list` (LDS, optional): compact work list of the projected points for the in-workgroup BRIEF step — 6 ints per entry
+// (q, previous point, xL, yL, xR, yR), count in *n_list — so that step does not chase rec[] through HBM point by point.
+__device__ __forceinline__ void wg_recover_project(const DevCfg& c, const DevBuf& b, int s, int n_lost, int pb_prev, const double* w2c,
+                                                   int32_t* list = nullptr, int list_cap = 0, int* n_list = nullptr) {
   const PtView pv = pts_of(c, b, s, pb_prev);
   const int32_t* lost = b.lost + (size_t)s * c.MAXP;
   int32_t* rec = b.rec + (size_t)s * c.MAXP * 6;
@@ -97,6 +100,10 @@ __device__ __forceinline__ void wg_recover_project(const DevCfg& c, const DevBuf
       }
     }
     rec[6 * q] = ok; rec[6 * q + 1] = xL; rec[6 * q + 2] = yL; rec[6 * q + 3] = xR; rec[6 * q + 4] = yR; rec[6 * q + 5] = 0;
+    if (ok && list) {
+      const int k = atomicAdd(n_list, 1);
+      if (k < list_cap) { int32_t* e = list + 6 * k; e[0] = q; e[1] = ip; e[2] = xL; e[3] = yL; e[4] = xR; e[5] = yR; }
+    }
   }
 }
 
@@ -145,6 +152,98 @@ __device__ __forceinline__ void recover_brief_wave(const DevCfg& c, const DevBuf
   }
 }
 
+// Same computation with the two 49 x 49 box patches staged in LDS by coalesced 16-byte row loads (7 lanes per row):
+// the 1024 scattered 2-byte gathers per point of recover_brief_wave keep the CU's texture-address unit busy for ~1000
+// cycles; 12 wide loads take a fraction of that.  `patch` = this wavefront's LDS area, VS_RPATCH bytes.
+#define VS_RP_W 56
+#define VS_RP_H (2 * VSLAM_BRIEF_PATCH_HALF + 1)
+#define VS_RPATCH (2 * VS_RP_H * VS_RP_W * 2)
+__device__ __forceinline__ void recover_brief_patch(const DevCfg& c, const DevBuf& b, int s, int pb_prev, int q, int ip, int xL, int yL,
+                                                    int xR, int yR, int lane, double tau_track, double tau_tri, uint16_t* patch) {
+  int32_t* rec = b.rec + (size_t)s * c.MAXP * 6;
+  const PtView pv = pts_of(c, b, s, pb_prev);
+  const int xy[2][2] = {{xL, yL}, {xR, yR}};
+  constexpr int NLD = (VS_RP_H * 7 + 63) / 64;   // 6
+  uint4 v[2][NLD];
+  int cx[2];
+#pragma unroll
+  for (int sd = 0; sd < 2; ++sd) {
+    const int col0 = (xy[sd][0] - VSLAM_BRIEF_PATCH_HALF) & ~7;   // 16-byte aligned; the patch ends at col0 + 55 at most
+    cx[sd] = xy[sd][0] - col0;
+    const uint16_t* base = box_of(c, b, s, sd) + (size_t)(xy[sd][1] - VSLAM_BRIEF_PATCH_HALF) * c.bstride + col0;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int t = lane + 64 * u, row = t / 7, seg = t - 7 * row;
+      v[sd][u] = make_uint4(0u, 0u, 0u, 0u);
+      if (row < VS_RP_H) v[sd][u] = *reinterpret_cast<const uint4*>(base + (size_t)row * c.bstride + 8 * seg);
+    }
+  }
+  unsigned long long pd[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) pd[j] = reinterpret_cast<const unsigned long long*>(pv.desc + (size_t)64 * ip)[j];
+#pragma unroll
+  for (int sd = 0; sd < 2; ++sd)
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int t = lane + 64 * u, row = t / 7, seg = t - 7 * row;
+      if (row < VS_RP_H) *reinterpret_cast<uint4*>(patch + (sd * VS_RP_H + row) * VS_RP_W + 8 * seg) = v[sd][u];
+    }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  unsigned long long dL[4], dR[4];
+  int hL = 0, hR = 0, dist = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = j * 64 + lane;
+    const int oa = (VSLAM_BRIEF_PATCH_HALF + c_brief[i][0]) * VS_RP_W + c_brief[i][1], ob = (VSLAM_BRIEF_PATCH_HALF + c_brief[i][2]) * VS_RP_W + c_brief[i][3];
+    const uint16_t* pl = patch + cx[0];
+    const uint16_t* pr = patch + VS_RP_H * VS_RP_W + cx[1];
+    dL[j] = __builtin_bswap64(__brevll(__ballot(pl[oa] < pl[ob])));
+    dR[j] = __builtin_bswap64(__brevll(__ballot(pr[oa] < pr[ob])));
+    hL += __popcll(dL[j] ^ pd[j]);
+    hR += __popcll(dR[j] ^ pd[4 + j]);
+    dist += __popcll(dL[j] ^ dR[j]);
+  }
+  __builtin_amdgcn_wave_barrier();
+  int ok = 1;
+  if ((double)hL > tau_track) ok = 0;
+  if (ok && (double)((float)xy[0][0] - (float)xy[1][0]) < c.c.minimum_disparity_pixels) ok = 0;
+  if (ok && (double)hR > tau_track) ok = 0;
+  if (ok && (double)dist > tau_tri) ok = 0;
+  if (lane == 0) {
+    rec[6 * q] = ok; rec[6 * q + 5] = dist;
+    if (ok) {
+      unsigned long long* dl = reinterpret_cast<unsigned long long*>(b.rec_desc + ((size_t)s * c.MAXP + q) * 64);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { dl[j] = dL[j]; dl[4 + j] = dR[j]; }
+    }
+  }
+}
+
+// in-workgroup BRIEF step: the LDS work list first, then (list overflow only) the remaining points through rec[]
+#define VS_RLIST_OFF ((VS_WG / 64) * VS_RPATCH)
+#define VS_RLIST_CAP ((VS_ARENA - VS_RLIST_OFF) / 24)
+__device__ __forceinline__ void wg_recover_brief(const DevCfg& c, const DevBuf& b, int s, int pb_prev, int n_lost, int n_list,
+                                                 double tau_track, double tau_tri, unsigned char* arena) {
+  static_assert(VS_RLIST_OFF + 24 * 64 <= VS_ARENA, "recovery patches + work list must fit the LDS arena");
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint16_t* patch = reinterpret_cast<uint16_t*>(arena + (size_t)w * VS_RPATCH);
+  const int32_t* list = reinterpret_cast<const int32_t*>(arena + VS_RLIST_OFF);
+  if (n_list <= VS_RLIST_CAP) {
+    for (int k = w; k < n_list; k += VS_WG / 64) {
+      const int32_t* e = list + 6 * k;
+      recover_brief_patch(c, b, s, pb_prev, e[0], e[1], e[2], e[3], e[4], e[5], lane, tau_track, tau_tri, patch);
+    }
+  } else {
+    const int32_t* rec = b.rec + (size_t)s * c.MAXP * 6;
+    const int32_t* lost = b.lost + (size_t)s * c.MAXP;
+    for (int q = w; q < n_lost; q += VS_WG / 64) {
+      if (rec[6 * q] != 2) continue;   // wave-uniform
+      recover_brief_patch(c, b, s, pb_prev, q, lost[q], rec[6 * q + 1], rec[6 * q + 2], rec[6 * q + 3], rec[6 * q + 4], lane, tau_track, tau_tri, patch);
+    }
+  }
+}
+
 __device__ __forceinline__ void wg_recover_append(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_prev, int pb_cur) {
   const int tid = threadIdx.x;
   const PtView pv = pts_of(c, b, s, pb_prev);
@@ -186,11 +285,12 @@ __device__ __forceinline__ void wg_recover_append(const DevCfg& c, const DevBuf&
 
 // whole recovery inside one workgroup (stage path)
 __device__ __forceinline__ void wg_recover(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_prev, int pb_cur, const double* w2c,
-                           double tau_track, double tau_tri) {
-  wg_recover_project(c, b, s, sh.n_lost, pb_prev, w2c);
+                           double tau_track, double tau_tri, unsigned char* arena) {
+  if (threadIdx.x == 0) sh.n_proj = 0;
   __syncthreads();
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int q = w; q < sh.n_lost; q += VS_WG / 64) recover_brief_wave(c, b, s, pb_prev, q, lane, tau_track, tau_tri);
+  wg_recover_project(c, b, s, sh.n_lost, pb_prev, w2c, reinterpret_cast<int32_t*>(arena + VS_RLIST_OFF), VS_RLIST_CAP, &sh.n_proj);
+  __syncthreads();
+  wg_recover_brief(c, b, s, pb_prev, sh.n_lost, sh.n_proj, tau_track, tau_tri, arena);
   __syncthreads();
   wg_recover_append(c, b, s, sh, pb_prev, pb_cur);
 }
@@ -732,7 +832,7 @@ __global__ VS_FRAME_BOUNDS void k_frame(const DevCfg c, const DevBuf b, int phas
   if (phase <= 0) {   // ======================================= phase 0 =======================================
   if (tid == 0) {
     sh.status = status0; sh.win = st.win; sh.tau_track = st.tau_track; sh.attempts = 0; sh.broken = 0; sh.fallback = 0;
-    sh.aligner_ran = 0; sh.n_trk = 0; sh.n_lost = 0; sh.n_lm = 0; sh.n_cur = 0; sh.n_cand = 0; sh.its = 0; sh.conv = 0;
+    sh.aligner_ran = 0; sh.n_trk = 0; sh.n_lost = 0; sh.n_lm = 0; sh.n_cur = 0; sh.n_cand = 0; sh.its = 0; sh.conv = 0; sh.n_proj = 0;
     sh.inl = 0; sh.outl = 0; sh.E = 0; sh.flag = 0;
     for (int k = 0; k < 12; ++k) sh.T[k] = 0;
     for (int k = 0; k < 36; ++k) sh.H[k] = 0;
@@ -875,7 +975,10 @@ __global__ VS_FRAME_BOUNDS void k_frame(const DevCfg c, const DevBuf b, int phas
     wg_prune(c, b, s, sh, pb_prev, pb_cur, aligner_valid);
     if (tid == 0) st.dbg[6] += wall_clock64() - tP;
     n_after_prune = sh.n_cur;
-    if (c.c.enable_landmark_recovery) wg_recover_project(c, b, s, sh.n_lost, pb_prev, hpose_of(c, b, s, f) + 12);
+    if (c.c.enable_landmark_recovery) {
+      if (phase < 0) wg_recover_project(c, b, s, sh.n_lost, pb_prev, hpose_of(c, b, s, f) + 12, reinterpret_cast<int32_t*>(arena + VS_RLIST_OFF), VS_RLIST_CAP, &sh.n_proj);
+      else wg_recover_project(c, b, s, sh.n_lost, pb_prev, hpose_of(c, b, s, f) + 12);
+    }
   } else if (tid == 0) {
     info.n_tracked = 0; info.n_lost = 0; info.n_tracked_landmarks = 0; info.aligner_ran = 0; info.aligner_iterations = 0;
     info.aligner_converged = 0; info.n_inliers = 0; info.n_outliers = 0; info.total_error = 0; st.al_n = 0;
@@ -898,8 +1001,7 @@ __global__ VS_FRAME_BOUNDS void k_frame(const DevCfg c, const DevBuf b, int phas
     if (has_prev && c.c.enable_landmark_recovery) {
       const unsigned long long tr = wall_clock64();
       if (phase < 0) {
-        const int lane = tid & 63, w = tid >> 6;
-        for (int q = w; q < sh.n_lost; q += VS_WG / 64) recover_brief_wave(c, b, s, pb_prev, q, lane, fc.tau_gen, fc.tau_tri);
+        wg_recover_brief(c, b, s, pb_prev, sh.n_lost, sh.n_proj, fc.tau_gen, fc.tau_tri, arena);
         __syncthreads();
       }
       wg_recover_append(c, b, s, sh, pb_prev, pb_cur);
@@ -1024,7 +1126,7 @@ __global__ __launch_bounds__(VS_WG) void k_stage(const DevCfg c, const DevBuf b,
     wg_prune(c, b, s, sh, pb_prev, pb_cur, st.aligner_valid != 0);
     const int n_after = sh.n_cur;
     int n_rec = 0;
-    if (arg) { wg_recover(c, b, s, sh, pb_prev, pb_cur, hpose_of(c, b, s, f) + 12, st.tau_gen, st.tau_tri); n_rec = sh.flag; }
+    if (arg) { wg_recover(c, b, s, sh, pb_prev, pb_cur, hpose_of(c, b, s, f) + 12, st.tau_gen, st.tau_tri, arena); n_rec = sh.flag; }
     if (tid == 0) {
       st.n_cur = sh.n_cur; st.n_after_prune = n_after; st.n_recovered = n_rec;
       info.n_after_prune = n_after; info.n_recovered = n_rec; info.n_points = sh.n_cur;
