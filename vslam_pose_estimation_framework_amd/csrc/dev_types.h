@@ -127,7 +127,9 @@ struct DevBuf {
   double* p_lm;        // [..][3]
   int32_t* n_points;   // [B][2]
   // track candidates / resolution  [B][MAXP]
-  int32_t* proj;       // [..][4] row, col, candidate count (-1 = projection outside the image), |epipolar offset|
+  int32_t* proj;       // [..][8] row, col, candidate count (-1 = projection outside the image), |epipolar offset|,
+                       //         right-candidate count of the first left candidate (-1 dead, 9 overflow), its x, -, -
+  uint32_t* cand_rkey; // [..][8] sorted (reject << 31 | distance << 16 | right feature index)
   double* proj_q;      // [..][2] right-image projection u/w, v/w of the previous point under the prior
   uint32_t* cand_key;  // [..][VS_MAXCAND] sorted (primary << 16 | left feature index)
   int32_t* res;        // [..][8] fl, fr, dist, flag (bit0 success, bit1 lost-eligible), x of fl, row of fr, pad

@@ -69,37 +69,61 @@ __device__ __forceinline__ bool project_prev(const DevCfg& c, const double* T, c
   return true;
 }
 
+// triangulation-distance rule of initialize() (stereo_framepoint_generator.cpp:109-125); frame status = tracker status
+__device__ __forceinline__ double tau_tri_rule(const DevCfg& c, int status, int n_left) {
+  if (status == VSLAM_LOCALIZING) return fmin(0.1 * 256, c.c.maximum_matching_distance_triangulation);
+  const double ratio = fmin((double)n_left / (double)c.target_kp, 1.0);
+  return fmax(ratio * c.c.maximum_matching_distance_triangulation, 0.1 * 256);
+}
+
 // Per previous point i the wide candidate kernel leaves everything of track() that depends only on the motion prior:
-//   proj[i]    = {row, col, n_candidates (-1: projection outside the image), |epipolar offset|}
+//   proj[i]    = {row, col, n_candidates (-1: projection outside the image), |epipolar offset|,
+//                 n_right (see below), x of the first left candidate, -, -}
 //   proj_q[i]  = right-image projection (u/w, v/w) before the left-match correction (:541-556)
 //   cand_key[i][0..15] = the left features inside the search window below the descriptor distance, as sorted keys
 //                (primary << 16 | feature index): primary = Hamming distance (appearance mode) or squared pixel distance
 //                (projection mode, < 10000 only).  Features are stored row-major, so ordering by index is the reference's
 //                (row, col) tie-break and the first key whose feature is still present IS the reference's match.
+//   cand_rkey[i][0..7] = for the FIRST left candidate (the match unless an earlier point removed it): the right features
+//                its search (:541-590) can return, sorted by (distance, index) — the first one still present is the
+//                reference's pick — as (reject << 31 | distance << 16 | index); reject = the pair fails the disparity or
+//                the previous-right-descriptor gate (:597-608), i.e. the point is neither tracked nor lost.
+//                n_right = -1: the right projection leaves the image (never tracked, never lost); 9 = more than 8.
 // One group of 16 lanes per point (four points per wavefront: in Tracking state the window is ~21 rows): the lanes split
 // the window rows; the row/cell CSR bounds each row to the 16-px cells the window overlaps; a rank sort through LDS
 // orders the (at most 16) keys.  `lane` is the lane inside the group, `cw` the group's LDS slot.
 #define VS_CGL 16
-struct CandWave { int cnt; uint32_t keys[VS_MAXCAND]; };
+#define VS_MAXRCAND 8
+struct CandWave {
+  int cnt, rcnt;
+  uint32_t keys[VS_MAXCAND];
+  uint32_t rkeys[VS_MAXRCAND];
+  int32_t kxy[VS_MAXCAND];          // x | y << 16 and descriptor of every left candidate: the right search of the first
+  uint32_t kdesc[VS_MAXCAND][8];    // one starts from LDS instead of two more HBM round trips
+};
 
 __device__ __forceinline__ void candidates_wave(const DevCfg& c, const DevBuf& b, int s, int pb_prev, int i, int lane, CandWave* cw,
-                                const double* T, int d, double tau, int by_app) {
+                                const double* T, int d, double tau, double tau_tri, int by_app) {
   const PtView pv = pts_of(c, b, s, pb_prev);
   const size_t gi = (size_t)s * c.MAXP + i;
   double uvw[3];
   int row, col;
   const bool ok = project_prev(c, T, pv.cam + 3 * (size_t)i, uvw, &row, &col);
-  if (lane == 0) cw->cnt = 0;
+  if (lane == 0) { cw->cnt = 0; cw->rcnt = 0; }
   if (!ok) {
-    if (lane == 0) { b.proj[gi * 4 + 0] = row; b.proj[gi * 4 + 1] = col; b.proj[gi * 4 + 2] = -1; b.proj[gi * 4 + 3] = 0; }
+    if (lane == 0) *reinterpret_cast<int4*>(b.proj + gi * 8) = make_int4(row, col, -1, 0);
     return;
   }
   const int rows = c.c.rows, cols = c.c.cols;
   const int r0 = max(row - d, 0), r1 = min(row + d + 1, rows);
   const int c0 = max(col - d, 0), c1 = min(col + d + 1, cols);
-  uint32_t pd[8];
+  const int kk = (int)fabs((double)pv.meta[(size_t)i * META + M_EPI]);
+  uint32_t pd[8], prd[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) pd[k] = reinterpret_cast<const uint32_t*>(pv.desc + (size_t)64 * i)[k];
+  for (int k = 0; k < 8; ++k) {
+    pd[k] = reinterpret_cast<const uint32_t*>(pv.desc + (size_t)64 * i)[k];
+    prd[k] = reinterpret_cast<const uint32_t*>(pv.desc + (size_t)64 * i + 32)[k];
+  }
   const int32_t* rowcell = rowcell_of(c, b, s, 0);
   const int16_t* kxy = kpxy_of(c, b, s, 0);
   const uint8_t* desc = desc_of(c, b, s, 0);
@@ -108,32 +132,99 @@ __device__ __forceinline__ void candidates_wave(const DevCfg& c, const DevBuf& b
     for (int r = r0 + lane; r < r1; r += VS_CGL) {
       const int lo = rowcell[(size_t)r * (c.CW + 1) + cl], hi = rowcell[(size_t)r * (c.CW + 1) + ch];
       for (int k = lo; k < hi; ++k) {
-        const int x = kxy[2 * k];
+        // coordinates and descriptor in flight together (the descriptor of a feature outside the column range is wasted)
+        const int32_t xy = *reinterpret_cast<const int32_t*>(kxy + 2 * k);
+        uint32_t kd[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) kd[u] = reinterpret_cast<const uint32_t*>(desc + (size_t)32 * k)[u];
+        const int x = (int16_t)(xy & 0xFFFF);
         if (x < c0 || x >= c1) continue;
-        const int h = hamming32(pd, reinterpret_cast<const uint32_t*>(desc + (size_t)32 * k));
+        const int h = hamming32(pd, kd);
         if (!((double)h < tau)) continue;
         unsigned prim;
         if (by_app) prim = (unsigned)h;
         else { const int dr = row - r, dc = col - x; prim = (unsigned)(dr * dr + dc * dc); if (prim >= 10000u) continue; }
         const int slot = atomicAdd(&cw->cnt, 1);
-        if (slot < VS_MAXCAND) cw->keys[slot] = (prim << 16) | (unsigned)k;
+        if (slot < VS_MAXCAND) {
+          cw->keys[slot] = (prim << 16) | (unsigned)k;
+          cw->kxy[slot] = xy;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) cw->kdesc[slot][u] = kd[u];
+        }
       }
     }
   }
   __builtin_amdgcn_wave_barrier();
   const int cnt = __hip_atomic_load(&cw->cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  if (cnt <= VS_MAXCAND && lane < cnt) {
-    const uint32_t mine = __hip_atomic_load(&cw->keys[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    int rank = 0;
-    for (int j = 0; j < cnt; ++j) rank += __hip_atomic_load(&cw->keys[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < mine ? 1 : 0;
-    b.cand_key[gi * VS_MAXCAND + rank] = mine;
+  uint32_t first = 0xFFFFFFFFu;   // smallest key == first left candidate
+  int first_slot = 0;
+  if (cnt <= VS_MAXCAND) {
+    for (int j = 0; j < cnt; ++j) {
+      const uint32_t kj = __hip_atomic_load(&cw->keys[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (kj < first) { first = kj; first_slot = j; }
+    }
+    if (lane < cnt) {
+      const uint32_t mine = __hip_atomic_load(&cw->keys[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      int rank = 0;
+      for (int j = 0; j < cnt; ++j) rank += __hip_atomic_load(&cw->keys[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < mine ? 1 : 0;
+      b.cand_key[gi * VS_MAXCAND + rank] = mine;
+    }
+  }
+  double uR[3];
+  for (int k = 0; k < 3; ++k) uR[k] = uvw[k] + c.c.baseline_h[k];
+  const double qx = uR[0] / uR[2], qy = uR[1] / uR[2];
+  // ---- right candidates of the first left candidate -------------------------------------------------------------------
+  int n_right = 9, flx = 0;
+  if (cnt >= 1 && cnt <= VS_MAXCAND) {
+    const int fxy = __hip_atomic_load(&cw->kxy[first_slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    flx = (int16_t)(fxy & 0xFFFF);
+    const int fly = fxy >> 16;
+    const float ex = (float)col - (float)flx, ey = (float)row - (float)fly;
+    int colR, rowR;
+    if (!to_int32(qx - ex, &colR) || !to_int32(qy - ey, &rowR) || colR < 0 || colR > cols || rowR < 0 || rowR > rows) {
+      n_right = -1;
+    } else {
+      const int rr0 = max(rowR - kk, 0), rr1 = min(rowR + kk + 1, rows);
+      const int rc0 = max(colR - d, 0), rc1 = min(colR + d + 1, flx);
+      if (rc1 > rc0) {
+        uint32_t ld[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ld[k] = __hip_atomic_load(&cw->kdesc[first_slot][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int32_t* rowcellR = rowcell_of(c, b, s, 1);
+        const int16_t* kxyR = kpxy_of(c, b, s, 1);
+        const uint8_t* descR = desc_of(c, b, s, 1);
+        for (int r = rr0 + lane; r < rr1; r += VS_CGL) {
+          const int lo = rowcellR[(size_t)r * (c.CW + 1) + (rc0 >> 4)], hi = rowcellR[(size_t)r * (c.CW + 1) + ((rc1 - 1) >> 4) + 1];
+          for (int g = lo; g < hi; ++g) {
+            const int gx = kxyR[2 * g];
+            uint32_t gd[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) gd[k] = reinterpret_cast<const uint32_t*>(descR + (size_t)32 * g)[k];
+            if (gx < rc0 || gx >= rc1) continue;
+            const int h = hamming32(ld, gd);
+            if (!((double)h < tau_tri)) continue;
+            const bool rej = ((double)(flx - gx) < c.c.minimum_disparity_pixels) || ((double)hamming32(gd, prd) > tau);
+            const int slot = atomicAdd(&cw->rcnt, 1);
+            if (slot < VS_MAXRCAND) cw->rkeys[slot] = (rej ? 0x80000000u : 0u) | ((unsigned)h << 16) | (unsigned)g;
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int rc = __hip_atomic_load(&cw->rcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      n_right = min(rc, 9);
+      if (rc <= VS_MAXRCAND && lane < rc) {
+        const uint32_t mine = __hip_atomic_load(&cw->rkeys[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        int rank = 0;
+        for (int j = 0; j < rc; ++j)
+          rank += (__hip_atomic_load(&cw->rkeys[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & 0x7FFFFFFFu) < (mine & 0x7FFFFFFFu) ? 1 : 0;
+        b.cand_rkey[gi * VS_MAXRCAND + rank] = mine;
+      }
+    }
   }
   if (lane == 0) {
-    double uR[3];
-    for (int k = 0; k < 3; ++k) uR[k] = uvw[k] + c.c.baseline_h[k];
-    b.proj[gi * 4 + 0] = row; b.proj[gi * 4 + 1] = col; b.proj[gi * 4 + 2] = cnt;
-    b.proj[gi * 4 + 3] = (int)fabs((double)pv.meta[(size_t)i * META + M_EPI]);
-    b.proj_q[gi * 2] = uR[0] / uR[2]; b.proj_q[gi * 2 + 1] = uR[1] / uR[2];
+    *reinterpret_cast<int4*>(b.proj + gi * 8) = make_int4(row, col, cnt, kk);
+    *reinterpret_cast<int4*>(b.proj + gi * 8 + 4) = make_int4(n_right, flx, 0, 0);
+    b.proj_q[gi * 2] = qx; b.proj_q[gi * 2 + 1] = qy;
   }
   __builtin_amdgcn_wave_barrier();
 }
@@ -153,7 +244,8 @@ __global__ __launch_bounds__(256) void k_track_candidates(const DevCfg c, const 
   const int d = (mode < 0 && by_app) ? c.c.maximum_projection_tracking_distance_pixels : st.win;
   double T[12];
   for (int k = 0; k < 12; ++k) T[k] = st.prior[k];
-  for (int i = wave; i < P; i += nwaves) candidates_wave(c, b, s, pb_prev, i, lane, &cw[w], T, d, st.tau_track, by_app);
+  const double tau_tri = mode < 0 ? tau_tri_rule(c, st.status, b.n_kp[s * 2]) : st.tau_tri;
+  for (int i = wave; i < P; i += nwaves) candidates_wave(c, b, s, pb_prev, i, lane, &cw[w], T, d, st.tau_track, tau_tri, by_app);
 }
 
 // ==============================================================================================
@@ -172,7 +264,6 @@ struct FrameShared {
   int inl, outl, its, conv;
   double red4[VS_WG / 64][4][32];
   unsigned long long key;
-  CandWave cw[VS_WG / VS_CGL];
 };
 
 __device__ __forceinline__ unsigned long long key3(unsigned a, int row, int col) {
@@ -195,7 +286,11 @@ __device__ __forceinline__ void evaluate_point(const DevCfg& c, const DevBuf& b,
   const size_t gi = (size_t)s * c.MAXP + i;
   out[0] = -1; out[1] = -1; out[2] = 0; out[3] = 0; out[4] = 0; out[5] = 0;
   // everything whose address is known up front, in flight together
-  const int4 pr = *reinterpret_cast<const int4*>(b.proj + gi * 4);
+  const int4 pr = *reinterpret_cast<const int4*>(b.proj + gi * 8);
+  const int4 pr2 = *reinterpret_cast<const int4*>(b.proj + gi * 8 + 4);
+  uint4 rv[VS_MAXRCAND / 4];
+#pragma unroll
+  for (int k = 0; k < VS_MAXRCAND / 4; ++k) rv[k] = reinterpret_cast<const uint4*>(b.cand_rkey + gi * VS_MAXRCAND)[k];
   const double2 q = *reinterpret_cast<const double2*>(b.proj_q + gi * 2);
   uint4 kv[VS_MAXCAND / 4];
 #pragma unroll
@@ -245,6 +340,20 @@ __device__ __forceinline__ void evaluate_point(const DevCfg& c, const DevBuf& b,
       }
   }
   if (fl < 0) { out[3] = 2; return; }  // no left match: lost-eligible
+  // ---- right search, usual case: the first left candidate survived and its right candidates are tabulated -------------
+  if (cnt <= VS_MAXCAND && fl == (int)(reinterpret_cast<const uint32_t*>(kv)[0] & 0xFFFFu) && pr2.x <= VS_MAXRCAND) {
+    if (pr2.x < 0) return;                       // right projection outside the image: continue (:553-556)
+    const uint32_t* rk = reinterpret_cast<const uint32_t*>(rv);
+    uint32_t pick = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < VS_MAXRCAND; ++k)
+      if (pick == 0xFFFFFFFFu && k < pr2.x && ld_kill(tt.killR + (rk[k] & 0xFFFFu)) >= i) pick = rk[k];
+    if (pick == 0xFFFFFFFFu) { out[3] = 2; return; }   // no right match: lost-eligible
+    if (pick & 0x80000000u) return;                      // disparity / previous-right-descriptor gate: continue
+    const int fr = (int)(pick & 0xFFFFu);
+    out[0] = fl; out[1] = fr; out[2] = (int)((pick >> 16) & 0x7FFFu); out[3] = 1; out[4] = pr2.y; out[5] = tt.xyR[2 * fr + 1];
+    return;
+  }
   // ---- right search (:541-590) --------------------------------------------------------------
   const int fxy = *reinterpret_cast<const int32_t*>(kxyL + 2 * fl);
   uint32_t ld[8];

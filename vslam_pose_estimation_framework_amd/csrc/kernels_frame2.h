@@ -803,12 +803,6 @@ __device__ __forceinline__ void set_pose(const DevCfg& c, const DevBuf& b, int s
   tf_inverse(c2w, hp + 12);
 }
 
-// triangulation-distance rule of initialize() (stereo_framepoint_generator.cpp:109-125); frame status = tracker status
-__device__ __forceinline__ double tau_tri_rule(const DevCfg& c, int status, int n_left) {
-  if (status == VSLAM_LOCALIZING) return fmin(0.1 * 256, c.c.maximum_matching_distance_triangulation);
-  const double ratio = fmin((double)n_left / (double)c.target_kp, 1.0);
-  return fmax(ratio * c.c.maximum_matching_distance_triangulation, 0.1 * 256);
-}
 
 // The frame is processed by three phase launches of this kernel with wide kernels in between (fused path):
 //   phase 0  track resolution, registration (aligner, recursion, fallback / break), prune, recovery projection
@@ -867,7 +861,7 @@ __global__ VS_FRAME_BOUNDS void k_frame(const DevCfg c, const DevBuf b, int phas
         const unsigned long long tc = wall_clock64();
         // initialize(frame, false): fresh feature stores; candidates for the new prior / window / mode
         const int lane = tid % VS_CGL, w = tid / VS_CGL;
-        for (int i = w; i < P; i += VS_WG / VS_CGL) candidates_wave(c, b, s, pb_prev, i, lane, &sh.cw[w], prior, win, tau_gen, by_app);
+        for (int i = w; i < P; i += VS_WG / VS_CGL) candidates_wave(c, b, s, pb_prev, i, lane, reinterpret_cast<CandWave*>(arena) + w, prior, win, tau_gen, tau_tri, by_app);
         __syncthreads();
         if (tid == 0) st.ticks[0] += wall_clock64() - tc;
       }
