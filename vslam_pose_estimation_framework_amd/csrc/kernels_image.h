@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
       const int r = i / 18, q = i - r * 18;
       const int gy = min(max(y0 - 4 + r, 0), rows - 1);
       v[u] = 0;
-      if (i < (VS_TILE_H + 8) * 18) v[u] = *reinterpret_cast<const uint32_t*>(img + (size_t)gy * stride + (x0 - 4 + 4 * q));
+      if (i < (VS_TILE_H + 8) * 18) v[u] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(img + (size_t)gy * stride + (x0 - 4 + 4 * q)));
     }
 #pragma unroll
     for (int u = 0; u < NST; ++u) {
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
 #pragma unroll
     for (int j = 0; j < RW; ++j) {
       const int r = rbase + j, gy = y0 + r;
-      if (gy < rows && x0 + px < c.bstride) *reinterpret_cast<u16x2*>(box + (size_t)gy * c.bstride + x0 + px) = acc;
+      if (gy < rows && x0 + px < c.bstride) __builtin_nontemporal_store(__builtin_bit_cast(uint32_t, acc), reinterpret_cast<uint32_t*>(box + (size_t)gy * c.bstride + x0 + px));
       if (j < RW - 1) acc += *reinterpret_cast<const u16x2*>(&hs[r + 9][px]) - *reinterpret_cast<const u16x2*>(&hs[r][px]);
     }
   }
@@ -392,9 +392,9 @@ __device__ __forceinline__ unsigned long long col_mask(int lo, int hi, int wx0) 
   return hi_m & ~((1ull << a) - 1ull);
 }
 
-#define VS_EMIT_WPT 16   // mask words a thread keeps in registers (16 * 512 words = 524288 px per image; more -> reload)
+#define VS_EMIT_WPT 8    // mask words a thread keeps in registers per pass (one pass = 512 * 8 words = 262144 px)
 __global__ __launch_bounds__(512, 4) void k_emit(const DevCfg c, const DevBuf b, int border, int run_controller) {
-  __shared__ int sh_scan[18];
+  __shared__ int sh_wave[8], sh_total;
   __shared__ int sh_cnt[VSLAM_MAX_REGIONS];
   __shared__ int sh_last;
   const int s = b.s0 + blockIdx.x, tid = threadIdx.x;
@@ -403,10 +403,11 @@ __global__ __launch_bounds__(512, 4) void k_emit(const DevCfg c, const DevBuf b,
   if (tid < VSLAM_MAX_REGIONS) sh_cnt[tid] = 0;
   __syncthreads();
   const int nwords = rows * TX;
-  // one 512-thread workgroup per image (blockIdx.y = side): at most 128 VGPRs, so it shares a CU with a frame workgroup
-  const int side = blockIdx.y, ht = tid, lane = tid & 63;
-  const int chunk = (nwords + 511) / 512;
-  const bool cached = chunk <= VS_EMIT_WPT;
+  // one 512-thread workgroup per image (blockIdx.y = side).
+  // Word order = keypoint order.  A pass covers 4096 consecutive mask words: wave w owns words [512 w, 512 w + 512)
+  // of the pass, lane l its words l, l + 64, ... — every load and store of a wave covers consecutive words (coalesced),
+  // and the prefix over the words is 8 wave scans + one 8-entry scan across waves.
+  const int side = blockIdx.y, lane = tid & 63, w = tid >> 6;
   {
     const unsigned long long* mask = mask_of(c, b, s, side);
     const uint8_t* score8 = score_of(c, b, s, side);
@@ -414,87 +415,88 @@ __global__ __launch_bounds__(512, 4) void k_emit(const DevCfg c, const DevBuf b,
     uint8_t* ksc = kpscore_of(c, b, s, side);
     int32_t* rowcell = rowcell_of(c, b, s, side);
     uint8_t* used = used_of(c, b, s, side);
-    const int w0 = min(ht * chunk, nwords), w1 = min(w0 + chunk, nwords);
-    // all mask words of the thread in flight at once (the scan is otherwise a chain of dependent L2 round trips)
-    unsigned long long mw[VS_EMIT_WPT];
-#pragma unroll
-    for (int j = 0; j < VS_EMIT_WPT; ++j) mw[j] = (cached && w0 + j < w1) ? mask[w0 + j] : 0ull;
-    const int row0 = w0 / TX, t0 = w0 - row0 * TX;
     auto filtered = [&](unsigned long long m, int row, int t) -> unsigned long long {
       const bool row_ok = row >= border && row < rows - border;
       return row_ok ? (m & col_mask(border, cols - border, t * 64)) : 0ull;
     };
-    int local = 0;
-    if (cached) {
-      int row = row0, t = t0;
+    int done = 0;   // keypoints of earlier passes
+    const int q64 = 64 / TX, r64 = 64 - q64 * TX;   // (row, word-in-row) of word + 64 without a division
+    for (int p0 = 0; p0 < nwords; p0 += 512 * VS_EMIT_WPT) {
+      const int wbase = p0 + w * 64 * VS_EMIT_WPT + lane;
+      const int row_b = wbase / TX, t_b = wbase - row_b * TX;
+      unsigned long long mw[VS_EMIT_WPT];
 #pragma unroll
-      for (int j = 0; j < VS_EMIT_WPT; ++j) {
-        local += __popcll(filtered(mw[j], row, t));
-        if (++t == TX) { t = 0; ++row; }
-      }
-    } else {
-      for (int w = w0; w < w1; ++w) { const int row = w / TX; local += __popcll(filtered(mask[w], row, w - row * TX)); }
-    }
-    // raw detections per region (controller input): every corner bit lies in exactly one region; one LDS atomic
-    // per wavefront and region
-    for (int r = 0; r < c.n_regions; ++r) {
-      const DevRegion& R = c.regions[r];
-      int n = 0;
-      if (cached) {
-        int row = row0, t = t0;
+      for (int j = 0; j < VS_EMIT_WPT; ++j) mw[j] = (wbase + 64 * j < nwords) ? mask[wbase + 64 * j] : 0ull;
+      // raw detections per region (controller input): every corner bit lies in exactly one region
+      for (int r = 0; r < c.n_regions; ++r) {
+        const DevRegion& R = c.regions[r];
+        int n = 0, row = row_b, t = t_b;
 #pragma unroll
         for (int j = 0; j < VS_EMIT_WPT; ++j) {
           if (row >= R.y + 3 && row < R.y + R.h - 3) n += __popcll(mw[j] & col_mask(R.x + 3, R.x + R.w - 3, t * 64));
-          if (++t == TX) { t = 0; ++row; }
+          t += r64; row += q64; if (t >= TX) { t -= TX; ++row; }
         }
-      } else {
-        for (int w = w0; w < w1; ++w) {
-          const int row = w / TX;
-          if (row >= R.y + 3 && row < R.y + R.h - 3) n += __popcll(mask[w] & col_mask(R.x + 3, R.x + R.w - 3, (w - row * TX) * 64));
-        }
-      }
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
-      if (lane == 0 && n) atomicAdd(&sh_cnt[r], n);
-    }
-    int total;
-    int off = block_exclusive_scan(local, sh_scan, &total);
-    if (total > c.NMAX) { if (ht == 0) atomicOr(&st.error_flags, 1); }
-    // keypoints (x, row) in row-major order + the row/cell CSR: stores only
-    auto emit_word = [&](unsigned long long m, int row, int t) {
-      unsigned long long f = filtered(m, row, t);
-      int32_t* rc = rowcell + (size_t)row * (CW + 1) + t * 4;
-      rc[0] = min(off, c.NMAX);
-      rc[1] = min(off + __popcll(f & 0xFFFFull), c.NMAX);
-      rc[2] = min(off + __popcll(f & 0xFFFFFFFFull), c.NMAX);
-      rc[3] = min(off + __popcll(f & 0xFFFFFFFFFFFFull), c.NMAX);
-      if (t == TX - 1) rc[4] = min(off + __popcll(f), c.NMAX);
-      while (f) {
-        const int bit = __ffsll((long long)f) - 1;
-        f &= f - 1;
-        if (off < c.NMAX) {
-          kxy[2 * off] = (int16_t)(t * 64 + bit);
-          kxy[2 * off + 1] = (int16_t)row;
-          used[off] = 0;
-        }
-        ++off;
+        for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+        if (lane == 0 && n) atomicAdd(&sh_cnt[r], n);
       }
-    };
-    if (cached) {
-      int row = row0, t = t0;
+      // exclusive prefix of the filtered counts in word order
+      int ex[VS_EMIT_WPT];
+      int carry = 0;
+      int row = row_b, t = t_b;
 #pragma unroll
       for (int j = 0; j < VS_EMIT_WPT; ++j) {
-        if (w0 + j < w1) emit_word(mw[j], row, t);
-        if (++t == TX) { t = 0; ++row; }
+        const int wd = wbase + 64 * j;
+        mw[j] = wd < nwords ? filtered(mw[j], row, t) : 0ull;   // from here on only the border-filtered bits matter
+        t += r64; row += q64; if (t >= TX) { t -= TX; ++row; }
+        const int cnt = __popcll(mw[j]);
+        int inc = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(inc, o, 64); if (lane >= o) inc += up; }
+        ex[j] = carry + inc - cnt;
+        carry += __shfl(inc, 63, 64);
       }
-    } else {
-      for (int w = w0; w < w1; ++w) { const int row = w / TX; emit_word(mask[w], row, w - row * TX); }
+      __syncthreads();   // sh_wave / sh_total of the previous pass are consumed
+      if (lane == 0) sh_wave[w] = carry;
+      __syncthreads();
+      if (tid == 0) { int acc = 0; for (int i = 0; i < 8; ++i) { const int v = sh_wave[i]; sh_wave[i] = acc; acc += v; } sh_total = acc; }
+      __syncthreads();
+      const int wave_off = done + sh_wave[w];
+      // keypoints (x, row) in row-major order + the row/cell CSR: stores only, consecutive lanes -> consecutive addresses
+      row = row_b; t = t_b;
+#pragma unroll
+      for (int j = 0; j < VS_EMIT_WPT; ++j) {
+        const int wd = wbase + 64 * j;
+        if (wd < nwords) {
+          unsigned long long f = mw[j];
+          int off = wave_off + ex[j];
+          int32_t* rc = rowcell + (size_t)row * (CW + 1) + t * 4;
+          rc[0] = min(off, c.NMAX);
+          rc[1] = min(off + __popcll(f & 0xFFFFull), c.NMAX);
+          rc[2] = min(off + __popcll(f & 0xFFFFFFFFull), c.NMAX);
+          rc[3] = min(off + __popcll(f & 0xFFFFFFFFFFFFull), c.NMAX);
+          if (t == TX - 1) rc[4] = min(off + __popcll(f), c.NMAX);
+          while (f) {
+            const int bit = __ffsll((long long)f) - 1;
+            f &= f - 1;
+            if (off < c.NMAX) {
+              *reinterpret_cast<int32_t*>(kxy + 2 * off) = (t * 64 + bit) | (row << 16);
+              used[off] = 0;
+            }
+            ++off;
+          }
+        }
+        t += r64; row += q64; if (t >= TX) { t -= TX; ++row; }
+      }
+      done += sh_total;
     }
-    if (ht == 0) b.n_kp[s * 2 + side] = min(total, c.NMAX);
+    const int total = done;
+    if (total > c.NMAX) { if (tid == 0) atomicOr(&st.error_flags, 1); }
+    if (tid == 0) b.n_kp[s * 2 + side] = min(total, c.NMAX);
     __syncthreads();   // the workgroup's keypoint stores are visible to its own loads below
     // scores: one keypoint per thread, four gathers in flight
     const int nk = min(total, c.NMAX);
-    for (int i0 = ht; i0 < nk; i0 += 4 * 512) {
+    for (int i0 = tid; i0 < nk; i0 += 4 * 512) {
       int px[4];
       uint8_t v[4];
 #pragma unroll
