@@ -1,4 +1,5 @@
-"""Per-stream, per-step phase durations of k_frame (in-kernel clocks): where the slowest stream of a step spends
+"""Per-stream, per-step phase durations of k_frame (in-kernel clocks; build the library with
+`make -C vslam_pose_estimation_framework_amd/csrc clean all EXTRA=-DVS_PROFILE_PHASES` first): where the slowest stream of a step spends
 its time.  Usage: python tools/dbg_tail.py [B] [K]"""
 import sys, os, ctypes as C
 sys.path.insert(0, os.getcwd())
@@ -40,4 +41,5 @@ print("mean of per-step max total:", round(float(d[:, :, 13].max(axis=1).mean())
 print("track: jacobi iterations/frame (x100 ticks->count)", round(float(d[:, :, 12].mean()) * 100, 2), "iterate us", round(float(d[:, :, 14].mean()), 1), "flags+compaction us", round(float(d[:, :, 15].mean()), 1))
 print("stereo cumulative: after sub/prepass", round(float(d[:, :, 10].mean()), 1), "after step A", round(float(d[:, :, 6].mean()), 1))
 print("stereo staging us", round(float(d[:, :, 16].mean()), 1))
+print("aligner per frame (us): compute+reduce+sync %.1f, gather %.1f, solve %.1f, update+sync %.1f" % tuple(float(d[:, :, 5 + k].mean()) for k in (5, 9, 10, 11)))
 print("prune (dbg6)", round(float(d[:, :, 11].mean()), 1), "stereo stamps dbg0-4:", [round(float(d[:, :, 5 + i].mean()), 1) for i in range(5)])

@@ -1,0 +1,28 @@
+#!/bin/bash
+# HBM traffic per kernel launch from rocprofv3 PMC counters (separate passes, kernel-trace only — see
+# /opt/skills/guides/MI355X_MICROARCH.md).  Run on the GPU box from the repo root:  bash tools/pmc_traffic.sh <tag>
+set -e
+TAG=${1:-run}
+OUT=$PWD/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -- python3 bench.py --no-cpu --steps 8 > $OUT/$C.log 2>&1
+done
+python3 - "$OUT" << 'PY'
+import csv, glob, json, sys, collections
+out = sys.argv[1]
+res = collections.defaultdict(dict)
+for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+    files = glob.glob(out + "/" + cname + "/*/*counter_collection.csv")
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != cname: continue
+            k = r["Kernel_Name"].split("(")[0]
+            acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
+    for k, (v, n) in acc.items():
+        if k.startswith("k_") and not k.startswith("k_synth"): res[k][cname] = round(v / n, 1)
+json.dump({"per_launch_KB": res}, open(out + "/summary.json", "w"), indent=1)
+print(json.dumps(res, indent=1))
+PY

@@ -17,6 +17,18 @@
 #include "kernels_image.h"
 #include "dev_math.h"
 
+// Fine-grained phase clocks of the frame kernel (tools/dbg_tail.py): compiled in only with -DVS_PROFILE_PHASES, every
+// stamp is a global read-modify-write by thread 0 and costs about a microsecond.
+#ifdef VS_PROFILE_PHASES
+#define VS_PHASE_BEGIN(var) unsigned long long var = wall_clock64()
+#define VS_PHASE_STAMP(k, var) do { if (threadIdx.x == 0) { const unsigned long long tn_ = wall_clock64(); b.st[s].dbg[k] += tn_ - var; var = tn_; } } while (0)
+#define VS_PHASE_COUNT(k) do { if (threadIdx.x == 0) b.st[s].dbg[k] += 1; } while (0)
+#else
+#define VS_PHASE_BEGIN(var) do { } while (0)
+#define VS_PHASE_STAMP(k, var) do { } while (0)
+#define VS_PHASE_COUNT(k) do { } while (0)
+#endif
+
 #define META 6
 #define M_DIST 0
 #define M_EPI 1
@@ -426,9 +438,8 @@ __device__ __forceinline__ void wg_track_resolve(const DevCfg& c, const DevBuf& 
   int32_t* res = b.res + (size_t)s * c.MAXP * 8;
   for (int i = tid; i < P; i += VS_WG) { res[8 * i] = -1; res[8 * i + 1] = -1; res[8 * i + 2] = 0; res[8 * i + 3] = 0; }
   __syncthreads();
-  unsigned long long tq = wall_clock64();
   for (int iter = 0; iter <= P + 1; ++iter) {
-    if (tid == 0) b.st[s].dbg[7] += 1;
+    VS_PHASE_COUNT(7);
     for (int f = tid; f < nL; f += VS_WG) __hip_atomic_store(tt.killL + f, 0x7FFFFFFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     for (int f = tid; f < nR; f += VS_WG) __hip_atomic_store(tt.killR + f, 0x7FFFFFFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __syncthreads();
@@ -457,7 +468,6 @@ __device__ __forceinline__ void wg_track_resolve(const DevCfg& c, const DevBuf& 
     }
     if (!__syncthreads_or(changed)) break;
   }
-  if (tid == 0) { const unsigned long long tn = wall_clock64(); b.st[s].dbg[9] += tn - tq; tq = tn; }
   // used flags == every feature some final success removed (matched_indices_* + prune, :646-672)
   uint8_t* usedL = used_of(c, b, s, 0);
   uint8_t* usedR = used_of(c, b, s, 1);
@@ -488,7 +498,7 @@ __device__ __forceinline__ void wg_track_resolve(const DevCfg& c, const DevBuf& 
       lost[ol++] = i;
     }
   }
-  if (tid == 0) { sh.n_trk = tot_t; sh.n_lost = tot_l; sh.n_lm = tot_lm; b.st[s].dbg[10] += wall_clock64() - tq; }
+  if (tid == 0) { sh.n_trk = tot_t; sh.n_lost = tot_l; sh.n_lm = tot_lm; }
   __syncthreads();
 }
 
@@ -634,6 +644,7 @@ __device__ __forceinline__ double dpp_row_sum(double v) {
 __device__ __forceinline__ void align_point(const DevCfg& c, const double* T, const AlignPoint& P, bool ignore_outliers,
                                             double* acc, double* chi_out, uint8_t* inl_out) {
   const double* K = c.c.K;
+  const bool pinhole = K[1] == 0 && K[3] == 0 && K[6] == 0 && K[7] == 0 && K[8] == 1;   // uniform
   double chi_w = -1;
   uint8_t inl_w = 0;
   double omega = P.om;
@@ -662,24 +673,41 @@ __device__ __forceinline__ void align_point(const DevCfg& c, const double* T, co
       acc[28] += 1.0;
     }
     if (use) {
+      // The Jacobian products and the H, b accumulation may fuse multiply-adds: their sums already differ from the
+      // reference's serial order by rounding (parallel reduction), a gate-free part of the computation.  Everything
+      // that feeds a comparison (projection, chi, the kernel test above) stays unfused like the oracle.
+#pragma clang fp contract(fast)
       acc[27] += chi;
       const double wt = P.wt;
       // K * [w*I3 | -2*skew(p)]
       const double Jt[3][6] = {{wt, 0, 0, 0, 2 * p[2], -2 * p[1]}, {0, wt, 0, -2 * p[2], 0, 2 * p[0]}, {0, 0, wt, 2 * p[1], -2 * p[0], 0}};
       double KJ[3][6];
+      if (pinhole) {
+        // K = [fx 0 cx; 0 fy cy; 0 0 1]: the products with the structural zeros of K and Jt are exact zeros, and adding an
+        // exact zero is exact, so dropping them leaves every KJ entry bit-identical to the full triple product
+        const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+        KJ[0][0] = fx * Jt[0][0]; KJ[0][1] = 0;                KJ[0][2] = cx * Jt[2][2];
+        KJ[0][3] = cx * Jt[2][3];  KJ[0][4] = fx * Jt[0][4] + cx * Jt[2][4]; KJ[0][5] = fx * Jt[0][5];
+        KJ[1][0] = 0;              KJ[1][1] = fy * Jt[1][1];  KJ[1][2] = cy * Jt[2][2];
+        KJ[1][3] = fy * Jt[1][3] + cy * Jt[2][3]; KJ[1][4] = cy * Jt[2][4]; KJ[1][5] = fy * Jt[1][5];
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 6; ++j) KJ[2][j] = Jt[2][j];
+      } else {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) KJ[i][j] = (K[3 * i] * Jt[0][j] + K[3 * i + 1] * Jt[1][j]) + K[3 * i + 2] * Jt[2][j];
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 6; ++j) KJ[i][j] = (K[3 * i] * Jt[0][j] + K[3 * i + 1] * Jt[1][j]) + K[3 * i + 2] * Jt[2][j];
+      }
       const double icL = 1 / cL, icR = 1 / cR, icL2 = icL * icL, icR2 = icR * icR;
       const double jl0 = -aL[0] * icL2, jl1 = -aL[1] * icL2, jr0 = -aR[0] * icR2, jr1 = -aR[1] * icR2;
+      // rows of the projection Jacobian times KJ; the reference's explicit 0 * x terms are exact zeros (finite x)
       double J[4][6];
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
-        J[0][j] = (icL * KJ[0][j] + 0 * KJ[1][j]) + jl0 * KJ[2][j];
-        J[1][j] = (0 * KJ[0][j] + icL * KJ[1][j]) + jl1 * KJ[2][j];
-        J[2][j] = (icR * KJ[0][j] + 0 * KJ[1][j]) + jr0 * KJ[2][j];
-        J[3][j] = (0 * KJ[0][j] + icR * KJ[1][j]) + jr1 * KJ[2][j];
+        J[0][j] = icL * KJ[0][j] + jl0 * KJ[2][j];
+        J[1][j] = icL * KJ[1][j] + jl1 * KJ[2][j];
+        J[2][j] = icR * KJ[0][j] + jr0 * KJ[2][j];
+        J[3][j] = icR * KJ[1][j] + jr1 * KJ[2][j];
       }
       int q = 0;
 #pragma unroll
@@ -710,6 +738,7 @@ __device__ __forceinline__ void wg_one_round(const DevCfg& c, const DevBuf& b, i
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   double* chi_o = b.al_chi + (size_t)s * c.MAXP;
   uint8_t* inl_o = b.al_inl + (size_t)s * c.MAXP;
+  VS_PHASE_BEGIN(tp0);
   double T[12];
   for (int k = 0; k < 12; ++k) T[k] = sh.T[k];
   double acc[NACC];
@@ -735,6 +764,7 @@ __device__ __forceinline__ void wg_one_round(const DevCfg& c, const DevBuf& b, i
     }
   }
   __syncthreads();
+  VS_PHASE_STAMP(5, tp0);
   if (w == 0) {
     // lane k < 29 owns total k; the 6x6 system then lives one element per lane (column-major: lane = 6*col+row,
     // right-hand side in lanes 36..41) and is solved by wave_solve6 without leaving registers.
@@ -755,7 +785,9 @@ __device__ __forceinline__ void wg_one_round(const DevCfg& c, const DevBuf& b, i
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     double dx[6];
+    VS_PHASE_STAMP(9, tp0);
     if (!ldlt_solve6(sh.H, sh.bvec, dx)) wave_solve6(a, lane, dx, &sh.key);
+    VS_PHASE_STAMP(10, tp0);
     if (lane == 0) {
       double D[12], Tn[12];
       v2t(dx, D);
@@ -783,6 +815,7 @@ __device__ __forceinline__ void wg_one_round(const DevCfg& c, const DevBuf& b, i
     }
   }
   __syncthreads();
+  VS_PHASE_STAMP(11, tp0);
 }
 
 // converge (:210-264) on the aligner SoA of stream s (n measurements), starting from T_init

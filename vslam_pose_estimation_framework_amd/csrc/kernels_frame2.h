@@ -508,8 +508,8 @@ __device__ __forceinline__ void wg_stereo(const DevCfg& c, const DevBuf& b, int 
   uint4* sd4 = reinterpret_cast<uint4*>(arena + ((stage_bytes + 15) & ~(size_t)15));
   const int itau = (int)ceil(tau_tri);   // integer h < tau_tri  <=>  h < ceil(tau_tri)
   int n_cand = 0;
-  unsigned long long tq = wall_clock64();
-#define DBG_STAMP(k) do { __syncthreads(); if (tid == 0) { const unsigned long long tn = wall_clock64(); b.st[s].dbg[k] += tn - tq; tq = tn; } } while (0)
+  VS_PHASE_BEGIN(tq);
+#define DBG_STAMP(k) do { __syncthreads(); VS_PHASE_STAMP(k, tq); } while (0)
   for (int oi = 0; oi < c.n_offsets; ++oi) {
     const int o = c.offsets[oi];
     uint8_t* sdist = b.sdist + (size_t)s * c.NMAX * 16;
@@ -527,7 +527,6 @@ __device__ __forceinline__ void wg_stereo(const DevCfg& c, const DevBuf& b, int 
         for (int i = tid; i < nL; i += VS_WG) sd4[i] = reinterpret_cast<const uint4*>(sdist)[i];
       }
       __syncthreads();
-      if (tid == 0) { const unsigned long long tn = wall_clock64(); b.st[s].dbg[11] += tn - tq; }
       // distances of the first pass came from k_stereo_dist (image pipeline); later offsets recompute them here
       if (oi > 0) {
         for (int i = tid; i < nL; i += VS_WG) {
@@ -573,7 +572,6 @@ __device__ __forceinline__ void wg_stereo(const DevCfg& c, const DevBuf& b, int 
           ssuf[i] = suf; sval[i] = (uint16_t)val; smL[i] = (uint8_t)m;
         }
         __syncthreads();
-        if (tid == 0) { const unsigned long long tn = wall_clock64(); b.st[s].dbg[1] += tn - tq; }
         // ---- step B ---------------------------------------------------------------------------------------------------
         for (int r = tid; r < rows; r += VS_WG) {
           const int rr = r - o;  // right row: L.row == R.row + o
@@ -842,7 +840,7 @@ __global__ VS_FRAME_BOUNDS void k_frame(const DevCfg c, const DevBuf b, int phas
   double tau_gen = tau_track;               // generator's _maximum_descriptor_distance_tracking (last _track)
   __syncthreads();
   const double* prev_c2w = hpose_of(c, b, s, f > 0 ? f - 1 : 0);
-  int n_tracked_landmarks = 0, n_after_prune = 0, n_recovered = 0;
+  int n_tracked_landmarks = 0, n_after_prune = 0;
   bool aligner_valid = false;
 
   if (has_prev) {
@@ -965,9 +963,9 @@ __global__ VS_FRAME_BOUNDS void k_frame(const DevCfg c, const DevBuf b, int phas
       for (int k = 0; k < 12; ++k) st.al_T[k] = sh.T[k];
       for (int k = 0; k < 36; ++k) st.al_H[k] = sh.H[k];
     }
-    const unsigned long long tP = wall_clock64();
+    VS_PHASE_BEGIN(tP);
     wg_prune(c, b, s, sh, pb_prev, pb_cur, aligner_valid);
-    if (tid == 0) st.dbg[6] += wall_clock64() - tP;
+    VS_PHASE_STAMP(6, tP);
     n_after_prune = sh.n_cur;
     if (c.c.enable_landmark_recovery) {
       if (phase < 0) wg_recover_project(c, b, s, sh.n_lost, pb_prev, hpose_of(c, b, s, f) + 12, reinterpret_cast<int32_t*>(arena + VS_RLIST_OFF), VS_RLIST_CAP, &sh.n_proj);
