@@ -27,6 +27,7 @@ from vslam_pose_estimation_framework_amd import hip, sharding, synth  # noqa: E4
 
 SEQ_FRAMES = 4541          # KITTI odometry sequence 00
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PMC_SUMMARY = "r01_f_pmc_traffic.json"   # tools/pmc_traffic.sh of this build (rocprofv3 --pmc, separate passes)
 
 
 def load_oracle():
@@ -180,7 +181,7 @@ def main():
         # rocprofv3 --pmc summary (separate FETCH_SIZE / WRITE_SIZE passes of this same command) when it matches B
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_d_pmc_traffic_final.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", PMC_SUMMARY)))
             if B == 160 and groups == 1 and dom in pm["per_launch_KB"]:
                 traffic = int((pm["per_launch_KB"][dom]["FETCH_SIZE"] + pm["per_launch_KB"][dom]["WRITE_SIZE"]) * 1024)
         except (OSError, KeyError, ValueError):

@@ -444,18 +444,30 @@ __global__ __launch_bounds__(256) void k_update_landmarks(const DevCfg c, const 
 template <class XR>
 __device__ __forceinline__ void stereo_dist_row(const uint8_t* descL, const uint8_t* descR, int i, int g0, int g1, int xl, XR xr,
                                                 uint8_t* sdist) {
-  int m = 0;
-  while (g0 + m < g1 && m < 255 && xl - xr(g0 + m) >= 0) ++m;
+  int m;
+  {  // m = right features of the row with x <= xl (x-sorted): binary search, 6 dependent loads instead of up to 255
+    int lo = g0, hi = g1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (xl - xr(mid) >= 0) lo = mid + 1; else hi = mid; }
+    m = min(lo - g0, 255);
+  }
   if (m == 0 || m >= 255) return;
   const int w0 = max(m - 16, 0), mw = m - w0;
   const uint4 la = reinterpret_cast<const uint4*>(descL + (size_t)32 * i)[0], lb = reinterpret_cast<const uint4*>(descL + (size_t)32 * i)[1];
   uint32_t pk[4] = {0, 0, 0, 0};
-  for (int k = 0; k < mw; ++k) {
-    const uint4* rp = reinterpret_cast<const uint4*>(descR + (size_t)32 * (g0 + w0 + k));
-    const uint4 ra = rp[0], rb = rp[1];
-    const int h = __popc(la.x ^ ra.x) + __popc(la.y ^ ra.y) + __popc(la.z ^ ra.z) + __popc(la.w ^ ra.w) +
-                  __popc(lb.x ^ rb.x) + __popc(lb.y ^ rb.y) + __popc(lb.z ^ rb.z) + __popc(lb.w ^ rb.w);
-    pk[k >> 2] |= (uint32_t)(h > 255 ? 255 : h) << (8 * (k & 3));
+  // four right descriptors in flight per step (the window is a contiguous index range)
+  for (int k0 = 0; k0 < mw; k0 += 4) {
+    uint4 ra[4], rb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint4* rp = reinterpret_cast<const uint4*>(descR + (size_t)32 * (g0 + w0 + min(k0 + u, mw - 1)));
+      ra[u] = rp[0]; rb[u] = rp[1];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int h = __popc(la.x ^ ra[u].x) + __popc(la.y ^ ra[u].y) + __popc(la.z ^ ra[u].z) + __popc(la.w ^ ra[u].w) +
+                    __popc(lb.x ^ rb[u].x) + __popc(lb.y ^ rb[u].y) + __popc(lb.z ^ rb[u].z) + __popc(lb.w ^ rb[u].w);
+      if (k0 + u < mw) pk[k0 >> 2] |= (uint32_t)(h > 255 ? 255 : h) << (8 * u);
+    }
   }
   *reinterpret_cast<uint4*>(sdist + (size_t)i * 16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
 }
