@@ -259,6 +259,27 @@ int vslam_align_points(vslam_ctx* ctx, int32_t n, const double* moving, const do
                        double T_out[12], double* chi, uint8_t* inlier, int32_t* n_inliers,
                        double* total_error, int32_t* iterations, double H_out[36]);
 
+/* StereoFramePointGenerator::track (stereo_framepoint_generator.cpp:464-681, with
+ * IntensityFeatureMatcher::getMatchingFeatureInRectangularRegion, intensity_feature_matcher.cpp:81-148) on
+ * caller-provided data, for known-answer tests: nP previous points (left-camera coordinates n*3, left / right
+ * descriptors n*32, epipolar offsets), motion prior T, window d, the feature sets of the current images as
+ * (row, col) pairs + descriptors (one feature per pixel).  Geometry (rows, cols, K, baseline) from ctx's config.
+ * out4 = (previous index, left feature, right feature, L-R distance) per tracked point in the order of the
+ * previous points, cap nP; lost = indices of the previous points that go to the lost list, cap nP. */
+int vslam_track_match(vslam_ctx* ctx, const double T[12], int32_t d, double tau_track, double tau_tri,
+                      int32_t by_appearance, int32_t nP, const double* cam, const uint8_t* prev_desc_left,
+                      const uint8_t* prev_desc_right, const int32_t* epipolar_offset, int32_t nL,
+                      const int32_t* rc_left, const uint8_t* desc_left, int32_t nR, const int32_t* rc_right,
+                      const uint8_t* desc_right, int32_t* n_tracked, int32_t* out4, int32_t* n_lost, int32_t* lost);
+
+/* StereoFramePointGenerator::compute (stereo_framepoint_generator.cpp:135-462: epipolar sweep over the configured
+ * offsets, ordering constraint, minimum disparity, bin competition if enabled in ctx's config) on caller-provided
+ * feature sets ((row, col) pairs + descriptors, one feature per pixel), for known-answer tests.
+ * out4 = (left feature, right feature, L-R distance, epipolar offset) per new framepoint in emission order. */
+int vslam_stereo_match(vslam_ctx* ctx, double tau_tri, int32_t nL, const int32_t* rc_left, const uint8_t* desc_left,
+                       int32_t nR, const int32_t* rc_right, const uint8_t* desc_right, int32_t cap, int32_t* n_out,
+                       int32_t* out4);
+
 /* ---- multi-GPU: trajectory assembly ---------------------------------------------------------
  * No reference counterpart (single process).  The pose all-gather is issued by the host
  * launcher through RCCL (torch.distributed backend "nccl"); these helpers pack/unpack. */

@@ -1418,6 +1418,46 @@ ORC_API int orc_stereo_match(const vslam_config* cfg, double tau_tri, int32_t nL
   return VSLAM_OK;
 }
 
+/* StereoFramePointGenerator::track (:464-681) on caller-provided data: previous points (left-camera coordinates,
+ * both descriptors, epipolar offset), the motion prior T, window d, both feature sets.  out4 = (previous index, left
+ * feature, right feature, L-R distance) per tracked point in order; lost = indices of the lost-eligible points. */
+ORC_API int orc_track_match(const vslam_config* cfg, const double T[12], int32_t d, double tau_track, double tau_tri, int32_t by_appearance,
+                            int32_t nP, const double* cam, const uint8_t* pdL, const uint8_t* pdR, const int32_t* epi,
+                            int32_t nL, const int32_t* rcL, const uint8_t* dL, int32_t nR, const int32_t* rcR, const uint8_t* dR,
+                            int32_t* n_tracked, int32_t* out4, int32_t* n_lost, int32_t* lost) {
+  Stream s;
+  s.configure(*cfg);
+  s.tau_tri = tau_tri; s.gen_tau_track = tau_track; s.win = d;
+  std::vector<Feature> fl(nL), fr(nR);
+  for (int i = 0; i < nL; ++i) { fl[i].row = rcL[2 * i]; fl[i].col = rcL[2 * i + 1]; fl[i].score = 0; std::memcpy(fl[i].desc, dL + 32 * i, 32); }
+  for (int i = 0; i < nR; ++i) { fr[i].row = rcR[2 * i]; fr[i].col = rcR[2 * i + 1]; fr[i].score = 0; std::memcpy(fr[i].desc, dR + 32 * i, 32); }
+  s.storeL.set_features(fl);
+  s.storeR.set_features(fr);
+  FrameRec prev, cur;
+  prev.points.resize(nP);
+  for (int i = 0; i < nP; ++i) {
+    Point& p = prev.points[i];
+    std::memset(&p, 0, sizeof p);
+    for (int k = 0; k < 3; ++k) p.cam[k] = cam[3 * i + k];
+    std::memcpy(p.dL, pdL + 32 * i, 32); std::memcpy(p.dR, pdR + 32 * i, 32);
+    p.epi = epi[i]; p.prev = -1; p.lm = -1; p.has_next = false;
+  }
+  Tf Tt;
+  std::memcpy(&Tt, T, sizeof(double) * 12);
+  s.track(cur, prev, Tt, by_appearance != 0);
+  *n_tracked = (int32_t)cur.points.size();
+  for (size_t i = 0; i < cur.points.size(); ++i) {
+    const Point& p = cur.points[i];
+    int il = -1, ir = -1;   /* ids by coordinates (unique pixels in the fixtures) */
+    for (int k = 0; k < nL; ++k) if (fl[k].row == p.yL && fl[k].col == p.xL) il = k;
+    for (int k = 0; k < nR; ++k) if (fr[k].row == p.yR && fr[k].col == p.xR) ir = k;
+    out4[4 * i + 0] = p.prev; out4[4 * i + 1] = il; out4[4 * i + 2] = ir; out4[4 * i + 3] = p.dist;
+  }
+  *n_lost = (int32_t)s.lost.size();
+  for (size_t i = 0; i < s.lost.size(); ++i) lost[i] = s.lost[i];
+  return VSLAM_OK;
+}
+
 /* ---- synthetic data + trajectory error (test / bench infrastructure) ---------------------- */
 ORC_API void orc_synth_default_kitti(synth_scene* s) { synth_default_kitti(s); }
 ORC_API void orc_synth_pose(const synth_scene* s, int k, double cam_to_world[12]) {

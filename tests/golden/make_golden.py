@@ -442,6 +442,154 @@ def gen_stereo(rng):
     np.savez_compressed(os.path.join(HERE, "stereo.npz"), **out)
 
 
+# ---- temporal tracking (StereoFramePointGenerator::track + getMatchingFeatureInRectangularRegion) --------------------
+def _trunc32(v):
+    """C++ double -> int32 conversion (toward zero); None outside the int32 range / NaN."""
+    if not (v > -2147483648.0 and v < 2147483648.0):
+        return None
+    return int(v)
+
+
+def _match_in_region(lattice, feats, row_ref, col_ref, desc_ref, r0, r1, c0, c1, max_dist, by_appearance):
+    """intensity_feature_matcher.cpp:81-148 on a dict lattice {(row, col): id}; returns (id or -1, distance)."""
+    best, dist_best = -1, max_dist
+    pix_best = 10000
+    for r in range(r0, r1):
+        for c in range(c0, c1):
+            fid = lattice.get((r, c), -1)
+            if fid < 0:
+                continue
+            dd = float(hamming(desc_ref, feats[fid][2]))
+            if by_appearance:
+                if dd < dist_best:
+                    dist_best, best = dd, fid
+            elif dd < max_dist:
+                pix = (row_ref - r) ** 2 + (col_ref - c) ** 2
+                if pix < pix_best:
+                    pix_best, dist_best, best = pix, dd, fid
+    return best, dist_best
+
+
+def track_ref(K, bh, rows, cols, T, prev, featsL, featsR, d, tau_track, tau_tri, by_appearance, min_disp):
+    """stereo_framepoint_generator.cpp:464-681, independent of the C++ oracle.
+    prev: list of (cam xyz, descL, descR, epipolar offset); feats*: list of (row, col, desc).
+    Returns (tracked [(prev, fl, fr, dist)], lost [prev indices])."""
+    latL = {}
+    for i, f in enumerate(featsL):
+        latL[(f[0], f[1])] = i
+    latR = {}
+    for i, f in enumerate(featsR):
+        latR[(f[0], f[1])] = i
+    tracked, lost = [], []
+    R, t = np.asarray(T[:, :3], np.float64), np.asarray(T[:, 3], np.float64)
+    for ip, (cam, pdL, pdR, epi) in enumerate(prev):
+        q = np.array([(R[i, 0] * cam[0] + R[i, 1] * cam[1]) + R[i, 2] * cam[2] + t[i] for i in range(3)])
+        uvw = np.array([(K[i, 0] * q[0] + K[i, 1] * q[1]) + K[i, 2] * q[2] for i in range(3)])
+        if not (uvw[2] > 0):        # the oracle's documented deviation B.5 (the reference divides regardless)
+            continue
+        col, row = _trunc32(uvw[0] / uvw[2]), _trunc32(uvw[1] / uvw[2])
+        if col is None or row is None or col < 0 or col > cols or row < 0 or row > rows:
+            continue
+        has_next = False
+        r0, r1 = max(row - d, 0), min(row + d + 1, rows)
+        c0, c1 = max(col - d, 0), min(col + d + 1, cols)
+        fl, _ = _match_in_region(latL, featsL, row, col, pdL, r0, r1, c0, c1, tau_track, by_appearance)
+        if fl >= 0:
+            FL = featsL[fl]
+            ex = np.float32(col) - np.float32(FL[1])
+            ey = np.float32(row) - np.float32(FL[0])
+            uR = uvw + bh
+            colR, rowR = _trunc32(uR[0] / uR[2] - float(ex)), _trunc32(uR[1] / uR[2] - float(ey))
+            if colR is None or rowR is None or colR < 0 or colR > cols or rowR < 0 or rowR > rows:
+                continue                                # :561 — skips the lost list too
+            k = int(abs(float(epi)))
+            rr0, rr1 = max(rowR - k, 0), min(rowR + k + 1, rows)
+            rc0, rc1 = max(colR - d, 0), min(colR + d + 1, FL[1])
+            fr, dist = _match_in_region(latR, featsR, rowR, colR, FL[2], rr0, rr1, rc0, rc1, tau_tri, True)
+            if fr >= 0:
+                FR = featsR[fr]
+                if FL[1] - FR[1] < min_disp:
+                    continue                            # :599
+                if float(hamming(FR[2], pdR)) > tau_track:
+                    continue                            # :607
+                for c in range(FR[1] + 1, FL[1]):       # parallax clearing :612-621
+                    latR.pop((FR[0], c), None)
+                tracked.append((ip, fl, fr, int(dist)))
+                has_next = True
+                latL.pop((FL[0], FL[1]), None)
+                latR.pop((FR[0], FR[1]), None)
+        if not has_next:
+            lost.append(ip)
+    return tracked, lost
+
+
+def gen_track(rng):
+    """Small images packed with features so that order-dependent conflicts, parallax clearing, both search modes,
+    the truncating projections and the inclusive image gate all occur."""
+    rows, cols = 96, 160
+    f, cx, cy, base = 120.0, 80.0, 48.0, 0.4
+    K = np.array([[f, 0, cx], [0, f, cy], [0, 0, 1.0]])
+    bh = np.array([-f * base, 0.0, 0.0])
+    out = {"K": K, "bh": bh, "rows": np.int32(rows), "cols": np.int32(cols)}
+
+    def near(dsc, k):
+        bits = np.unpackbits(dsc)
+        idx = rng.choice(256, size=k, replace=False)
+        bits[idx] ^= 1
+        return np.packbits(bits)
+    n_case = 0
+    for by_app in (1, 0):
+        for d in (3, 9):
+            for trial in range(3):
+                T = np.eye(4)[:3]
+                T = T.copy()
+                T[:, 3] = rng.normal(0, 0.02, 3)
+                ang = rng.normal(0, 0.01)
+                T[0, 0], T[0, 2], T[2, 0], T[2, 2] = np.cos(ang), np.sin(ang), -np.sin(ang), np.cos(ang)
+                prev, featsL, featsR = [], [], []
+                usedL, usedR = set(), set()
+                nP = 70
+                for ip in range(nP):
+                    z = float(rng.uniform(2.0, 25.0))
+                    u, v = float(rng.uniform(-6, cols + 6)), float(rng.uniform(-6, rows + 6))
+                    cam = np.array([(u - cx) * z / f, (v - cy) * z / f, z])
+                    dLp = rng.integers(0, 256, 32, dtype=np.uint8)
+                    dRp = near(dLp, int(rng.integers(0, 20)))
+                    prev.append((cam, dLp, dRp, int(rng.integers(-1, 2))))
+                    # a few current features around the projection, left and right
+                    for _ in range(int(rng.integers(0, 4))):
+                        r = int(round(v)) + int(rng.integers(-d - 1, d + 2)); c = int(round(u)) + int(rng.integers(-d - 1, d + 2))
+                        if 0 <= r < rows and 0 <= c < cols and (r, c) not in usedL:
+                            usedL.add((r, c)); featsL.append((r, c, near(dLp, int(rng.integers(0, 45)))))
+                            disp = f * base / z
+                            for _ in range(int(rng.integers(0, 3))):
+                                rr = r + int(rng.integers(-1, 2)); cc = int(round(c - disp)) + int(rng.integers(-3, 4))
+                                if 0 <= rr < rows and 0 <= cc < cols and (rr, cc) not in usedR:
+                                    usedR.add((rr, cc)); featsR.append((rr, cc, near(featsL[-1][2], int(rng.integers(0, 35)))))
+                # clutter
+                for _ in range(60):
+                    r, c = int(rng.integers(0, rows)), int(rng.integers(0, cols))
+                    if (r, c) not in usedL:
+                        usedL.add((r, c)); featsL.append((r, c, rng.integers(0, 256, 32, dtype=np.uint8)))
+                    r, c = int(rng.integers(0, rows)), int(rng.integers(0, cols))
+                    if (r, c) not in usedR:
+                        usedR.add((r, c)); featsR.append((r, c, rng.integers(0, 256, 32, dtype=np.uint8)))
+                tau_track, tau_tri = 50.0, 40.0
+                tr, lost = track_ref(K, bh, rows, cols, T, prev, featsL, featsR, d, tau_track, tau_tri, bool(by_app), 1.0)
+                key = "c%d_" % n_case
+                out[key + "T"] = T; out[key + "d"] = np.int32(d); out[key + "by_app"] = np.int32(by_app)
+                out[key + "tau_track"] = np.float64(tau_track); out[key + "tau_tri"] = np.float64(tau_tri)
+                out[key + "cam"] = np.array([p[0] for p in prev]); out[key + "pdL"] = np.array([p[1] for p in prev], np.uint8)
+                out[key + "pdR"] = np.array([p[2] for p in prev], np.uint8); out[key + "epi"] = np.array([p[3] for p in prev], np.int32)
+                out[key + "rcL"] = np.array([(a[0], a[1]) for a in featsL], np.int32); out[key + "dL"] = np.array([a[2] for a in featsL], np.uint8)
+                out[key + "rcR"] = np.array([(a[0], a[1]) for a in featsR], np.int32); out[key + "dR"] = np.array([a[2] for a in featsR], np.uint8)
+                out[key + "tracked"] = np.array(tr, np.int32).reshape(-1, 4); out[key + "lost"] = np.array(lost, np.int32)
+                n_case += 1
+    out["n_cases"] = np.int32(n_case)
+    np.savez_compressed(os.path.join(HERE, "track.npz"), **out)
+    return n_case
+
+
 def main():
     rng = np.random.default_rng(20261003)
     gen_hamming(rng)
@@ -450,6 +598,7 @@ def main():
     gen_controller()
     gen_aligner(rng)
     gen_stereo(rng)
+    gen_track(np.random.default_rng(20261004))   # own stream: added later, the fixtures above stay byte-identical
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

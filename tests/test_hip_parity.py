@@ -42,6 +42,52 @@ def test_aligner_golden(gpu, golden):
     pc.check_aligner(gpu, golden["aligner"], rtol_pose=1e-7)
 
 
+def test_track_golden(golden):
+    """vslam_track_match (k_track_candidates + the order-exact resolution of the frame kernel) against the fixture of
+    the independent numpy restatement of StereoFramePointGenerator::track: exact tuples, exact lost list."""
+    g = golden["track"]
+    api = hip.load()
+    cfg = api.default_config("kitti")
+    cfg.rows, cfg.cols = int(g["rows"]), int(g["cols"])
+    for i in range(9):
+        cfg.K[i] = float(g["K"].reshape(-1)[i])
+    for i in range(3):
+        cfg.baseline_h[i] = float(g["bh"][i])
+    cfg.minimum_disparity_pixels = 1.0
+    cfg.max_keypoints, cfg.max_points, cfg.max_history_frames = 256, 128, 2
+    api.create(cfg, 0, 1)
+    total = 0
+    for k in range(int(g["n_cases"])):
+        key = "c%d_" % k
+        tracked, lost = api.track_match(g[key + "T"], int(g[key + "d"]), float(g[key + "tau_track"]), float(g[key + "tau_tri"]),
+                                        int(g[key + "by_app"]), g[key + "cam"], g[key + "pdL"], g[key + "pdR"], g[key + "epi"],
+                                        g[key + "rcL"], g[key + "dL"], g[key + "rcR"], g[key + "dR"])
+        np.testing.assert_array_equal(tracked, g[key + "tracked"], err_msg="case %d tracked" % k)
+        np.testing.assert_array_equal(lost, g[key + "lost"], err_msg="case %d lost" % k)
+        total += len(tracked)
+    assert total > 100
+    api.destroy()
+
+
+def test_stereo_sweep_golden(golden):
+    """vslam_stereo_match (k_stereo_dist + the suffix-argmin sweep of the frame kernel) against the fixture of the
+    independent numpy restatement of StereoFramePointGenerator::compute: ties, ordering constraint, minimum disparity
+    without cursor advance, multi-offset pruning — exact (left, right, distance, offset) rows in emission order."""
+    g = golden["stereo"]
+    for name in ("hand", "random"):
+        for epi in (0, 1):
+            api = hip.load()
+            cfg = api.default_config("kitti")
+            cfg.rows, cfg.cols = 128, 640
+            cfg.enable_keypoint_binning = 0
+            cfg.maximum_epipolar_search_offset_pixels = epi
+            cfg.max_keypoints, cfg.max_points, cfg.max_history_frames = 512, 512, 2
+            api.create(cfg, 0, 1)
+            out = api.stereo_match(float(g[name + "_tau"]), g[name + "_rcL"], g[name + "_dL"], g[name + "_rcR"], g[name + "_dR"])
+            np.testing.assert_array_equal(out, g["%s_epi%d_matches" % (name, epi)], err_msg="%s epi %d" % (name, epi))
+            api.destroy()
+
+
 def compare_frame(o, g, s, k, tag=""):
     fo, fg = o.frame_info(s), g.frame_info(s)
     for name in INT_FIELDS:

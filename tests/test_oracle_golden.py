@@ -80,3 +80,39 @@ def test_stereo_sweep(oracle, golden):
             assert rc == 0
             np.testing.assert_array_equal(out[:n.value], g["%s_epi%d_matches" % (name, epi)],
                                           err_msg="%s epi %d" % (name, epi))
+
+
+def test_track_known_answers(oracle, golden):
+    """StereoFramePointGenerator::track (order-dependent lattice removal, both search modes, truncating projections,
+    parallax clearing, lost-list `continue` semantics) against the independent numpy restatement in make_golden.py."""
+    g = golden["track"]
+    n_tracked_total = 0
+    for k in range(int(g["n_cases"])):
+        key = "c%d_" % k
+        cfg = oracle.default_config("kitti")
+        cfg.rows, cfg.cols = int(g["rows"]), int(g["cols"])
+        for i in range(9):
+            cfg.K[i] = float(g["K"].reshape(-1)[i])
+        for i in range(3):
+            cfg.baseline_h[i] = float(g["bh"][i])
+        cfg.minimum_disparity_pixels = 1.0
+        T = np.ascontiguousarray(g[key + "T"], np.float64)
+        cam = np.ascontiguousarray(g[key + "cam"], np.float64)
+        pdL = np.ascontiguousarray(g[key + "pdL"]); pdR = np.ascontiguousarray(g[key + "pdR"])
+        epi = np.ascontiguousarray(g[key + "epi"], np.int32)
+        rcL = np.ascontiguousarray(g[key + "rcL"]); dL = np.ascontiguousarray(g[key + "dL"])
+        rcR = np.ascontiguousarray(g[key + "rcR"]); dR = np.ascontiguousarray(g[key + "dR"])
+        nP = len(cam)
+        out = np.zeros((nP, 4), np.int32); lost = np.zeros(nP, np.int32)
+        nt, nl = C.c_int32(), C.c_int32()
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        rc = oracle.lib.orc_track_match(C.byref(cfg), p(T), C.c_int32(int(g[key + "d"])), C.c_double(float(g[key + "tau_track"])),
+                                        C.c_double(float(g[key + "tau_tri"])), C.c_int32(int(g[key + "by_app"])),
+                                        C.c_int32(nP), p(cam), p(pdL), p(pdR), p(epi),
+                                        C.c_int32(len(rcL)), p(rcL), p(dL), C.c_int32(len(rcR)), p(rcR), p(dR),
+                                        C.byref(nt), p(out), C.byref(nl), p(lost))
+        assert rc == 0
+        np.testing.assert_array_equal(out[:nt.value], g[key + "tracked"], err_msg="case %d tracked" % k)
+        np.testing.assert_array_equal(lost[:nl.value], g[key + "lost"], err_msg="case %d lost" % k)
+        n_tracked_total += nt.value
+    assert n_tracked_total > 100

@@ -272,6 +272,40 @@ class CApi(object):
                     iterations=its.value, H=H.reshape(6, 6))
 
 
+    def track_match(self, T, d, tau_track, tau_tri, by_appearance, cam, prev_desc_left, prev_desc_right, epi,
+                    rc_left, desc_left, rc_right, desc_right):
+        """StereoFramePointGenerator::track on caller-provided data (known-answer tests): returns (tracked [n][4], lost)."""
+        T = np.ascontiguousarray(T, np.float64).reshape(12)
+        cam = np.ascontiguousarray(cam, np.float64)
+        pdl = np.ascontiguousarray(prev_desc_left, np.uint8); pdr = np.ascontiguousarray(prev_desc_right, np.uint8)
+        epi = np.ascontiguousarray(epi, np.int32)
+        rcl = np.ascontiguousarray(rc_left, np.int32); dl = np.ascontiguousarray(desc_left, np.uint8)
+        rcr = np.ascontiguousarray(rc_right, np.int32); dr = np.ascontiguousarray(desc_right, np.uint8)
+        n = cam.shape[0]
+        out = np.zeros((max(n, 1), 4), np.int32)
+        lost = np.zeros(max(n, 1), np.int32)
+        nt, nl = C.c_int32(), C.c_int32()
+        self.check(self.fn("track_match")(self.ctx, _p(T, C.c_double), C.c_int32(int(d)), C.c_double(float(tau_track)),
+                                          C.c_double(float(tau_tri)), C.c_int32(int(by_appearance)), C.c_int32(n),
+                                          _p(cam, C.c_double), _p(pdl, C.c_uint8), _p(pdr, C.c_uint8), _p(epi, C.c_int32),
+                                          C.c_int32(rcl.shape[0]), _p(rcl, C.c_int32), _p(dl, C.c_uint8),
+                                          C.c_int32(rcr.shape[0]), _p(rcr, C.c_int32), _p(dr, C.c_uint8),
+                                          C.byref(nt), _p(out, C.c_int32), C.byref(nl), _p(lost, C.c_int32)))
+        return out[:nt.value].copy(), lost[:nl.value].copy()
+
+
+    def stereo_match(self, tau_tri, rc_left, desc_left, rc_right, desc_right, cap=8192):
+        """StereoFramePointGenerator::compute on caller-provided features: (left, right, distance, offset) rows."""
+        rcl = np.ascontiguousarray(rc_left, np.int32); dl = np.ascontiguousarray(desc_left, np.uint8)
+        rcr = np.ascontiguousarray(rc_right, np.int32); dr = np.ascontiguousarray(desc_right, np.uint8)
+        out = np.zeros((cap, 4), np.int32)
+        n = C.c_int32()
+        self.check(self.fn("stereo_match")(self.ctx, C.c_double(float(tau_tri)), C.c_int32(rcl.shape[0]), _p(rcl, C.c_int32),
+                                           _p(dl, C.c_uint8), C.c_int32(rcr.shape[0]), _p(rcr, C.c_int32), _p(dr, C.c_uint8),
+                                           C.c_int32(cap), C.byref(n), _p(out, C.c_int32)))
+        return out[:n.value].copy()
+
+
 def _extra_methods():
     def copy_poses_device(self, first, count, dst_ptr):
         self.check(self.fn("copy_poses_device")(self.ctx, C.c_int32(first), C.c_int32(count), C.c_void_p(dst_ptr)))

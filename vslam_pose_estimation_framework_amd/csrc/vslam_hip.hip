@@ -718,6 +718,152 @@ VS_API int vslam_align_points(vslam_ctx* c, int32_t n, const double* moving, con
   return rc;
 }
 
+// features of one image of scratch context t as the image pipeline would leave them: row-major order, coordinates,
+// descriptors, cleared used flags, the row / 16-px-cell CSR.  order[k] = caller index of sorted feature k.
+static int upload_features(vslam_ctx* c, vslam_ctx* t, int side, int n, const int32_t* rcx, const uint8_t* dx, std::vector<int>& ord) {
+  const DevCfg& dc = t->cfg;
+  const int rows = dc.c.rows, cols = dc.c.cols, CW1 = dc.CW + 1;
+  ord.resize(n);
+  for (int i = 0; i < n; ++i) {
+    ord[i] = i;
+    if (rcx[2 * i] < 0 || rcx[2 * i] >= rows || rcx[2 * i + 1] < 0 || rcx[2 * i + 1] >= cols) return fail(c, VSLAM_ERR_INVALID, "feature outside the image");
+  }
+  std::sort(ord.begin(), ord.end(), [&](int a, int b) { return rcx[2 * a] != rcx[2 * b] ? rcx[2 * a] < rcx[2 * b] : rcx[2 * a + 1] < rcx[2 * b + 1]; });
+  std::vector<int16_t> xy((size_t)std::max(n, 1) * 2);
+  std::vector<uint8_t> ds((size_t)std::max(n, 1) * 32), used((size_t)std::max(n, 1), 0);
+  std::vector<int32_t> rowcell((size_t)rows * CW1);
+  for (int k = 0; k < n; ++k) {
+    xy[2 * k] = (int16_t)rcx[2 * ord[k] + 1]; xy[2 * k + 1] = (int16_t)rcx[2 * ord[k]];
+    std::memcpy(&ds[(size_t)32 * k], dx + (size_t)32 * ord[k], 32);
+  }
+  int k = 0;
+  for (int r = 0; r < rows; ++r)
+    for (int cc = 0; cc < CW1; ++cc) {
+      while (k < n && (xy[2 * k + 1] < r || (xy[2 * k + 1] == r && xy[2 * k] < 16 * cc))) ++k;
+      rowcell[(size_t)r * CW1 + cc] = k;
+    }
+  const size_t N = dc.NMAX;
+  hipError_t e = hipSuccess;
+  if (n) e = hipMemcpyAsync(t->buf.kp_xy + side * N * 2, xy.data(), (size_t)n * 4, hipMemcpyHostToDevice, t->stream);
+  if (e == hipSuccess && n) e = hipMemcpyAsync(t->buf.desc + side * N * 32, ds.data(), (size_t)n * 32, hipMemcpyHostToDevice, t->stream);
+  if (e == hipSuccess && n) e = hipMemcpyAsync(t->buf.used + side * N, used.data(), (size_t)n, hipMemcpyHostToDevice, t->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(t->buf.rowcell + (size_t)side * rows * CW1, rowcell.data(), rowcell.size() * 4, hipMemcpyHostToDevice, t->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(t->buf.n_kp + side, &n, 4, hipMemcpyHostToDevice, t->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(t->stream);   // the host vectors go out of scope
+  if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
+  return VSLAM_OK;
+}
+
+VS_API int vslam_track_match(vslam_ctx* c, const double T[12], int32_t d, double tau_track, double tau_tri, int32_t by_appearance,
+                             int32_t nP, const double* cam, const uint8_t* pdL, const uint8_t* pdR, const int32_t* epi,
+                             int32_t nL, const int32_t* rcL, const uint8_t* dL, int32_t nR, const int32_t* rcR, const uint8_t* dR,
+                             int32_t* n_tracked, int32_t* out4, int32_t* n_lost, int32_t* lost) {
+  if (!c || !T || nP < 0 || nL < 0 || nR < 0 || !n_tracked || !out4 || !n_lost || !lost) return VSLAM_ERR_INVALID;
+  if ((nP && (!cam || !pdL || !pdR || !epi)) || (nL && (!rcL || !dL)) || (nR && (!rcR || !dR))) return VSLAM_ERR_INVALID;
+  vslam_ctx* t = nullptr;
+  vslam_config cfg = c->cfg.c;
+  cfg.max_points = std::max(64, nP); cfg.max_keypoints = std::max(64, std::max(nL, nR)); cfg.max_history_frames = 2;
+  int rc = create_internal(&cfg, c->device, 1, &t);
+  if (rc != VSLAM_OK) { c->err = g_create_error; return rc; }
+  std::vector<int> order[2];
+  rc = upload_features(c, t, 0, nL, rcL, dL, order[0]);
+  if (rc == VSLAM_OK) rc = upload_features(c, t, 1, nR, rcR, dR, order[1]);
+  hipError_t e = hipSuccess;
+  if (rc == VSLAM_OK) {
+    // previous points in point buffer 0
+    std::vector<uint8_t> pdesc((size_t)std::max(nP, 1) * 64);
+    std::vector<int32_t> meta((size_t)std::max(nP, 1) * META, 0);
+    for (int i = 0; i < nP; ++i) {
+      std::memcpy(&pdesc[(size_t)64 * i], pdL + (size_t)32 * i, 32); std::memcpy(&pdesc[(size_t)64 * i + 32], pdR + (size_t)32 * i, 32);
+      meta[(size_t)i * META + M_EPI] = epi[i]; meta[(size_t)i * META + M_PREV] = -1;
+    }
+    if (nP) e = hipMemcpyAsync(t->buf.p_cam, cam, (size_t)nP * 3 * sizeof(double), hipMemcpyHostToDevice, t->stream);
+    if (e == hipSuccess && nP) e = hipMemcpyAsync(t->buf.p_desc, pdesc.data(), (size_t)nP * 64, hipMemcpyHostToDevice, t->stream);
+    if (e == hipSuccess && nP) e = hipMemcpyAsync(t->buf.p_meta, meta.data(), (size_t)nP * META * 4, hipMemcpyHostToDevice, t->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(t->buf.n_points, &nP, 4, hipMemcpyHostToDevice, t->stream);
+    StreamState st;
+    if (e == hipSuccess) e = hipMemcpyAsync(&st, t->buf.st, sizeof st, hipMemcpyDeviceToHost, t->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+    if (e == hipSuccess) {
+      st.has_prev = 1; st.cur = 0; st.win = d; st.tau_track = tau_track; st.tau_tri = tau_tri;
+      st.status = by_appearance ? VSLAM_LOCALIZING : VSLAM_TRACKING;
+      std::memcpy(st.prior, T, sizeof(double) * 12);
+      e = hipMemcpyAsync(t->buf.st, &st, sizeof st, hipMemcpyHostToDevice, t->stream);
+    }
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_track_candidates, dim3(16, 1), dim3(256), 0, t->stream, t->cfg, t->buf, by_appearance ? 1 : 0);
+      hipLaunchKernelGGL(k_stage, dim3(1), dim3(VS_WG), 0, t->stream, t->cfg, t->buf, (int)VS_STAGE_TRACK, by_appearance ? 1 : 0);
+      e = hipMemcpyAsync(&st, t->buf.st, sizeof st, hipMemcpyDeviceToHost, t->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+    }
+    if (e == hipSuccess) {
+      std::vector<int32_t> trk((size_t)std::max(st.n_trk, 1) * 4), ls((size_t)std::max(st.n_lost, 1));
+      if (st.n_trk) e = hipMemcpy(trk.data(), t->buf.trk, (size_t)st.n_trk * 16, hipMemcpyDeviceToHost);
+      if (e == hipSuccess && st.n_lost) e = hipMemcpy(ls.data(), t->buf.lost, (size_t)st.n_lost * 4, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) {
+        *n_tracked = st.n_trk; *n_lost = st.n_lost;
+        for (int u = 0; u < st.n_trk; ++u) {
+          out4[4 * u] = trk[4 * u]; out4[4 * u + 1] = order[0][trk[4 * u + 1]]; out4[4 * u + 2] = order[1][trk[4 * u + 2]]; out4[4 * u + 3] = trk[4 * u + 3];
+        }
+        for (int u = 0; u < st.n_lost; ++u) lost[u] = ls[u];
+      }
+    }
+    if (e != hipSuccess) rc = fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
+  }
+  vslam_destroy(t);
+  return rc;
+}
+
+VS_API int vslam_stereo_match(vslam_ctx* c, double tau_tri, int32_t nL, const int32_t* rcL, const uint8_t* dL, int32_t nR,
+                              const int32_t* rcR, const uint8_t* dR, int32_t cap, int32_t* n_out, int32_t* out4) {
+  if (!c || nL < 0 || nR < 0 || cap < 0 || !n_out || (cap && !out4) || (nL && (!rcL || !dL)) || (nR && (!rcR || !dR))) return VSLAM_ERR_INVALID;
+  vslam_ctx* t = nullptr;
+  vslam_config cfg = c->cfg.c;
+  cfg.max_keypoints = std::max(64, std::max(nL, nR)); cfg.max_points = std::max(64, nL); cfg.max_history_frames = 2;
+  int rc = create_internal(&cfg, c->device, 1, &t);
+  if (rc != VSLAM_OK) { c->err = g_create_error; return rc; }
+  std::vector<int> order[2];
+  rc = upload_features(c, t, 0, nL, rcL, dL, order[0]);
+  if (rc == VSLAM_OK) rc = upload_features(c, t, 1, nR, rcR, dR, order[1]);
+  if (rc == VSLAM_OK) {
+    StreamState st;
+    hipError_t e = hipMemcpyAsync(&st, t->buf.st, sizeof st, hipMemcpyDeviceToHost, t->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+    if (e == hipSuccess) {
+      st.tau_tri = tau_tri; st.n_cur = 0; st.cur = 0;
+      e = hipMemcpyAsync(t->buf.st, &st, sizeof st, hipMemcpyHostToDevice, t->stream);
+    }
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_stereo_dist, dim3((t->cfg.NMAX + 255) / 256, 1), dim3(256), 0, t->stream, t->cfg, t->buf);
+      hipLaunchKernelGGL(k_stage, dim3(1), dim3(VS_WG), 0, t->stream, t->cfg, t->buf, (int)VS_STAGE_STEREO, 0);
+      e = hipMemcpyAsync(&st, t->buf.st, sizeof st, hipMemcpyDeviceToHost, t->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+    }
+    if (e == hipSuccess) {
+      const int n = st.n_new;
+      *n_out = n;
+      if (n > cap) rc = fail(c, VSLAM_ERR_CAPACITY, "stereo_match: output capacity too small");
+      else if (n) {
+        // the new points were written to point buffer 1 (current = previous ^ 1)
+        const size_t P = t->cfg.MAXP;
+        std::vector<int16_t> kp((size_t)n * 4);
+        std::vector<int32_t> meta((size_t)n * META);
+        e = hipMemcpy(kp.data(), t->buf.p_kp + P * 4, (size_t)n * 8, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(meta.data(), t->buf.p_meta + P * META, (size_t)n * META * 4, hipMemcpyDeviceToHost);
+        for (int i = 0; i < n && e == hipSuccess; ++i) {
+          int il = -1, ir = -1;   // ids by coordinates (one feature per pixel)
+          for (int k = 0; k < nL; ++k) if (rcL[2 * k] == kp[4 * i + 1] && rcL[2 * k + 1] == kp[4 * i]) il = k;
+          for (int k = 0; k < nR; ++k) if (rcR[2 * k] == kp[4 * i + 3] && rcR[2 * k + 1] == kp[4 * i + 2]) ir = k;
+          out4[4 * i] = il; out4[4 * i + 1] = ir; out4[4 * i + 2] = meta[(size_t)i * META + M_DIST]; out4[4 * i + 3] = meta[(size_t)i * META + M_EPI];
+        }
+      }
+    }
+    if (e != hipSuccess) rc = fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
+  }
+  vslam_destroy(t);
+  return rc;
+}
+
 // ---- stage entry points (the reference's plug-in virtuals; control flow stays with the caller) ----------
 static int launch_begin(vslam_ctx* c) {
   for (auto& g : c->groups) hipLaunchKernelGGL(k_begin, dim3(g.n), dim3(256), 0, g.st_frm, c->cfg, buf_set(c, c->last_set, g.s0));
