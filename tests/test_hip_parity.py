@@ -88,6 +88,22 @@ def test_stereo_sweep_golden(golden):
             api.destroy()
 
 
+def test_harness_record(golden):
+    """The committed 30-frame record of the whole harness (per-frame counters, thresholds, descriptor distance, poses):
+    the HIP path against fixture DATA, no oracle in the loop (the oracle library only renders the images)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_harness as mh
+    from _oracle import Oracle
+    g = golden["harness"]
+    counters, thr, tau, poses = mh.run(hip.load, Oracle())
+    np.testing.assert_array_equal(counters, g["counters"])
+    np.testing.assert_array_equal(thr, g["thresholds"])
+    np.testing.assert_array_equal(tau, g["tau_track"])
+    for k in range(len(poses)):
+        assert np.linalg.norm(poses[k] - g["poses"][k]) / np.linalg.norm(g["poses"][k]) <= POSE_RTOL
+
+
 def compare_frame(o, g, s, k, tag=""):
     fo, fg = o.frame_info(s), g.frame_info(s)
     for name in INT_FIELDS:

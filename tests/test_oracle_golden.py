@@ -116,3 +116,19 @@ def test_track_known_answers(oracle, golden):
         np.testing.assert_array_equal(lost[:nl.value], g[key + "lost"], err_msg="case %d lost" % k)
         n_tracked_total += nt.value
     assert n_tracked_total > 100
+
+
+def test_harness_regression_record(golden):
+    """The whole PoseTracker3D::compute harness on the committed 30-frame record (tests/golden/make_harness.py)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_harness as mh
+    from _oracle import Oracle
+    g = golden["harness"]
+    assert list(g["fields"]) == mh.FIELDS
+    counters, thr, tau, poses = mh.run(Oracle, Oracle())
+    np.testing.assert_array_equal(counters, g["counters"])
+    np.testing.assert_array_equal(thr, g["thresholds"])
+    np.testing.assert_array_equal(tau, g["tau_track"])
+    np.testing.assert_allclose(poses, g["poses"], rtol=0, atol=1e-9)
+    assert g["counters"][-1][0] == 1 and g["counters"][:, 6].max() > 30   # Tracking, real tracks
