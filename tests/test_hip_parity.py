@@ -182,6 +182,17 @@ def test_pipeline_parity_full_resolution_kitti():
     run_sequence(Oracle, dict(scale=1.0), 6)
 
 
+def test_pipeline_parity_long_run_history_ring():
+    # 100 frames at 0.6 scale with a 64-frame history ring: the ring wraps around (tracks longer than the ring would be
+    # truncated and flagged with error bit 4, which the comparison of error_flags excludes here), the window and the
+    # tracking distance settle, recovery and landmark refinement run on long tracks — every frame compared in full
+    from _oracle import Oracle
+
+    def edit(cfg):
+        cfg.max_history_frames = 64
+    run_sequence(Oracle, dict(scale=0.6), 100, cfg_edit=edit)
+
+
 def test_pipeline_parity_standstill_and_fallback():
     # zero motion: the aligner result is below the movement thresholds -> _fallbackEstimate path
     from _oracle import Oracle
@@ -322,6 +333,28 @@ def test_keypoint_capacity_overflow_is_flagged_not_fatal():
         assert fi.n_keypoints_left <= 128 and fi.n_points <= 64
         xy, score, desc = g.keypoints(0, 0)
         assert len(xy) == fi.n_keypoints_left
+    finally:
+        g.destroy()
+
+
+def test_history_ring_shorter_than_tracks_is_flagged_not_fatal():
+    """Tracks longer than max_history_frames: landmark refinement uses the newest ring-full of measurements, error_flags
+    bit 2 (value 4) reports it, tracking carries on."""
+    from _oracle import Oracle
+    o = Oracle()
+    sc = o.scene_kitti(scale=0.5, seed=5)
+    cfg = o.config_for_scene(sc)
+    cfg.max_history_frames = 8
+    g = hip.load()
+    g.create(cfg, 0, 1)
+    try:
+        flagged = False
+        for f in range(30):
+            g.process_host(*o.render(sc, f))
+            fi = g.frame_info(0)
+            flagged = flagged or bool(fi.error_flags & 4)
+        assert flagged
+        assert fi.status == 1 and fi.n_tracked > 20 and np.isfinite(np.array(fi.camera_left_to_world)).all()
     finally:
         g.destroy()
 
