@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Run the MI355X front end on a KITTI odometry folder and write the trajectory (the I/O formats
+either side of the hot path; executables/test_stereo_frontend.cpp:106-111,256-312 of the reference is the template).
+
+    python tools/run_kitti.py <sequence dir with image_0/ image_1/ calib.txt [times.txt]> [--out traj.txt]
+                              [--format kitti|tum] [--gt poses.txt] [--max-frames N] [--config kitti|euroc]
+
+The sequence runs in exact mode (one stream, whole sequence, bit-for-bit the reference port's arithmetic); images are
+uploaded frame by frame through vslam_process_host.  With --gt (KITTI 3x4 rows) the ATE-RMSE after rigid alignment is
+printed, as trajectory_analyzer.cpp:212-284 computes it."""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+from vslam_pose_estimation_framework_amd import evaluation, hip, io_formats  # noqa: E402
+
+
+def run(seq_dir, out_path=None, fmt="kitti", gt_path=None, max_frames=0, which="kitti", device=0, log=print):
+    seq = io_formats.KittiSequence(seq_dir)
+    n = len(seq) if max_frames <= 0 else min(len(seq), max_frames)
+    if n == 0:
+        raise SystemExit("no images under %s/image_0" % seq_dir)
+    left, right = seq.pair(0)
+    api = hip.load()
+    cfg = api.default_config(which)
+    io_formats.apply_calib(cfg, seq.K, seq.baseline, left.shape[0], left.shape[1])
+    cfg.max_history_frames = 512
+    api.create(cfg, device, 1)
+    t0 = time.perf_counter()
+    flags = 0
+    for k in range(n):
+        if k:
+            left, right = seq.pair(k)
+        api.process_host(left, right)
+        if k % 100 == 99 or k == n - 1:
+            fi = api.frame_info(0)
+            flags |= fi.error_flags
+            log("frame %6d  status %s  points %5d  tracked %5d  inliers %5d" % (
+                k, "tracking" if fi.status == 1 else "localizing", fi.n_points, fi.n_tracked, fi.n_inliers))
+    poses = api.poses(0, 0, n)
+    dt = time.perf_counter() - t0
+    api.destroy()
+    log("%d frames in %.2f s (%.1f frames/s incl. PNG decode and upload), error flags %d" % (n, dt, n / dt, flags))
+    if out_path:
+        if fmt == "tum":
+            io_formats.write_trajectory_tum(out_path, poses, seq.times[:n])
+        else:
+            io_formats.write_trajectory_kitti(out_path, poses)
+        log("trajectory (%s) -> %s" % (fmt, out_path))
+    result = {"frames": n, "seconds": dt, "error_flags": flags, "poses": poses}
+    if gt_path:
+        gt = io_formats.read_trajectory_kitti(gt_path)[:n]
+        result["ate_rmse_aligned"] = evaluation.ate_rmse(poses[:len(gt)], gt)
+        log("ATE-RMSE after rigid alignment: %.4f m over %d frames" % (result["ate_rmse_aligned"], len(gt)))
+    return result
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("sequence")
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--format", choices=("kitti", "tum"), default="kitti")
+    ap.add_argument("--gt", default=None)
+    ap.add_argument("--max-frames", type=int, default=0)
+    ap.add_argument("--config", choices=("kitti", "euroc"), default="kitti")
+    ap.add_argument("--device", type=int, default=0)
+    a = ap.parse_args()
+    run(a.sequence, a.out, a.format, a.gt, a.max_frames, a.config, a.device)
+
+
+if __name__ == "__main__":
+    main()
