@@ -1,6 +1,6 @@
 // kernels_frame.h — per-stream kernels: temporal-track candidate search (K4) and the frame kernel
 // (K5): order-exact track resolution, StereoUVAligner, tracker control logic, prune, recovery,
-// landmark refinement, stereo sweep + binning.  One 1024-thread workgroup owns one stream, so the
+// landmark refinement, stereo sweep + binning.  One 512-thread workgroup owns one stream, so the
 // reference's sequential per-frame control flow (PoseTracker3D::compute) runs on the device with
 // workgroup barriers only: no inter-workgroup hand-off, no host round trip.
 //

@@ -69,9 +69,9 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* sh, int* total) 
 
 // ==============================================================================================
 // K1: FAST-9/16 score + strict 3x3 NMS -> 1 bit/pixel corner mask (+ sparse u8 scores), fused with
-// the 9x9 box-sum image BRIEF samples.  One 64x16 output tile per 256-thread workgroup; the u8
+// the 9x9 box-sum image BRIEF samples.  One 64x32 output tile per 256-thread workgroup; the u8
 // tile with a 4 px halo (FAST ring 3 + NMS 1 == box radius 4) is staged once in LDS.
-// HBM traffic per pixel: 1 B read, 2 B box write, 1/8 B mask write.
+// HBM traffic per pixel: 1 B read, 2 B box write, 1/8 B mask write, sparse scores.
 // ==============================================================================================
 // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (block b and b+8 share an L2), so the
 // linear block id is re-labelled such that CONSECUTIVE tiles (x fastest, then y, then image) run on the same XCD
@@ -86,49 +86,6 @@ __device__ __forceinline__ void xcd_tile(int* tx, int* ty, int* tz) {
   const int r = lin / gx;
   *ty = r % gy;
   *tz = r / gy;
-}
-
-// v - ring pixel for the 16 positions of the Bresenham circle (OpenCV order) around tile position (ly,lx)
-__device__ __forceinline__ void fast_ring_diffs(const uint8_t (*t)[80], int ly, int lx, int* d) {
-  const int v = t[ly][lx];
-  d[0] = v - t[ly + 3][lx];      d[1] = v - t[ly + 3][lx + 1];  d[2] = v - t[ly + 2][lx + 2];  d[3] = v - t[ly + 1][lx + 3];
-  d[4] = v - t[ly][lx + 3];      d[5] = v - t[ly - 1][lx + 3];  d[6] = v - t[ly - 2][lx + 2];  d[7] = v - t[ly - 3][lx + 1];
-  d[8] = v - t[ly - 3][lx];      d[9] = v - t[ly - 3][lx - 1];  d[10] = v - t[ly - 2][lx - 2]; d[11] = v - t[ly - 1][lx - 3];
-  d[12] = v - t[ly][lx - 3];     d[13] = v - t[ly + 1][lx - 3]; d[14] = v - t[ly + 2][lx - 2]; d[15] = v - t[ly + 3][lx - 1];
-}
-// cornerScore<16> of a pixel known to be a corner: max(thr, max_arcs min d, -min_arcs max d) - 1
-__device__ __forceinline__ int fast_corner_score(const int* d, int thr) {
-  int mn2[16], mx2[16], mn4[16], mx4[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
-#pragma unroll
-  for (int k = 0; k < 16; ++k) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
-  int A = -1000, Bm = 1000;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int mn9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
-    const int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
-    A = max(A, mn9);
-    Bm = min(Bm, mx9);
-  }
-  const int a0 = max(thr, A);
-  const int b0 = min(-a0, Bm);
-  return -b0 - 1;
-}
-// 9-contiguous-of-16 test on wave-wide predicate masks: bit l of m[k] = "ring pixel k of lane l's pixel passes".
-// Pure 64-bit scalar logic (SALU), no per-lane bit assembly.
-__device__ __forceinline__ unsigned long long arc9_any(const unsigned long long* m) {
-  unsigned long long r1[16], r2[16], r4[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) r1[k] = m[k] & m[(k + 1) & 15];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) r2[k] = r1[k] & r1[(k + 2) & 15];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) r4[k] = r2[k] & r2[(k + 4) & 15];
-  unsigned long long any = 0;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) any |= r4[k] & m[(k + 8) & 15];
-  return any;
 }
 
 // threshold of the detector region whose FAST-valid area (ROI minus 3 px) contains (x,y), or -1
