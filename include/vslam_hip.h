@@ -259,6 +259,15 @@ int vslam_align_points(vslam_ctx* ctx, int32_t n, const double* moving, const do
                        double T_out[12], double* chi, uint8_t* inlier, int32_t* n_inliers,
                        double* total_error, int32_t* iterations, double H_out[36]);
 
+/* UVDAligner (RGB-D mode, uvd_aligner.cpp:72-232) on caller-provided correspondences: moving n*3 (previous camera
+ * coordinates), fixed n*3 (u, v, depth), omega_uv n and omega_depth n (the diagonal of the information matrix:
+ * uvd_aligner.cpp:28-61 sets (1 + landmark updates) and 10x that, or 0 for unreliable depth), weight n (translation
+ * weight).  Same solver, damping, convergence rule and outputs as vslam_align_points; inlier-only rounds need more
+ * than 100 inliers (uvd_aligner.cpp:211).  SURVEY.md 8f row 4, first half. */
+int vslam_align_points_uvd(vslam_ctx* ctx, int32_t n, const double* moving, const double* fixed_uvd,
+                           const double* omega_uv, const double* omega_depth, const double* weight,
+                           const double T_init[12], double T_out[12], double* chi, uint8_t* inlier,
+                           int32_t* n_inliers, double* total_error, int32_t* iterations, double H_out[36]);
 /* StereoFramePointGenerator::track (stereo_framepoint_generator.cpp:464-681, with
  * IntensityFeatureMatcher::getMatchingFeatureInRectangularRegion, intensity_feature_matcher.cpp:81-148) on
  * caller-provided data, for known-answer tests: nP previous points (left-camera coordinates n*3, left / right

@@ -371,6 +371,7 @@ struct AlignerIO {
   int n_inliers = 0, n_outliers = 0, iterations = 0, converged = 0;
   real total_error = 0;
   real H[36];
+  bool uvd = false;           /* UVDAligner: fixed = (u, v, depth, depth information), omega = u/v information */
 };
 
 struct AlignerParams {
@@ -440,10 +441,64 @@ void aligner_linearize(const AlignerParams& P, AlignerIO& io, bool ignore_outlie
   io.n_outliers = io.n - io.n_inliers;
 }
 
+/* UVDAligner::linearize (uvd_aligner.cpp:72-171): residual (u, v, depth), diagonal information */
+void aligner_linearize_uvd(const AlignerParams& P, AlignerIO& io, bool ignore_outliers, real H[36], real b[6]) {
+  std::memset(H, 0, 36 * sizeof(real));
+  std::memset(b, 0, 6 * sizeof(real));
+  io.n_inliers = 0;
+  io.total_error = 0;
+  for (int u = 0; u < io.n; ++u) {
+    io.errors[u] = -1;
+    io.inliers[u] = 0;
+    real w_uv = io.omega[u], w_d = io.fixed[4 * u + 3];
+    real p[3];
+    tf_apply(io.T, &io.moving[3 * u], p);
+    if (p[2] <= P.min_depth) continue;                                                       /* :91 */
+    real a[3];
+    mat3_mul_vec(P.K, p, a);
+    const real uu = a[0] / a[2], vv = a[1] / a[2];
+    if (uu < 0 || uu > P.cols || vv < 0 || vv > P.rows) continue;                            /* :105-108 */
+    const real e[3] = {uu - io.fixed[4 * u + 0], vv - io.fixed[4 * u + 1], p[2] - io.fixed[4 * u + 2]};
+    const real chi = ((e[0] * w_uv) * e[0] + (e[1] * w_uv) * e[1]) + (e[2] * w_d) * e[2];   /* e^T Omega e, Omega diagonal */
+    io.errors[u] = chi;
+    if (chi > P.kernel) {
+      if (ignore_outliers) continue;
+      const real sc = P.kernel / chi;
+      w_uv *= sc; w_d *= sc;
+    } else {
+      io.inliers[u] = 1;
+      ++io.n_inliers;
+    }
+    io.total_error += chi;
+    const real w = io.weight[u];
+    real Jt[3][6] = {{w, 0, 0, 0, 2 * p[2], -2 * p[1]},
+                     {0, w, 0, -2 * p[2], 0, 2 * p[0]},
+                     {0, 0, w, 2 * p[1], -2 * p[0], 0}};
+    real KJ[3][6];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 6; ++j)
+        KJ[i][j] = (P.K[3 * i + 0] * Jt[0][j] + P.K[3 * i + 1] * Jt[1][j]) + P.K[3 * i + 2] * Jt[2][j];
+    const real iz = 1 / p[2], iz2 = iz * iz;                                                 /* :140-141 */
+    real J[3][6];
+    for (int j = 0; j < 6; ++j) {
+      J[0][j] = iz * KJ[0][j] + (-a[0] * iz2) * KJ[2][j];
+      J[1][j] = iz * KJ[1][j] + (-a[1] * iz2) * KJ[2][j];
+      J[2][j] = KJ[2][j];
+    }
+    for (int r = 0; r < 6; ++r) {
+      for (int c = 0; c < 6; ++c)
+        H[6 * r + c] += w_uv * (J[0][r] * J[0][c] + J[1][r] * J[1][c]) + w_d * (J[2][r] * J[2][c]);
+      b[r] += w_uv * (J[0][r] * e[0] + J[1][r] * e[1]) + w_d * (J[2][r] * e[2]);
+    }
+  }
+  io.n_outliers = io.n - io.n_inliers;
+}
+
 /* oneRound (:190-207) */
 void aligner_one_round(const AlignerParams& P, AlignerIO& io, bool ignore_outliers) {
   real b[6];
-  aligner_linearize(P, io, ignore_outliers, io.H, b);
+  if (io.uvd) aligner_linearize_uvd(P, io, ignore_outliers, io.H, b);
+  else aligner_linearize(P, io, ignore_outliers, io.H, b);
   for (int i = 0; i < 6; ++i) io.H[7 * i] += P.damping * io.n;
   real nb[6], dx[6];
   for (int i = 0; i < 6; ++i) nb[i] = -b[i];
@@ -476,7 +531,7 @@ void aligner_converge(const AlignerParams& P, AlignerIO& io) {
     aligner_one_round(P, io, false);
     if (P.delta > std::fabs(total_error_previous - io.total_error)) {
       total_error_previous = io.total_error;
-      if (io.n_inliers > P.min_inliers && io.n_inliers > io.n_outliers) {
+      if (io.n_inliers > (io.uvd ? 100 : P.min_inliers) && io.n_inliers > io.n_outliers) {   /* uvd_aligner.cpp:211 */
         for (int it2 = 0; it2 < P.max_it; ++it2) {
           aligner_one_round(P, io, true);
           if (std::fabs(total_error_previous - io.total_error) < P.delta) {
@@ -1339,6 +1394,30 @@ ORC_API int orc_align_points(orc_ctx* c, int32_t n, const double* moving, const 
   io.n = n;
   io.moving.assign(moving, moving + 3 * n); io.fixed.assign(fixed, fixed + 4 * n);
   io.omega.assign(omega, omega + n); io.weight.assign(weight, weight + n);
+  std::memcpy(io.T.m, T_init, sizeof(double) * 12);
+  AlignerParams P = c->streams[0].aligner_params();
+  aligner_converge(P, io);
+  if (T_out) std::memcpy(T_out, io.T.m, sizeof(double) * 12);
+  for (int i = 0; i < n; ++i) { if (chi) chi[i] = io.errors[i]; if (inlier) inlier[i] = io.inliers[i]; }
+  if (n_inliers) *n_inliers = io.n_inliers;
+  if (total_error) *total_error = io.total_error;
+  if (iterations) *iterations = io.iterations;
+  if (H_out) std::memcpy(H_out, io.H, sizeof(double) * 36);
+  return VSLAM_OK;
+}
+/* UVDAligner on caller-provided correspondences (uvd_aligner.cpp): fixed n*3 = (u, v, depth) */
+ORC_API int orc_align_points_uvd(orc_ctx* c, int32_t n, const double* moving, const double* fixed_uvd, const double* omega_uv,
+                                 const double* omega_depth, const double* weight, const double T_init[12], double T_out[12],
+                                 double* chi, uint8_t* inlier, int32_t* n_inliers, double* total_error, int32_t* iterations,
+                                 double H_out[36]) {
+  if (!c || c->streams.empty() || n < 0) return VSLAM_ERR_INVALID;
+  AlignerIO io;
+  io.uvd = true;
+  io.n = n;
+  io.moving.assign(moving, moving + 3 * n);
+  io.fixed.resize((size_t)4 * n);
+  for (int i = 0; i < n; ++i) { for (int k = 0; k < 3; ++k) io.fixed[4 * i + k] = fixed_uvd[3 * i + k]; io.fixed[4 * i + 3] = omega_depth[i]; }
+  io.omega.assign(omega_uv, omega_uv + n); io.weight.assign(weight, weight + n);
   std::memcpy(io.T.m, T_init, sizeof(double) * 12);
   AlignerParams P = c->streams[0].aligner_params();
   aligner_converge(P, io);

@@ -348,6 +348,100 @@ def gen_aligner(rng):
     np.savez_compressed(os.path.join(HERE, "aligner.npz"), **out)
 
 
+# ---- UVDAligner (RGB-D mode, uvd_aligner.cpp) ---------------------------------------------------------------------
+def linearize_uvd(T, moving, fixed, w_uv, w_d, weight, ignore_outliers, kernel=4.0, min_depth=0.1, rows=376, cols=1241):
+    H = np.zeros((6, 6)); b = np.zeros(6); E = 0.0; ninl = 0
+    n = len(moving)
+    chi_out = -np.ones(n); inl = np.zeros(n, np.uint8)
+    for u in range(n):
+        p = T[:3, :3] @ moving[u] + T[:3, 3]
+        if p[2] <= min_depth:
+            continue
+        a = KITTI_K @ p
+        uv = a[:2] / a[2]
+        if uv[0] < 0 or uv[0] > cols or uv[1] < 0 or uv[1] > rows:
+            continue
+        e = np.array([uv[0] - fixed[u, 0], uv[1] - fixed[u, 1], p[2] - fixed[u, 2]])
+        Om = np.diag([w_uv[u], w_uv[u], w_d[u]])
+        chi = e @ Om @ e
+        chi_out[u] = chi
+        if chi > kernel:
+            if ignore_outliers:
+                continue
+            Om = Om * (kernel / chi)
+        else:
+            inl[u] = 1
+            ninl += 1
+        E += chi
+        Jt = np.hstack([weight[u] * np.eye(3), -2 * skew(p)])
+        iz = 1 / p[2]
+        Jp = np.array([[iz, 0, -a[0] * iz * iz], [0, iz, -a[1] * iz * iz], [0, 0, 1.0]])
+        J = Jp @ KITTI_K @ Jt
+        H += J.T @ Om @ J
+        b += J.T @ Om @ e
+    return H, b, E, ninl, chi_out, inl
+
+
+def converge_uvd(T, moving, fixed, w_uv, w_d, weight, damping=5.0, delta=1e-3, max_it=1000):
+    its = 0
+    Eprev = 0.0
+
+    def one_round(T, ignore):
+        H, b, E, ninl, chi, inl = linearize_uvd(T, moving, fixed, w_uv, w_d, weight, ignore)
+        H = H + damping * len(moving) * np.eye(6)
+        dx = np.linalg.solve(H, -b)
+        T = v2t(dx) @ T
+        R = T[:3, :3]
+        T[:3, :3] = R - 0.5 * R @ (R.T @ R - np.eye(3))
+        return T, H, E, ninl, chi, inl
+    for it in range(max_it):
+        T, H, E, ninl, chi, inl = one_round(T, False); its += 1
+        if delta > abs(Eprev - E):
+            Eprev = E
+            if ninl > 100 and ninl > len(moving) - ninl:          # uvd_aligner.cpp:211
+                for it2 in range(max_it):
+                    T, H, E, ninl, chi, inl = one_round(T, True); its += 1
+                    conv = abs(Eprev - E) < delta
+                    Eprev = E
+                    if conv:
+                        break
+            break
+        Eprev = E
+    return T, H, E, ninl, chi, inl, its
+
+
+def gen_aligner_uvd(rng):
+    out = {}
+    for name, n, noise_px, noise_d, outlier_frac in (("m80_clean", 80, 0.0, 0.0, 0.0), ("m400_noisy", 400, 0.4, 0.02, 0.1)):
+        X = np.stack([rng.uniform(-3, 3, n), rng.uniform(-1.2, 1.2, n), rng.uniform(0.8, 8.0, n)], 1)
+        vtrue = np.array([0.01, -0.005, -0.06, 0.002, 0.01, -0.001])
+        Ttrue = v2t(vtrue)
+        P = (Ttrue[:3, :3] @ X.T).T + Ttrue[:3, 3]
+        a = (KITTI_K @ P.T).T
+        fixed = np.hstack([a[:, :2] / a[:, 2:3], P[:, 2:3]])
+        if noise_px > 0:
+            fixed[:, :2] += rng.normal(0, noise_px, (n, 2))
+            fixed[:, 2] += rng.normal(0, noise_d, n)
+        nout = int(outlier_frac * n)
+        if nout:
+            fixed[:nout, :2] += rng.uniform(-25, 25, (nout, 2))
+        X[-1] = [0.0, 0.0, -2.0]          # behind the camera
+        X[-2] = [40.0, 0.0, 3.0]          # projects outside the image
+        upd = rng.integers(0, 12, n)
+        w_uv = np.where(rng.random(n) < 0.5, 1.0, 1.0 + upd)        # (1 + numberOfUpdates) for landmarks (:44)
+        unreliable = rng.random(n) < 0.15
+        w_d = np.where(unreliable, 0.0, 10.0 * w_uv)                # :52-61
+        weight = np.where(unreliable, 0.0, np.minimum(5.0 / P[:, 2], 1.0))
+        T0 = np.eye(4)
+        H, b, E, ninl, chi, inl = linearize_uvd(T0, X, fixed, w_uv, w_d, weight, False)
+        Tc, Hc, Ec, ninlc, chic, inlc, its = converge_uvd(T0.copy(), X, fixed, w_uv, w_d, weight)
+        out.update({name + "_moving": X, name + "_fixed": fixed, name + "_w_uv": w_uv, name + "_w_d": w_d, name + "_weight": weight,
+                    name + "_E0": E, name + "_ninl0": np.int32(ninl), name + "_T": Tc[:3, :], name + "_ninl": np.int32(ninlc),
+                    name + "_E": Ec, name + "_its": np.int32(its), name + "_inl": inlc, name + "_chi": chic,
+                    name + "_Ttrue": Ttrue[:3, :]})
+    np.savez_compressed(os.path.join(HERE, "aligner_uvd.npz"), **out)
+
+
 # ---------------------------------------------------------------------------------------------
 def stereo_sweep(rcL, dL, rcR, dR, tau, min_disp, offsets):
     """compute() restated row by row (stereo_framepoint_generator.cpp:278-426): rows are independent,
@@ -599,6 +693,7 @@ def main():
     gen_aligner(rng)
     gen_stereo(rng)
     gen_track(np.random.default_rng(20261004))   # own stream: added later, the fixtures above stay byte-identical
+    gen_aligner_uvd(np.random.default_rng(20261005))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

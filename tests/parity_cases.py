@@ -70,3 +70,23 @@ def check_aligner(api, g, rtol_pose=1e-9):
     assert np.linalg.norm(r["T"] - Tt) / np.linalg.norm(Tt) < 1e-4
     # skipped points (behind the camera / outside the image) keep error -1 and count as outliers
     assert r["chi"][-1] == -1 and r["chi"][-2] == -1 and r["inlier"][-1] == 0
+
+
+def check_aligner_uvd(api, g, rtol_pose=1e-9):
+    """UVDAligner (RGB-D residual u, v, depth) on caller-provided correspondences against the numpy restatement."""
+    for name in ("m80_clean", "m400_noisy"):
+        T0 = np.eye(4)[:3]
+        r = api.align_points_uvd(g[name + "_moving"], g[name + "_fixed"], g[name + "_w_uv"], g[name + "_w_d"], g[name + "_weight"], T0)
+        Tg = g[name + "_T"]
+        rel = np.linalg.norm(r["T"] - Tg) / np.linalg.norm(Tg)
+        assert rel <= rtol_pose, (name, rel)
+        assert r["n_inliers"] == int(g[name + "_ninl"]), name
+        np.testing.assert_array_equal(r["inlier"], g[name + "_inl"], err_msg=name)
+        assert r["iterations"] == int(g[name + "_its"]), name
+        np.testing.assert_allclose(r["total_error"], float(g[name + "_E"]), rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(r["chi"], g[name + "_chi"], rtol=1e-7, atol=1e-9)
+        assert np.allclose(r["H"], r["H"].T, rtol=1e-12, atol=1e-9)
+        assert r["chi"][-1] == -1 and r["chi"][-2] == -1 and r["inlier"][-1] == 0   # behind the camera / outside the image
+    Tt = g["m80_clean_Ttrue"]
+    r = api.align_points_uvd(g["m80_clean_moving"], g["m80_clean_fixed"], np.ones(80), 10 * np.ones(80), np.ones(80), np.eye(4)[:3])
+    assert np.linalg.norm(r["T"] - Tt) / np.linalg.norm(Tt) < 1e-3

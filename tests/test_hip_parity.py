@@ -42,6 +42,10 @@ def test_aligner_golden(gpu, golden):
     pc.check_aligner(gpu, golden["aligner"], rtol_pose=1e-7)
 
 
+def test_aligner_uvd_golden(gpu, golden):
+    pc.check_aligner_uvd(gpu, golden["aligner_uvd"], rtol_pose=1e-7)
+
+
 def test_track_golden(golden):
     """vslam_track_match (k_track_candidates + the order-exact resolution of the frame kernel) against the fixture of
     the independent numpy restatement of StereoFramePointGenerator::track: exact tuples, exact lost list."""

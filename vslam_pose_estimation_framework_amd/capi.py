@@ -272,6 +272,28 @@ class CApi(object):
                     iterations=its.value, H=H.reshape(6, 6))
 
 
+    def align_points_uvd(self, moving, fixed_uvd, omega_uv, omega_depth, weight, T_init):
+        moving = np.ascontiguousarray(moving, np.float64)
+        fixed = np.ascontiguousarray(fixed_uvd, np.float64)
+        ouv = np.ascontiguousarray(omega_uv, np.float64)
+        od = np.ascontiguousarray(omega_depth, np.float64)
+        weight = np.ascontiguousarray(weight, np.float64)
+        T_init = np.ascontiguousarray(T_init, np.float64).reshape(12)
+        n = moving.shape[0]
+        T = np.zeros(12, np.float64)
+        chi = np.zeros(n, np.float64)
+        inl = np.zeros(n, np.uint8)
+        ninl, its = C.c_int32(), C.c_int32()
+        err = C.c_double()
+        H = np.zeros(36, np.float64)
+        self.check(self.fn("align_points_uvd")(self.ctx, C.c_int32(n), _p(moving, C.c_double), _p(fixed, C.c_double),
+                                               _p(ouv, C.c_double), _p(od, C.c_double), _p(weight, C.c_double),
+                                               _p(T_init, C.c_double), _p(T, C.c_double), _p(chi, C.c_double),
+                                               _p(inl, C.c_uint8), C.byref(ninl), C.byref(err), C.byref(its),
+                                               _p(H, C.c_double)))
+        return dict(T=T.reshape(3, 4), chi=chi, inlier=inl, n_inliers=ninl.value, total_error=err.value,
+                    iterations=its.value, H=H.reshape(6, 6))
+
     def track_match(self, T, d, tau_track, tau_tri, by_appearance, cam, prev_desc_left, prev_desc_right, epi,
                     rc_left, desc_left, rc_right, desc_right):
         """StereoFramePointGenerator::track on caller-provided data (known-answer tests): returns (tracked [n][4], lost)."""

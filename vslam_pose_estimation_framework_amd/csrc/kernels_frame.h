@@ -724,6 +724,65 @@ __device__ __forceinline__ void align_point(const DevCfg& c, const double* T, co
   *inl_out = inl_w;
 }
 
+// UVDAligner::linearize body (uvd_aligner.cpp:78-171), RGB-D mode: residual (u, v, depth), diagonal information
+// (P.om, P.om, P.f[3]), measurement (P.f[0], P.f[1], P.f[2]); same accumulator layout as align_point.
+__device__ __forceinline__ void align_point_uvd(const DevCfg& c, const double* T, const AlignPoint& P, bool ignore_outliers,
+                                                double* acc, double* chi_out, uint8_t* inl_out) {
+  const double* K = c.c.K;
+  double chi_w = -1;
+  uint8_t inl_w = 0;
+  double w_uv = P.om, w_d = P.f[3];
+  double p[3];
+  tf_apply(T, P.m, p);
+  bool skip = p[2] <= c.c.minimum_depth_meters;
+  double a[3];
+  mat3_mul_vec(K, p, a);
+  const double u = a[0] / a[2], v = a[1] / a[2];
+  if (!skip && (u < 0 || u > c.c.cols || v < 0 || v > c.c.rows)) skip = true;
+  if (!skip) {
+    const double e[3] = {u - P.f[0], v - P.f[1], p[2] - P.f[2]};
+    const double chi = ((e[0] * w_uv) * e[0] + (e[1] * w_uv) * e[1]) + (e[2] * w_d) * e[2];
+    chi_w = chi;
+    bool use = true;
+    if (chi > c.c.aligner_maximum_error_kernel) {
+      if (ignore_outliers) use = false;
+      else { const double sc = c.c.aligner_maximum_error_kernel / chi; w_uv *= sc; w_d *= sc; }
+    } else {
+      inl_w = 1;
+      acc[28] += 1.0;
+    }
+    if (use) {
+      acc[27] += chi;
+      const double wt = P.wt;
+      const double Jt[3][6] = {{wt, 0, 0, 0, 2 * p[2], -2 * p[1]}, {0, wt, 0, -2 * p[2], 0, 2 * p[0]}, {0, 0, wt, 2 * p[1], -2 * p[0], 0}};
+      double KJ[3][6];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) KJ[i][j] = (K[3 * i] * Jt[0][j] + K[3 * i + 1] * Jt[1][j]) + K[3 * i + 2] * Jt[2][j];
+      const double iz = 1 / p[2], iz2 = iz * iz;
+      const double j0 = -a[0] * iz2, j1 = -a[1] * iz2;
+      double J[3][6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        J[0][j] = iz * KJ[0][j] + j0 * KJ[2][j];
+        J[1][j] = iz * KJ[1][j] + j1 * KJ[2][j];
+        J[2][j] = KJ[2][j];
+      }
+      int q = 0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+#pragma unroll
+        for (int cc = r; cc < 6; ++cc) acc[q++] += w_uv * (J[0][r] * J[0][cc] + J[1][r] * J[1][cc]) + w_d * (J[2][r] * J[2][cc]);
+      }
+#pragma unroll
+      for (int r = 0; r < 6; ++r) acc[21 + r] += w_uv * (J[0][r] * e[0] + J[1][r] * e[1]) + w_d * (J[2][r] * e[2]);
+    }
+  }
+  *chi_out = chi_w;
+  *inl_out = inl_w;
+}
+
 __device__ __forceinline__ void load_align_point(const DevCfg& c, const DevBuf& b, int s, int u, AlignPoint& P) {
   const double* moving = b.al_moving + (size_t)s * c.MAXP * 3;
   const double* fixed = b.al_fixed + (size_t)s * c.MAXP * 4;
@@ -733,6 +792,7 @@ __device__ __forceinline__ void load_align_point(const DevCfg& c, const DevBuf& 
   P.wt = (b.al_weight + (size_t)s * c.MAXP)[u];
 }
 
+template <bool UVD>
 __device__ __forceinline__ void wg_one_round(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int n, bool ignore_outliers,
                              const AlignPoint* cache, double* chi_reg, uint8_t* inl_reg) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -747,12 +807,16 @@ __device__ __forceinline__ void wg_one_round(const DevCfg& c, const DevBuf& b, i
 #pragma unroll
   for (int q = 0; q < VS_ALCACHE; ++q) {
     const int u = tid + q * VS_WG;
-    if (u < n) align_point(c, T, cache[q], ignore_outliers, acc, &chi_reg[q], &inl_reg[q]);   // stored after the last round
+    if (u < n) {   // error / inlier flag are stored after the last round
+      if constexpr (UVD) align_point_uvd(c, T, cache[q], ignore_outliers, acc, &chi_reg[q], &inl_reg[q]);
+      else align_point(c, T, cache[q], ignore_outliers, acc, &chi_reg[q], &inl_reg[q]);
+    }
   }
   for (int u = tid + VS_ALCACHE * VS_WG; u < n; u += VS_WG) {
     AlignPoint P;
     load_align_point(c, b, s, u, P);
-    align_point(c, T, P, ignore_outliers, acc, chi_o + u, inl_o + u);
+    if constexpr (UVD) align_point_uvd(c, T, P, ignore_outliers, acc, chi_o + u, inl_o + u);
+    else align_point(c, T, P, ignore_outliers, acc, chi_o + u, inl_o + u);
   }
   // deterministic reduction: DPP sums inside each 16-lane row, then a fixed-order sum of the 4 row totals of
   // every wave that owns measurements (w*64 < n); the other waves contribute exact zeros.
@@ -819,6 +883,7 @@ __device__ __forceinline__ void wg_one_round(const DevCfg& c, const DevBuf& b, i
 }
 
 // converge (:210-264) on the aligner SoA of stream s (n measurements), starting from T_init
+template <bool UVD = false>
 __device__ __forceinline__ void wg_align_converge(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int n, const double* T_init) {
   const int tid = threadIdx.x;
   __syncthreads();
@@ -845,13 +910,16 @@ __device__ __forceinline__ void wg_align_converge(const DevCfg& c, const DevBuf&
   int it = 0, it2 = 0;
   bool refine = false;
   while (true) {
-    wg_one_round(c, b, s, sh, n, refine, cache, chi_reg, inl_reg);
+    wg_one_round<UVD>(c, b, s, sh, n, refine, cache, chi_reg, inl_reg);
     const double E = sh.E;
     if (!refine) {
       ++it;
       if (delta > fabs(e_prev - E)) {
         e_prev = E;
-        if (sh.inl > c.c.aligner_minimum_number_of_inliers && sh.inl > sh.outl && max_it > 0) { refine = true; continue; }
+        // inlier-only rounds: StereoUVAligner asks for more than the configured minimum (stereouv_aligner.cpp:224),
+        // UVDAligner for more than a hard-wired 100 (uvd_aligner.cpp:211)
+        const int min_inl = UVD ? 100 : c.c.aligner_minimum_number_of_inliers;
+        if (sh.inl > min_inl && sh.inl > sh.outl && max_it > 0) { refine = true; continue; }
         if (tid == 0) sh.conv = 1;
         break;
       }
@@ -907,12 +975,13 @@ __device__ __forceinline__ void wg_align(const DevCfg& c, const DevBuf& b, int s
   wg_align_converge(c, b, s, sh, n, T_init);
 }
 
-// stand-alone aligner on caller-provided correspondences (vslam_align_points)
+// stand-alone aligner on caller-provided correspondences (vslam_align_points, vslam_align_points_uvd)
+template <bool UVD>
 __global__ __launch_bounds__(VS_WG) void k_align_points(const DevCfg c, const DevBuf b, int n, const double* T_init) {
   __shared__ FrameShared sh;
   double T0[12];
   for (int k = 0; k < 12; ++k) T0[k] = T_init[k];
-  wg_align_converge(c, b, 0, sh, n, T0);
+  wg_align_converge<UVD>(c, b, 0, sh, n, T0);
   if (threadIdx.x == 0) {
     StreamState& st = b.st[0];
     st.al_n = n; st.al_inliers = sh.inl; st.al_outliers = sh.outl; st.al_iterations = sh.its; st.al_converged = sh.conv;

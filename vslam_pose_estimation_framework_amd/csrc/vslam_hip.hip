@@ -682,10 +682,9 @@ VS_API int vslam_knn2(vslam_ctx* c, int norm, int32_t nq, const uint8_t* q, int3
   if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   return VSLAM_OK;
 }
-VS_API int vslam_align_points(vslam_ctx* c, int32_t n, const double* moving, const double* fixed, const double* omega,
-                              const double* weight, const double T_init[12], double T_out[12], double* chi, uint8_t* inlier,
-                              int32_t* n_inliers, double* total_error, int32_t* iterations, double H_out[36]) {
-  if (!c || n < 0 || !moving || !fixed || !omega || !weight || !T_init) return VSLAM_ERR_INVALID;
+static int align_points_impl(vslam_ctx* c, bool uvd, int32_t n, const double* moving, const double* fixed4, const double* omega,
+                             const double* weight, const double T_init[12], double T_out[12], double* chi, uint8_t* inlier,
+                             int32_t* n_inliers, double* total_error, int32_t* iterations, double H_out[36]) {
   vslam_ctx* t = nullptr;
   vslam_config cfg = c->cfg.c;
   cfg.max_points = std::max(64, n); cfg.max_keypoints = 64; cfg.max_history_frames = 2;
@@ -695,11 +694,12 @@ VS_API int vslam_align_points(vslam_ctx* c, int32_t n, const double* moving, con
   hipError_t e = dalloc(t, &dT, 12);
   if (e == hipSuccess) e = hipMemcpyAsync(dT, T_init, 12 * sizeof(double), hipMemcpyHostToDevice, t->stream);
   if (e == hipSuccess && n) e = hipMemcpyAsync(t->buf.al_moving, moving, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, t->stream);
-  if (e == hipSuccess && n) e = hipMemcpyAsync(t->buf.al_fixed, fixed, (size_t)n * 4 * sizeof(double), hipMemcpyHostToDevice, t->stream);
+  if (e == hipSuccess && n) e = hipMemcpyAsync(t->buf.al_fixed, fixed4, (size_t)n * 4 * sizeof(double), hipMemcpyHostToDevice, t->stream);
   if (e == hipSuccess && n) e = hipMemcpyAsync(t->buf.al_omega, omega, (size_t)n * sizeof(double), hipMemcpyHostToDevice, t->stream);
   if (e == hipSuccess && n) e = hipMemcpyAsync(t->buf.al_weight, weight, (size_t)n * sizeof(double), hipMemcpyHostToDevice, t->stream);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_align_points, dim3(1), dim3(VS_WG), 0, t->stream, t->cfg, t->buf, n, dT);
+    if (uvd) hipLaunchKernelGGL(k_align_points<true>, dim3(1), dim3(VS_WG), 0, t->stream, t->cfg, t->buf, n, dT);
+    else hipLaunchKernelGGL(k_align_points<false>, dim3(1), dim3(VS_WG), 0, t->stream, t->cfg, t->buf, n, dT);
     StreamState st;
     e = hipMemcpyAsync(&st, t->buf.st, sizeof st, hipMemcpyDeviceToHost, t->stream);
     if (e == hipSuccess && chi && n) e = hipMemcpyAsync(chi, t->buf.al_chi, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, t->stream);
@@ -716,6 +716,21 @@ VS_API int vslam_align_points(vslam_ctx* c, int32_t n, const double* moving, con
   if (e != hipSuccess) rc = fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   vslam_destroy(t);
   return rc;
+}
+VS_API int vslam_align_points(vslam_ctx* c, int32_t n, const double* moving, const double* fixed, const double* omega,
+                              const double* weight, const double T_init[12], double T_out[12], double* chi, uint8_t* inlier,
+                              int32_t* n_inliers, double* total_error, int32_t* iterations, double H_out[36]) {
+  if (!c || n < 0 || !moving || !fixed || !omega || !weight || !T_init) return VSLAM_ERR_INVALID;
+  return align_points_impl(c, false, n, moving, fixed, omega, weight, T_init, T_out, chi, inlier, n_inliers, total_error, iterations, H_out);
+}
+VS_API int vslam_align_points_uvd(vslam_ctx* c, int32_t n, const double* moving, const double* fixed_uvd, const double* omega_uv,
+                                  const double* omega_depth, const double* weight, const double T_init[12], double T_out[12],
+                                  double* chi, uint8_t* inlier, int32_t* n_inliers, double* total_error, int32_t* iterations,
+                                  double H_out[36]) {
+  if (!c || n < 0 || !moving || !fixed_uvd || !omega_uv || !omega_depth || !weight || !T_init) return VSLAM_ERR_INVALID;
+  std::vector<double> f4((size_t)std::max(n, 1) * 4);   // (u, v, depth, depth information) per measurement
+  for (int i = 0; i < n; ++i) { f4[4 * (size_t)i] = fixed_uvd[3 * (size_t)i]; f4[4 * (size_t)i + 1] = fixed_uvd[3 * (size_t)i + 1]; f4[4 * (size_t)i + 2] = fixed_uvd[3 * (size_t)i + 2]; f4[4 * (size_t)i + 3] = omega_depth[i]; }
+  return align_points_impl(c, true, n, moving, f4.data(), omega_uv, weight, T_init, T_out, chi, inlier, n_inliers, total_error, iterations, H_out);
 }
 
 // features of one image of scratch context t as the image pipeline would leave them: row-major order, coordinates,
