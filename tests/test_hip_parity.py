@@ -197,6 +197,30 @@ def test_pipeline_parity_long_run_history_ring():
     run_sequence(Oracle, dict(scale=0.6), 100, cfg_edit=edit)
 
 
+def test_pipeline_parity_large_image():
+    # 1613 x 489 (scale 1.3): four mask passes in k_emit, rows with more than 16 keypoints (stereo windows slide), more
+    # than 4000 keypoints per image, tiles of every border class
+    from _oracle import Oracle
+
+    def edit(cfg):
+        cfg.max_keypoints, cfg.max_points = 16384, 8192
+    run_sequence(Oracle, dict(scale=1.3), 5, cfg_edit=edit)
+
+
+@pytest.mark.parametrize("seed,scale,bin_px,epi,binning,recovery", [
+    (31, 0.45, 11, 0, 1, 1), (32, 0.7, 22, 3, 1, 1), (33, 0.55, 15, 1, 0, 1), (34, 0.5, 9, 2, 1, 0), (35, 0.62, 30, 0, 0, 0)])
+def test_pipeline_parity_config_sweep(seed, scale, bin_px, epi, binning, recovery):
+    # different scenes, image sizes, bin grids, epipolar search depths, with / without binning and landmark recovery
+    from _oracle import Oracle
+
+    def edit(cfg):
+        cfg.bin_size_pixels = bin_px
+        cfg.maximum_epipolar_search_offset_pixels = epi
+        cfg.enable_keypoint_binning = binning
+        cfg.enable_landmark_recovery = recovery
+    run_sequence(Oracle, dict(scale=scale), 9, cfg_edit=edit, seeds=[seed])
+
+
 def test_pipeline_parity_standstill_and_fallback():
     # zero motion: the aligner result is below the movement thresholds -> _fallbackEstimate path
     from _oracle import Oracle
