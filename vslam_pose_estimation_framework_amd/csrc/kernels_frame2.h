@@ -821,7 +821,15 @@ __device__ __forceinline__ void set_pose(const DevCfg& c, const DevBuf& b, int s
 //   [k_update_landmarks] landmark creation / refinement, one thread per framepoint; [k_stereo_dist] L-R distances
 //   phase 2  status switch, stereo sweep + binning + emission, report
 // phase < 0 runs everything in one launch (the wide steps inside the workgroup).
-__global__ VS_FRAME_BOUNDS void k_frame(const DevCfg c, const DevBuf b, int phase) {
+// The configuration and the buffer table arrive as pointers into the CONSTANT address space (device-resident copies the
+// context uploads once): passed by value, the ~60 pointers of DevBuf are all loaded in the prologue, cannot stay in the
+// 100-odd SGPRs and are parked in VGPR lanes — 1900 v_readlane instructions kernel-wide, ~190 in every aligner round.
+// Through the constant address space each use is a scalar load next to where it is needed.
+typedef const DevCfg __attribute__((address_space(4))) ConstDevCfg;
+typedef const DevBuf __attribute__((address_space(4))) ConstDevBuf;
+__global__ VS_FRAME_BOUNDS void k_frame(ConstDevCfg* cp, ConstDevBuf* bp, int phase) {
+  const DevCfg& c = *(const DevCfg*)cp;
+  const DevBuf& b = *(const DevBuf*)bp;
   __shared__ FrameShared sh;
   __shared__ __align__(16) unsigned char arena[VS_ARENA];
   const int s = b.s0 + blockIdx.x, tid = threadIdx.x;

@@ -35,6 +35,8 @@ struct vslam_ctx {
   std::vector<Group> groups;
   std::string err;
   std::vector<void*> allocs;
+  DevCfg* d_cfg = nullptr;            // device-resident copies read by k_frame through the constant address space
+  DevBuf* d_bufs = nullptr;           // [2 product sets][groups]
   uint8_t* upload[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [step parity][left/right]
   int up_stride = 0;
   size_t up_stream_stride = 0;
@@ -317,6 +319,22 @@ static int create_internal(const vslam_config* cfg, int device, int n_streams, v
   // score8 must read 0 where no corner was ever written only through the mask, box/mask are fully
   // rewritten every frame; nothing else needs initialisation besides the stream state.
   for (int i = 0; i < 6; ++i) (void)hipEventCreate(&c->ev[i]);
+  {
+    // the frame kernel's view of the configuration and of the buffer table (image pointers excluded: it never reads them)
+    const size_t G = c->groups.size();
+    std::vector<DevBuf> hb(2 * G);
+    for (int q = 0; q < 2; ++q) for (size_t g = 0; g < G; ++g) hb[q * G + g] = buf_set(c, q, c->groups[g].s0);
+    e = dalloc(c, &c->d_cfg, 1);
+    if (e == hipSuccess) e = dalloc(c, &c->d_bufs, 2 * G);
+    if (e == hipSuccess) e = hipMemcpy(c->d_cfg, &c->cfg, sizeof(DevCfg), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(c->d_bufs, hb.data(), sizeof(DevBuf) * 2 * G, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      std::string msg = std::string("vslam_create: device tables: ") + hipGetErrorString(e);
+      for (void* p : c->allocs) (void)hipFree(p);
+      delete c;
+      return fail(nullptr, VSLAM_ERR_HIP, msg);
+    }
+  }
   int rc = init_state(c);
   if (rc != VSLAM_OK) { g_create_error = c->err; for (void* p : c->allocs) (void)hipFree(p); delete c; return rc; }
   *out = c;
@@ -362,6 +380,9 @@ VS_API int vslam_set_hip_stream(vslam_ctx* c, void* s) {
   c->groups.push_back(q);
   c->stream = q.st_frm; c->stream_img = q.st_img;
   c->own_stream = false;
+  // the frame kernel's buffer table for the single group
+  DevBuf hb[2] = {buf_set(c, 0, 0), buf_set(c, 1, 0)};
+  HIP_TRY(c, hipMemcpy(c->d_bufs, hb, sizeof hb, hipMemcpyHostToDevice));
   return VSLAM_OK;
 }
 VS_API int vslam_synchronize(vslam_ctx* c) {
@@ -405,19 +426,22 @@ static int frame_done(vslam_ctx* c) {
   return VSLAM_OK;
 }
 static int launch_frame(vslam_ctx* c) {
+  size_t gi = 0;
   for (auto& g : c->groups) {
     const DevBuf bs = buf_set(c, c->last_set, g.s0);
+    ConstDevCfg* kc = (ConstDevCfg*)c->d_cfg;
+    ConstDevBuf* kb = (ConstDevBuf*)(c->d_bufs + c->last_set * c->groups.size() + gi++);
     const int gx = std::max(4, std::min(128, 2048 / std::max(g.n, 1)));
     { KernelTimer t(c, 3, g.st_frm); hipLaunchKernelGGL(k_track_candidates, dim3(gx, g.n), dim3(256), 0, g.st_frm, c->cfg, bs, -1); }
     if (!c->split) {
       KernelTimer t(c, 4, g.st_frm);
-      hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, c->cfg, bs, -1);
+      hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, kc, kb, -1);
     } else {
-      { KernelTimer t(c, 4, g.st_frm, false); hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, c->cfg, bs, 0); }
+      { KernelTimer t(c, 4, g.st_frm, false); hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, kc, kb, 0); }
       if (c->cfg.c.enable_landmark_recovery) { KernelTimer t(c, 5, g.st_frm); hipLaunchKernelGGL(k_recover_brief, dim3(std::max(4, std::min(64, 1024 / std::max(g.n, 1))), g.n), dim3(256), 0, g.st_frm, c->cfg, bs); }
-      { KernelTimer t(c, 4, g.st_frm, false); hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, c->cfg, bs, 1); }
+      { KernelTimer t(c, 4, g.st_frm, false); hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, kc, kb, 1); }
       { KernelTimer t(c, 6, g.st_frm); hipLaunchKernelGGL(k_update_landmarks, dim3((c->cfg.MAXP + 255) / 256, g.n), dim3(256), 0, g.st_frm, c->cfg, bs); }
-      { KernelTimer t(c, 4, g.st_frm); hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, c->cfg, bs, 2); }
+      { KernelTimer t(c, 4, g.st_frm); hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, kc, kb, 2); }
     }
   }
   HIP_TRY(c, hipGetLastError());
