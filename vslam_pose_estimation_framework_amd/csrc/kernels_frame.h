@@ -821,10 +821,28 @@ __device__ __forceinline__ void wg_one_round(const DevCfg& c, const DevBuf& b, i
   // deterministic reduction: DPP sums inside each 16-lane row, then a fixed-order sum of the 4 row totals of
   // every wave that owns measurements (w*64 < n); the other waves contribute exact zeros.
   if (w * 64 < n) {
+    // four accumulators per step: a DPP read of a VGPR needs two wait states after the VALU write, the other three
+    // chains fill them (one value at a time costs ~100 s_nop per round)
 #pragma unroll
-    for (int k = 0; k < NACC; ++k) {
-      const double v = dpp_row_sum(acc[k]);
-      if ((lane & 15) == 15) sh.red4[w][lane >> 4][k] = v;
+    for (int k0 = 0; k0 < NACC; k0 += 4) {
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = k0 + u < NACC ? acc[k0 + u] : 0.0;
+#define VS_DPP4(ctrl)                                                                                     \
+      {                                                                                                   \
+        int lo[4], hi[4];                                                                                 \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                   \
+          const long long bits = __double_as_longlong(v[u]);                                              \
+          lo[u] = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xFFFFFFFFll), ctrl, 0xF, 0xF, true);       \
+          hi[u] = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), ctrl, 0xF, 0xF, true);                \
+        }                                                                                                 \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) v[u] += __longlong_as_double(((long long)hi[u] << 32) | (unsigned)lo[u]); \
+      }
+      VS_DPP4(0x111) VS_DPP4(0x112) VS_DPP4(0x114) VS_DPP4(0x118)
+#undef VS_DPP4
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (k0 + u < NACC && (lane & 15) == 15) sh.red4[w][lane >> 4][k0 + u] = v[u];
     }
   }
   __syncthreads();
