@@ -622,7 +622,7 @@ __device__ __forceinline__ void wave_solve6(double a, int lane, double* x, unsig
 }
 
 #define NACC 29   // 21 upper-triangular H + 6 b + E + inlier count
-#define VS_ALCACHE 1   // measurements per thread kept in registers across rounds (covers M <= 3*VS_WG)
+#define VS_ALCACHE 1   // measurements per thread kept in registers across rounds (the first chunk of VS_WG measurements)
 
 struct AlignPoint { double m[3], f[4], om, wt; };
 
@@ -640,17 +640,24 @@ __device__ __forceinline__ double dpp_row_sum(double v) {
   return v;
 }
 
-// contribution of one measurement to H, b, E (linearize body, stereouv_aligner.cpp:81-185)
-__device__ __forceinline__ void align_point(const DevCfg& c, const double* T, const AlignPoint& P, bool ignore_outliers,
-                                            double* acc, double* chi_out, uint8_t* inl_out) {
+// One measurement of the linearization (StereoUVAligner::linearize body, stereouv_aligner.cpp:81-185; UVDAligner,
+// uvd_aligner.cpp:78-171) as its residual rows: Jacobian rows J (4 x 6, stereo; 3 x 6, RGB-D), residual e, row
+// weights (w_uv for the image rows, w_d for the depth row of the RGB-D model) and its share of E / the inlier count.
+// A measurement that is skipped, ignored or out of range (`have` false) gets zero weights and FINITE rows, so that every
+// lane can take part in the wave-wide reduction of the products without branches.
+struct AlignRows { double J[4][6]; double e[4]; double w_uv, w_d, E, cnt; };
+
+template <bool UVD>
+__device__ __forceinline__ void align_rows(const DevCfg& c, const double* T, const AlignPoint& P, bool have, bool ignore_outliers,
+                                           AlignRows& R, double* chi_out, uint8_t* inl_out) {
   const double* K = c.c.K;
   const bool pinhole = K[1] == 0 && K[3] == 0 && K[6] == 0 && K[7] == 0 && K[8] == 1;   // uniform
   double chi_w = -1;
   uint8_t inl_w = 0;
-  double omega = P.om;
+  double w_uv = P.om, w_d = UVD ? P.f[3] : 0.0;
   double p[3];
   tf_apply(T, P.m, p);
-  bool skip = p[2] < c.c.minimum_depth_meters;
+  bool skip = !have || (UVD ? p[2] <= c.c.minimum_depth_meters : p[2] < c.c.minimum_depth_meters);
   double aL[3], aR[3];
   mat3_mul_vec(K, p, aL);
   for (int k = 0; k < 3; ++k) aR[k] = aL[k] + c.c.baseline_h[k];
@@ -658,129 +665,136 @@ __device__ __forceinline__ void align_point(const DevCfg& c, const double* T, co
   const double uL = aL[0] / cL, vL = aL[1] / cL, uR = aR[0] / cR, vR = aR[1] / cR;
   if (!skip) {
     if (uL < 0 || uL > c.c.cols || vL < 0 || vL > c.c.rows) skip = true;
-    if (uR < 0 || uR > c.c.cols || vR < 0 || vR > c.c.rows) skip = true;
+    if (!UVD && (uR < 0 || uR > c.c.cols || vR < 0 || vR > c.c.rows)) skip = true;
   }
+  bool use = false;
+  R.E = 0; R.cnt = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) R.e[k] = 0;
   if (!skip) {
-    const double e[4] = {uL - P.f[0], vL - P.f[1], uR - P.f[2], vR - P.f[3]};
-    const double chi = omega * (((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]) + e[3] * e[3]);
-    chi_w = chi;
-    bool use = true;
-    if (chi > c.c.aligner_maximum_error_kernel) {
-      if (ignore_outliers) use = false;
-      else omega *= c.c.aligner_maximum_error_kernel / chi;
+    double chi;
+    if constexpr (UVD) {
+      R.e[0] = uL - P.f[0]; R.e[1] = vL - P.f[1]; R.e[2] = p[2] - P.f[2];
+      chi = ((R.e[0] * w_uv) * R.e[0] + (R.e[1] * w_uv) * R.e[1]) + (R.e[2] * w_d) * R.e[2];
     } else {
-      inl_w = 1;
-      acc[28] += 1.0;
+      R.e[0] = uL - P.f[0]; R.e[1] = vL - P.f[1]; R.e[2] = uR - P.f[2]; R.e[3] = vR - P.f[3];
+      chi = w_uv * (((R.e[0] * R.e[0] + R.e[1] * R.e[1]) + R.e[2] * R.e[2]) + R.e[3] * R.e[3]);
     }
-    if (use) {
-      // The Jacobian products and the H, b accumulation may fuse multiply-adds: their sums already differ from the
-      // reference's serial order by rounding (parallel reduction), a gate-free part of the computation.  Everything
-      // that feeds a comparison (projection, chi, the kernel test above) stays unfused like the oracle.
-#pragma clang fp contract(fast)
-      acc[27] += chi;
-      const double wt = P.wt;
-      // K * [w*I3 | -2*skew(p)]
-      const double Jt[3][6] = {{wt, 0, 0, 0, 2 * p[2], -2 * p[1]}, {0, wt, 0, -2 * p[2], 0, 2 * p[0]}, {0, 0, wt, 2 * p[1], -2 * p[0], 0}};
-      double KJ[3][6];
-      if (pinhole) {
-        // K = [fx 0 cx; 0 fy cy; 0 0 1]: the products with the structural zeros of K and Jt are exact zeros, and adding an
-        // exact zero is exact, so dropping them leaves every KJ entry bit-identical to the full triple product
-        const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
-        KJ[0][0] = fx * Jt[0][0]; KJ[0][1] = 0;                KJ[0][2] = cx * Jt[2][2];
-        KJ[0][3] = cx * Jt[2][3];  KJ[0][4] = fx * Jt[0][4] + cx * Jt[2][4]; KJ[0][5] = fx * Jt[0][5];
-        KJ[1][0] = 0;              KJ[1][1] = fy * Jt[1][1];  KJ[1][2] = cy * Jt[2][2];
-        KJ[1][3] = fy * Jt[1][3] + cy * Jt[2][3]; KJ[1][4] = cy * Jt[2][4]; KJ[1][5] = fy * Jt[1][5];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) KJ[2][j] = Jt[2][j];
-      } else {
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int j = 0; j < 6; ++j) KJ[i][j] = (K[3 * i] * Jt[0][j] + K[3 * i + 1] * Jt[1][j]) + K[3 * i + 2] * Jt[2][j];
-      }
-      const double icL = 1 / cL, icR = 1 / cR, icL2 = icL * icL, icR2 = icR * icR;
-      const double jl0 = -aL[0] * icL2, jl1 = -aL[1] * icL2, jr0 = -aR[0] * icR2, jr1 = -aR[1] * icR2;
-      // rows of the projection Jacobian times KJ; the reference's explicit 0 * x terms are exact zeros (finite x)
-      double J[4][6];
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        J[0][j] = icL * KJ[0][j] + jl0 * KJ[2][j];
-        J[1][j] = icL * KJ[1][j] + jl1 * KJ[2][j];
-        J[2][j] = icR * KJ[0][j] + jr0 * KJ[2][j];
-        J[3][j] = icR * KJ[1][j] + jr1 * KJ[2][j];
-      }
-      int q = 0;
-#pragma unroll
-      for (int r = 0; r < 6; ++r) {
-#pragma unroll
-        for (int cc = r; cc < 6; ++cc)
-          acc[q++] += omega * (((J[0][r] * J[0][cc] + J[1][r] * J[1][cc]) + J[2][r] * J[2][cc]) + J[3][r] * J[3][cc]);
-      }
-#pragma unroll
-      for (int r = 0; r < 6; ++r) acc[21 + r] += omega * (((J[0][r] * e[0] + J[1][r] * e[1]) + J[2][r] * e[2]) + J[3][r] * e[3]);
-    }
-  }
-  *chi_out = chi_w;
-  *inl_out = inl_w;
-}
-
-// UVDAligner::linearize body (uvd_aligner.cpp:78-171), RGB-D mode: residual (u, v, depth), diagonal information
-// (P.om, P.om, P.f[3]), measurement (P.f[0], P.f[1], P.f[2]); same accumulator layout as align_point.
-__device__ __forceinline__ void align_point_uvd(const DevCfg& c, const double* T, const AlignPoint& P, bool ignore_outliers,
-                                                double* acc, double* chi_out, uint8_t* inl_out) {
-  const double* K = c.c.K;
-  double chi_w = -1;
-  uint8_t inl_w = 0;
-  double w_uv = P.om, w_d = P.f[3];
-  double p[3];
-  tf_apply(T, P.m, p);
-  bool skip = p[2] <= c.c.minimum_depth_meters;
-  double a[3];
-  mat3_mul_vec(K, p, a);
-  const double u = a[0] / a[2], v = a[1] / a[2];
-  if (!skip && (u < 0 || u > c.c.cols || v < 0 || v > c.c.rows)) skip = true;
-  if (!skip) {
-    const double e[3] = {u - P.f[0], v - P.f[1], p[2] - P.f[2]};
-    const double chi = ((e[0] * w_uv) * e[0] + (e[1] * w_uv) * e[1]) + (e[2] * w_d) * e[2];
     chi_w = chi;
-    bool use = true;
+    use = true;
     if (chi > c.c.aligner_maximum_error_kernel) {
       if (ignore_outliers) use = false;
       else { const double sc = c.c.aligner_maximum_error_kernel / chi; w_uv *= sc; w_d *= sc; }
     } else {
       inl_w = 1;
-      acc[28] += 1.0;
+      R.cnt = 1.0;
     }
-    if (use) {
-      acc[27] += chi;
-      const double wt = P.wt;
-      const double Jt[3][6] = {{wt, 0, 0, 0, 2 * p[2], -2 * p[1]}, {0, wt, 0, -2 * p[2], 0, 2 * p[0]}, {0, 0, wt, 2 * p[1], -2 * p[0], 0}};
-      double KJ[3][6];
+    if (use) R.E = chi;
+  }
+  *chi_out = chi_w;
+  *inl_out = inl_w;
+  R.w_uv = use ? w_uv : 0.0;
+  R.w_d = use ? w_d : 0.0;
+  // rows: finite for every lane (unused measurements: unit depths, their weights are zero)
+  const double cLs = use ? cL : 1.0, cRs = use ? cR : 1.0;
+  {
+    // The Jacobian products (and the H, b products formed from them) use explicit fused multiply-adds: their sums
+    // already differ from the reference's serial order by rounding (parallel reduction), a gate-free part of the
+    // computation.  Explicit fma() rather than a contraction pragma: every instantiation of this code (fused kernel,
+    // stage kernel, stand-alone aligner) rounds identically.  Everything that feeds a comparison (projection, chi, the
+    // kernel test above) stays unfused like the oracle.
+    const double wt = P.wt;
+    // K * [w*I3 | -2*skew(p)]
+    const double Jt[3][6] = {{wt, 0, 0, 0, 2 * p[2], -2 * p[1]}, {0, wt, 0, -2 * p[2], 0, 2 * p[0]}, {0, 0, wt, 2 * p[1], -2 * p[0], 0}};
+    double KJ[3][6];
+    if (pinhole) {
+      // K = [fx 0 cx; 0 fy cy; 0 0 1]: the products with the structural zeros of K and Jt are exact zeros, and adding an
+      // exact zero is exact, so dropping them leaves every KJ entry bit-identical to the full triple product
+      const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+      KJ[0][0] = fx * Jt[0][0]; KJ[0][1] = 0;                KJ[0][2] = cx * Jt[2][2];
+      KJ[0][3] = cx * Jt[2][3];  KJ[0][4] = fma(fx, Jt[0][4], cx * Jt[2][4]); KJ[0][5] = fx * Jt[0][5];
+      KJ[1][0] = 0;              KJ[1][1] = fy * Jt[1][1];  KJ[1][2] = cy * Jt[2][2];
+      KJ[1][3] = fma(fy, Jt[1][3], cy * Jt[2][3]); KJ[1][4] = cy * Jt[2][4]; KJ[1][5] = fy * Jt[1][5];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) KJ[2][j] = Jt[2][j];
+    } else {
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 6; ++j) KJ[i][j] = (K[3 * i] * Jt[0][j] + K[3 * i + 1] * Jt[1][j]) + K[3 * i + 2] * Jt[2][j];
-      const double iz = 1 / p[2], iz2 = iz * iz;
-      const double j0 = -a[0] * iz2, j1 = -a[1] * iz2;
-      double J[3][6];
+    }
+    if constexpr (UVD) {
+      const double iz = 1 / (use ? p[2] : 1.0), iz2 = iz * iz;
+      const double j0 = -aL[0] * iz2, j1 = -aL[1] * iz2;
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
-        J[0][j] = iz * KJ[0][j] + j0 * KJ[2][j];
-        J[1][j] = iz * KJ[1][j] + j1 * KJ[2][j];
-        J[2][j] = KJ[2][j];
+        R.J[0][j] = fma(iz, KJ[0][j], j0 * KJ[2][j]);
+        R.J[1][j] = fma(iz, KJ[1][j], j1 * KJ[2][j]);
+        R.J[2][j] = KJ[2][j];
+        R.J[3][j] = 0;
       }
-      int q = 0;
+    } else {
+      const double icL = 1 / cLs, icR = 1 / cRs, icL2 = icL * icL, icR2 = icR * icR;
+      const double jl0 = -aL[0] * icL2, jl1 = -aL[1] * icL2, jr0 = -aR[0] * icR2, jr1 = -aR[1] * icR2;
+      // rows of the projection Jacobian times KJ; the reference's explicit 0 * x terms are exact zeros (finite x)
 #pragma unroll
-      for (int r = 0; r < 6; ++r) {
-#pragma unroll
-        for (int cc = r; cc < 6; ++cc) acc[q++] += w_uv * (J[0][r] * J[0][cc] + J[1][r] * J[1][cc]) + w_d * (J[2][r] * J[2][cc]);
+      for (int j = 0; j < 6; ++j) {
+        R.J[0][j] = fma(icL, KJ[0][j], jl0 * KJ[2][j]);
+        R.J[1][j] = fma(icL, KJ[1][j], jl1 * KJ[2][j]);
+        R.J[2][j] = fma(icR, KJ[0][j], jr0 * KJ[2][j]);
+        R.J[3][j] = fma(icR, KJ[1][j], jr1 * KJ[2][j]);
       }
-#pragma unroll
-      for (int r = 0; r < 6; ++r) acc[21 + r] += w_uv * (J[0][r] * e[0] + J[1][r] * e[1]) + w_d * (J[2][r] * e[2]);
     }
   }
-  *chi_out = chi_w;
-  *inl_out = inl_w;
+}
+
+// accumulator q of the measurement: 0..20 upper triangle of H = J^T W J (row-major), 21..26 b = J^T W e, 27 E, 28 inliers
+template <bool UVD, int Q>
+__device__ __forceinline__ double align_entry(const AlignRows& R) {
+  if constexpr (Q < 21) {
+    constexpr int r = Q < 6 ? 0 : Q < 11 ? 1 : Q < 15 ? 2 : Q < 18 ? 3 : Q < 20 ? 4 : 5;
+    constexpr int first = r == 0 ? 0 : r == 1 ? 6 : r == 2 ? 11 : r == 3 ? 15 : r == 4 ? 18 : 20;
+    constexpr int cc = r + (Q - first);
+    if constexpr (UVD) return fma(R.w_uv, fma(R.J[1][r], R.J[1][cc], R.J[0][r] * R.J[0][cc]), R.w_d * (R.J[2][r] * R.J[2][cc]));
+    else return R.w_uv * fma(R.J[3][r], R.J[3][cc], fma(R.J[2][r], R.J[2][cc], fma(R.J[1][r], R.J[1][cc], R.J[0][r] * R.J[0][cc])));
+  } else if constexpr (Q < 27) {
+    constexpr int r = Q - 21;
+    if constexpr (UVD) return fma(R.w_uv, fma(R.J[1][r], R.e[1], R.J[0][r] * R.e[0]), R.w_d * (R.J[2][r] * R.e[2]));
+    else return R.w_uv * fma(R.J[3][r], R.e[3], fma(R.J[2][r], R.e[2], fma(R.J[1][r], R.e[1], R.J[0][r] * R.e[0])));
+  } else if constexpr (Q == 27) {
+    return R.E;
+  } else {
+    return R.cnt;
+  }
+}
+
+// four accumulators Q0 .. Q0+3 of every lane's measurement: DPP row sums (row_shr 1, 2, 4, 8 inside each 16-lane row; four
+// chains in lockstep fill the two wait states a DPP read needs after a VALU write), lanes 15 / 31 / 47 / 63 put the row
+// totals into LDS (first chunk of measurements) or add them to what is there (further chunks, n > workgroup size)
+template <bool UVD, int Q0>
+__device__ __forceinline__ void align_reduce4(const AlignRows& R, double (*red)[32], int lane, bool first_chunk) {
+  double v[4];
+  v[0] = align_entry<UVD, Q0>(R);
+  v[1] = Q0 + 1 < NACC ? align_entry<UVD, (Q0 + 1 < NACC ? Q0 + 1 : 0)>(R) : 0.0;
+  v[2] = Q0 + 2 < NACC ? align_entry<UVD, (Q0 + 2 < NACC ? Q0 + 2 : 0)>(R) : 0.0;
+  v[3] = Q0 + 3 < NACC ? align_entry<UVD, (Q0 + 3 < NACC ? Q0 + 3 : 0)>(R) : 0.0;
+#define VS_DPP4(ctrl)                                                                                     \
+  {                                                                                                       \
+    int lo[4], hi[4];                                                                                     \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                       \
+      const long long bits = __double_as_longlong(v[u]);                                                  \
+      lo[u] = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xFFFFFFFFll), ctrl, 0xF, 0xF, true);           \
+      hi[u] = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), ctrl, 0xF, 0xF, true);                    \
+    }                                                                                                     \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) v[u] += __longlong_as_double(((long long)hi[u] << 32) | (unsigned)lo[u]); \
+  }
+  VS_DPP4(0x111) VS_DPP4(0x112) VS_DPP4(0x114) VS_DPP4(0x118)
+#undef VS_DPP4
+  if ((lane & 15) == 15) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (Q0 + u < NACC) { if (first_chunk) red[lane >> 4][Q0 + u] = v[u]; else red[lane >> 4][Q0 + u] += v[u]; }
+  }
 }
 
 __device__ __forceinline__ void load_align_point(const DevCfg& c, const DevBuf& b, int s, int u, AlignPoint& P) {
@@ -801,48 +815,28 @@ __device__ __forceinline__ void wg_one_round(const DevCfg& c, const DevBuf& b, i
   VS_PHASE_BEGIN(tp0);
   double T[12];
   for (int k = 0; k < 12; ++k) T[k] = sh.T[k];
-  double acc[NACC];
-#pragma unroll
-  for (int k = 0; k < NACC; ++k) acc[k] = 0;
-#pragma unroll
-  for (int q = 0; q < VS_ALCACHE; ++q) {
-    const int u = tid + q * VS_WG;
-    if (u < n) {   // error / inlier flag are stored after the last round
-      if constexpr (UVD) align_point_uvd(c, T, cache[q], ignore_outliers, acc, &chi_reg[q], &inl_reg[q]);
-      else align_point(c, T, cache[q], ignore_outliers, acc, &chi_reg[q], &inl_reg[q]);
+  // one measurement per thread and chunk: its rows, then the 29 products reduced four at a time — nothing but the rows
+  // stays live (29 fp64 accumulators per thread were what pushed the kernel to 256 VGPRs and into scratch)
+  for (int base = 0; base < n; base += VS_WG) {
+    const int u = base + tid;
+    const bool have = u < n;
+    AlignRows R;
+    if (base == 0) {
+      align_rows<UVD>(c, T, cache[0], have, ignore_outliers, R, &chi_reg[0], &inl_reg[0]);   // stored after the last round
+    } else {
+      AlignPoint P;
+      P.m[0] = P.m[1] = P.m[2] = 0; P.f[0] = P.f[1] = P.f[2] = P.f[3] = 0; P.om = 0; P.wt = 0;
+      if (have) load_align_point(c, b, s, u, P);
+      double chi_w; uint8_t inl_w;
+      align_rows<UVD>(c, T, P, have, ignore_outliers, R, &chi_w, &inl_w);
+      if (have) { chi_o[u] = chi_w; inl_o[u] = inl_w; }
     }
-  }
-  for (int u = tid + VS_ALCACHE * VS_WG; u < n; u += VS_WG) {
-    AlignPoint P;
-    load_align_point(c, b, s, u, P);
-    if constexpr (UVD) align_point_uvd(c, T, P, ignore_outliers, acc, chi_o + u, inl_o + u);
-    else align_point(c, T, P, ignore_outliers, acc, chi_o + u, inl_o + u);
-  }
-  // deterministic reduction: DPP sums inside each 16-lane row, then a fixed-order sum of the 4 row totals of
-  // every wave that owns measurements (w*64 < n); the other waves contribute exact zeros.
-  if (w * 64 < n) {
-    // four accumulators per step: a DPP read of a VGPR needs two wait states after the VALU write, the other three
-    // chains fill them (one value at a time costs ~100 s_nop per round)
-#pragma unroll
-    for (int k0 = 0; k0 < NACC; k0 += 4) {
-      double v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = k0 + u < NACC ? acc[k0 + u] : 0.0;
-#define VS_DPP4(ctrl)                                                                                     \
-      {                                                                                                   \
-        int lo[4], hi[4];                                                                                 \
-        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                   \
-          const long long bits = __double_as_longlong(v[u]);                                              \
-          lo[u] = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xFFFFFFFFll), ctrl, 0xF, 0xF, true);       \
-          hi[u] = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), ctrl, 0xF, 0xF, true);                \
-        }                                                                                                 \
-        _Pragma("unroll") for (int u = 0; u < 4; ++u) v[u] += __longlong_as_double(((long long)hi[u] << 32) | (unsigned)lo[u]); \
-      }
-      VS_DPP4(0x111) VS_DPP4(0x112) VS_DPP4(0x114) VS_DPP4(0x118)
-#undef VS_DPP4
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (k0 + u < NACC && (lane & 15) == 15) sh.red4[w][lane >> 4][k0 + u] = v[u];
+    if (base + w * 64 < n) {   // waves without a measurement in this chunk would add exact zeros
+      double (*red)[32] = sh.red4[w];
+      const bool fc = base == 0;
+      align_reduce4<UVD, 0>(R, red, lane, fc);  align_reduce4<UVD, 4>(R, red, lane, fc);  align_reduce4<UVD, 8>(R, red, lane, fc);
+      align_reduce4<UVD, 12>(R, red, lane, fc); align_reduce4<UVD, 16>(R, red, lane, fc); align_reduce4<UVD, 20>(R, red, lane, fc);
+      align_reduce4<UVD, 24>(R, red, lane, fc); align_reduce4<UVD, 28>(R, red, lane, fc);
     }
   }
   __syncthreads();
@@ -920,6 +914,9 @@ __device__ __forceinline__ void wg_align_converge(const DevCfg& c, const DevBuf&
   for (int q = 0; q < VS_ALCACHE; ++q) {
     const int u = tid + q * VS_WG;
     chi_reg[q] = -1; inl_reg[q] = 0;
+    // threads without a measurement carry zeros: their (finite) rows enter the reduction with zero weight
+    cache[q].m[0] = cache[q].m[1] = cache[q].m[2] = 0; cache[q].f[0] = cache[q].f[1] = cache[q].f[2] = cache[q].f[3] = 0;
+    cache[q].om = 0; cache[q].wt = 0;
     if (u < n) load_align_point(c, b, s, u, cache[q]);
   }
   // converge() as one loop (single inlined copy of the round): outer rounds use the saturated kernel, after the
