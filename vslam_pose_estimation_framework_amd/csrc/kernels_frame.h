@@ -269,6 +269,7 @@ struct FrameShared {
   int n_trk, n_lost, n_lm, n_cur, n_cand, n_proj;
   int status, win, attempts, broken, fallback, aligner_ran;
   double tau_track;
+  double prior[12];      // _previous_to_current_camera of the frame in flight
   double T[12];          // aligner estimate
   double H[36];
   double bvec[6];
@@ -511,12 +512,13 @@ __device__ __forceinline__ void wg_track_resolve(const DevCfg& c, const DevBuf& 
 // (same class of difference as the H,b summation order).  Returns false when a pivot is not safely positive; the
 // caller then falls back to the exact full-pivot wave solver (rank-deficient systems keep reference semantics).
 __device__ __forceinline__ bool ldlt_solve6(const double* Hs, const double* rhs, double* x) {
+  // upper triangle only (21 entries; the eliminated matrix stays symmetric, so A[i][k] below the diagonal is A[k][i])
   double A[6][6], y[6], invd[6];
   double dmax = 0;
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) A[i][j] = Hs[6 * i + j];
+    for (int j = i; j < 6; ++j) A[i][j] = Hs[6 * i + j];
     y[i] = rhs[i];
     dmax = fmax(dmax, fabs(A[i][i]));
   }
@@ -529,15 +531,11 @@ __device__ __forceinline__ bool ldlt_solve6(const double* Hs, const double* rhs,
     invd[k] = inv;
 #pragma unroll
     for (int i = k + 1; i < 6; ++i) {
-      const double f = A[i][k] * inv;
+      const double f = A[k][i] * inv;
 #pragma unroll
-      for (int j = i; j < 6; ++j) A[i][j] -= f * A[k][j];   // trailing block stays symmetric: update the upper part
+      for (int j = i; j < 6; ++j) A[i][j] -= f * A[k][j];
       y[i] -= f * y[k];
     }
-#pragma unroll
-    for (int i = k + 1; i < 6; ++i)
-#pragma unroll
-      for (int j = i + 1; j < 6; ++j) A[j][i] = A[i][j];
   }
 #pragma unroll
   for (int i = 5; i >= 0; --i) {

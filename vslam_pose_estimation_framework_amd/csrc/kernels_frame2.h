@@ -852,8 +852,9 @@ __global__ VS_FRAME_BOUNDS void k_frame(ConstDevCfg* cp, ConstDevBuf* bp, int ph
   }
   const unsigned long long tK0 = wall_clock64();
   (void)tK0;
-  double prior[12];
-  for (int k = 0; k < 12; ++k) prior[k] = st.prior[k];
+  // the motion prior lives in LDS (sh.prior), not in 24 VGPRs of every thread across the whole registration loop
+  if (tid < 12) sh.prior[tid] = st.prior[tid];
+  const double* prior = sh.prior;
   const double tau_tri = tau_tri_rule(c, status0, b.n_kp[s * 2]);
   int win = st.win;
   double tau_track = st.tau_track;          // tracker's _current_descriptor_distance_tracking
@@ -926,7 +927,7 @@ __global__ VS_FRAME_BOUNDS void k_frame(ConstDevCfg* cp, ConstDevBuf* bp, int ph
         const double rel = (double)n_tracked_landmarks / (double)n_lm_prev;
         if (n_tracked_landmarks == 0 || rel < 0.1) {
           if (attempt < 2) {
-            tf_identity(prior);
+            if (tid == 0) tf_identity(sh.prior);
             by_app = 1;
           } else {
             brk = true; done = true;
@@ -951,10 +952,10 @@ __global__ VS_FRAME_BOUNDS void k_frame(ConstDevCfg* cp, ConstDevBuf* bp, int ph
         const double dang = rotation_angle(sh.T);
         const double dtr = sqrt((sh.T[3] * sh.T[3] + sh.T[7] * sh.T[7]) + sh.T[11] * sh.T[11]);
         if (dang > c.c.minimum_delta_angular_for_movement || dtr > c.c.minimum_delta_translational_for_movement) {
-          for (int k = 0; k < 12; ++k) prior[k] = sh.T[k];
           if (tid == 0) {
+            for (int k = 0; k < 12; ++k) sh.prior[k] = sh.T[k];
             double inv[12], c2w[12];
-            tf_inverse(prior, inv);
+            tf_inverse(sh.T, inv);
             tf_mul(prev_c2w, inv, c2w);
             set_pose(c, b, s, f, c2w);
           }
@@ -963,12 +964,10 @@ __global__ VS_FRAME_BOUNDS void k_frame(ConstDevCfg* cp, ConstDevBuf* bp, int ph
         }
       }
       if (fall) {  // _fallbackEstimate (:551-566)
-        tf_identity(prior);
-        if (tid == 0) { set_pose(c, b, s, f, prev_c2w); sh.fallback = 1; }
+        if (tid == 0) { tf_identity(sh.prior); set_pose(c, b, s, f, prev_c2w); sh.fallback = 1; }
       }
       if (brk) {   // breakTrack (:422-435)
-        tf_identity(prior);
-        if (tid == 0) { set_pose(c, b, s, f, prev_c2w); sh.broken = 1; sh.status = VSLAM_LOCALIZING; }
+        if (tid == 0) { tf_identity(sh.prior); set_pose(c, b, s, f, prev_c2w); sh.broken = 1; sh.status = VSLAM_LOCALIZING; }
       }
       __syncthreads();
     }
