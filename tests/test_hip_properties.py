@@ -136,3 +136,35 @@ def test_knn2_linearity_and_symmetry_at_full_size():
     iba, dba = api.knn2(bq, a, norm=0)
     assert (dba[iab[:, 0], 0] <= dab[:, 0]).all()
     api.destroy()
+
+
+def test_caller_stream_equals_internal_streams():
+    """vslam_set_hip_stream: the whole pipeline on ONE caller-provided HIP stream (a torch stream here) gives the same
+    results as the context's own image / frame streams — the double-buffered products and the device-resident buffer
+    table of the frame kernel are re-pointed correctly."""
+    import torch
+    from _oracle import Oracle
+    o = Oracle()
+    scene = o.scene_kitti(scale=0.5, seed=17)
+    cfg = o.config_for_scene(scene)
+    a = hip.load(); a.create(cfg, 0, 2)
+    b2 = hip.load(); b2.create(cfg, 0, 2)
+    stream = torch.cuda.Stream()
+    b2.set_hip_stream(stream.cuda_stream)
+    try:
+        for k in range(8):
+            L0, R0 = o.render(scene, k)
+            L1, R1 = o.render(scene, k + 40)
+            L = np.stack([L0, L1]); R = np.stack([R0, R1])
+            a.process_host(L, R)
+            b2.process_host(L, R)
+            stream.synchronize()
+            for s in range(2):
+                fa, fb = a.frame_info(s), b2.frame_info(s)
+                assert fa.as_dict() == fb.as_dict(), (k, s)
+                pa, pb = a.points(s), b2.points(s)
+                for key in ("kp", "meta", "cam", "lm"):
+                    np.testing.assert_array_equal(pa[key], pb[key])
+        assert fa.status == 1
+    finally:
+        a.destroy(); b2.destroy()
