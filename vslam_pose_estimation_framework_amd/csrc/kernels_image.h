@@ -548,7 +548,7 @@ __global__ __launch_bounds__(256) void k_brief(const DevCfg c, const DevBuf b) {
     const int r = y0 + tid;
     int lo = 0, n = 0;
     if (r < rows) {
-      const int c0 = min(8 * tx, c.CW), c1 = min(8 * tx + 8, c.CW);
+      const int c0 = min((VS_BT_W / 16) * tx, c.CW), c1 = min((VS_BT_W / 16) * (tx + 1), c.CW);
       lo = rowcell[(size_t)r * (c.CW + 1) + c0];
       n = rowcell[(size_t)r * (c.CW + 1) + c1] - lo;
     }
