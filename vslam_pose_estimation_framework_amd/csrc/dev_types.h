@@ -30,7 +30,9 @@
 #else
 #define VS_FRAME_BOUNDS __launch_bounds__(VS_WG)
 #endif
+#ifndef VS_ARENA
 #define VS_ARENA (128 * 1024) // bytes of LDS scratch the frame kernel stages hot index arrays in (one frame workgroup per CU)
+#endif
 #define VS_POSE_LOG 32768    // frames of trajectory kept per stream
 
 struct DevRegion { int32_t x, y, w, h; };

@@ -458,6 +458,29 @@ static int set_images_device(vslam_ctx* c, const uint8_t* L, const uint8_t* R, i
 static int upload_images(vslam_ctx* c, const uint8_t* L, const uint8_t* R, int32_t row_stride, size_t image_stride) {
   if (!L || !R) return fail(c, VSLAM_ERR_INVALID, "called with empty frame");
   if (row_stride < c->cfg.c.cols) return fail(c, VSLAM_ERR_INVALID, "row stride smaller than image width");
+  // Host images of all streams in one (nearly) dense block: one copy per side, the caller's strides kept on the device
+  // (2 B strided 2-D copies per step cost more in submission than in transfer).
+  const size_t span = (size_t)(c->B - 1) * image_stride + (size_t)(c->cfg.c.rows - 1) * row_stride + c->cfg.c.cols;   // last byte the caller owns
+  const size_t dense = (size_t)c->B * c->cfg.c.rows * c->cfg.c.cols;
+  const bool ordered = c->B == 1 || image_stride >= (size_t)c->cfg.c.rows * row_stride;
+  if (c->groups.size() == 1 && ordered && span <= (size_t)c->B * c->up_stream_stride && span <= dense + dense / 8) {
+    hipStream_t st = c->parity ? c->groups[0].st_img2 : c->groups[0].st_img;
+    HIP_TRY(c, hipMemcpyAsync(c->upload[c->parity][0], L, span, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->upload[c->parity][1], R, span, hipMemcpyHostToDevice, st));
+    return set_images_device(c, c->upload[c->parity][0], c->upload[c->parity][1], row_stride, image_stride);
+  }
+  if (row_stride <= c->up_stride) {
+    // one contiguous copy per image, rows keep the caller's stride (a pitched host-to-device copy is issued row by row
+    // by the runtime: measured 0.13 GB/s against 43 GB/s for the plain copy)
+    for (int s = 0; s < c->B; ++s) {
+      const vslam_ctx::Group& gg = c->groups[group_of(c, s)];
+      hipStream_t st = c->parity ? gg.st_img2 : gg.st_img;
+      const size_t bytes = (size_t)(c->cfg.c.rows - 1) * row_stride + c->cfg.c.cols;
+      HIP_TRY(c, hipMemcpyAsync(c->upload[c->parity][0] + s * c->up_stream_stride, L + s * image_stride, bytes, hipMemcpyHostToDevice, st));
+      HIP_TRY(c, hipMemcpyAsync(c->upload[c->parity][1] + s * c->up_stream_stride, R + s * image_stride, bytes, hipMemcpyHostToDevice, st));
+    }
+    return set_images_device(c, c->upload[c->parity][0], c->upload[c->parity][1], row_stride, c->up_stream_stride);
+  }
   for (int s = 0; s < c->B; ++s) {
     const vslam_ctx::Group& gg = c->groups[group_of(c, s)];
     hipStream_t st = c->parity ? gg.st_img2 : gg.st_img;
