@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--steps", type=int, default=0, help="timed steps (0 = the whole chunked job)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("VSLAM_BENCH_STREAMS", "160")))
-    ap.add_argument("--overlap", type=int, default=5)
+    ap.add_argument("--overlap", type=int, default=10, help="warm-up frames per chunk (SURVEY.md 8e default)")
     ap.add_argument("--cpu-frames", type=int, default=240)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
