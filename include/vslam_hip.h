@@ -161,7 +161,9 @@ int vslam_set_hip_stream(vslam_ctx* ctx, void* hip_stream);
  * on the context stream; no host synchronisation.
  *   left/right: n_streams images each; image s starts at base + s*image_stride_bytes.
  *   *_device variant: pointers are device memory (inputs already resident in HBM).
- *   host variant: pointers are host memory, copied with hipMemcpy2DAsync first. */
+ *   host variant: pointers are host memory, copied to the device first (hipMemcpyAsync on the image stream: one
+ *     copy per side when the images are back to back, else one per image; pinned memory makes it truly asynchronous).
+ *     The buffers must stay valid and unchanged until the copy has run (vslam_synchronize, or any read-back call). */
 int vslam_process_device(vslam_ctx* ctx, const uint8_t* left, const uint8_t* right,
                          int32_t row_stride_bytes, size_t image_stride_bytes);
 int vslam_process_host(vslam_ctx* ctx, const uint8_t* left, const uint8_t* right,
