@@ -4,7 +4,7 @@ import os
 from .capi import CApi
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB = os.path.join(CSRC, "libvslam_hip.so")
+LIB = os.environ.get("VSLAM_HIP_LIB") or os.path.join(CSRC, "libvslam_hip.so")   # override: build variants of the same HIP library
 
 
 def lib_path():
