@@ -76,11 +76,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU (RCCL).  VSLAM_BENCH_BACKEND=gloo is a rehearsal aid only: several ranks on the one GPU of a
+    # test box, same code path, the single all-gather staged through the host
+    backend = os.environ.get("VSLAM_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     B = args.streams
     overlap = args.overlap
@@ -112,7 +119,7 @@ def main():
                          torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
 
-    api.create(cfg, local_rank, B)
+    api.create(cfg, dev_index, B)
 
     def run_steps(n):
         for k in range(n):
@@ -216,7 +223,7 @@ def main():
         per_chunk = min(K, args.cpu_frames)
         orc.create(cfg, 0, 1)
         chk = hip.load()
-        chk.create(cfg, local_rank, 1)
+        chk.create(cfg, dev_index, 1)
         cpu_t = 0.0
         mism, max_rel, nfr = 0, 0.0, 0
         for sidx in range(n_chunks):
