@@ -291,6 +291,49 @@ int vslam_stereo_match(vslam_ctx* ctx, double tau_tri, int32_t nL, const int32_t
                        int32_t nR, const int32_t* rc_right, const uint8_t* desc_right, int32_t cap, int32_t* n_out,
                        int32_t* out4);
 
+/* ---- RGB-D components: the pieces of DepthFramePointGenerator, stand-alone -----------------
+ * Not wired into the fused stereo tracker; same role as vslam_align_points_uvd (the RGB-D aligner): the kernels a
+ * depth-mode shim calls, each checked against the oracle and an independent fixture. */
+typedef struct vslam_depth_params {
+  int32_t rows, cols;
+  double K_left[9];             /* _camera_left->cameraMatrix(), row-major                                        */
+  double K_left_inverse[9];     /* its inverse as the caller's linear algebra gives it (Eigen .inverse() upstream) */
+  double K_right_inverse[9];    /* inverse of the depth camera's matrix (depth_framepoint_generator.cpp:443)      */
+  double right_to_left[12];     /* _camera_left->robotToCamera()*_camera_right->cameraToRobot() (:446), 3x4       */
+  double depth_scale_factor_intensity_to_meters;       /* parameters.h:251 (1e-3)                               */
+  double minimum_depth_meters, maximum_depth_meters;    /* parameters.h:197-198                                   */
+  int32_t enable_point_triangulation;                   /* parameters.h:256                                       */
+  int32_t enable_keypoint_binning, bin_size_pixels;     /* base generator parameters                              */
+} vslam_depth_params;
+
+/* DepthFramePointGenerator::_computeDepthMap (depth_framepoint_generator.cpp:410-485) without the optional bilateral
+ * filter: every non-zero u16 depth pixel is back-projected through K_right_inverse, moved into the left camera,
+ * projected with K_left and z-buffered (strict "stored float > new double", scan order) into the rows x cols x 3 float
+ * space map, initialised to (0, 0, maximum_depth); row_map / col_map receive the winning source pixel (-1: none).
+ * depth: host image, row stride in ELEMENTS.  Outputs may be NULL; the map also stays resident in the context for
+ * vslam_depth_compute. */
+int vslam_depth_space_map(vslam_ctx* ctx, const vslam_depth_params* p, const uint16_t* depth, int32_t row_stride,
+                          float* space_map, int16_t* row_map, int16_t* col_map);
+
+/* DepthFramePointGenerator::compute (:45-164) on caller-provided features: rc_features = nF (row, col) pairs in the
+ * feature vector's order (row-major sorted), rc_tracked = nT (row, col) of the framepoints the frame already holds
+ * (tracked / recovered: they own their bin).  space_map: host map (rows*cols*3 floats) or NULL = the one the last
+ * vslam_depth_space_map call left in the context.  New points (measured depth) come back in emission order — bin grid
+ * row-major when binning is on (lower depth wins an untracked bin, first wins ties), feature order otherwise — as
+ * feature index + left-camera coordinates; temporary points (depth >= maximum and triangulation enabled, :84-96) in
+ * feature order with the coordinates K_left_inverse * (col*max, row*max, max).  cap bounds both lists. */
+int vslam_depth_compute(vslam_ctx* ctx, const vslam_depth_params* p, const float* space_map, int32_t nF,
+                        const int32_t* rc_features, int32_t nT, const int32_t* rc_tracked, int32_t cap, int32_t* n_new,
+                        int32_t* new_feature, double* new_xyz, int32_t* n_temporary, int32_t* temporary_feature,
+                        double* temporary_xyz);
+
+/* BaseFramePointGenerator::getPointInCamera (base_framepoint_generator.cpp:461-494) for n point pairs: midpoint
+ * triangulation of a previous / current image point pair under the motion T (previous -> current camera); the 3x2
+ * least-squares problem is solved through its singular value decomposition (minimum-norm for a rank-deficient pair).
+ * xy_*: n*2 floats; out: n*3 doubles.  Floating point: agrees with the reference's JacobiSVD to rounding (tests: 1e-9). */
+int vslam_point_in_camera(vslam_ctx* ctx, int32_t n, const float* xy_previous, const float* xy_current,
+                          const double T[12], const double K[9], double* out);
+
 /* ---- multi-GPU: trajectory assembly ---------------------------------------------------------
  * No reference counterpart (single process).  The pose all-gather is issued by the host
  * launcher through RCCL (torch.distributed backend "nccl"); these helpers pack/unpack. */

@@ -1537,6 +1537,140 @@ ORC_API int orc_track_match(const vslam_config* cfg, const double T[12], int32_t
   return VSLAM_OK;
 }
 
+/* ---- RGB-D components (DepthFramePointGenerator) ------------------------------------------ */
+/* _computeDepthMap (depth_framepoint_generator.cpp:410-485), bilateral filter off (configuration_{icl,tum,xtion}.yaml) */
+ORC_API int orc_depth_space_map(const vslam_depth_params* p, const uint16_t* depth, int32_t stride, float* space,
+                                int16_t* row_map, int16_t* col_map) {
+  const int rows = p->rows, cols = p->cols;
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) {                                   /* :428-432 */
+      float* d = space + ((size_t)r * cols + c) * 3;
+      d[0] = 0; d[1] = 0; d[2] = (float)p->maximum_depth_meters;
+      if (row_map) row_map[(size_t)r * cols + c] = -1;                 /* :434-438 */
+      if (col_map) col_map[(size_t)r * cols + c] = -1;
+    }
+  Tf r2l;
+  std::memcpy(r2l.m, p->right_to_left, sizeof r2l.m);
+  for (int r = 0; r < rows; ++r) {
+    const uint16_t* raw = depth + (size_t)r * stride;
+    for (int c = 0; c < cols; ++c) {
+      if (!raw[c]) continue;                                            /* :449 */
+      const real dm = raw[c] * p->depth_scale_factor_intensity_to_meters;   /* :452 */
+      const real ph[3] = {c * dm, r * dm, dm};
+      real pr[3], pl[3], px[3];
+      mat3_mul_vec(p->K_right_inverse, ph, pr);                        /* :454 */
+      tf_apply(r2l, pr, pl);                                            /* :456 */
+      const real zl = pl[2];
+      if (zl <= 0) continue;                                            /* :458-460 */
+      mat3_mul_vec(p->K_left, pl, px);                                  /* :462 */
+      const real u = px[0] / px[2], v = px[1] / px[2];                  /* :463 */
+      const int32_t dr = (int32_t)std::round(v), dc = (int32_t)std::round(u);   /* :466-467 */
+      if (dr < 0 || dr >= rows || dc < 0 || dc >= cols) continue;       /* :470-474 */
+      float* d = space + ((size_t)dr * cols + dc) * 3;
+      if (d[2] > zl) {                                                  /* :479: stored float against the new double */
+        d[0] = (float)pl[0]; d[1] = (float)pl[1]; d[2] = (float)pl[2];
+        if (row_map) row_map[(size_t)dr * cols + dc] = (int16_t)r;
+        if (col_map) col_map[(size_t)dr * cols + dc] = (int16_t)c;
+      }
+    }
+  }
+  return VSLAM_OK;
+}
+
+/* compute (:45-164) on caller-provided features; bins: -1 empty, -2 owned by a tracked point, >= 0 new feature */
+ORC_API int orc_depth_compute(const vslam_depth_params* p, const float* space, int32_t nF, const int32_t* rcF, int32_t nT,
+                              const int32_t* rcT, int32_t cap, int32_t* n_new, int32_t* new_feat, double* new_xyz,
+                              int32_t* n_temp, int32_t* temp_feat, double* temp_xyz) {
+  const int rows = p->rows, cols = p->cols, bin = p->bin_size_pixels;
+  const int rows_bin = p->enable_keypoint_binning ? rows / bin + 1 : 0, cols_bin = p->enable_keypoint_binning ? cols / bin + 1 : 0;   /* base_framepoint_generator.cpp:304-305 */
+  std::vector<int32_t> bins((size_t)(rows_bin + 1) * (cols_bin + 1), -1);   /* +1: rint() can reach the grid size */
+  auto bin_of = [&](int row, int col) -> int32_t& {
+    const int rb = (int)std::rint((real)row / bin), cb = (int)std::rint((real)col / bin);   /* :59-60, :113-114 */
+    return bins[(size_t)rb * (cols_bin + 1) + cb];
+  };
+  if (p->enable_keypoint_binning) for (int i = 0; i < nT; ++i) bin_of(rcT[2 * i], rcT[2 * i + 1]) = -2;   /* :57-63 */
+  std::vector<int32_t> fresh;        /* framepoints_new, feature order */
+  std::vector<real> depth_of(nF, 0);
+  int nt = 0;
+  for (int i = 0; i < nF; ++i) {
+    const int row = rcF[2 * i], col = rcF[2 * i + 1];
+    const float* d = space + ((size_t)row * cols + col) * 3;
+    if (d[2] < p->minimum_depth_meters) continue;                                            /* :80 */
+    if (d[2] >= p->maximum_depth_meters && p->enable_point_triangulation) {                  /* :89-101 */
+      const real m = p->maximum_depth_meters;
+      const real ph[3] = {col * m, row * m, m};
+      real x[3];
+      mat3_mul_vec(p->K_left_inverse, ph, x);
+      if (nt < cap) { temp_feat[nt] = i; for (int k = 0; k < 3; ++k) temp_xyz[3 * nt + k] = x[k]; }
+      ++nt;
+      continue;
+    }
+    fresh.push_back(i);                                                                      /* :104-108 */
+    depth_of[i] = (real)d[2];
+    if (p->enable_keypoint_binning) {                                                        /* :111-130 */
+      int32_t& b = bin_of(row, col);
+      if (b != -1) { if (b >= 0 && depth_of[i] < depth_of[b]) b = i; }
+      else b = i;
+    }
+  }
+  std::vector<int32_t> out;
+  if (p->enable_keypoint_binning) {                                                          /* :141-157 */
+    for (int rb = 0; rb < rows_bin; ++rb)
+      for (int cb = 0; cb < cols_bin; ++cb) { const int32_t b = bins[(size_t)rb * (cols_bin + 1) + cb]; if (b >= 0) out.push_back(b); }
+  } else {
+    out = fresh;                                                                             /* :160-162 */
+  }
+  *n_new = (int32_t)out.size(); *n_temp = nt;
+  if ((int32_t)out.size() > cap || nt > cap) return VSLAM_ERR_CAPACITY;
+  for (size_t k = 0; k < out.size(); ++k) {
+    const int i = out[k];
+    const float* d = space + ((size_t)rcF[2 * i] * cols + rcF[2 * i + 1]) * 3;
+    new_feat[k] = i;
+    for (int q = 0; q < 3; ++q) new_xyz[3 * k + q] = (real)d[q];
+  }
+  return VSLAM_OK;
+}
+
+/* getPointInCamera (base_framepoint_generator.cpp:461-494).  JacobiSVD::solve of the 3x2 system restated as QR of the
+ * two columns followed by the triangular solve, minimum-norm when the columns are parallel to rounding (Eigen's rank
+ * rule: singular values <= 2 eps * largest count as zero; here sigma_min ~ r00 r11 / sigma_max against the Frobenius
+ * bound of sigma_max). */
+static void point_in_camera(const float xp[2], const float xc[2], const Tf& T, const real K[9], real out[3]) {
+  const real a0 = (xp[0] - K[2]) / K[0], b0 = (xp[1] - K[5]) / K[4];     /* :470-473 */
+  const real a1 = (xc[0] - K[2]) / K[0], b1 = (xc[1] - K[5]) / K[4];
+  const real x0[3] = {a0, b0, 1}, x1[3] = {a1, b1, 1};
+  real c0[3], c1[3] = {a1, b1, 1}, t[3];
+  for (int i = 0; i < 3; ++i) { c0[i] = -((T.m[4 * i] * x0[0] + T.m[4 * i + 1] * x0[1]) + T.m[4 * i + 2] * x0[2]); t[i] = T.m[4 * i + 3]; }   /* :480-483 */
+  const real r00 = std::sqrt((c0[0] * c0[0] + c0[1] * c0[1]) + c0[2] * c0[2]);
+  real q0[3];
+  for (int i = 0; i < 3; ++i) q0[i] = c0[i] / r00;
+  const real r01 = (q0[0] * c1[0] + q0[1] * c1[1]) + q0[2] * c1[2];
+  real v[3];
+  for (int i = 0; i < 3; ++i) v[i] = c1[i] - r01 * q0[i];
+  const real r11 = std::sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+  const real g0 = (q0[0] * t[0] + q0[1] * t[1]) + q0[2] * t[2];
+  const real fro2 = (r00 * r00 + r01 * r01) + r11 * r11;
+  real z0, z1;
+  if (r00 * r11 > 2 * 2.220446049250313e-16 * fro2) {
+    const real g1 = ((v[0] * t[0] + v[1] * t[1]) + v[2] * t[2]) / r11;
+    z1 = g1 / r11;
+    z0 = (g0 - r01 * z1) / r00;
+  } else {   /* rank 1: minimum-norm solution of r00 z0 + r01 z1 = g0 */
+    const real n2 = r00 * r00 + r01 * r01;
+    z0 = g0 * r00 / n2; z1 = g0 * r01 / n2;
+  }
+  const real pp[3] = {x0[0] * z0, x0[1] * z0, x0[2] * z0}, pc[3] = {x1[0] * z1, x1[1] * z1, x1[2] * z1};   /* :489-490 */
+  real moved[3];
+  tf_apply(T, pp, moved);
+  for (int i = 0; i < 3; ++i) out[i] = (pc[i] + moved[i]) / 2.0;        /* :493 */
+}
+ORC_API int orc_point_in_camera(int32_t n, const float* xy_prev, const float* xy_cur, const double T[12], const double K[9], double* out) {
+  Tf Tt;
+  std::memcpy(Tt.m, T, sizeof Tt.m);
+  for (int i = 0; i < n; ++i) point_in_camera(xy_prev + 2 * i, xy_cur + 2 * i, Tt, K, out + 3 * i);
+  return VSLAM_OK;
+}
+
 /* ---- synthetic data + trajectory error (test / bench infrastructure) ---------------------- */
 ORC_API void orc_synth_default_kitti(synth_scene* s) { synth_default_kitti(s); }
 ORC_API void orc_synth_pose(const synth_scene* s, int k, double cam_to_world[12]) {

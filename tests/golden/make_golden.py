@@ -684,6 +684,132 @@ def gen_track(rng):
     return n_case
 
 
+# ---------------------------------------------------------------------------------------------
+# RGB-D components (DepthFramePointGenerator): pure-Python loops over small images, numpy scalars for the float / double
+# distinction of the z-buffer test, numpy.linalg.lstsq (SVD) for the midpoint triangulation.
+def _c_round(x):
+    return int(np.floor(x + 0.5)) if x >= 0 else -int(np.floor(-x + 0.5))
+
+
+def depth_space_map_ref(depth, Kl, Kri, r2l, scale, max_depth):
+    rows, cols = depth.shape
+    space = np.zeros((rows, cols, 3), np.float32)
+    space[:, :, 2] = np.float32(max_depth)
+    rmap = -np.ones((rows, cols), np.int16); cmap = -np.ones((rows, cols), np.int16)
+    R = r2l[:, :3]; t = r2l[:, 3]
+    for r in range(rows):
+        for c in range(cols):
+            raw = int(depth[r, c])
+            if raw == 0:
+                continue
+            dm = raw * scale
+            ph = np.array([c * dm, r * dm, dm])
+            pr = np.array([(Kri[i, 0] * ph[0] + Kri[i, 1] * ph[1]) + Kri[i, 2] * ph[2] for i in range(3)])
+            pl = np.array([((R[i, 0] * pr[0] + R[i, 1] * pr[1]) + R[i, 2] * pr[2]) + t[i] for i in range(3)])
+            if pl[2] <= 0:
+                continue
+            px = np.array([(Kl[i, 0] * pl[0] + Kl[i, 1] * pl[1]) + Kl[i, 2] * pl[2] for i in range(3)])
+            dr, dc = _c_round(px[1] / px[2]), _c_round(px[0] / px[2])
+            if dr < 0 or dr >= rows or dc < 0 or dc >= cols:
+                continue
+            if float(space[dr, dc, 2]) > pl[2]:
+                space[dr, dc] = pl.astype(np.float32)
+                rmap[dr, dc] = r; cmap[dr, dc] = c
+    return space, rmap, cmap
+
+
+def depth_compute_ref(space, feats, tracked, Kli, min_depth, max_depth, triangulate, binning, bin_px):
+    bins = {}
+    if binning:
+        for (row, col) in tracked:
+            bins[(round(row / bin_px), round(col / bin_px))] = "tracked"   # Python round == rint (half to even)
+    fresh, temp, depth_of = [], [], {}
+    for i, (row, col) in enumerate(feats):
+        d = space[row, col]
+        if float(d[2]) < min_depth:
+            continue
+        if float(d[2]) >= max_depth and triangulate:
+            ph = np.array([col * max_depth, row * max_depth, max_depth])
+            temp.append((i, [(Kli[k, 0] * ph[0] + Kli[k, 1] * ph[1]) + Kli[k, 2] * ph[2] for k in range(3)]))
+            continue
+        fresh.append(i); depth_of[i] = float(d[2])
+        if binning:
+            key = (round(row / bin_px), round(col / bin_px))
+            if key in bins:
+                if bins[key] != "tracked" and depth_of[i] < depth_of[bins[key]]:
+                    bins[key] = i
+            else:
+                bins[key] = i
+    if binning:
+        rows_bin, cols_bin = space.shape[0] // bin_px + 1, space.shape[1] // bin_px + 1
+        out = [bins[(rb, cb)] for rb in range(rows_bin) for cb in range(cols_bin) if (rb, cb) in bins and bins[(rb, cb)] != "tracked"]
+    else:
+        out = fresh
+    return out, temp
+
+
+def point_in_camera_ref(xp, xc, T, K):
+    a0, b0 = (float(xp[0]) - K[0, 2]) / K[0, 0], (float(xp[1]) - K[1, 2]) / K[1, 1]
+    a1, b1 = (float(xc[0]) - K[0, 2]) / K[0, 0], (float(xc[1]) - K[1, 2]) / K[1, 1]
+    x0 = np.array([a0, b0, 1.0]); x1 = np.array([a1, b1, 1.0])
+    A = np.stack([-T[:, :3] @ x0, x1], axis=1)
+    z = np.linalg.lstsq(A, T[:, 3], rcond=None)[0]
+    return (x1 * z[1] + (T[:, :3] @ (x0 * z[0]) + T[:, 3])) / 2.0
+
+
+def gen_depth(rng):
+    out = {}
+    rows, cols = 40, 56
+    Kr = np.array([[60.0, 0, 27.5], [0, 60.0, 19.5], [0, 0, 1]])
+    cases = {
+        # registered RGB-D (identity, same K): every pixel maps onto itself
+        "registered": (Kr.copy(), np.hstack([np.eye(3), np.zeros((3, 1))])),
+        # the left camera sees the scene at 0.55x: ~3.3 depth pixels land on one cell, equal raw depths collide
+        "shrunk": (np.array([[33.0, 0, 27.5], [0, 33.0, 19.5], [0, 0, 1]]), np.hstack([np.eye(3), np.zeros((3, 1))])),
+        # small rotation + baseline: general forward warp with holes and occlusions
+        "offset": (np.array([[58.0, 0, 28.0], [0, 58.0, 19.0], [0, 0, 1]]), None),
+    }
+    ang = 0.03
+    Rz = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    cases["offset"] = (cases["offset"][0], np.hstack([Rz, np.array([[0.05], [-0.01], [0.02]])]))
+    for name, (Kl, r2l) in cases.items():
+        depth = rng.integers(400, 9000, (rows, cols)).astype(np.uint16)
+        depth[rng.random((rows, cols)) < 0.15] = 0                         # holes
+        depth[rng.random((rows, cols)) < 0.05] = 12000                     # beyond maximum_depth (10 m)
+        depth[10:14, 20:30] = 2500                                         # a fronto-parallel patch: exact depth ties
+        depth[20:23, 5:15] = 1001                                          # 1.001 m: float(z) != z, both rounding directions
+        depth[25:28, 30:40] = 1003
+        depth[0, 0] = 50                                                   # below minimum_depth
+        Kri = np.linalg.inv(Kr)
+        space, rmap, cmap = depth_space_map_ref(depth, Kl, Kri, r2l, 1e-3, 10.0)
+        out[name + "_depth"] = depth; out[name + "_Kl"] = Kl; out[name + "_Kri"] = Kri; out[name + "_r2l"] = r2l
+        out[name + "_space"] = space; out[name + "_rmap"] = rmap; out[name + "_cmap"] = cmap
+        # features: a random subset of pixels in row-major order; tracked points: a few more
+        flat = np.sort(rng.choice(rows * cols, 300, replace=False))
+        feats = [(int(v // cols), int(v % cols)) for v in flat[:260]]
+        tracked = [(int(v // cols), int(v % cols)) for v in flat[260:]]
+        Kli = np.linalg.inv(Kl)
+        out[name + "_feats"] = np.array(feats, np.int32); out[name + "_tracked"] = np.array(tracked, np.int32); out[name + "_Kli"] = Kli
+        for tag, (tri, binning) in {"bin_tri": (1, 1), "nobin_tri": (1, 0), "bin_notri": (0, 1)}.items():
+            new, temp = depth_compute_ref(space, feats, tracked, Kli, 0.1, 10.0, tri, binning, 6)
+            out["%s_%s_new" % (name, tag)] = np.array(new, np.int32)
+            out["%s_%s_temp" % (name, tag)] = np.array([i for i, _ in temp], np.int32)
+            out["%s_%s_temp_xyz" % (name, tag)] = np.array([x for _, x in temp], np.float64).reshape(-1, 3)
+    # midpoint triangulation: points seen from two poses (well-conditioned), plus near-degenerate pairs
+    K = np.array([[525.0, 0, 319.5], [0, 525.0, 239.5], [0, 0, 1]])
+    n = 64
+    v = np.array([0.08, -0.03, 0.05, 0.01, -0.02, 0.015])
+    T = v2t(v)[:3, :]
+    P = np.stack([rng.uniform(-2, 2, n), rng.uniform(-1.5, 1.5, n), rng.uniform(1.5, 8, n)], axis=1)
+    Pc = (T[:, :3] @ P.T).T + T[:, 3]
+    xp = (K @ P.T).T; xp = (xp[:, :2] / xp[:, 2:]).astype(np.float32)
+    xc = (K @ Pc.T).T; xc = (xc[:, :2] / xc[:, 2:] + rng.normal(0, 0.3, (n, 2))).astype(np.float32)
+    out["tri_K"] = K; out["tri_T"] = T; out["tri_xp"] = xp; out["tri_xc"] = xc
+    out["tri_xyz"] = np.array([point_in_camera_ref(xp[i], xc[i], T, K) for i in range(n)])
+    np.savez_compressed(os.path.join(HERE, "depth.npz"), **out)
+    return len(cases)
+
+
 def main():
     rng = np.random.default_rng(20261003)
     gen_hamming(rng)
@@ -694,6 +820,7 @@ def main():
     gen_stereo(rng)
     gen_track(np.random.default_rng(20261004))   # own stream: added later, the fixtures above stay byte-identical
     gen_aligner_uvd(np.random.default_rng(20261005))
+    gen_depth(np.random.default_rng(20261006))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

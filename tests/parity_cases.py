@@ -90,3 +90,31 @@ def check_aligner_uvd(api, g, rtol_pose=1e-9):
     Tt = g["m80_clean_Ttrue"]
     r = api.align_points_uvd(g["m80_clean_moving"], g["m80_clean_fixed"], np.ones(80), 10 * np.ones(80), np.ones(80), np.eye(4)[:3])
     assert np.linalg.norm(r["T"] - Tt) / np.linalg.norm(Tt) < 1e-3
+
+
+def check_depth_components(api, g, resident_map=False):
+    """DepthFramePointGenerator pieces (space map, compute, midpoint triangulation) against the pure-Python fixture.
+    Bit-exact for the map (floats, source indices) and the point lists; 1e-9 for the triangulation (SVD vs QR)."""
+    from vslam_pose_estimation_framework_amd.capi import DepthParams
+    for name in ("registered", "shrunk", "offset"):
+        depth = g[name + "_depth"]
+        rows, cols = depth.shape
+        for tag, (tri, binning) in {"bin_tri": (1, 1), "nobin_tri": (1, 0), "bin_notri": (0, 1)}.items():
+            p = DepthParams.make(rows, cols, g[name + "_Kl"], g[name + "_Kli"], g[name + "_Kri"], g[name + "_r2l"], 1e-3, 0.1, 10.0,
+                                 tri, binning, 6)
+            space, rmap, cmap = api.depth_space_map(p, depth)
+            np.testing.assert_array_equal(space.view(np.uint32), g[name + "_space"].view(np.uint32), err_msg=name)
+            np.testing.assert_array_equal(rmap, g[name + "_rmap"], err_msg=name)
+            np.testing.assert_array_equal(cmap, g[name + "_cmap"], err_msg=name)
+            new, xyz, temp, txyz = api.depth_compute(p, None if resident_map else space, g[name + "_feats"], g[name + "_tracked"])
+            np.testing.assert_array_equal(new, g["%s_%s_new" % (name, tag)], err_msg=name + tag)
+            np.testing.assert_array_equal(temp, g["%s_%s_temp" % (name, tag)], err_msg=name + tag)
+            np.testing.assert_array_equal(txyz, g["%s_%s_temp_xyz" % (name, tag)], err_msg=name + tag)
+            feats = g[name + "_feats"]
+            want = np.array([g[name + "_space"][feats[i, 0], feats[i, 1]] for i in new], np.float64).reshape(-1, 3)
+            np.testing.assert_array_equal(xyz, want, err_msg=name + tag)
+    out = api.point_in_camera(g["tri_xp"], g["tri_xc"], g["tri_T"], g["tri_K"])
+    np.testing.assert_allclose(out, g["tri_xyz"], rtol=1e-9, atol=1e-9)
+    # a pair without parallax (identity motion, same pixel): rank-deficient system, minimum-norm solution, finite result
+    deg = api.point_in_camera(g["tri_xp"][:4], g["tri_xp"][:4], np.eye(4)[:3], g["tri_K"])
+    assert np.all(np.isfinite(deg))

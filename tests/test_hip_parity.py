@@ -46,6 +46,13 @@ def test_aligner_uvd_golden(gpu, golden):
     pc.check_aligner_uvd(gpu, golden["aligner_uvd"], rtol_pose=1e-7)
 
 
+def test_depth_components_golden(gpu, golden):
+    """RGB-D components (space map z-buffer, DepthFramePointGenerator::compute, midpoint triangulation) against the
+    pure-Python fixture: bit-exact map / lists, then once more with the map left resident on the device."""
+    pc.check_depth_components(gpu, golden["depth"])
+    pc.check_depth_components(gpu, golden["depth"], resident_map=True)
+
+
 def test_track_golden(golden):
     """vslam_track_match (k_track_candidates + the order-exact resolution of the frame kernel) against the fixture of
     the independent numpy restatement of StereoFramePointGenerator::track: exact tuples, exact lost list."""

@@ -28,6 +28,10 @@ def test_aligner_uvd_known_answers(oracle, golden):
     pc.check_aligner_uvd(oracle, golden["aligner_uvd"])
 
 
+def test_depth_components_known_answers(oracle, golden):
+    pc.check_depth_components(oracle, golden["depth"])
+
+
 def test_aligner_first_linearization(oracle, golden):
     g = golden["aligner"]
     for name in pc.ALIGNER_CASES:

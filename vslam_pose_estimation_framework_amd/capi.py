@@ -82,6 +82,28 @@ class FrameInfo(C.Structure):
         return d
 
 
+class DepthParams(C.Structure):
+    """struct vslam_depth_params (include/vslam_hip.h)."""
+    _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("K_left", C.c_double * 9), ("K_left_inverse", C.c_double * 9),
+                ("K_right_inverse", C.c_double * 9), ("right_to_left", C.c_double * 12),
+                ("depth_scale_factor_intensity_to_meters", C.c_double), ("minimum_depth_meters", C.c_double),
+                ("maximum_depth_meters", C.c_double), ("enable_point_triangulation", C.c_int32),
+                ("enable_keypoint_binning", C.c_int32), ("bin_size_pixels", C.c_int32)]
+
+    @staticmethod
+    def make(rows, cols, K_left, K_left_inverse, K_right_inverse, right_to_left, scale=1e-3, min_depth=0.1, max_depth=10.0,
+             triangulation=1, binning=1, bin_px=6):
+        p = DepthParams()
+        p.rows, p.cols = int(rows), int(cols)
+        for name, a in (("K_left", K_left), ("K_left_inverse", K_left_inverse), ("K_right_inverse", K_right_inverse), ("right_to_left", right_to_left)):
+            flat = np.ascontiguousarray(a, np.float64).ravel()
+            getattr(p, name)[:] = list(flat)
+        p.depth_scale_factor_intensity_to_meters = scale
+        p.minimum_depth_meters, p.maximum_depth_meters = min_depth, max_depth
+        p.enable_point_triangulation, p.enable_keypoint_binning, p.bin_size_pixels = int(triangulation), int(binning), int(bin_px)
+        return p
+
+
 class VslamError(RuntimeError):
     """Raised for a negative vslam_status (the reference throws std::runtime_error)."""
 
@@ -327,6 +349,41 @@ class CApi(object):
                                            C.c_int32(cap), C.byref(n), _p(out, C.c_int32)))
         return out[:n.value].copy()
 
+    # -- RGB-D components.  The oracle's entry points (prefix orc_) take no context. --------------------------------
+    def _ctx_args(self):
+        return (self.ctx,) if self.prefix == "vslam_" else ()
+
+    def depth_space_map(self, params, depth):
+        depth = np.ascontiguousarray(depth, np.uint16)
+        rows, cols = depth.shape
+        space = np.zeros((rows, cols, 3), np.float32)
+        rmap = np.zeros((rows, cols), np.int16); cmap = np.zeros((rows, cols), np.int16)
+        self.check(self.fn("depth_space_map")(*self._ctx_args(), C.byref(params), _p(depth, C.c_uint16), C.c_int32(cols),
+                                              _p(space, C.c_float), _p(rmap, C.c_int16), _p(cmap, C.c_int16)))
+        return space, rmap, cmap
+
+    def depth_compute(self, params, space, rc_features, rc_tracked, cap=8192):
+        """space: host map or None (HIP only: the map the last depth_space_map call left on the device)."""
+        rcf = np.ascontiguousarray(rc_features, np.int32).reshape(-1, 2)
+        rct = np.ascontiguousarray(rc_tracked, np.int32).reshape(-1, 2)
+        sp = None if space is None else np.ascontiguousarray(space, np.float32)
+        nf, xyz = np.zeros(cap, np.int32), np.zeros((cap, 3), np.float64)
+        tf_, txyz = np.zeros(cap, np.int32), np.zeros((cap, 3), np.float64)
+        nn, nt = C.c_int32(), C.c_int32()
+        self.check(self.fn("depth_compute")(*self._ctx_args(), C.byref(params), None if sp is None else _p(sp, C.c_float),
+                                            C.c_int32(rcf.shape[0]), _p(rcf, C.c_int32), C.c_int32(rct.shape[0]),
+                                            _p(rct, C.c_int32), C.c_int32(cap), C.byref(nn), _p(nf, C.c_int32),
+                                            _p(xyz, C.c_double), C.byref(nt), _p(tf_, C.c_int32), _p(txyz, C.c_double)))
+        return nf[:nn.value].copy(), xyz[:nn.value].copy(), tf_[:nt.value].copy(), txyz[:nt.value].copy()
+
+    def point_in_camera(self, xy_previous, xy_current, T, K):
+        xp = np.ascontiguousarray(xy_previous, np.float32).reshape(-1, 2)
+        xc = np.ascontiguousarray(xy_current, np.float32).reshape(-1, 2)
+        T = np.ascontiguousarray(T, np.float64).reshape(12); K = np.ascontiguousarray(K, np.float64).reshape(9)
+        out = np.zeros((xp.shape[0], 3), np.float64)
+        self.check(self.fn("point_in_camera")(*self._ctx_args(), C.c_int32(xp.shape[0]), _p(xp, C.c_float), _p(xc, C.c_float),
+                                              _p(T, C.c_double), _p(K, C.c_double), _p(out, C.c_double)))
+        return out
 
 def _extra_methods():
     def copy_poses_device(self, first, count, dst_ptr):

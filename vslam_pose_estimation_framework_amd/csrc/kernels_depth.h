@@ -1,0 +1,207 @@
+// kernels_depth.h — RGB-D components: the pieces of DepthFramePointGenerator as stand-alone
+// kernels.  gfx950, wave64.  HBM-bound byte / float work: one thread per pixel, coalesced rows, no LDS needed.
+//
+// Reference code replaced (paths relative to the reference root):
+//   k_depth_*          DepthFramePointGenerator::_computeDepthMap   framepoint_generation/depth_framepoint_generator.cpp:410-485
+//   k_depth_compute    DepthFramePointGenerator::compute            framepoint_generation/depth_framepoint_generator.cpp:45-164
+//   k_point_in_camera  BaseFramePointGenerator::getPointInCamera    framepoint_generation/base_framepoint_generator.cpp:461-494
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/vslam_hip.h"
+
+// ---- space map --------------------------------------------------------------------------------------------------
+// The reference fills the map with a serial z-buffer whose test compares the STORED FLOAT with the new DOUBLE depth
+// (:479), in scan order.  Its fixed point, per destination pixel, with F0 = float(maximum_depth), fl() = rounding to
+// float and S = the sources whose fl(z) equals Fmin = min(F0, min fl(z)):
+//     winner = the last source of S (scan order) with z < Fmin, or — if Fmin < F0 and no later such source exists — the
+//     first source of S
+// (a source replaces the entry whenever the stored float is strictly above its double depth; once the minimum float is
+// stored only sources that round UP to it still pass).  Three order-free passes reproduce it exactly:
+//   min   atomicMin of the float bits (positive floats order like integers)
+//   pick  sources of S: atomicMin of the index ("first"), atomicMax of the index among those with z < Fmin ("last")
+//   write one thread per destination recomputes its winner (same arithmetic, same bits) and stores it
+struct DepthSource { double pl[3]; int dest; };
+
+__device__ __forceinline__ bool depth_source(const vslam_depth_params& p, const uint16_t* depth, int stride, int r, int c, DepthSource& s) {
+  const unsigned raw = depth[(size_t)r * stride + c];
+  if (!raw) return false;                                                                   // :449
+  const double dm = (double)(int)raw * p.depth_scale_factor_intensity_to_meters;            // :452
+  const double ph[3] = {c * dm, r * dm, dm};
+  double pr[3], px[3];
+  const double* Ki = p.K_right_inverse;
+  for (int i = 0; i < 3; ++i) pr[i] = (Ki[3 * i] * ph[0] + Ki[3 * i + 1] * ph[1]) + Ki[3 * i + 2] * ph[2];   // :454
+  const double* T = p.right_to_left;
+  for (int i = 0; i < 3; ++i) s.pl[i] = ((T[4 * i] * pr[0] + T[4 * i + 1] * pr[1]) + T[4 * i + 2] * pr[2]) + T[4 * i + 3];   // :456
+  if (s.pl[2] <= 0) return false;                                                           // :458-460
+  const double* K = p.K_left;
+  for (int i = 0; i < 3; ++i) px[i] = (K[3 * i] * s.pl[0] + K[3 * i + 1] * s.pl[1]) + K[3 * i + 2] * s.pl[2];   // :462
+  const double u = px[0] / px[2], v = px[1] / px[2];                                        // :463
+  const double ru = round(u), rv = round(v);                                                // :466-467 (half away from zero)
+  if (!(rv >= 0 && rv < p.rows && ru >= 0 && ru < p.cols)) return false;                    // :470-474
+  s.dest = (int)rv * p.cols + (int)ru;
+  return true;
+}
+
+__global__ __launch_bounds__(256) void k_depth_init(int n, uint32_t f0_bits, uint32_t* fmin, int32_t* first, int32_t* last) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { fmin[i] = f0_bits; first[i] = 0x7fffffff; last[i] = -1; }
+}
+
+__global__ __launch_bounds__(256) void k_depth_min(const vslam_depth_params p, const uint16_t* depth, int stride, uint32_t* fmin) {
+  const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+  if (c >= p.cols) return;
+  DepthSource s;
+  if (!depth_source(p, depth, stride, r, c, s)) return;
+  atomicMin(&fmin[s.dest], __float_as_uint((float)s.pl[2]));
+}
+
+__global__ __launch_bounds__(256) void k_depth_pick(const vslam_depth_params p, const uint16_t* depth, int stride, const uint32_t* fmin,
+                                                    int32_t* first, int32_t* last) {
+  const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+  if (c >= p.cols) return;
+  DepthSource s;
+  if (!depth_source(p, depth, stride, r, c, s)) return;
+  const uint32_t m = fmin[s.dest];
+  if (__float_as_uint((float)s.pl[2]) != m) return;
+  const int idx = r * p.cols + c;
+  atomicMin(&first[s.dest], idx);
+  if (s.pl[2] < (double)__uint_as_float(m)) atomicMax(&last[s.dest], idx);
+}
+
+__global__ __launch_bounds__(256) void k_depth_write(const vslam_depth_params p, const uint16_t* depth, int stride, uint32_t f0_bits,
+                                                     const uint32_t* fmin, const int32_t* first, const int32_t* last, float* space,
+                                                     int16_t* row_map, int16_t* col_map) {
+  const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+  if (c >= p.cols) return;
+  const int d = r * p.cols + c;
+  int win = last[d];
+  if (fmin[d] < f0_bits && first[d] != 0x7fffffff) win = max(win, first[d]);
+  float o[3] = {0.f, 0.f, __uint_as_float(f0_bits)};                                       // :428-432
+  int sr = -1, sc = -1;
+  if (win >= 0) {
+    sr = win / p.cols; sc = win - sr * p.cols;
+    DepthSource s;
+    depth_source(p, depth, stride, sr, sc, s);
+    o[0] = (float)s.pl[0]; o[1] = (float)s.pl[1]; o[2] = (float)s.pl[2];                  // :480-482
+  }
+  space[3 * (size_t)d] = o[0]; space[3 * (size_t)d + 1] = o[1]; space[3 * (size_t)d + 2] = o[2];
+  row_map[d] = (int16_t)sr; col_map[d] = (int16_t)sc;                                      // :483-484
+}
+
+// ---- compute ----------------------------------------------------------------------------------------------------
+// One 1024-thread workgroup per image (the unit of the reference's loop; ~2000 features).  The serial bin competition
+// "an untracked occupant is replaced by a strictly lower depth" (:117-129) ends with the FIRST feature of the bin's
+// minimum depth: atomicMin of (float bits of the depth << 32 | feature index); bins owned by a tracked point hold 0.
+// cls: 0 dropped, 1 new point, 2 temporary point (depth >= maximum, triangulation enabled).
+__device__ __forceinline__ int depth_bin(const vslam_depth_params& p, int row, int col, int cols_bin1) {
+  const int rb = (int)rint((double)row / p.bin_size_pixels), cb = (int)rint((double)col / p.bin_size_pixels);   // :59-60, :113-114
+  return rb * cols_bin1 + cb;
+}
+
+__global__ __launch_bounds__(1024) void k_depth_compute(const vslam_depth_params p, const float* space, int nF, const int32_t* rcF, int nT,
+                                                        const int32_t* rcT, unsigned long long* bins, int n_bins, int rows_bin, int cols_bin,
+                                                        int cap, int32_t* counts, int32_t* new_feat, double* new_xyz, int32_t* temp_feat,
+                                                        double* temp_xyz, uint8_t* cls) {
+  __shared__ int sh[17];
+  const int tid = threadIdx.x;
+  const int cols_bin1 = cols_bin + 1;   // rint() can reach the grid size (latent overflow upstream): spare row / column
+  for (int i = tid; i < n_bins; i += 1024) bins[i] = ~0ull;
+  __syncthreads();
+  if (p.enable_keypoint_binning)
+    for (int i = tid; i < nT; i += 1024) bins[depth_bin(p, rcT[2 * i], rcT[2 * i + 1], cols_bin1)] = 0ull;     // :57-63
+  __syncthreads();
+  for (int i = tid; i < nF; i += 1024) {
+    const int row = rcF[2 * i], col = rcF[2 * i + 1];
+    const float z = space[3 * ((size_t)row * p.cols + col) + 2];
+    uint8_t k = 0;
+    if (!((double)z < p.minimum_depth_meters)) {                                                               // :80
+      if ((double)z >= p.maximum_depth_meters && p.enable_point_triangulation) k = 2;                          // :89
+      else {
+        k = 1;
+        if (p.enable_keypoint_binning)
+          atomicMin(&bins[depth_bin(p, row, col, cols_bin1)], ((unsigned long long)__float_as_uint(z) << 32) | (unsigned)i);
+      }
+    }
+    cls[i] = k;
+  }
+  __syncthreads();
+  // temporary points, feature order (:92-100)
+  int n_temp = 0;
+  for (int base = 0; base < nF; base += 1024) {
+    const int i = base + tid;
+    const int mine = (i < nF && cls[i] == 2) ? 1 : 0;
+    int total;
+    const int at = n_temp + block_exclusive_scan(mine, sh, &total);
+    if (mine && at < cap) {
+      const double m = p.maximum_depth_meters;
+      const double ph[3] = {rcF[2 * i + 1] * m, rcF[2 * i] * m, m};
+      const double* Ki = p.K_left_inverse;
+      temp_feat[at] = i;
+      for (int q = 0; q < 3; ++q) temp_xyz[3 * (size_t)at + q] = (Ki[3 * q] * ph[0] + Ki[3 * q + 1] * ph[1]) + Ki[3 * q + 2] * ph[2];
+    }
+    n_temp += total;
+  }
+  // new points: bin grid row-major (:141-157) or feature order (:160-162)
+  int n_new = 0;
+  const int n_scan = p.enable_keypoint_binning ? rows_bin * cols_bin : nF;
+  for (int base = 0; base < n_scan; base += 1024) {
+    const int j = base + tid;
+    int feat = -1;
+    if (j < n_scan) {
+      if (p.enable_keypoint_binning) {
+        const int rb = j / cols_bin, cb = j - rb * cols_bin;
+        const unsigned long long key = bins[rb * cols_bin1 + cb];
+        if (key != ~0ull && key != 0ull) feat = (int)(key & 0xffffffffu);
+      } else if (cls[j] == 1) {
+        feat = j;
+      }
+    }
+    int total;
+    const int at = n_new + block_exclusive_scan(feat >= 0 ? 1 : 0, sh, &total);
+    if (feat >= 0 && at < cap) {
+      const float* d = space + 3 * ((size_t)rcF[2 * feat] * p.cols + rcF[2 * feat + 1]);
+      new_feat[at] = feat;
+      for (int q = 0; q < 3; ++q) new_xyz[3 * (size_t)at + q] = (double)d[q];
+    }
+    n_new += total;
+  }
+  if (tid == 0) { counts[0] = n_new; counts[1] = n_temp; }
+}
+
+// ---- midpoint triangulation -------------------------------------------------------------------------------------
+// The 3x2 least-squares system [-R x0 | x1] z = t (:480-486): QR of the two columns, triangular solve; minimum-norm
+// solution when the rays are parallel to rounding (JacobiSVD's rank rule: sigma_min <= 2 eps sigma_max).
+__global__ __launch_bounds__(256) void k_point_in_camera(int n, const float* xp, const float* xc, const double* Tg, const double* Kg, double* out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double T[12], K[9];
+  for (int k = 0; k < 12; ++k) T[k] = Tg[k];
+  for (int k = 0; k < 9; ++k) K[k] = Kg[k];
+  const double a0 = ((double)xp[2 * i] - K[2]) / K[0], b0 = ((double)xp[2 * i + 1] - K[5]) / K[4];   // :470-473
+  const double a1 = ((double)xc[2 * i] - K[2]) / K[0], b1 = ((double)xc[2 * i + 1] - K[5]) / K[4];
+  const double x0[3] = {a0, b0, 1}, x1[3] = {a1, b1, 1};
+  double c0[3], t[3];
+  for (int k = 0; k < 3; ++k) { c0[k] = -((T[4 * k] * x0[0] + T[4 * k + 1] * x0[1]) + T[4 * k + 2] * x0[2]); t[k] = T[4 * k + 3]; }
+  const double r00 = sqrt((c0[0] * c0[0] + c0[1] * c0[1]) + c0[2] * c0[2]);
+  double q0[3], v[3];
+  for (int k = 0; k < 3; ++k) q0[k] = c0[k] / r00;
+  const double r01 = (q0[0] * x1[0] + q0[1] * x1[1]) + q0[2] * x1[2];
+  for (int k = 0; k < 3; ++k) v[k] = x1[k] - r01 * q0[k];
+  const double r11 = sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+  const double g0 = (q0[0] * t[0] + q0[1] * t[1]) + q0[2] * t[2];
+  const double fro2 = (r00 * r00 + r01 * r01) + r11 * r11;
+  double z0, z1;
+  if (r00 * r11 > 2 * 2.220446049250313e-16 * fro2) {
+    const double g1 = ((v[0] * t[0] + v[1] * t[1]) + v[2] * t[2]) / r11;
+    z1 = g1 / r11;
+    z0 = (g0 - r01 * z1) / r00;
+  } else {
+    const double n2 = r00 * r00 + r01 * r01;
+    z0 = g0 * r00 / n2; z1 = g0 * r01 / n2;
+  }
+  const double pp[3] = {x0[0] * z0, x0[1] * z0, x0[2] * z0};                                        // :489
+  for (int k = 0; k < 3; ++k) {
+    const double moved = ((T[4 * k] * pp[0] + T[4 * k + 1] * pp[1]) + T[4 * k + 2] * pp[2]) + T[4 * k + 3];
+    out[3 * (size_t)i + k] = (x1[k] * z1 + moved) / 2.0;                                            // :490-493
+  }
+}

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "kernels_frame2.h"
+#include "kernels_depth.h"
 
 #define VS_API extern "C" __attribute__((visibility("default")))
 
@@ -49,6 +50,9 @@ struct vslam_ctx {
   std::vector<hipEvent_t> evpool;
   double kern_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int kern_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // RGB-D components: the space map of the last vslam_depth_space_map call stays resident for vslam_depth_compute
+  struct DepthMap { int rows = 0, cols = 0; uint16_t* depth = nullptr; uint32_t* fmin = nullptr; int32_t* first = nullptr; int32_t* last = nullptr;
+                    float* space = nullptr; int16_t* row_map = nullptr; int16_t* col_map = nullptr; bool valid = false; } dm;
   int split = 0;   // 1: frame processed by phase launches with wide kernels in between (measured slower); 0: one launch
   int sticky = VSLAM_OK;
 };
@@ -341,6 +345,12 @@ static int create_internal(const vslam_config* cfg, int device, int n_streams, v
   return VSLAM_OK;
 }
 
+static void depth_map_free(vslam_ctx* c) {
+  vslam_ctx::DepthMap& m = c->dm;
+  (void)hipFree(m.depth); (void)hipFree(m.fmin); (void)hipFree(m.first); (void)hipFree(m.last); (void)hipFree(m.space);
+  (void)hipFree(m.row_map); (void)hipFree(m.col_map);
+  m = vslam_ctx::DepthMap();
+}
 VS_API int vslam_create(const vslam_config* cfg, int device, int n_streams, vslam_ctx** out) {
   return create_internal(cfg, device, n_streams, out);
 }
@@ -349,6 +359,7 @@ VS_API void vslam_destroy(vslam_ctx* c) {
   (void)hipSetDevice(c->device);
   sync_all(c);
   for (void* p : c->allocs) (void)hipFree(p);
+  depth_map_free(c);
   for (int i = 0; i < 6; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   harvest_events(c);
   for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
@@ -600,6 +611,132 @@ VS_API int vslam_get_aligner_result(vslam_ctx* c, int s, int32_t cap, int32_t* n
   if (H) std::memcpy(H, st.al_H, sizeof(double) * 36);
   return VSLAM_OK;
 }
+// ---- RGB-D components (DepthFramePointGenerator pieces, stand-alone) ------------------------------------------------
+static int depth_params_ok(vslam_ctx* c, const vslam_depth_params* p) {
+  if (!c) return VSLAM_ERR_INVALID;
+  if (c->sticky != VSLAM_OK) return c->sticky;
+  if (!p || p->rows <= 0 || p->cols <= 0 || p->rows > 32767 || p->cols > 32767) return fail(c, VSLAM_ERR_INVALID, "depth: image size out of range");
+  if (!(p->maximum_depth_meters > 0) || (p->enable_keypoint_binning && p->bin_size_pixels <= 0)) return fail(c, VSLAM_ERR_INVALID, "depth: bad parameters");
+  return VSLAM_OK;
+}
+VS_API int vslam_depth_space_map(vslam_ctx* c, const vslam_depth_params* p, const uint16_t* depth, int32_t row_stride, float* space,
+                                 int16_t* row_map, int16_t* col_map) {
+  int rc = depth_params_ok(c, p);
+  if (rc != VSLAM_OK) return rc;
+  if (!depth) return fail(c, VSLAM_ERR_INVALID, "depth tracker requires a 16bit mono image to encode depth");   // :411-413
+  if (row_stride < p->cols) return fail(c, VSLAM_ERR_INVALID, "row stride smaller than image width");
+  HIP_TRY(c, hipSetDevice(c->device));
+  vslam_ctx::DepthMap& m = c->dm;
+  const size_t n = (size_t)p->rows * p->cols;
+  if (m.rows != p->rows || m.cols != p->cols) {
+    depth_map_free(c);
+    hipError_t e = hipMalloc((void**)&m.depth, n * sizeof(uint16_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&m.fmin, n * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&m.first, n * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&m.last, n * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&m.space, n * 3 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&m.row_map, n * sizeof(int16_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&m.col_map, n * sizeof(int16_t));
+    if (e != hipSuccess) { depth_map_free(c); return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e)); }
+    m.rows = p->rows; m.cols = p->cols;
+  }
+  m.valid = false;
+  // rows re-packed on the device side of the copy (dense device image, stride = cols)
+  if (row_stride == p->cols) HIP_TRY(c, hipMemcpyAsync(m.depth, depth, n * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+  else HIP_TRY(c, hipMemcpy2DAsync(m.depth, (size_t)p->cols * 2, depth, (size_t)row_stride * 2, (size_t)p->cols * 2, p->rows, hipMemcpyHostToDevice, c->stream));
+  const float f0 = (float)p->maximum_depth_meters;
+  uint32_t f0_bits;
+  std::memcpy(&f0_bits, &f0, 4);
+  const dim3 grid((p->cols + 255) / 256, p->rows);
+  hipLaunchKernelGGL(k_depth_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (int)n, f0_bits, m.fmin, m.first, m.last);
+  hipLaunchKernelGGL(k_depth_min, grid, dim3(256), 0, c->stream, *p, m.depth, p->cols, m.fmin);
+  hipLaunchKernelGGL(k_depth_pick, grid, dim3(256), 0, c->stream, *p, m.depth, p->cols, m.fmin, m.first, m.last);
+  hipLaunchKernelGGL(k_depth_write, grid, dim3(256), 0, c->stream, *p, m.depth, p->cols, f0_bits, m.fmin, m.first, m.last, m.space, m.row_map, m.col_map);
+  HIP_TRY(c, hipGetLastError());
+  if (space) HIP_TRY(c, hipMemcpyAsync(space, m.space, n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  if (row_map) HIP_TRY(c, hipMemcpyAsync(row_map, m.row_map, n * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
+  if (col_map) HIP_TRY(c, hipMemcpyAsync(col_map, m.col_map, n * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  m.valid = true;
+  return VSLAM_OK;
+}
+VS_API int vslam_depth_compute(vslam_ctx* c, const vslam_depth_params* p, const float* space, int32_t nF, const int32_t* rcF, int32_t nT,
+                               const int32_t* rcT, int32_t cap, int32_t* n_new, int32_t* new_feat, double* new_xyz, int32_t* n_temp,
+                               int32_t* temp_feat, double* temp_xyz) {
+  int rc = depth_params_ok(c, p);
+  if (rc != VSLAM_OK) return rc;
+  if (nF < 0 || nT < 0 || cap < 0 || !n_new || !n_temp || (nF && !rcF) || (nT && !rcT) || (cap && (!new_feat || !new_xyz || !temp_feat || !temp_xyz)))
+    return fail(c, VSLAM_ERR_INVALID, "depth_compute: bad argument");
+  for (int i = 0; i < nF; ++i) if (rcF[2 * i] < 0 || rcF[2 * i] >= p->rows || rcF[2 * i + 1] < 0 || rcF[2 * i + 1] >= p->cols) return fail(c, VSLAM_ERR_INVALID, "depth_compute: feature outside the image");
+  for (int i = 0; i < nT; ++i) if (rcT[2 * i] < 0 || rcT[2 * i] >= p->rows || rcT[2 * i + 1] < 0 || rcT[2 * i + 1] >= p->cols) return fail(c, VSLAM_ERR_INVALID, "depth_compute: point outside the image");
+  if (!space && !(c->dm.valid && c->dm.rows == p->rows && c->dm.cols == p->cols)) return fail(c, VSLAM_ERR_STATE, "depth_compute: no resident space map of this size");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t n = (size_t)p->rows * p->cols;
+  const int rows_bin = p->enable_keypoint_binning ? p->rows / p->bin_size_pixels + 1 : 0;   // base_framepoint_generator.cpp:304-305
+  const int cols_bin = p->enable_keypoint_binning ? p->cols / p->bin_size_pixels + 1 : 0;
+  const int n_bins = (rows_bin + 1) * (cols_bin + 1);
+  float* dspace = nullptr; int32_t *dF = nullptr, *dT = nullptr, *dcnt = nullptr, *dnf = nullptr, *dtf = nullptr;
+  double *dnx = nullptr, *dtx = nullptr; unsigned long long* dbins = nullptr; uint8_t* dcls = nullptr;
+  const size_t capa = std::max(cap, 1);
+  hipError_t e = hipSuccess;
+  if (space) { e = hipMalloc((void**)&dspace, n * 3 * sizeof(float)); if (e == hipSuccess) e = hipMemcpyAsync(dspace, space, n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream); }
+  if (e == hipSuccess) e = hipMalloc((void**)&dF, std::max(nF, 1) * 2 * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&dT, std::max(nT, 1) * 2 * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&dcnt, 2 * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&dnf, capa * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&dtf, capa * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&dnx, capa * 3 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&dtx, capa * 3 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&dbins, (size_t)n_bins * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMalloc((void**)&dcls, std::max(nF, 1));
+  if (e == hipSuccess && nF) e = hipMemcpyAsync(dF, rcF, (size_t)nF * 2 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess && nT) e = hipMemcpyAsync(dT, rcT, (size_t)nT * 2 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
+  int32_t cnt[2] = {0, 0};
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_depth_compute, dim3(1), dim3(1024), 0, c->stream, *p, space ? dspace : c->dm.space, nF, dF, nT, dT, dbins, n_bins,
+                       rows_bin, cols_bin, cap, dcnt, dnf, dnx, dtf, dtx, dcls);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(cnt, dcnt, sizeof cnt, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) {
+    *n_new = cnt[0]; *n_temp = cnt[1];
+    const int a = std::min(cnt[0], cap), b = std::min(cnt[1], cap);
+    if (a) { e = hipMemcpy(new_feat, dnf, (size_t)a * sizeof(int32_t), hipMemcpyDeviceToHost); if (e == hipSuccess) e = hipMemcpy(new_xyz, dnx, (size_t)a * 3 * sizeof(double), hipMemcpyDeviceToHost); }
+    if (e == hipSuccess && b) { e = hipMemcpy(temp_feat, dtf, (size_t)b * sizeof(int32_t), hipMemcpyDeviceToHost); if (e == hipSuccess) e = hipMemcpy(temp_xyz, dtx, (size_t)b * 3 * sizeof(double), hipMemcpyDeviceToHost); }
+  }
+  (void)hipFree(dspace); (void)hipFree(dF); (void)hipFree(dT); (void)hipFree(dcnt); (void)hipFree(dnf); (void)hipFree(dtf);
+  (void)hipFree(dnx); (void)hipFree(dtx); (void)hipFree(dbins); (void)hipFree(dcls);
+  if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
+  if (cnt[0] > cap || cnt[1] > cap) return fail(c, VSLAM_ERR_CAPACITY, "depth_compute: output capacity too small");
+  return VSLAM_OK;
+}
+VS_API int vslam_point_in_camera(vslam_ctx* c, int32_t n, const float* xp, const float* xc, const double T[12], const double K[9], double* out) {
+  if (!c) return VSLAM_ERR_INVALID;
+  if (c->sticky != VSLAM_OK) return c->sticky;
+  if (n < 0 || !T || !K || (n && (!xp || !xc || !out))) return fail(c, VSLAM_ERR_INVALID, "point_in_camera: bad argument");
+  if (n == 0) return VSLAM_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  float *dp = nullptr, *dc = nullptr; double *dT = nullptr, *dK = nullptr, *dout = nullptr;
+  hipError_t e = hipMalloc((void**)&dp, (size_t)n * 2 * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&dc, (size_t)n * 2 * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&dT, 12 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&dK, 9 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&dout, (size_t)n * 3 * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpyAsync(dp, xp, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dc, xc, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dT, T, 12 * sizeof(double), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dK, K, 9 * sizeof(double), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_point_in_camera, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, dp, dc, dT, dK, dout);
+    e = hipMemcpyAsync(out, dout, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(dp); (void)hipFree(dc); (void)hipFree(dT); (void)hipFree(dK); (void)hipFree(dout);
+  if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
+  return VSLAM_OK;
+}
+
 VS_API int vslam_get_poses(vslam_ctx* c, int s, int32_t first, int32_t nf, double* out) {
   int rc = check_stream(c, s);
   if (rc) return rc;
