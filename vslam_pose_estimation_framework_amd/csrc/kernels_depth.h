@@ -17,8 +17,9 @@
 //     first source of S
 // (a source replaces the entry whenever the stored float is strictly above its double depth; once the minimum float is
 // stored only sources that round UP to it still pass).  Three order-free passes reproduce it exactly:
-//   min   atomicMin of the float bits (positive floats order like integers)
-//   pick  sources of S: atomicMin of the index ("first"), atomicMax of the index among those with z < Fmin ("last")
+//   min   atomicMin of (float bits << 32 | source index): Fmin and the first source of S (positive floats order like
+//         integers)
+//   pick  sources of S with z < Fmin other than the first: atomicMax of the index ("last"); rare
 //   write one thread per destination recomputes its winner (same arithmetic, same bits) and stores it
 struct DepthSource { double pl[3]; int dest; };
 
@@ -42,40 +43,46 @@ __device__ __forceinline__ bool depth_source(const vslam_depth_params& p, const 
   return true;
 }
 
-__global__ __launch_bounds__(256) void k_depth_init(int n, uint32_t f0_bits, uint32_t* fmin, int32_t* first, int32_t* last) {
+__global__ __launch_bounds__(256) void k_depth_init(int n, uint32_t f0_bits, unsigned long long* key, int32_t* last) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) { fmin[i] = f0_bits; first[i] = 0x7fffffff; last[i] = -1; }
+  if (i < n) { key[i] = ((unsigned long long)f0_bits << 32) | 0xffffffffull; last[i] = -1; }
 }
 
-__global__ __launch_bounds__(256) void k_depth_min(const vslam_depth_params p, const uint16_t* depth, int stride, uint32_t* fmin) {
+// min + first in ONE 64-bit atomic per source: key = float bits of the depth << 32 | source index
+__global__ __launch_bounds__(256) void k_depth_min(const vslam_depth_params p, const uint16_t* depth, int stride, unsigned long long* key) {
   const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
   if (c >= p.cols) return;
   DepthSource s;
   if (!depth_source(p, depth, stride, r, c, s)) return;
-  atomicMin(&fmin[s.dest], __float_as_uint((float)s.pl[2]));
+  atomicMin(&key[s.dest], ((unsigned long long)__float_as_uint((float)s.pl[2]) << 32) | (unsigned)(r * p.cols + c));
 }
 
-__global__ __launch_bounds__(256) void k_depth_pick(const vslam_depth_params p, const uint16_t* depth, int stride, const uint32_t* fmin,
-                                                    int32_t* first, int32_t* last) {
+// "last": only sources that tie the minimum float, lie strictly below it as doubles and are not the first one already
+// recorded — with one source per destination (the usual case) no atomic is issued here at all
+__global__ __launch_bounds__(256) void k_depth_pick(const vslam_depth_params p, const uint16_t* depth, int stride, uint32_t f0_bits,
+                                                    const unsigned long long* key, int32_t* last) {
   const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
   if (c >= p.cols) return;
   DepthSource s;
   if (!depth_source(p, depth, stride, r, c, s)) return;
-  const uint32_t m = fmin[s.dest];
+  const unsigned long long k = key[s.dest];
+  const uint32_t m = (uint32_t)(k >> 32);
   if (__float_as_uint((float)s.pl[2]) != m) return;
   const int idx = r * p.cols + c;
-  atomicMin(&first[s.dest], idx);
-  if (s.pl[2] < (double)__uint_as_float(m)) atomicMax(&last[s.dest], idx);
+  if (!(s.pl[2] < (double)__uint_as_float(m))) return;
+  if (m < f0_bits && (uint32_t)idx == (uint32_t)k) return;   // the first source wins anyway unless a later one passes
+  atomicMax(&last[s.dest], idx);
 }
 
 __global__ __launch_bounds__(256) void k_depth_write(const vslam_depth_params p, const uint16_t* depth, int stride, uint32_t f0_bits,
-                                                     const uint32_t* fmin, const int32_t* first, const int32_t* last, float* space,
+                                                     const unsigned long long* key, const int32_t* last, float* space,
                                                      int16_t* row_map, int16_t* col_map) {
   const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
   if (c >= p.cols) return;
   const int d = r * p.cols + c;
+  const unsigned long long k = key[d];
   int win = last[d];
-  if (fmin[d] < f0_bits && first[d] != 0x7fffffff) win = max(win, first[d]);
+  if ((uint32_t)(k >> 32) < f0_bits && (uint32_t)k != 0xffffffffu) win = max(win, (int)(uint32_t)k);
   float o[3] = {0.f, 0.f, __uint_as_float(f0_bits)};                                       // :428-432
   int sr = -1, sc = -1;
   if (win >= 0) {

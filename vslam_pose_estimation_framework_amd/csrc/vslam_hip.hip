@@ -51,7 +51,7 @@ struct vslam_ctx {
   double kern_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int kern_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   // RGB-D components: the space map of the last vslam_depth_space_map call stays resident for vslam_depth_compute
-  struct DepthMap { int rows = 0, cols = 0; uint16_t* depth = nullptr; uint32_t* fmin = nullptr; int32_t* first = nullptr; int32_t* last = nullptr;
+  struct DepthMap { int rows = 0, cols = 0; uint16_t* depth = nullptr; unsigned long long* key = nullptr; int32_t* last = nullptr;
                     float* space = nullptr; int16_t* row_map = nullptr; int16_t* col_map = nullptr; bool valid = false; } dm;
   int split = 0;   // 1: frame processed by phase launches with wide kernels in between (measured slower); 0: one launch
   int sticky = VSLAM_OK;
@@ -347,7 +347,7 @@ static int create_internal(const vslam_config* cfg, int device, int n_streams, v
 
 static void depth_map_free(vslam_ctx* c) {
   vslam_ctx::DepthMap& m = c->dm;
-  (void)hipFree(m.depth); (void)hipFree(m.fmin); (void)hipFree(m.first); (void)hipFree(m.last); (void)hipFree(m.space);
+  (void)hipFree(m.depth); (void)hipFree(m.key); (void)hipFree(m.last); (void)hipFree(m.space);
   (void)hipFree(m.row_map); (void)hipFree(m.col_map);
   m = vslam_ctx::DepthMap();
 }
@@ -631,8 +631,7 @@ VS_API int vslam_depth_space_map(vslam_ctx* c, const vslam_depth_params* p, cons
   if (m.rows != p->rows || m.cols != p->cols) {
     depth_map_free(c);
     hipError_t e = hipMalloc((void**)&m.depth, n * sizeof(uint16_t));
-    if (e == hipSuccess) e = hipMalloc((void**)&m.fmin, n * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void**)&m.first, n * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&m.key, n * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void**)&m.last, n * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&m.space, n * 3 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m.row_map, n * sizeof(int16_t));
@@ -648,10 +647,10 @@ VS_API int vslam_depth_space_map(vslam_ctx* c, const vslam_depth_params* p, cons
   uint32_t f0_bits;
   std::memcpy(&f0_bits, &f0, 4);
   const dim3 grid((p->cols + 255) / 256, p->rows);
-  hipLaunchKernelGGL(k_depth_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (int)n, f0_bits, m.fmin, m.first, m.last);
-  hipLaunchKernelGGL(k_depth_min, grid, dim3(256), 0, c->stream, *p, m.depth, p->cols, m.fmin);
-  hipLaunchKernelGGL(k_depth_pick, grid, dim3(256), 0, c->stream, *p, m.depth, p->cols, m.fmin, m.first, m.last);
-  hipLaunchKernelGGL(k_depth_write, grid, dim3(256), 0, c->stream, *p, m.depth, p->cols, f0_bits, m.fmin, m.first, m.last, m.space, m.row_map, m.col_map);
+  hipLaunchKernelGGL(k_depth_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (int)n, f0_bits, m.key, m.last);
+  hipLaunchKernelGGL(k_depth_min, grid, dim3(256), 0, c->stream, *p, m.depth, p->cols, m.key);
+  hipLaunchKernelGGL(k_depth_pick, grid, dim3(256), 0, c->stream, *p, m.depth, p->cols, f0_bits, m.key, m.last);
+  hipLaunchKernelGGL(k_depth_write, grid, dim3(256), 0, c->stream, *p, m.depth, p->cols, f0_bits, m.key, m.last, m.space, m.row_map, m.col_map);
   HIP_TRY(c, hipGetLastError());
   if (space) HIP_TRY(c, hipMemcpyAsync(space, m.space, n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   if (row_map) HIP_TRY(c, hipMemcpyAsync(row_map, m.row_map, n * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
