@@ -327,6 +327,21 @@ int vslam_depth_compute(vslam_ctx* ctx, const vslam_depth_params* p, const float
                         int32_t* new_feature, double* new_xyz, int32_t* n_temporary, int32_t* temporary_feature,
                         double* temporary_xyz);
 
+/* DepthFramePointGenerator::track (:166-287) on caller-provided data: the previous frame's points followed by its
+ * temporary points (:181-184) as left-camera coordinates cam (nP*3), left descriptors (nP*32) and flags (bit 0: has a
+ * landmark, bit 1: hasUnreliableDepth); the motion prior T (previous -> current camera), the search window d, the
+ * descriptor threshold tau (minimum_descriptor_distance_tracking in the reference) and the search mode; the current left
+ * features as (row, col) pairs + descriptors (one feature per pixel); the space map as in vslam_depth_compute.
+ * Outputs, all in the order of the previous points (the greedy, order-dependent outcome of the serial loop, reproduced
+ * exactly): out2 = (previous index, left feature) of the tracked points with their measured coordinates xyz; temp2 = the
+ * same pairs for matches on pixels without depth (temporary points, triangulation enabled); lost = previous points that go
+ * to the lost list (:281-284).  Every list has room for nP entries. */
+int vslam_depth_track(vslam_ctx* ctx, const vslam_depth_params* p, const float* space_map, const double T[12], int32_t d,
+                      double tau, int32_t by_appearance, int32_t nP, const double* cam, const uint8_t* previous_desc,
+                      const uint8_t* previous_flags, int32_t nL, const int32_t* rc_left, const uint8_t* desc_left,
+                      int32_t* n_tracked, int32_t* out2, double* xyz, int32_t* n_temporary, int32_t* temp2, int32_t* n_lost,
+                      int32_t* lost, int32_t* n_tracked_landmarks);
+
 /* BaseFramePointGenerator::getPointInCamera (base_framepoint_generator.cpp:461-494) for n point pairs: midpoint
  * triangulation of a previous / current image point pair under the motion T (previous -> current camera); the 3x2
  * least-squares problem is solved through its singular value decomposition (minimum-norm for a rank-deficient pair).

@@ -1631,6 +1631,57 @@ ORC_API int orc_depth_compute(const vslam_depth_params* p, const float* space, i
   return VSLAM_OK;
 }
 
+/* DepthFramePointGenerator::track (:166-287) on caller-provided data.  Previous points = points + temporary points of the
+ * previous frame, in that order (:181-184); flags bit0 = has a landmark, bit1 = hasUnreliableDepth.  out2 = (previous index,
+ * left feature) per tracked point with its measured coordinates; temp2 = the same for the points whose pixel has no depth
+ * (:231-238, triangulation enabled); lost as in :264-268. */
+ORC_API int orc_depth_track(const vslam_depth_params* p, const float* space, const double T[12], int32_t d, double tau, int32_t by_appearance,
+                            int32_t nP, const double* cam, const uint8_t* pdesc, const uint8_t* pflags, int32_t nL, const int32_t* rcL,
+                            const uint8_t* dL, int32_t* n_tracked, int32_t* out2, double* xyz, int32_t* n_temp, int32_t* temp2,
+                            int32_t* n_lost, int32_t* lost, int32_t* n_tracked_landmarks) {
+  const int rows = p->rows, cols = p->cols;
+  FeatureStore store;
+  store.configure(rows, cols);
+  std::vector<Feature> fl(nL);
+  for (int i = 0; i < nL; ++i) { fl[i].row = rcL[2 * i]; fl[i].col = rcL[2 * i + 1]; fl[i].score = 0; std::memcpy(fl[i].desc, dL + 32 * i, 32); }
+  store.set_features(fl);
+  Tf Tt;
+  std::memcpy(Tt.m, T, sizeof Tt.m);
+  int nt = 0, ntmp = 0, nl = 0, nlm = 0;
+  for (int i = 0; i < nP; ++i) {
+    real q[3], uvw[3];
+    tf_apply(Tt, cam + 3 * i, q);                                       /* :197 */
+    mat3_mul_vec(p->K_left, q, uvw);                                    /* :200 */
+    if (!(uvw[2] > 0)) continue;                                        /* quirk B.5 (as in the stereo track): the reference divides regardless */
+    const real uc = uvw[0] / uvw[2], ur = uvw[1] / uvw[2];
+    if (!(uc > -2147483648.0 && uc < 2147483648.0 && ur > -2147483648.0 && ur < 2147483648.0)) continue;
+    const int32_t col = (int32_t)uc, row = (int32_t)ur;                 /* :201-202 */
+    if (col < 0 || col > cols || row < 0 || row > rows) continue;       /* :205-208 */
+    const int r0 = std::max(row - d, 0), r1 = std::min(row + d + 1, rows);   /* :214-217 */
+    const int c0 = std::max(col - d, 0), c1 = std::min(col + d + 1, cols);
+    real dist_best;
+    const int f = store.match_in_region(row, col, pdesc + 32 * i, r0, r1, c0, c1, tau, by_appearance != 0, dist_best);   /* :220-229 */
+    bool has_next = false;
+    if (f >= 0) {
+      const float* dp = space + ((size_t)fl[f].row * cols + fl[f].col) * 3;    /* :235 */
+      if (dp[2] < p->minimum_depth_meters) continue;                           /* :238-240 */
+      store.lattice[(size_t)fl[f].row * cols + fl[f].col] = -1;                /* :243-244 */
+      if (dp[2] >= p->maximum_depth_meters && p->enable_point_triangulation) { /* :247-256 */
+        temp2[2 * ntmp] = i; temp2[2 * ntmp + 1] = f; ++ntmp;
+        continue;
+      }
+      out2[2 * nt] = i; out2[2 * nt + 1] = f;                                  /* :259-273 */
+      for (int k = 0; k < 3; ++k) xyz[3 * nt + k] = (real)dp[k];
+      ++nt;
+      has_next = true;
+      if (pflags[i] & 1) ++nlm;                                                /* :275-277 */
+    }
+    if (!has_next && !(pflags[i] & 2)) lost[nl++] = i;                         /* :281-284 */
+  }
+  *n_tracked = nt; *n_temp = ntmp; *n_lost = nl; *n_tracked_landmarks = nlm;
+  return VSLAM_OK;
+}
+
 /* getPointInCamera (base_framepoint_generator.cpp:461-494).  JacobiSVD::solve of the 3x2 system restated as QR of the
  * two columns followed by the triangular solve, minimum-norm when the columns are parallel to rounding (Eigen's rank
  * rule: singular values <= 2 eps * largest count as zero; here sigma_min ~ r00 r11 / sigma_max against the Frobenius

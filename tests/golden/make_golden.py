@@ -757,6 +757,108 @@ def point_in_camera_ref(xp, xc, T, K):
     return (x1 * z[1] + (T[:, :3] @ (x0 * z[0]) + T[:, 3])) / 2.0
 
 
+def depth_track_ref(K, rows, cols, space, T, prev, feats, d, tau, by_appearance, min_depth, max_depth, triangulate):
+    """depth_framepoint_generator.cpp:166-287, independent of the C++ oracle.  prev: (cam xyz, desc, has_landmark,
+    unreliable_depth); feats: (row, col, desc).  Returns tracked [(prev, feature)], temporary [(prev, feature)], lost, landmarks."""
+    lat = {(f[0], f[1]): i for i, f in enumerate(feats)}
+    tracked, temp, lost, n_lm = [], [], [], 0
+    R, t = np.asarray(T[:, :3], np.float64), np.asarray(T[:, 3], np.float64)
+    for ip, (cam, pd, has_lm, unreliable) in enumerate(prev):
+        q = np.array([(R[i, 0] * cam[0] + R[i, 1] * cam[1]) + R[i, 2] * cam[2] + t[i] for i in range(3)])
+        uvw = np.array([(K[i, 0] * q[0] + K[i, 1] * q[1]) + K[i, 2] * q[2] for i in range(3)])
+        if not (uvw[2] > 0):        # same documented deviation as the stereo track (B.5)
+            continue
+        col, row = _trunc32(uvw[0] / uvw[2]), _trunc32(uvw[1] / uvw[2])
+        if col is None or row is None or col < 0 or col > cols or row < 0 or row > rows:
+            continue
+        r0, r1 = max(row - d, 0), min(row + d + 1, rows)
+        c0, c1 = max(col - d, 0), min(col + d + 1, cols)
+        f, _ = _match_in_region(lat, feats, row, col, pd, r0, r1, c0, c1, tau, by_appearance)
+        has_next = False
+        if f >= 0:
+            z = float(space[feats[f][0], feats[f][1], 2])
+            if z < min_depth:
+                continue
+            lat.pop((feats[f][0], feats[f][1]), None)
+            if z >= max_depth and triangulate:
+                temp.append((ip, f))
+                continue
+            tracked.append((ip, f))
+            has_next = True
+            if has_lm:
+                n_lm += 1
+        if not has_next and not unreliable:
+            lost.append(ip)
+    return tracked, temp, lost, n_lm
+
+
+def depth_track_space(zmap, cx, cy, f):
+    """space map of the track fixture from its depth channel (the .npz stores only z; tests rebuild x, y the same way)"""
+    rows, cols = zmap.shape
+    space = np.zeros((rows, cols, 3), np.float32)
+    space[:, :, 2] = zmap
+    space[:, :, 0] = ((np.arange(cols)[None, :] - cx) * zmap / f).astype(np.float32)
+    space[:, :, 1] = ((np.arange(rows)[:, None] - cy) * zmap / f).astype(np.float32)
+    return space
+
+
+def gen_depth_track(rng):
+    """Crowded small images: several previous points compete for the same feature (order decides), features on pixels
+    without depth (temporary points), below the minimum depth (skipped without consuming the feature), both search modes."""
+    rows, cols = 72, 96
+    f_, cx, cy = 90.0, 48.0, 36.0
+    K = np.array([[f_, 0, cx], [0, f_, cy], [0, 0, 1.0]])
+    out = {"K": K, "rows": np.int32(rows), "cols": np.int32(cols)}
+
+    def near(dsc, k):
+        bits = np.unpackbits(dsc)
+        bits[rng.choice(256, size=k, replace=False)] ^= 1
+        return np.packbits(bits)
+    n_case = 0
+    for by_app in (1, 0):
+        for d in (2, 7):
+            for tri in (1, 0):
+                T = np.eye(4)[:3].copy()
+                T[:, 3] = rng.normal(0, 0.02, 3)
+                ang = rng.normal(0, 0.01)
+                T[0, 0], T[0, 2], T[2, 0], T[2, 2] = np.cos(ang), np.sin(ang), -np.sin(ang), np.cos(ang)
+                zmap = (np.round(rng.uniform(0.5, 6.0, (rows, cols)) * 16) / 16).astype(np.float32)   # coarse: the fixture compresses
+                zmap[rng.random((rows, cols)) < 0.2] = np.float32(10.0)        # no measurement: maximum depth
+                zmap[rng.random((rows, cols)) < 0.1] = np.float32(0.05)        # below the minimum depth
+                space = depth_track_space(zmap, cx, cy, f_)
+                prev, feats, used = [], [], set()
+                for ip in range(90):
+                    z = float(rng.uniform(0.8, 6.0))
+                    u, v = float(rng.uniform(-4, cols + 4)), float(rng.uniform(-4, rows + 4))
+                    cam = np.array([(u - cx) * z / f_, (v - cy) * z / f_, z])
+                    dp = rng.integers(0, 256, 32, dtype=np.uint8)
+                    prev.append((cam, dp, int(rng.random() < 0.5), int(rng.random() < 0.15)))
+                    for _ in range(int(rng.integers(0, 3))):
+                        r = int(round(v)) + int(rng.integers(-d - 1, d + 2)); c = int(round(u)) + int(rng.integers(-d - 1, d + 2))
+                        if 0 <= r < rows and 0 <= c < cols and (r, c) not in used:
+                            used.add((r, c)); feats.append((r, c, near(dp, int(rng.integers(0, 40)))))
+                    if ip % 5 == 4:      # a rival: a second previous point with nearly the same appearance and position
+                        prev.append((cam + rng.normal(0, 0.01, 3), near(dp, 3), 1, 0))
+                for _ in range(50):
+                    r, c = int(rng.integers(0, rows)), int(rng.integers(0, cols))
+                    if (r, c) not in used:
+                        used.add((r, c)); feats.append((r, c, rng.integers(0, 256, 32, dtype=np.uint8)))
+                tau = 35.0
+                tr, tmp, lost, nlm = depth_track_ref(K, rows, cols, space, T, prev, feats, d, tau, bool(by_app), 0.1, 10.0, tri)
+                key = "c%d_" % n_case
+                out[key + "T"] = T; out[key + "d"] = np.int32(d); out[key + "by_app"] = np.int32(by_app); out[key + "tri"] = np.int32(tri)
+                out[key + "tau"] = np.float64(tau); out[key + "zmap"] = zmap
+                out[key + "cam"] = np.array([q[0] for q in prev]); out[key + "pd"] = np.array([q[1] for q in prev], np.uint8)
+                out[key + "flags"] = np.array([q[2] | (q[3] << 1) for q in prev], np.uint8)
+                out[key + "rc"] = np.array([(a[0], a[1]) for a in feats], np.int32); out[key + "desc"] = np.array([a[2] for a in feats], np.uint8)
+                out[key + "tracked"] = np.array(tr, np.int32).reshape(-1, 2); out[key + "temp"] = np.array(tmp, np.int32).reshape(-1, 2)
+                out[key + "lost"] = np.array(lost, np.int32); out[key + "n_lm"] = np.int32(nlm)
+                n_case += 1
+    out["n_cases"] = np.int32(n_case)
+    np.savez_compressed(os.path.join(HERE, "depth_track.npz"), **out)
+    return n_case
+
+
 def gen_depth(rng):
     out = {}
     rows, cols = 40, 56
@@ -821,6 +923,7 @@ def main():
     gen_track(np.random.default_rng(20261004))   # own stream: added later, the fixtures above stay byte-identical
     gen_aligner_uvd(np.random.default_rng(20261005))
     gen_depth(np.random.default_rng(20261006))
+    gen_depth_track(np.random.default_rng(20261007))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

@@ -53,6 +53,11 @@ def test_depth_components_golden(gpu, golden):
     pc.check_depth_components(gpu, golden["depth"], resident_map=True)
 
 
+def test_depth_track_golden(gpu, golden):
+    """DepthFramePointGenerator::track (order-exact parallel resolution) against the pure-Python fixture."""
+    pc.check_depth_track(gpu, golden["depth_track"])
+
+
 def test_track_golden(golden):
     """vslam_track_match (k_track_candidates + the order-exact resolution of the frame kernel) against the fixture of
     the independent numpy restatement of StereoFramePointGenerator::track: exact tuples, exact lost list."""

@@ -32,6 +32,10 @@ def test_depth_components_known_answers(oracle, golden):
     pc.check_depth_components(oracle, golden["depth"])
 
 
+def test_depth_track_known_answers(oracle, golden):
+    pc.check_depth_track(oracle, golden["depth_track"])
+
+
 def test_aligner_first_linearization(oracle, golden):
     g = golden["aligner"]
     for name in pc.ALIGNER_CASES:

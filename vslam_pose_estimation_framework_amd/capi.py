@@ -376,6 +376,24 @@ class CApi(object):
                                             _p(xyz, C.c_double), C.byref(nt), _p(tf_, C.c_int32), _p(txyz, C.c_double)))
         return nf[:nn.value].copy(), xyz[:nn.value].copy(), tf_[:nt.value].copy(), txyz[:nt.value].copy()
 
+    def depth_track(self, params, space, T, d, tau, by_appearance, cam, prev_desc, prev_flags, rc_left, desc_left):
+        """DepthFramePointGenerator::track on caller-provided data: (tracked [n][2], xyz [n][3], temporary [m][2], lost, landmarks)."""
+        T = np.ascontiguousarray(T, np.float64).reshape(12)
+        cam = np.ascontiguousarray(cam, np.float64).reshape(-1, 3)
+        pd = np.ascontiguousarray(prev_desc, np.uint8); pf = np.ascontiguousarray(prev_flags, np.uint8)
+        rc = np.ascontiguousarray(rc_left, np.int32).reshape(-1, 2); dl = np.ascontiguousarray(desc_left, np.uint8)
+        sp = None if space is None else np.ascontiguousarray(space, np.float32)
+        nP = cam.shape[0]
+        out2, xyz = np.zeros((max(nP, 1), 2), np.int32), np.zeros((max(nP, 1), 3), np.float64)
+        tmp2, lost = np.zeros((max(nP, 1), 2), np.int32), np.zeros(max(nP, 1), np.int32)
+        nt, ntmp, nl, nlm = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        self.check(self.fn("depth_track")(*self._ctx_args(), C.byref(params), None if sp is None else _p(sp, C.c_float), _p(T, C.c_double),
+                                          C.c_int32(int(d)), C.c_double(float(tau)), C.c_int32(int(by_appearance)), C.c_int32(nP),
+                                          _p(cam, C.c_double), _p(pd, C.c_uint8), _p(pf, C.c_uint8), C.c_int32(rc.shape[0]),
+                                          _p(rc, C.c_int32), _p(dl, C.c_uint8), C.byref(nt), _p(out2, C.c_int32), _p(xyz, C.c_double),
+                                          C.byref(ntmp), _p(tmp2, C.c_int32), C.byref(nl), _p(lost, C.c_int32), C.byref(nlm)))
+        return out2[:nt.value].copy(), xyz[:nt.value].copy(), tmp2[:ntmp.value].copy(), lost[:nl.value].copy(), nlm.value
+
     def point_in_camera(self, xy_previous, xy_current, T, K):
         xp = np.ascontiguousarray(xy_previous, np.float32).reshape(-1, 2)
         xc = np.ascontiguousarray(xy_current, np.float32).reshape(-1, 2)

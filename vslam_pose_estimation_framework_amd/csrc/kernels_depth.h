@@ -212,3 +212,139 @@ __global__ __launch_bounds__(256) void k_point_in_camera(int n, const float* xp,
     out[3 * (size_t)i + k] = (x1[k] * z1 + moved) / 2.0;                                            // :490-493
   }
 }
+
+// ---- track ------------------------------------------------------------------------------------------------------
+// The reference walks the previous points in order; a matched feature leaves the lattice, so a later point that would
+// have picked it takes its next-best one (:243-244).  Order-exact in parallel, as in the stereo tracker: iterate
+//   pick(i) = best feature of point i's window among those no EARLIER point holds;  hold(f) = min { i : pick(i) = f }
+// from "nobody holds anything" until nothing changes (point 0 is final after one sweep, point 1 after two, ...: the fixed
+// point is the serial outcome; a handful of sweeps in practice).  One workgroup per image, one thread per previous point
+// and sweep; features row-major with a (row, 16-px cell) CSR, so a window scan reads only the cells it overlaps.
+// A match on a pixel below the minimum depth is dropped WITHOUT taking the feature (:238-240).
+struct DepthTrack {
+  vslam_depth_params p;
+  double T[12];
+  int d, by_app;
+  double tau;
+  int nP, nL, CW;
+  const double* cam; const uint8_t* pdesc; const uint8_t* pflags;
+  const int16_t* kxy;        // [nL][2] x, y  (features sorted row-major)
+  const uint8_t* desc;       // [nL][32]
+  const int32_t* rowcell;    // [rows][CW + 1]
+  const float* space;
+  int32_t* hold;             // [2][nL]
+  int32_t* pick;             // [nP]  feature, -1 none, -2 projection outside
+  int32_t* counts;           // tracked, temporary, lost, tracked landmarks
+  int32_t* out2; double* xyz; int32_t* temp2; int32_t* lost;
+};
+
+__device__ __forceinline__ int depth_track_best(const DepthTrack& a, int i, int row, int col, const uint32_t* pd, const int32_t* hold) {
+  const int rows = a.p.rows, cols = a.p.cols;
+  const int r0 = max(row - a.d, 0), r1 = min(row + a.d + 1, rows);                  // :214-217
+  const int c0 = max(col - a.d, 0), c1 = min(col + a.d + 1, cols);
+  if (c1 <= c0) return -1;
+  const int cl = c0 >> 4, ch = ((c1 - 1) >> 4) + 1;
+  unsigned long long best = ~0ull;    // (primary << 32 | feature): row-major index == the reference's scan order for ties
+  for (int r = r0; r < r1; ++r) {
+    const int lo = a.rowcell[(size_t)r * (a.CW + 1) + cl], hi = a.rowcell[(size_t)r * (a.CW + 1) + ch];
+    for (int k = lo; k < hi; ++k) {
+      const int x = a.kxy[2 * k];
+      if (x < c0 || x >= c1) continue;
+      if (hold[k] < i) continue;                                                    // an earlier point removed it from the lattice
+      const uint32_t* kd = reinterpret_cast<const uint32_t*>(a.desc + (size_t)32 * k);
+      int h = 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) h += __popc(pd[u] ^ kd[u]);
+      if (!((double)h < a.tau)) continue;                                           // intensity_feature_matcher.cpp:100-121
+      unsigned prim;
+      if (a.by_app) prim = (unsigned)h;
+      else { const int dr = row - r, dc = col - x; prim = (unsigned)(dr * dr + dc * dc); if (prim >= 10000u) continue; }
+      const unsigned long long key = ((unsigned long long)prim << 32) | (unsigned)k;
+      if (key < best) best = key;
+    }
+  }
+  return best == ~0ull ? -1 : (int)(best & 0xffffffffu);
+}
+
+__global__ __launch_bounds__(1024) void k_depth_track(const DepthTrack a) {
+  __shared__ int sh[17];
+  __shared__ int changed;
+  const int tid = threadIdx.x;
+  int32_t* hold = a.hold;
+  int32_t* next = a.hold + a.nL;
+  for (int k = tid; k < a.nL; k += 1024) hold[k] = 0x7fffffff;
+  __syncthreads();
+  for (int sweep = 0; sweep <= a.nP; ++sweep) {
+    for (int k = tid; k < a.nL; k += 1024) next[k] = 0x7fffffff;
+    if (tid == 0) changed = 0;
+    __syncthreads();
+    for (int i = tid; i < a.nP; i += 1024) {
+      double q[3], uvw[3];
+      const double* cm = a.cam + 3 * (size_t)i;
+      for (int k = 0; k < 3; ++k) q[k] = ((a.T[4 * k] * cm[0] + a.T[4 * k + 1] * cm[1]) + a.T[4 * k + 2] * cm[2]) + a.T[4 * k + 3];   // :197
+      for (int k = 0; k < 3; ++k) uvw[k] = (a.p.K_left[3 * k] * q[0] + a.p.K_left[3 * k + 1] * q[1]) + a.p.K_left[3 * k + 2] * q[2];     // :200
+      int f = -2;
+      if (uvw[2] > 0) {
+        const double uc = uvw[0] / uvw[2], ur = uvw[1] / uvw[2];
+        if (uc > -2147483648.0 && uc < 2147483648.0 && ur > -2147483648.0 && ur < 2147483648.0) {
+          const int col = (int)uc, row = (int)ur;                                   // :201-202 (truncation)
+          if (!(col < 0 || col > a.p.cols || row < 0 || row > a.p.rows)) {          // :205-208
+            uint32_t pd[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pd[u] = reinterpret_cast<const uint32_t*>(a.pdesc + (size_t)32 * i)[u];
+            f = depth_track_best(a, i, row, col, pd, hold);
+          }
+        }
+      }
+      if (f >= 0) {
+        const float z = a.space[3 * ((size_t)a.kxy[2 * f + 1] * a.p.cols + a.kxy[2 * f]) + 2];
+        if (!((double)z < a.p.minimum_depth_meters)) atomicMin(&next[f], i);        // :238-244
+      }
+      a.pick[i] = f;
+    }
+    __syncthreads();
+    for (int k = tid; k < a.nL; k += 1024) if (next[k] != hold[k]) changed = 1;
+    __syncthreads();
+    const bool again = changed != 0;
+    int32_t* t = hold; hold = next; next = t;
+    __syncthreads();
+    if (!again) break;
+  }
+  // outcome of every point under the final holds, lists in the order of the previous points
+  int n_trk = 0, n_tmp = 0, n_lost = 0, n_lm = 0;
+  for (int base = 0; base < a.nP; base += 1024) {
+    const int i = base + tid;
+    int kind = 0;   // 1 tracked, 2 temporary, 3 lost
+    int f = -1;
+    if (i < a.nP) {
+      f = a.pick[i];
+      if (f >= 0) {
+        const float z = a.space[3 * ((size_t)a.kxy[2 * f + 1] * a.p.cols + a.kxy[2 * f]) + 2];
+        if ((double)z < a.p.minimum_depth_meters) kind = 0;                                            // :238-240: neither tracked nor lost
+        else if ((double)z >= a.p.maximum_depth_meters && a.p.enable_point_triangulation) kind = 2;   // :247-256
+        else kind = 1;
+      } else if (f == -1 && !(a.pflags[i] & 2)) {
+        kind = 3;                                                                                      // :281-284
+      }
+    }
+    int total;
+    const int at1 = n_trk + block_exclusive_scan(kind == 1 ? 1 : 0, sh, &total);
+    n_trk += total;
+    const int at2 = n_tmp + block_exclusive_scan(kind == 2 ? 1 : 0, sh, &total);
+    n_tmp += total;
+    const int at3 = n_lost + block_exclusive_scan(kind == 3 ? 1 : 0, sh, &total);
+    n_lost += total;
+    block_exclusive_scan((kind == 1 && (a.pflags[min(i, a.nP - 1)] & 1)) ? 1 : 0, sh, &total);
+    n_lm += total;
+    if (kind == 1) {
+      const float* dp = a.space + 3 * ((size_t)a.kxy[2 * f + 1] * a.p.cols + a.kxy[2 * f]);
+      a.out2[2 * at1] = i; a.out2[2 * at1 + 1] = f;
+      for (int k = 0; k < 3; ++k) a.xyz[3 * (size_t)at1 + k] = (double)dp[k];
+    } else if (kind == 2) {
+      a.temp2[2 * at2] = i; a.temp2[2 * at2 + 1] = f;
+    } else if (kind == 3) {
+      a.lost[at3] = i;
+    }
+  }
+  if (tid == 0) { a.counts[0] = n_trk; a.counts[1] = n_tmp; a.counts[2] = n_lost; a.counts[3] = n_lm; }
+}

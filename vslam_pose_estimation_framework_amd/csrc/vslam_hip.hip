@@ -710,6 +710,86 @@ VS_API int vslam_depth_compute(vslam_ctx* c, const vslam_depth_params* p, const 
   if (cnt[0] > cap || cnt[1] > cap) return fail(c, VSLAM_ERR_CAPACITY, "depth_compute: output capacity too small");
   return VSLAM_OK;
 }
+VS_API int vslam_depth_track(vslam_ctx* c, const vslam_depth_params* p, const float* space, const double T[12], int32_t d, double tau,
+                             int32_t by_appearance, int32_t nP, const double* cam, const uint8_t* pdesc, const uint8_t* pflags, int32_t nL,
+                             const int32_t* rcL, const uint8_t* dL, int32_t* n_tracked, int32_t* out2, double* xyz, int32_t* n_temp,
+                             int32_t* temp2, int32_t* n_lost, int32_t* lost, int32_t* n_tracked_landmarks) {
+  int rc = depth_params_ok(c, p);
+  if (rc != VSLAM_OK) return rc;
+  if (!T || d < 0 || nP < 0 || nL < 0 || !n_tracked || !n_temp || !n_lost || !n_tracked_landmarks || (nP && (!cam || !pdesc || !pflags || !out2 || !xyz || !temp2 || !lost)) ||
+      (nL && (!rcL || !dL)))
+    return fail(c, VSLAM_ERR_INVALID, "depth_track: bad argument");
+  if (!space && !(c->dm.valid && c->dm.rows == p->rows && c->dm.cols == p->cols)) return fail(c, VSLAM_ERR_STATE, "depth_track: no resident space map of this size");
+  const int rows = p->rows, cols = p->cols, CW = (cols + 15) / 16, CW1 = CW + 1;
+  // features row-major + (row, 16-px cell) CSR, as the image pipeline leaves them (k_emit)
+  std::vector<int> ord(nL);
+  for (int i = 0; i < nL; ++i) {
+    ord[i] = i;
+    if (rcL[2 * i] < 0 || rcL[2 * i] >= rows || rcL[2 * i + 1] < 0 || rcL[2 * i + 1] >= cols) return fail(c, VSLAM_ERR_INVALID, "feature outside the image");
+  }
+  std::sort(ord.begin(), ord.end(), [&](int a, int b) { return rcL[2 * a] != rcL[2 * b] ? rcL[2 * a] < rcL[2 * b] : rcL[2 * a + 1] < rcL[2 * b + 1]; });
+  std::vector<int16_t> xy((size_t)std::max(nL, 1) * 2);
+  std::vector<uint8_t> ds((size_t)std::max(nL, 1) * 32);
+  std::vector<int32_t> rowcell((size_t)rows * CW1);
+  for (int k = 0; k < nL; ++k) {
+    xy[2 * k] = (int16_t)rcL[2 * ord[k] + 1]; xy[2 * k + 1] = (int16_t)rcL[2 * ord[k]];
+    std::memcpy(&ds[(size_t)32 * k], dL + (size_t)32 * ord[k], 32);
+  }
+  for (int r = 0, k = 0; r < rows; ++r)
+    for (int cc = 0; cc < CW1; ++cc) {
+      while (k < nL && (xy[2 * k + 1] < r || (xy[2 * k + 1] == r && xy[2 * k] < 16 * cc))) ++k;
+      rowcell[(size_t)r * CW1 + cc] = k;
+    }
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t n = (size_t)rows * cols, P1 = std::max(nP, 1), L1 = std::max(nL, 1);
+  DepthTrack a;
+  std::memset(&a, 0, sizeof a);
+  a.p = *p; std::memcpy(a.T, T, sizeof a.T); a.d = d; a.by_app = by_appearance ? 1 : 0; a.tau = tau; a.nP = nP; a.nL = nL; a.CW = CW;
+  float* dspace = nullptr; double *dcam = nullptr, *dxyz = nullptr; uint8_t *dpd = nullptr, *dpf = nullptr, *dds = nullptr; int16_t* dxy = nullptr;
+  int32_t *drc = nullptr, *dhold = nullptr, *dpick = nullptr, *dcnt = nullptr, *dout2 = nullptr, *dtmp2 = nullptr, *dlost = nullptr;
+  hipError_t e = hipSuccess;
+  if (space) { e = hipMalloc((void**)&dspace, n * 3 * sizeof(float)); if (e == hipSuccess) e = hipMemcpyAsync(dspace, space, n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream); }
+  if (e == hipSuccess) e = hipMalloc((void**)&dcam, P1 * 3 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&dxyz, P1 * 3 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&dpd, P1 * 32);
+  if (e == hipSuccess) e = hipMalloc((void**)&dpf, P1);
+  if (e == hipSuccess) e = hipMalloc((void**)&dds, L1 * 32);
+  if (e == hipSuccess) e = hipMalloc((void**)&dxy, L1 * 2 * sizeof(int16_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&drc, rowcell.size() * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&dhold, L1 * 2 * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&dpick, P1 * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&dcnt, 4 * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&dout2, P1 * 2 * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&dtmp2, P1 * 2 * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&dlost, P1 * sizeof(int32_t));
+  if (e == hipSuccess && nP) e = hipMemcpyAsync(dcam, cam, (size_t)nP * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess && nP) e = hipMemcpyAsync(dpd, pdesc, (size_t)nP * 32, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess && nP) e = hipMemcpyAsync(dpf, pflags, (size_t)nP, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess && nL) e = hipMemcpyAsync(dds, ds.data(), (size_t)nL * 32, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess && nL) e = hipMemcpyAsync(dxy, xy.data(), (size_t)nL * 4, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(drc, rowcell.data(), rowcell.size() * 4, hipMemcpyHostToDevice, c->stream);
+  int32_t cnt[4] = {0, 0, 0, 0};
+  if (e == hipSuccess) {
+    a.cam = dcam; a.pdesc = dpd; a.pflags = dpf; a.kxy = dxy; a.desc = dds; a.rowcell = drc; a.space = space ? dspace : c->dm.space;
+    a.hold = dhold; a.pick = dpick; a.counts = dcnt; a.out2 = dout2; a.xyz = dxyz; a.temp2 = dtmp2; a.lost = dlost;
+    hipLaunchKernelGGL(k_depth_track, dim3(1), dim3(1024), 0, c->stream, a);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(cnt, dcnt, sizeof cnt, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // also: the host staging vectors may go out of scope now
+  if (e == hipSuccess) {
+    *n_tracked = cnt[0]; *n_temp = cnt[1]; *n_lost = cnt[2]; *n_tracked_landmarks = cnt[3];
+    if (cnt[0]) { e = hipMemcpy(out2, dout2, (size_t)cnt[0] * 8, hipMemcpyDeviceToHost); if (e == hipSuccess) e = hipMemcpy(xyz, dxyz, (size_t)cnt[0] * 24, hipMemcpyDeviceToHost); }
+    if (e == hipSuccess && cnt[1]) e = hipMemcpy(temp2, dtmp2, (size_t)cnt[1] * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && cnt[2]) e = hipMemcpy(lost, dlost, (size_t)cnt[2] * 4, hipMemcpyDeviceToHost);
+    for (int u = 0; u < cnt[0]; ++u) out2[2 * u + 1] = ord[out2[2 * u + 1]];     // back to the caller's feature numbering
+    for (int u = 0; u < cnt[1]; ++u) temp2[2 * u + 1] = ord[temp2[2 * u + 1]];
+  }
+  (void)hipFree(dspace); (void)hipFree(dcam); (void)hipFree(dxyz); (void)hipFree(dpd); (void)hipFree(dpf); (void)hipFree(dds); (void)hipFree(dxy);
+  (void)hipFree(drc); (void)hipFree(dhold); (void)hipFree(dpick); (void)hipFree(dcnt); (void)hipFree(dout2); (void)hipFree(dtmp2); (void)hipFree(dlost);
+  if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
+  return VSLAM_OK;
+}
 VS_API int vslam_point_in_camera(vslam_ctx* c, int32_t n, const float* xp, const float* xc, const double T[12], const double K[9], double* out) {
   if (!c) return VSLAM_ERR_INVALID;
   if (c->sticky != VSLAM_OK) return c->sticky;
