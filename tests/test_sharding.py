@@ -29,6 +29,19 @@ def test_plan_covers_every_frame_once():
         assert covered == list(range(total))
 
 
+def test_sequence_assignment_lpt():
+    """Exact mode: whole sequences per stream; KITTI 00-10 lengths on 8 and 4 ranks."""
+    kitti = [4541, 1101, 4661, 801, 271, 2761, 1101, 1101, 4071, 1591, 1201]
+    ranks, load = sharding.plan_sequences(kitti, 8)
+    assert sorted(i for r in ranks for i in r) == list(range(11))
+    assert max(load) == 4661 and sum(load) == sum(kitti)          # the longest sequence bounds the makespan
+    ranks4, load4 = sharding.plan_sequences([kitti[i] for i in (0, 2, 5, 6)], 4)
+    assert all(len(r) == 1 for r in ranks4) and sorted(load4) == [1101, 2761, 4541, 4661]
+    ranks2, load2 = sharding.plan_sequences(kitti, 2)
+    assert abs(load2[0] - load2[1]) <= min(kitti)                 # LPT balances two ranks to within the smallest job
+    assert sharding.plan_sequences([], 3) == ([[], [], []], [0, 0, 0])
+
+
 def test_assembly_is_exact_for_exact_chunks():
     rng = np.random.default_rng(3)
     total = 57

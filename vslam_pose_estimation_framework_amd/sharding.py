@@ -24,6 +24,20 @@ def plan_chunks(total_frames, n_chunks, overlap):
     return plan, L
 
 
+def plan_sequences(lengths, world):
+    """Whole sequences onto `world` ranks, longest-processing-time first (the exact mode — every
+    sequence runs start to end on one stream of one GPU, results identical to the sequential reference).
+    Returns (per-rank lists of sequence indices, per-rank frame totals).  KITTI 00-10 on 8 ranks: makespan 4661."""
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    ranks = [[] for _ in range(world)]
+    load = [0] * world
+    for i in order:
+        r = min(range(world), key=lambda q: (load[q], q))
+        ranks[r].append(i)
+        load[r] += int(lengths[i])
+    return ranks, load
+
+
 def assemble_trajectory(chunk_poses, plan):
     """chunk_poses[c]: array [n_processed_c, 3, 4] (camera-to-chunk-world), plan from plan_chunks.
     Returns [total, 3, 4] in the first chunk's world frame."""
