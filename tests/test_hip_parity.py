@@ -58,6 +58,10 @@ def test_depth_track_golden(gpu, golden):
     pc.check_depth_track(gpu, golden["depth_track"])
 
 
+def test_depth_edge_cases(gpu, golden):
+    pc.check_depth_edge_cases(gpu, golden["depth"])
+
+
 def test_track_golden(golden):
     """vslam_track_match (k_track_candidates + the order-exact resolution of the frame kernel) against the fixture of
     the independent numpy restatement of StereoFramePointGenerator::track: exact tuples, exact lost list."""

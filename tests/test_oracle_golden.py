@@ -36,6 +36,10 @@ def test_depth_track_known_answers(oracle, golden):
     pc.check_depth_track(oracle, golden["depth_track"])
 
 
+def test_depth_edge_cases(oracle, golden):
+    pc.check_depth_edge_cases(oracle, golden["depth"])
+
+
 def test_aligner_first_linearization(oracle, golden):
     g = golden["aligner"]
     for name in pc.ALIGNER_CASES:
