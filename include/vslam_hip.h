@@ -342,6 +342,20 @@ int vslam_depth_track(vslam_ctx* ctx, const vslam_depth_params* p, const float* 
                       int32_t* n_tracked, int32_t* out2, double* xyz, int32_t* n_temporary, int32_t* temp2, int32_t* n_lost,
                       int32_t* lost, int32_t* n_tracked_landmarks);
 
+/* DepthFramePointGenerator::recoverPoints (:289-407) on caller-provided data: the lost points' landmarks in world
+ * coordinates (n*3; has_landmark[i] = 0 skips the point as :305 does), their last left descriptors (n*32), the frame's
+ * world_to_camera_left (3x4), the LEFT intensity image (host, u8) and the keypoint size (7 for FAST; the search border is
+ * 5*size + 1 px).  A landmark is recovered when it projects into the image, its pixel (rint of the projection) has a
+ * measured depth in [minimum, maximum), the projection keeps the border and BRIEF at the projection — the ROI origin is
+ * the rounded corner, cv::Rect_<float> -> cv::Rect — is within tau of the previous descriptor.  Outputs in the order of
+ * the lost list, room for n entries each: rec_index (position in the lost list), rec_xy (the new keypoint: the sub-pixel
+ * projection as the reference's float arithmetic leaves it), rec_desc, rec_xyz (the space-map entry).  A projection whose
+ * rounded pixel falls outside the map (x == cols or y == rows: an out-of-bounds read upstream) is skipped. */
+int vslam_depth_recover(vslam_ctx* ctx, const vslam_depth_params* p, const float* space_map, const uint8_t* image_left,
+                        int32_t row_stride, const double world_to_camera_left[12], int32_t n, const uint8_t* has_landmark,
+                        const double* landmark_world, const uint8_t* previous_desc, float keypoint_size, double tau,
+                        int32_t* n_recovered, int32_t* rec_index, float* rec_xy, uint8_t* rec_desc, double* rec_xyz);
+
 /* BaseFramePointGenerator::getPointInCamera (base_framepoint_generator.cpp:461-494) for n point pairs: midpoint
  * triangulation of a previous / current image point pair under the motion T (previous -> current camera); the 3x2
  * least-squares problem is solved through its singular value decomposition (minimum-norm for a rank-deficient pair).

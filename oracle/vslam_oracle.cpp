@@ -1682,6 +1682,47 @@ ORC_API int orc_depth_track(const vslam_depth_params* p, const float* space, con
   return VSLAM_OK;
 }
 
+/* DepthFramePointGenerator::recoverPoints (:289-407) on caller-provided data */
+ORC_API int orc_depth_recover(const vslam_depth_params* p, const float* space, const uint8_t* img, int32_t stride, const double w2c[12],
+                              int32_t n, const uint8_t* has_lm, const double* lm, const uint8_t* pdesc, float kp_size, double tau,
+                              int32_t* n_rec, int32_t* rec_index, float* rec_xy, uint8_t* rec_desc, double* rec_xyz) {
+  const int rows = p->rows, cols = p->cols;
+  std::vector<int32_t> sum;
+  integral_image(img, rows, cols, stride, sum);
+  Tf W;
+  std::memcpy(W.m, w2c, sizeof W.m);
+  int nr = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!has_lm[i]) continue;                                                     /* :305-307 */
+    real pc[3], pi[3];
+    tf_apply(W, lm + 3 * i, pc);                                                  /* :317 */
+    mat3_mul_vec(p->K_left, pc, pi);                                              /* :325 */
+    const real x = pi[0] / pi[2], y = pi[1] / pi[2];                              /* :326 */
+    if (!(x >= 0 && x <= cols && y >= 0 && y <= rows)) continue;                  /* :329-332 (NaN never passes) */
+    const float px = (float)x, py = (float)y;                                     /* :335 */
+    const float fr = std::rint(py), fc = std::rint(px);                           /* :338 */
+    if (!(fr >= 0 && fr < rows && fc >= 0 && fc < cols)) continue;                /* out-of-bounds read upstream */
+    const float* dp = space + ((size_t)(int)fr * cols + (int)fc) * 3;
+    if (dp[2] < p->minimum_depth_meters || dp[2] >= p->maximum_depth_meters) continue;   /* :341-344 */
+    const float rbc = 5 * kp_size;                                                /* :347 */
+    if (px <= rbc + 1 || px >= cols - rbc - 1 || py <= rbc + 1 || py >= rows - rbc - 1) continue;   /* :352-359 */
+    const float cxf = px - rbc, cyf = py - rbc;                                   /* :362 */
+    const int ox = (int)std::lrint(cxf), oy = (int)std::lrint(cyf);               /* cv::Rect_<float> -> cv::Rect: saturate_cast = cvRound */
+    const int bx = ox + (int)(rbc + 0.5f), by = oy + (int)(rbc + 0.5f);           /* BRIEF rounds the keypoint (rbc, rbc) of the ROI */
+    if (!brief_inside(rows, cols, bx, by)) continue;                              /* :376-378 (cannot happen behind the border gate) */
+    uint8_t d[32];
+    brief_at(sum, cols, bx, by, d);                                               /* :369-373 */
+    if (hamming32(pdesc + 32 * i, d) > tau) continue;                             /* :381-383 */
+    rec_index[nr] = i;
+    rec_xy[2 * nr] = rbc + cxf; rec_xy[2 * nr + 1] = rbc + cyf;                   /* :384 keypoint.pt += corner_left */
+    std::memcpy(rec_desc + 32 * nr, d, 32);
+    for (int k = 0; k < 3; ++k) rec_xyz[3 * nr + k] = (real)dp[k];                /* :390 */
+    ++nr;
+  }
+  *n_rec = nr;
+  return VSLAM_OK;
+}
+
 /* getPointInCamera (base_framepoint_generator.cpp:461-494).  JacobiSVD::solve of the 3x2 system restated as QR of the
  * two columns followed by the triangular solve, minimum-norm when the columns are parallel to rounding (Eigen's rank
  * rule: singular values <= 2 eps * largest count as zero; here sigma_min ~ r00 r11 / sigma_max against the Frobenius

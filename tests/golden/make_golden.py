@@ -859,6 +859,81 @@ def gen_depth_track(rng):
     return n_case
 
 
+def depth_recover_ref(K, rows, cols, space, img, pat, w2c, lost, kp_size, tau, min_depth, max_depth):
+    """depth_framepoint_generator.cpp:289-407; lost: (has_landmark, world xyz, previous descriptor).  Floats as np.float32."""
+    out = []
+    R, t = w2c[:, :3], w2c[:, 3]
+    f32 = np.float32
+    for i, (has_lm, X, pd) in enumerate(lost):
+        if not has_lm:
+            continue
+        pc = np.array([((R[k, 0] * X[0] + R[k, 1] * X[1]) + R[k, 2] * X[2]) + t[k] for k in range(3)])
+        pi = np.array([(K[k, 0] * pc[0] + K[k, 1] * pc[1]) + K[k, 2] * pc[2] for k in range(3)])
+        with np.errstate(divide="ignore", invalid="ignore"):
+            x, y = pi[0] / pi[2], pi[1] / pi[2]
+        if not (x >= 0 and x <= cols and y >= 0 and y <= rows):
+            continue
+        px, py = f32(x), f32(y)
+        fr, fc = int(round(float(py))), int(round(float(px)))       # rint: half to even
+        if not (0 <= fr < rows and 0 <= fc < cols):
+            continue
+        z = float(space[fr, fc, 2])
+        if z < min_depth or z >= max_depth:
+            continue
+        rbc = f32(5) * f32(kp_size)
+        if px <= rbc + f32(1) or px >= f32(cols) - rbc - f32(1) or py <= rbc + f32(1) or py >= f32(rows) - rbc - f32(1):
+            continue
+        cxf, cyf = f32(px - rbc), f32(py - rbc)
+        bx, by = int(round(float(cxf))) + int(float(rbc) + 0.5), int(round(float(cyf))) + int(float(rbc) + 0.5)
+        d = brief32(img, bx, by, pat)
+        if hamming(pd, d) > tau:
+            continue
+        out.append((i, f32(rbc + cxf), f32(rbc + cyf), d, space[fr, fc].astype(np.float64)))
+    return out
+
+
+def gen_depth_recover(rng):
+    pat = read_brief_pattern()
+    rows, cols = 150, 200
+    f_, cx, cy = 160.0, 99.5, 74.5
+    K = np.array([[f_, 0, cx], [0, f_, cy], [0, 0, 1.0]])
+    img = block_image(rng, rows, cols, 4)
+    zmap = (np.round(rng.uniform(0.5, 6.0, (rows, cols)) * 16) / 16).astype(np.float32)
+    zmap[rng.random((rows, cols)) < 0.15] = np.float32(10.0)
+    zmap[rng.random((rows, cols)) < 0.05] = np.float32(0.05)
+    space = depth_track_space(zmap, cx, cy, f_)
+    ang = 0.02
+    w2c = np.hstack([np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]]), np.array([[0.03], [-0.02], [0.05]])])
+    c2w_R, c2w_t = w2c[:, :3].T, -w2c[:, :3].T @ w2c[:, 3]
+    lost = []
+    for i in range(140):
+        z = float(rng.uniform(0.8, 6.0))
+        # sub-pixel projections all over the image, some in the border band, some outside; a few exactly on .5
+        u = float(rng.uniform(25, cols - 25)); v = float(rng.uniform(25, rows - 25))
+        if i % 10 == 3:
+            u = float(rng.uniform(-5, cols + 5)); v = float(rng.uniform(-5, rows + 5))
+        if i % 9 == 0:
+            u, v = np.floor(u) + 0.5, np.floor(v) + 0.5
+        pc = np.array([(u - cx) * z / f_, (v - cy) * z / f_, z])
+        X = c2w_R @ pc + c2w_t
+        has_lm = int(rng.random() < 0.85)
+        # the previous descriptor: BRIEF near the projection with some bits flipped (or random clutter)
+        bx, by = int(np.clip(round(u), 28, cols - 29)), int(np.clip(round(v), 28, rows - 29))
+        base = brief32(img, bx, by, pat)
+        bits = np.unpackbits(base)
+        bits[rng.choice(256, size=int(rng.integers(0, 50)), replace=False)] ^= 1
+        lost.append((has_lm, X, np.packbits(bits)))
+    tau = 35.0
+    rec = depth_recover_ref(K, rows, cols, space, img, pat, w2c, lost, 7.0, tau, 0.1, 10.0)
+    out = {"K": K, "img": img, "zmap": zmap, "w2c": w2c, "tau": np.float64(tau),
+           "has_lm": np.array([q[0] for q in lost], np.uint8), "lm": np.array([q[1] for q in lost]),
+           "pd": np.array([q[2] for q in lost], np.uint8),
+           "rec_index": np.array([r[0] for r in rec], np.int32), "rec_xy": np.array([[r[1], r[2]] for r in rec], np.float32).reshape(-1, 2),
+           "rec_desc": np.array([r[3] for r in rec], np.uint8).reshape(-1, 32), "rec_xyz": np.array([r[4] for r in rec], np.float64).reshape(-1, 3)}
+    np.savez_compressed(os.path.join(HERE, "depth_recover.npz"), **out)
+    return len(rec)
+
+
 def gen_depth(rng):
     out = {}
     rows, cols = 40, 56
@@ -924,6 +999,7 @@ def main():
     gen_aligner_uvd(np.random.default_rng(20261005))
     gen_depth(np.random.default_rng(20261006))
     gen_depth_track(np.random.default_rng(20261007))
+    gen_depth_recover(np.random.default_rng(20261008))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

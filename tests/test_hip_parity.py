@@ -62,6 +62,11 @@ def test_depth_edge_cases(gpu, golden):
     pc.check_depth_edge_cases(gpu, golden["depth"])
 
 
+def test_depth_recover_golden(gpu, golden):
+    """DepthFramePointGenerator::recoverPoints (projection gates, BRIEF at the rounded ROI, descriptor gate)."""
+    pc.check_depth_recover(gpu, golden["depth_recover"])
+
+
 def test_track_golden(golden):
     """vslam_track_match (k_track_candidates + the order-exact resolution of the frame kernel) against the fixture of
     the independent numpy restatement of StereoFramePointGenerator::track: exact tuples, exact lost list."""

@@ -40,6 +40,10 @@ def test_depth_edge_cases(oracle, golden):
     pc.check_depth_edge_cases(oracle, golden["depth"])
 
 
+def test_depth_recover_known_answers(oracle, golden):
+    pc.check_depth_recover(oracle, golden["depth_recover"])
+
+
 def test_aligner_first_linearization(oracle, golden):
     g = golden["aligner"]
     for name in pc.ALIGNER_CASES:

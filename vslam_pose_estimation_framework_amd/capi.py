@@ -394,6 +394,24 @@ class CApi(object):
                                           C.byref(ntmp), _p(tmp2, C.c_int32), C.byref(nl), _p(lost, C.c_int32), C.byref(nlm)))
         return out2[:nt.value].copy(), xyz[:nt.value].copy(), tmp2[:ntmp.value].copy(), lost[:nl.value].copy(), nlm.value
 
+    def depth_recover(self, params, space, image_left, world_to_camera_left, has_landmark, landmark_world, prev_desc, keypoint_size, tau):
+        """DepthFramePointGenerator::recoverPoints on caller-provided data: (lost-list index, keypoint xy, descriptor, xyz)."""
+        img = np.ascontiguousarray(image_left, np.uint8)
+        w2c = np.ascontiguousarray(world_to_camera_left, np.float64).reshape(12)
+        hl = np.ascontiguousarray(has_landmark, np.uint8); lm = np.ascontiguousarray(landmark_world, np.float64).reshape(-1, 3)
+        pd = np.ascontiguousarray(prev_desc, np.uint8)
+        sp = None if space is None else np.ascontiguousarray(space, np.float32)
+        n = lm.shape[0]
+        idx, xy = np.zeros(max(n, 1), np.int32), np.zeros((max(n, 1), 2), np.float32)
+        desc, xyz = np.zeros((max(n, 1), 32), np.uint8), np.zeros((max(n, 1), 3), np.float64)
+        nr = C.c_int32()
+        self.check(self.fn("depth_recover")(*self._ctx_args(), C.byref(params), None if sp is None else _p(sp, C.c_float), _p(img, C.c_uint8),
+                                            C.c_int32(img.shape[1]), _p(w2c, C.c_double), C.c_int32(n), _p(hl, C.c_uint8), _p(lm, C.c_double),
+                                            _p(pd, C.c_uint8), C.c_float(float(keypoint_size)), C.c_double(float(tau)), C.byref(nr),
+                                            _p(idx, C.c_int32), _p(xy, C.c_float), _p(desc, C.c_uint8), _p(xyz, C.c_double)))
+        k = nr.value
+        return idx[:k].copy(), xy[:k].copy(), desc[:k].copy(), xyz[:k].copy()
+
     def point_in_camera(self, xy_previous, xy_current, T, K):
         xp = np.ascontiguousarray(xy_previous, np.float32).reshape(-1, 2)
         xc = np.ascontiguousarray(xy_current, np.float32).reshape(-1, 2)

@@ -348,3 +348,86 @@ __global__ __launch_bounds__(1024) void k_depth_track(const DepthTrack a) {
   }
   if (tid == 0) { a.counts[0] = n_trk; a.counts[1] = n_tmp; a.counts[2] = n_lost; a.counts[3] = n_lm; }
 }
+
+// ---- recoverPoints ----------------------------------------------------------------------------------------------
+// One thread per lost point: projection of its landmark, field-of-view, depth and border gates (:317-359), the pixel
+// BRIEF has to be evaluated at (ROI origin = rounded corner: cv::Rect_<float> -> cv::Rect) and the keypoint the new
+// feature gets (:384).  k_brief_at then describes the pixels; k_depth_recover_finish applies the descriptor gate
+// (:381-383) and emits the survivors in the order of the lost list.
+struct DepthRecover {
+  vslam_depth_params p;
+  double w2c[12];
+  float kp_size;
+  double tau;
+  int n;
+  const uint8_t* has_lm; const double* lm; const uint8_t* pdesc;
+  const float* space;
+  int16_t* bxy;       // [n][2] pixel for BRIEF (0, 0 = rejected: outside the descriptor border, k_brief_at keeps 0)
+  float* kxy;         // [n][2] keypoint of the recovered feature
+  int32_t* cell;      // [n] space-map index of the depth lookup, -1 rejected
+  const uint8_t* keep; const uint8_t* desc;   // k_brief_at outputs
+  int32_t* count; int32_t* rec_index; float* rec_xy; uint8_t* rec_desc; double* rec_xyz;
+};
+
+__global__ __launch_bounds__(256) void k_depth_recover_project(const DepthRecover a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  int cell = -1, bx = 0, by = 0;
+  float kx = 0.f, ky = 0.f;
+  if (a.has_lm[i]) {                                                              // :305-307
+    const double* X = a.lm + 3 * (size_t)i;
+    double pc[3], pi[3];
+    for (int k = 0; k < 3; ++k) pc[k] = ((a.w2c[4 * k] * X[0] + a.w2c[4 * k + 1] * X[1]) + a.w2c[4 * k + 2] * X[2]) + a.w2c[4 * k + 3];   // :317
+    for (int k = 0; k < 3; ++k) pi[k] = (a.p.K_left[3 * k] * pc[0] + a.p.K_left[3 * k + 1] * pc[1]) + a.p.K_left[3 * k + 2] * pc[2];       // :325
+    const double x = pi[0] / pi[2], y = pi[1] / pi[2];                            // :326
+    const int rows = a.p.rows, cols = a.p.cols;
+    if (x >= 0 && x <= cols && y >= 0 && y <= rows) {                             // :329-332
+      const float px = (float)x, py = (float)y;                                   // :335
+      const float fr = rintf(py), fc = rintf(px);                                 // :338
+      if (fr >= 0 && fr < rows && fc >= 0 && fc < cols) {
+        const int cl = (int)fr * cols + (int)fc;
+        const float z = a.space[3 * (size_t)cl + 2];
+        if (!((double)z < a.p.minimum_depth_meters || (double)z >= a.p.maximum_depth_meters)) {   // :341-344
+          const float rbc = 5 * a.kp_size;                                        // :347
+          if (!(px <= rbc + 1 || px >= cols - rbc - 1 || py <= rbc + 1 || py >= rows - rbc - 1)) {   // :352-359
+            const float cxf = px - rbc, cyf = py - rbc;                           // :362
+            bx = (int)rintf(cxf) + (int)(rbc + 0.5f); by = (int)rintf(cyf) + (int)(rbc + 0.5f);
+            kx = rbc + cxf; ky = rbc + cyf;                                       // :384
+            cell = cl;
+          }
+        }
+      }
+    }
+  }
+  a.cell[i] = cell;
+  a.bxy[2 * i] = (int16_t)(cell >= 0 ? bx : 0); a.bxy[2 * i + 1] = (int16_t)(cell >= 0 ? by : 0);
+  a.kxy[2 * i] = kx; a.kxy[2 * i + 1] = ky;
+}
+
+__global__ __launch_bounds__(1024) void k_depth_recover_finish(const DepthRecover a) {
+  __shared__ int sh[17];
+  const int tid = threadIdx.x;
+  int n_rec = 0;
+  for (int base = 0; base < a.n; base += 1024) {
+    const int i = base + tid;
+    int ok = 0;
+    if (i < a.n && a.cell[i] >= 0 && a.keep[i]) {
+      const uint32_t* d = reinterpret_cast<const uint32_t*>(a.desc + (size_t)32 * i);
+      const uint32_t* q = reinterpret_cast<const uint32_t*>(a.pdesc + (size_t)32 * i);
+      int h = 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) h += __popc(d[u] ^ q[u]);
+      ok = !((double)h > a.tau);                                                  // :381-383
+    }
+    int total;
+    const int at = n_rec + block_exclusive_scan(ok, sh, &total);
+    n_rec += total;
+    if (ok) {
+      a.rec_index[at] = i;
+      a.rec_xy[2 * at] = a.kxy[2 * i]; a.rec_xy[2 * at + 1] = a.kxy[2 * i + 1];
+      for (int u = 0; u < 8; ++u) reinterpret_cast<uint32_t*>(a.rec_desc + (size_t)32 * at)[u] = reinterpret_cast<const uint32_t*>(a.desc + (size_t)32 * i)[u];
+      for (int k = 0; k < 3; ++k) a.rec_xyz[3 * (size_t)at + k] = (double)a.space[3 * (size_t)a.cell[i] + k];   // :390
+    }
+  }
+  if (tid == 0) a.count[0] = n_rec;
+}

@@ -612,6 +612,7 @@ VS_API int vslam_get_aligner_result(vslam_ctx* c, int s, int32_t cap, int32_t* n
   return VSLAM_OK;
 }
 // ---- RGB-D components (DepthFramePointGenerator pieces, stand-alone) ------------------------------------------------
+static int make_scratch_ctx(vslam_ctx* parent, int rows, int cols, int nmax, int maxp, vslam_ctx** out);
 static int depth_params_ok(vslam_ctx* c, const vslam_depth_params* p) {
   if (!c) return VSLAM_ERR_INVALID;
   if (c->sticky != VSLAM_OK) return c->sticky;
@@ -789,6 +790,71 @@ VS_API int vslam_depth_track(vslam_ctx* c, const vslam_depth_params* p, const fl
   (void)hipFree(drc); (void)hipFree(dhold); (void)hipFree(dpick); (void)hipFree(dcnt); (void)hipFree(dout2); (void)hipFree(dtmp2); (void)hipFree(dlost);
   if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   return VSLAM_OK;
+}
+VS_API int vslam_depth_recover(vslam_ctx* c, const vslam_depth_params* p, const float* space, const uint8_t* img, int32_t row_stride,
+                               const double w2c[12], int32_t n, const uint8_t* has_lm, const double* lm, const uint8_t* pdesc, float kp_size,
+                               double tau, int32_t* n_rec, int32_t* rec_index, float* rec_xy, uint8_t* rec_desc, double* rec_xyz) {
+  int rc = depth_params_ok(c, p);
+  if (rc != VSLAM_OK) return rc;
+  if (!img || !w2c || n < 0 || !n_rec || (n && (!has_lm || !lm || !pdesc || !rec_index || !rec_xy || !rec_desc || !rec_xyz)))
+    return fail(c, VSLAM_ERR_INVALID, "depth_recover: bad argument");
+  if (row_stride < p->cols) return fail(c, VSLAM_ERR_INVALID, "row stride smaller than image width");
+  if (!space && !(c->dm.valid && c->dm.rows == p->rows && c->dm.cols == p->cols)) return fail(c, VSLAM_ERR_STATE, "depth_recover: no resident space map of this size");
+  *n_rec = 0;
+  if (n == 0) return VSLAM_OK;
+  // box image of the left image through the image pipeline's own kernel (scratch context of the image size)
+  vslam_ctx* t = nullptr;
+  rc = make_scratch_ctx(c, p->rows, p->cols, 64, 64, &t);
+  if (rc != VSLAM_OK) return rc;
+  const size_t npx = (size_t)p->rows * p->cols;
+  DepthRecover a;
+  std::memset(&a, 0, sizeof a);
+  a.p = *p; std::memcpy(a.w2c, w2c, sizeof a.w2c); a.kp_size = kp_size; a.tau = tau; a.n = n;
+  float *dspace = nullptr, *dkxy = nullptr, *drxy = nullptr; double *dlm = nullptr, *drxyz = nullptr; uint8_t *dhl = nullptr, *dpd = nullptr, *dkeep = nullptr, *ddesc = nullptr, *drdesc = nullptr;
+  int16_t* dbxy = nullptr; int32_t *dcell = nullptr, *dcnt = nullptr, *dridx = nullptr;
+  hipError_t e = hipSuccess;
+  if (space) { e = dalloc(t, &dspace, npx * 3); if (e == hipSuccess) e = hipMemcpyAsync(dspace, space, npx * 3 * sizeof(float), hipMemcpyHostToDevice, t->stream_img); }
+  if (e == hipSuccess) e = dalloc(t, &dkxy, (size_t)n * 2);
+  if (e == hipSuccess) e = dalloc(t, &drxy, (size_t)n * 2);
+  if (e == hipSuccess) e = dalloc(t, &dlm, (size_t)n * 3);
+  if (e == hipSuccess) e = dalloc(t, &drxyz, (size_t)n * 3);
+  if (e == hipSuccess) e = dalloc(t, &dhl, (size_t)n);
+  if (e == hipSuccess) e = dalloc(t, &dpd, (size_t)n * 32);
+  if (e == hipSuccess) e = dalloc(t, &dkeep, (size_t)n);
+  if (e == hipSuccess) e = dalloc(t, &ddesc, (size_t)n * 32);
+  if (e == hipSuccess) e = dalloc(t, &drdesc, (size_t)n * 32);
+  if (e == hipSuccess) e = dalloc(t, &dbxy, (size_t)n * 2);
+  if (e == hipSuccess) e = dalloc(t, &dcell, (size_t)n);
+  if (e == hipSuccess) e = dalloc(t, &dcnt, 1);
+  if (e == hipSuccess) e = dalloc(t, &dridx, (size_t)n);
+  if (e == hipSuccess) e = hipMemcpyAsync(dhl, has_lm, (size_t)n, hipMemcpyHostToDevice, t->stream_img);
+  if (e == hipSuccess) e = hipMemcpyAsync(dlm, lm, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, t->stream_img);
+  if (e == hipSuccess) e = hipMemcpyAsync(dpd, pdesc, (size_t)n * 32, hipMemcpyHostToDevice, t->stream_img);
+  rc = e == hipSuccess ? upload_images(t, img, img, row_stride, 0) : fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
+  if (rc == VSLAM_OK) {
+    if (!space) (void)hipStreamSynchronize(c->stream);   // the resident map was written on the parent's stream
+    a.has_lm = dhl; a.lm = dlm; a.pdesc = dpd; a.space = space ? dspace : c->dm.space; a.bxy = dbxy; a.kxy = dkxy; a.cell = dcell;
+    a.keep = dkeep; a.desc = ddesc; a.count = dcnt; a.rec_index = dridx; a.rec_xy = drxy; a.rec_desc = drdesc; a.rec_xyz = drxyz;
+    dim3 g1(t->cfg.TX, (p->rows + VS_TILE_H - 1) / VS_TILE_H, 2);
+    hipLaunchKernelGGL(k_fast_box, g1, dim3(256), 0, t->stream_img, t->cfg, t->buf);
+    hipLaunchKernelGGL(k_depth_recover_project, dim3((n + 255) / 256), dim3(256), 0, t->stream_img, a);
+    hipLaunchKernelGGL(k_brief_at, dim3(std::min(64, (n + 3) / 4)), dim3(256), 0, t->stream_img, t->buf.box, t->cfg.bstride, p->rows, p->cols, n, dbxy, dkeep, ddesc);
+    hipLaunchKernelGGL(k_depth_recover_finish, dim3(1), dim3(1024), 0, t->stream_img, a);
+    e = hipGetLastError();
+    int32_t cnt = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&cnt, dcnt, 4, hipMemcpyDeviceToHost, t->stream_img);
+    if (e == hipSuccess) e = hipStreamSynchronize(t->stream_img);
+    if (e == hipSuccess && cnt) {
+      e = hipMemcpy(rec_index, dridx, (size_t)cnt * 4, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(rec_xy, drxy, (size_t)cnt * 8, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(rec_desc, drdesc, (size_t)cnt * 32, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(rec_xyz, drxyz, (size_t)cnt * 24, hipMemcpyDeviceToHost);
+    }
+    if (e == hipSuccess) *n_rec = cnt;
+    else rc = fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
+  }
+  vslam_destroy(t);
+  return rc;
 }
 VS_API int vslam_point_in_camera(vslam_ctx* c, int32_t n, const float* xp, const float* xc, const double T[12], const double K[9], double* out) {
   if (!c) return VSLAM_ERR_INVALID;
