@@ -363,6 +363,31 @@ int vslam_depth_recover(vslam_ctx* ctx, const vslam_depth_params* p, const float
 int vslam_point_in_camera(vslam_ctx* ctx, int32_t n, const float* xy_previous, const float* xy_current,
                           const double T[12], const double K[9], double* out);
 
+/* ---- OrbDetector components (first half; base_framepoint_generator.cpp:52-70) ----------------------
+ * The reference's OrbDetector is cv::ORB::create(5000, 1.2, 8, 31, 0, 2, HARRIS_SCORE, 31, threshold) used as a DETECTOR
+ * (descriptors still come from the configured extractor).  OpenCV is not in the reference tree: the published algorithm
+ * (features2d/src/orb.cpp computeKeyPoints, imgproc resize) is restated [recalled]; parity is pinned against the
+ * repo's independent numpy restatement only. */
+
+/* cv::resize(src, dst, dsize, 0, 0, INTER_LINEAR) for 8-bit single channel: 11-bit fixed-point bilinear weights,
+ * horizontal pass in 32-bit, vertical pass ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2.  Host images. */
+int vslam_resize_linear_u8(vslam_ctx* ctx, const uint8_t* src, int32_t rows, int32_t cols, int32_t row_stride,
+                           uint8_t* dst, int32_t dst_rows, int32_t dst_cols);
+
+/* HarrisResponses (block 7, k = 0.04) and ICAngles (half patch 15, fastAtan2) of orb.cpp at n integer pixel positions
+ * (xy: n*2 int16, at least 16 px from the border): response n floats, angle n floats (degrees). */
+int vslam_harris_angle(vslam_ctx* ctx, const uint8_t* image, int32_t rows, int32_t cols, int32_t row_stride, int32_t n,
+                       const int16_t* xy, float* response, float* angle);
+
+/* ORB::detect with HARRIS_SCORE, firstLevel 0, no mask: pyramid by successive INTER_LINEAR resizes, FAST-9/16 + NMS per
+ * level, 31 px border filter, retainBest(2 n_level) on the FAST score, Harris response, retainBest(n_level), intensity
+ * centroid angle, coordinates scaled back to level 0.  retainBest keeps every keypoint whose response ties the n-th
+ * (as KeyPointsFilter does); within a level the keypoints stay in row-major order (std::nth_element leaves the order
+ * unspecified upstream).  out: 6 floats per keypoint (x, y, size, angle, response, octave), levels in ascending order. */
+int vslam_orb_detect(vslam_ctx* ctx, const uint8_t* image, int32_t rows, int32_t cols, int32_t row_stride,
+                     int32_t nfeatures, float scale_factor, int32_t nlevels, int32_t edge_threshold, int32_t patch_size,
+                     int32_t fast_threshold, int32_t cap, int32_t* n, float* keypoints);
+
 /* ---- multi-GPU: trajectory assembly ---------------------------------------------------------
  * No reference counterpart (single process).  The pose all-gather is issued by the host
  * launcher through RCCL (torch.distributed backend "nccl"); these helpers pack/unpack. */

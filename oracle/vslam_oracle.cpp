@@ -1763,6 +1763,171 @@ ORC_API int orc_point_in_camera(int32_t n, const float* xy_prev, const float* xy
   return VSLAM_OK;
 }
 
+/* ---- OrbDetector components (base_framepoint_generator.cpp:52-70: cv::ORB as a detector) [recalled: OpenCV 3.x] ---- */
+static inline int cv_round(double v) { return (int)std::lrint(v); }               /* cvRound: half to even */
+static inline short sat_short(float v) { const int i = (int)std::lrint(v); return (short)std::min(std::max(i, -32768), 32767); }
+/* imgproc resize.cpp, INTER_LINEAR, 8UC1: resizeGeneric_<HResizeLinear<uchar,int,short,2048>, VResizeLinear<uchar,int,short,FixedPtCast<22>>> */
+static void resize_linear_u8(const uint8_t* src, int rows, int cols, int stride, uint8_t* dst, int drows, int dcols) {
+  const double sx_scale = (double)cols / dcols, sy_scale = (double)rows / drows;
+  std::vector<int> xofs(dcols), yofs(drows);
+  std::vector<short> alpha(2 * dcols), beta(2 * drows);
+  int xmax = dcols;
+  for (int dx = 0; dx < dcols; ++dx) {
+    float fx = (float)((dx + 0.5) * sx_scale - 0.5);
+    int sx = (int)std::floor(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= cols - 1) { xmax = std::min(xmax, dx); fx = 0; sx = cols - 1; }
+    xofs[dx] = sx;
+    alpha[2 * dx] = sat_short((1.f - fx) * 2048); alpha[2 * dx + 1] = sat_short(fx * 2048);
+  }
+  for (int dy = 0; dy < drows; ++dy) {
+    float fy = (float)((dy + 0.5) * sy_scale - 0.5);
+    int sy = (int)std::floor(fy);
+    fy -= sy;
+    yofs[dy] = sy;
+    beta[2 * dy] = sat_short((1.f - fy) * 2048); beta[2 * dy + 1] = sat_short(fy * 2048);
+  }
+  std::vector<int> r0(dcols), r1(dcols);
+  auto hrow = [&](int sy, std::vector<int>& D) {
+    const uint8_t* S = src + (size_t)std::min(std::max(sy, 0), rows - 1) * stride;
+    for (int dx = 0; dx < dcols; ++dx)
+      D[dx] = dx < xmax ? S[xofs[dx]] * alpha[2 * dx] + S[xofs[dx] + 1] * alpha[2 * dx + 1] : S[xofs[dx]] * 2048;
+  };
+  for (int dy = 0; dy < drows; ++dy) {
+    hrow(yofs[dy], r0); hrow(yofs[dy] + 1, r1);
+    const int b0 = beta[2 * dy], b1 = beta[2 * dy + 1];
+    for (int dx = 0; dx < dcols; ++dx)
+      dst[(size_t)dy * dcols + dx] = (uint8_t)((((b0 * (r0[dx] >> 4)) >> 16) + ((b1 * (r1[dx] >> 4)) >> 16) + 2) >> 2);
+  }
+}
+ORC_API int orc_resize_linear_u8(const uint8_t* src, int32_t rows, int32_t cols, int32_t stride, uint8_t* dst, int32_t drows, int32_t dcols) {
+  if (!src || !dst || rows < 2 || cols < 2 || drows < 1 || dcols < 1) return VSLAM_ERR_INVALID;
+  resize_linear_u8(src, rows, cols, stride, dst, drows, dcols);
+  return VSLAM_OK;
+}
+/* core mathfuncs fastAtan2 (float, degrees) */
+static float fast_atan2f(float y, float x) {
+  const float s = (float)(180.0 / 3.14159265358979323846);
+  const float p1 = 0.9997878412794807f * s, p3 = -0.3258083974640975f * s, p5 = 0.1555786518463281f * s, p7 = -0.04432655554792128f * s;
+  const float ax = std::fabs(x), ay = std::fabs(y);
+  float a, c, c2;
+  if (ax >= ay) { c = ay / (ax + (float)2.220446049250313e-16); c2 = c * c; a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+  else { c = ax / (ay + (float)2.220446049250313e-16); c2 = c * c; a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+static void orb_umax(int half, std::vector<int>& umax) {   /* orb.cpp computeKeyPoints: circular patch rows */
+  umax.assign(half + 2, 0);
+  const int vmax = (int)std::floor(half * std::sqrt(2.f) / 2 + 1), vmin = (int)std::ceil(half * std::sqrt(2.f) / 2);
+  for (int v = 0; v <= vmax; ++v) umax[v] = cv_round(std::sqrt((double)half * half - v * v));
+  for (int v = half, v0 = 0; v >= vmin; --v) { while (umax[v0] == umax[v0 + 1]) ++v0; umax[v] = v0; ++v0; }
+}
+static float harris_response(const uint8_t* img, int stride, int x0, int y0) {   /* orb.cpp HarrisResponses, blockSize 7, k 0.04 */
+  const int r = 3;
+  int a = 0, b = 0, c = 0;
+  for (int i = 0; i < 7; ++i)
+    for (int j = 0; j < 7; ++j) {
+      const uint8_t* q = img + (size_t)(y0 - r + i) * stride + (x0 - r + j);
+      const int Ix = (q[1] - q[-1]) * 2 + (q[-stride + 1] - q[-stride - 1]) + (q[stride + 1] - q[stride - 1]);
+      const int Iy = (q[stride] - q[-stride]) * 2 + (q[stride - 1] - q[-stride - 1]) + (q[stride + 1] - q[-stride + 1]);
+      a += Ix * Ix; b += Iy * Iy; c += Ix * Iy;
+    }
+  const float scale = 1.f / ((1 << 2) * 7 * 255.f), scale_sq_sq = scale * scale * scale * scale;
+  return ((float)a * b - (float)c * c - 0.04f * ((float)a + b) * ((float)a + b)) * scale_sq_sq;
+}
+static float ic_angle(const uint8_t* img, int stride, int x0, int y0, int half, const std::vector<int>& umax) {   /* orb.cpp ICAngles */
+  const uint8_t* center = img + (size_t)y0 * stride + x0;
+  int m_01 = 0, m_10 = 0;
+  for (int u = -half; u <= half; ++u) m_10 += u * center[u];
+  for (int v = 1; v <= half; ++v) {
+    int v_sum = 0;
+    const int d = umax[v];
+    for (int u = -d; u <= d; ++u) {
+      const int vp = center[u + v * stride], vm = center[u - v * stride];
+      v_sum += vp - vm;
+      m_10 += u * (vp + vm);
+    }
+    m_01 += v * v_sum;
+  }
+  return fast_atan2f((float)m_01, (float)m_10);
+}
+ORC_API int orc_harris_angle(const uint8_t* img, int32_t rows, int32_t cols, int32_t stride, int32_t n, const int16_t* xy, float* response, float* angle) {
+  if (!img || n < 0 || (n && (!xy || !response || !angle))) return VSLAM_ERR_INVALID;
+  std::vector<int> umax;
+  orb_umax(15, umax);
+  for (int i = 0; i < n; ++i) {
+    const int x = xy[2 * i], y = xy[2 * i + 1];
+    if (x < 16 || y < 16 || x >= cols - 16 || y >= rows - 16) return VSLAM_ERR_INVALID;
+    response[i] = harris_response(img, stride, x, y);
+    angle[i] = ic_angle(img, stride, x, y, 15, umax);
+  }
+  return VSLAM_OK;
+}
+/* KeyPointsFilter::retainBest: keeps every keypoint whose response ties the n-th; order = input order (nth_element's is unspecified) */
+template <typename KP> static void retain_best(std::vector<KP>& k, int n) {
+  if (n >= (int)k.size()) return;
+  if (n == 0) { k.clear(); return; }
+  std::vector<float> r(k.size());
+  for (size_t i = 0; i < k.size(); ++i) r[i] = k[i].response;
+  std::nth_element(r.begin(), r.begin() + (n - 1), r.end(), std::greater<float>());
+  const float amb = r[n - 1];
+  size_t m = 0;
+  for (size_t i = 0; i < k.size(); ++i) if (k[i].response >= amb) k[m++] = k[i];
+  k.resize(m);
+}
+struct OrbKp { float x, y, response, angle; };
+ORC_API int orc_orb_detect(const uint8_t* img, int32_t rows, int32_t cols, int32_t stride, int32_t nfeatures, float scale_factor, int32_t nlevels,
+                           int32_t edge, int32_t patch, int32_t fast_threshold, int32_t cap, int32_t* n, float* out) {
+  if (!img || !n || nlevels < 1 || nlevels > 16 || nfeatures < 0 || patch < 3) return VSLAM_ERR_INVALID;
+  /* features per level (orb.cpp computeKeyPoints) */
+  std::vector<int> per(nlevels);
+  {
+    const float factor = (float)(1.0 / scale_factor);
+    float nd = nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int l = 0; l < nlevels - 1; ++l) { per[l] = cv_round(nd); sum += per[l]; nd *= factor; }
+    per[nlevels - 1] = std::max(nfeatures - sum, 0);
+  }
+  const int half = patch / 2;
+  std::vector<int> umax;
+  orb_umax(half, umax);
+  std::vector<uint8_t> prev(img, img + 0), cur;
+  const uint8_t* lev = img;
+  int lrows = rows, lcols = cols, lstride = stride;
+  int total = 0;
+  for (int l = 0; l < nlevels; ++l) {
+    const float sc = (float)std::pow((double)scale_factor, (double)l);   /* getScale(level, 0, scaleFactor) */
+    if (l > 0) {
+      const int nr = cv_round(rows / sc), nc = cv_round(cols / sc);       /* Size sz(cvRound(cols/scale), cvRound(rows/scale)) */
+      if (nr < 2 * edge + 8 || nc < 2 * edge + 8) break;                  /* nothing can survive the border filter */
+      cur.assign((size_t)nr * nc, 0);
+      resize_linear_u8(lev, lrows, lcols, lstride, cur.data(), nr, nc);   /* level l from level l-1 */
+      prev.swap(cur);
+      lev = prev.data(); lrows = nr; lcols = nc; lstride = nc;
+    }
+    std::vector<Keypoint> k;
+    fast_detect_roi(lev, lstride, 0, 0, lcols, lrows, fast_threshold, k);   /* FastFeatureDetector::create(fastThreshold, true) */
+    std::vector<OrbKp> kp;
+    for (const Keypoint& q : k)                                             /* runByImageBorder(edgeThreshold) */
+      if (q.x >= edge && q.x < lcols - edge && q.y >= edge && q.y < lrows - edge) kp.push_back({(float)q.x, (float)q.y, (float)q.score, -1.f});
+    retain_best(kp, 2 * per[l]);                                            /* HARRIS_SCORE: twice the budget on the FAST score first */
+    for (OrbKp& q : kp) q.response = harris_response(lev, lstride, (int)q.x, (int)q.y);
+    retain_best(kp, per[l]);
+    for (OrbKp& q : kp) q.angle = ic_angle(lev, lstride, (int)q.x, (int)q.y, half, umax);
+    for (const OrbKp& q : kp) {
+      if (total < cap) {
+        float* o = out + 6 * (size_t)total;
+        o[0] = l ? q.x * sc : q.x; o[1] = l ? q.y * sc : q.y; o[2] = patch * sc; o[3] = q.angle; o[4] = q.response; o[5] = (float)l;
+      }
+      ++total;
+    }
+  }
+  *n = total;
+  return total > cap ? VSLAM_ERR_CAPACITY : VSLAM_OK;
+}
+
 /* ---- synthetic data + trajectory error (test / bench infrastructure) ---------------------- */
 ORC_API void orc_synth_default_kitti(synth_scene* s) { synth_default_kitti(s); }
 ORC_API void orc_synth_pose(const synth_scene* s, int k, double cam_to_world[12]) {

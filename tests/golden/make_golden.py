@@ -987,6 +987,160 @@ def gen_depth(rng):
     return len(cases)
 
 
+# ---------------------------------------------------------------------------------------------
+# OrbDetector components: cv::resize INTER_LINEAR (8UC1), orb.cpp HarrisResponses / ICAngles / computeKeyPoints [recalled],
+# with numpy arrays where the C++ has loops and numpy float32 scalars for the float arithmetic.
+def resize_linear_ref(src, drows, dcols):
+    rows, cols = src.shape
+    S = src.astype(np.int64)
+
+    def coeffs(n_dst, n_src):
+        ofs, a0, a1, nmax = [], [], [], n_dst
+        sc = n_src / n_dst
+        for d in range(n_dst):
+            f = np.float32((d + 0.5) * sc - 0.5)
+            s0 = int(np.floor(f))
+            f = np.float32(f - np.float32(s0))
+            ofs.append(s0); a0.append(int(np.rint(np.float32(np.float32(1) - f) * np.float32(2048)))); a1.append(int(np.rint(f * np.float32(2048))))
+        return ofs, a0, a1
+    xo, xa0, xa1 = coeffs(dcols, cols)
+    yo, yb0, yb1 = coeffs(drows, rows)
+    # horizontal pass for every source row (the left edge clamps the offset with weight 1 on the first pixel, the right
+    # edge replicates the last pixel with the full weight)
+    H = np.zeros((rows, dcols), np.int64)
+    for dx in range(dcols):
+        sx, a0, a1 = xo[dx], xa0[dx], xa1[dx]
+        if sx < 0:
+            H[:, dx] = S[:, 0] * 2048 + S[:, 1] * 0
+        elif sx >= cols - 1:
+            H[:, dx] = S[:, cols - 1] * 2048
+        else:
+            H[:, dx] = S[:, sx] * a0 + S[:, sx + 1] * a1
+    out = np.zeros((drows, dcols), np.uint8)
+    for dy in range(drows):
+        r0 = H[min(max(yo[dy], 0), rows - 1)]; r1 = H[min(max(yo[dy] + 1, 0), rows - 1)]
+        out[dy] = ((((yb0[dy] * (r0 >> 4)) >> 16) + ((yb1[dy] * (r1 >> 4)) >> 16) + 2) >> 2).astype(np.uint8)
+    return out
+
+
+def fast_atan2_ref(y, x):
+    f = np.float32
+    s = f(180.0 / np.pi)
+    p1, p3, p5, p7 = f(0.9997878412794807) * s, f(-0.3258083974640975) * s, f(0.1555786518463281) * s, f(-0.04432655554792128) * s
+    ax, ay = f(abs(x)), f(abs(y))
+    eps = f(2.220446049250313e-16)
+    if ax >= ay:
+        c = ay / (ax + eps); c2 = c * c
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c
+    else:
+        c = ax / (ay + eps); c2 = c * c
+        a = f(90) - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c
+    if x < 0:
+        a = f(180) - a
+    if y < 0:
+        a = f(360) - a
+    return f(a)
+
+
+def orb_umax_ref(half):
+    umax = [0] * (half + 2)
+    vmax = int(np.floor(np.float32(half) * np.sqrt(np.float32(2)) / np.float32(2) + np.float32(1)))
+    vmin = int(np.ceil(np.float32(half) * np.sqrt(np.float32(2)) / np.float32(2)))
+    for v in range(vmax + 1):
+        umax[v] = int(np.rint(np.sqrt(float(half * half - v * v))))
+    v0 = 0
+    for v in range(half, vmin - 1, -1):
+        while umax[v0] == umax[v0 + 1]:
+            v0 += 1
+        umax[v] = v0
+        v0 += 1
+    return umax
+
+
+def harris_ref(img, x0, y0):
+    I = img.astype(np.int64)
+    P = I[y0 - 4:y0 + 5, x0 - 4:x0 + 5]      # 9x9 around the 7x7 block
+    Ix = (P[1:-1, 2:] - P[1:-1, :-2]) * 2 + (P[:-2, 2:] - P[:-2, :-2]) + (P[2:, 2:] - P[2:, :-2])
+    Iy = (P[2:, 1:-1] - P[:-2, 1:-1]) * 2 + (P[2:, :-2] - P[:-2, :-2]) + (P[2:, 2:] - P[:-2, 2:])
+    a, b, c = int((Ix * Ix).sum()), int((Iy * Iy).sum()), int((Ix * Iy).sum())
+    f = np.float32
+    scale = f(1) / (f(4 * 7) * f(255))
+    ssq = scale * scale * scale * scale
+    return f((f(a) * f(b) - f(c) * f(c) - f(0.04) * (f(a) + f(b)) * (f(a) + f(b))) * ssq)
+
+
+def ic_angle_ref(img, x0, y0, half, umax):
+    I = img.astype(np.int64)
+    m10 = sum(u * int(I[y0, x0 + u]) for u in range(-half, half + 1))
+    m01 = 0
+    for v in range(1, half + 1):
+        d = umax[v]
+        vp = I[y0 + v, x0 - d:x0 + d + 1]; vm = I[y0 - v, x0 - d:x0 + d + 1]
+        us = np.arange(-d, d + 1)
+        m01 += v * int((vp - vm).sum())
+        m10 += int((us * (vp + vm)).sum())
+    return fast_atan2_ref(np.float32(m01), np.float32(m10))
+
+
+def retain_best_ref(kps, n):
+    """kps: list of dicts with 'response'; keeps every keypoint tying the n-th response, input order."""
+    if n >= len(kps):
+        return kps
+    if n == 0:
+        return []
+    amb = sorted((k["response"] for k in kps), reverse=True)[n - 1]
+    return [k for k in kps if k["response"] >= amb]
+
+
+def orb_detect_ref(img, nfeatures, scale_factor, nlevels, edge, patch, fast_thr):
+    f = np.float32
+    factor = f(1.0 / scale_factor)
+    nd = f(nfeatures) * (f(1) - factor) / (f(1) - f(np.power(float(factor), float(nlevels))))
+    per, tot = [], 0
+    for l in range(nlevels - 1):
+        per.append(int(np.rint(nd))); tot += per[-1]; nd = f(nd * factor)
+    per.append(max(nfeatures - tot, 0))
+    half = patch // 2
+    umax = orb_umax_ref(half)
+    rows, cols = img.shape
+    lev = img
+    out = []
+    for l in range(nlevels):
+        sc = f(np.power(float(f(scale_factor)), float(l)))
+        if l > 0:
+            nr, nc = int(np.rint(rows / float(sc))), int(np.rint(cols / float(sc)))
+            if nr < 2 * edge + 8 or nc < 2 * edge + 8:
+                break
+            lev = resize_linear_ref(lev, nr, nc)
+        lr, lc = lev.shape
+        kps = [dict(x=x, y=y, response=np.float32(s)) for (x, y, s) in fast9_16(lev, fast_thr)
+               if edge <= x < lc - edge and edge <= y < lr - edge]
+        kps = retain_best_ref(kps, 2 * per[l])
+        for k in kps:
+            k["response"] = harris_ref(lev, k["x"], k["y"])
+        kps = retain_best_ref(kps, per[l])
+        for k in kps:
+            ang = ic_angle_ref(lev, k["x"], k["y"], half, umax)
+            out.append([f(k["x"]) * sc if l else f(k["x"]), f(k["y"]) * sc if l else f(k["y"]), f(patch) * sc, ang, k["response"], f(l)])
+    return np.array(out, np.float32).reshape(-1, 6)
+
+
+def gen_orb(rng):
+    img = block_image(rng, 150, 190, 6)
+    out = {"img": img}
+    for name, (dr, dc) in {"down12": (125, 158), "down2": (75, 95), "odd": (101, 77), "up": (180, 228)}.items():
+        out["resize_" + name] = resize_linear_ref(img, dr, dc)
+    pts = np.stack([rng.integers(16, 190 - 16, 48), rng.integers(16, 150 - 16, 48)], axis=1).astype(np.int16)
+    umax = orb_umax_ref(15)
+    out["ha_xy"] = pts
+    out["ha_response"] = np.array([harris_ref(img, int(x), int(y)) for x, y in pts], np.float32)
+    out["ha_angle"] = np.array([ic_angle_ref(img, int(x), int(y), 15, umax) for x, y in pts], np.float32)
+    out["orb_a"] = orb_detect_ref(img, 60, 1.2, 4, 31, 31, 20)       # budgets bind on every level
+    out["orb_b"] = orb_detect_ref(img, 5000, 1.2, 8, 31, 31, 12)     # the reference's OrbDetector parameters: nothing is cut
+    np.savez_compressed(os.path.join(HERE, "orb.npz"), **out)
+    return len(out["orb_a"]), len(out["orb_b"])
+
+
 def main():
     rng = np.random.default_rng(20261003)
     gen_hamming(rng)
@@ -1000,6 +1154,7 @@ def main():
     gen_depth(np.random.default_rng(20261006))
     gen_depth_track(np.random.default_rng(20261007))
     gen_depth_recover(np.random.default_rng(20261008))
+    gen_orb(np.random.default_rng(20261009))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

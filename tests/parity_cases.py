@@ -198,3 +198,17 @@ def check_depth_recover(api, g):
     # nothing lost: nothing recovered
     idx, xy, desc, xyz = api.depth_recover(p, space, g["img"], g["w2c"], np.zeros(0, np.uint8), np.zeros((0, 3)), np.zeros((0, 32), np.uint8), 7.0, 35.0)
     assert len(idx) == 0
+
+
+def check_orb_components(api, g):
+    """cv::resize INTER_LINEAR, HarrisResponses / ICAngles and ORB::detect against the numpy restatement: bytes exact, floats bit-exact."""
+    img = g["img"]
+    for name, (dr, dc) in {"down12": (125, 158), "down2": (75, 95), "odd": (101, 77), "up": (180, 228)}.items():
+        np.testing.assert_array_equal(api.resize_linear_u8(img, dr, dc), g["resize_" + name], err_msg=name)
+    resp, ang = api.harris_angle(img, g["ha_xy"])
+    np.testing.assert_array_equal(resp.view(np.uint32), g["ha_response"].view(np.uint32))
+    np.testing.assert_array_equal(ang.view(np.uint32), g["ha_angle"].view(np.uint32))
+    a = api.orb_detect(img, 60, 1.2, 4, 31, 31, 20)
+    np.testing.assert_array_equal(a.view(np.uint32), g["orb_a"].view(np.uint32))
+    b = api.orb_detect(img, 5000, 1.2, 8, 31, 31, 12)
+    np.testing.assert_array_equal(b.view(np.uint32), g["orb_b"].view(np.uint32))

@@ -62,6 +62,12 @@ def test_depth_edge_cases(gpu, golden):
     pc.check_depth_edge_cases(gpu, golden["depth"])
 
 
+def test_orb_components_golden(gpu, golden):
+    """OrbDetector pieces (INTER_LINEAR pyramid level, Harris response, intensity-centroid angle, ORB::detect) against the
+    numpy restatement: bytes exact, floats bit for bit."""
+    pc.check_orb_components(gpu, golden["orb"])
+
+
 def test_depth_recover_golden(gpu, golden):
     """DepthFramePointGenerator::recoverPoints (projection gates, BRIEF at the rounded ROI, descriptor gate)."""
     pc.check_depth_recover(gpu, golden["depth_recover"])

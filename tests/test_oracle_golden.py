@@ -44,6 +44,10 @@ def test_depth_recover_known_answers(oracle, golden):
     pc.check_depth_recover(oracle, golden["depth_recover"])
 
 
+def test_orb_components_known_answers(oracle, golden):
+    pc.check_orb_components(oracle, golden["orb"])
+
+
 def test_aligner_first_linearization(oracle, golden):
     g = golden["aligner"]
     for name in pc.ALIGNER_CASES:

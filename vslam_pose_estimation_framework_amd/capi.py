@@ -412,6 +412,34 @@ class CApi(object):
         k = nr.value
         return idx[:k].copy(), xy[:k].copy(), desc[:k].copy(), xyz[:k].copy()
 
+    # -- OrbDetector components -------------------------------------------------------------------------------------
+    def resize_linear_u8(self, image, dst_rows, dst_cols):
+        img = np.ascontiguousarray(image, np.uint8)
+        dst = np.zeros((int(dst_rows), int(dst_cols)), np.uint8)
+        self.check(self.fn("resize_linear_u8")(*self._ctx_args(), _p(img, C.c_uint8), C.c_int32(img.shape[0]), C.c_int32(img.shape[1]),
+                                               C.c_int32(img.shape[1]), _p(dst, C.c_uint8), C.c_int32(dst.shape[0]), C.c_int32(dst.shape[1])))
+        return dst
+
+    def harris_angle(self, image, xy):
+        img = np.ascontiguousarray(image, np.uint8)
+        pts = np.ascontiguousarray(xy, np.int16).reshape(-1, 2)
+        resp, ang = np.zeros(pts.shape[0], np.float32), np.zeros(pts.shape[0], np.float32)
+        self.check(self.fn("harris_angle")(*self._ctx_args(), _p(img, C.c_uint8), C.c_int32(img.shape[0]), C.c_int32(img.shape[1]),
+                                           C.c_int32(img.shape[1]), C.c_int32(pts.shape[0]), _p(pts, C.c_int16), _p(resp, C.c_float),
+                                           _p(ang, C.c_float)))
+        return resp, ang
+
+    def orb_detect(self, image, nfeatures=5000, scale_factor=1.2, nlevels=8, edge_threshold=31, patch_size=31, fast_threshold=20, cap=20000):
+        """cv::ORB::detect (HARRIS_SCORE): rows of (x, y, size, angle, response, octave)."""
+        img = np.ascontiguousarray(image, np.uint8)
+        out = np.zeros((cap, 6), np.float32)
+        n = C.c_int32()
+        self.check(self.fn("orb_detect")(*self._ctx_args(), _p(img, C.c_uint8), C.c_int32(img.shape[0]), C.c_int32(img.shape[1]),
+                                         C.c_int32(img.shape[1]), C.c_int32(int(nfeatures)), C.c_float(float(scale_factor)), C.c_int32(int(nlevels)),
+                                         C.c_int32(int(edge_threshold)), C.c_int32(int(patch_size)), C.c_int32(int(fast_threshold)),
+                                         C.c_int32(cap), C.byref(n), _p(out, C.c_float)))
+        return out[:n.value].copy()
+
     def point_in_camera(self, xy_previous, xy_current, T, K):
         xp = np.ascontiguousarray(xy_previous, np.float32).reshape(-1, 2)
         xc = np.ascontiguousarray(xy_current, np.float32).reshape(-1, 2)

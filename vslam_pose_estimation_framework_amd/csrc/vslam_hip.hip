@@ -11,6 +11,7 @@
 
 #include "kernels_frame2.h"
 #include "kernels_depth.h"
+#include "kernels_orb.h"
 
 #define VS_API extern "C" __attribute__((visibility("default")))
 
@@ -880,6 +881,156 @@ VS_API int vslam_point_in_camera(vslam_ctx* c, int32_t n, const float* xp, const
   (void)hipFree(dp); (void)hipFree(dc); (void)hipFree(dT); (void)hipFree(dK); (void)hipFree(dout);
   if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   return VSLAM_OK;
+}
+
+// ---- OrbDetector components ---------------------------------------------------------------------------------------
+VS_API int vslam_resize_linear_u8(vslam_ctx* c, const uint8_t* src, int32_t rows, int32_t cols, int32_t row_stride, uint8_t* dst, int32_t drows,
+                                  int32_t dcols) {
+  if (!c) return VSLAM_ERR_INVALID;
+  if (c->sticky != VSLAM_OK) return c->sticky;
+  if (!src || !dst || rows < 2 || cols < 2 || drows < 1 || dcols < 1 || row_stride < cols) return fail(c, VSLAM_ERR_INVALID, "resize: bad argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  uint8_t *ds = nullptr, *dd = nullptr;
+  hipError_t e = hipMalloc((void**)&ds, (size_t)rows * row_stride);
+  if (e == hipSuccess) e = hipMalloc((void**)&dd, (size_t)drows * dcols);
+  if (e == hipSuccess) e = hipMemcpyAsync(ds, src, (size_t)(rows - 1) * row_stride + cols, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_resize_linear_u8, dim3((dcols + 255) / 256, drows), dim3(256), 0, c->stream, ds, rows, cols, row_stride, dd, drows, dcols, dcols);
+    e = hipMemcpyAsync(dst, dd, (size_t)drows * dcols, hipMemcpyDeviceToHost, c->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(ds); (void)hipFree(dd);
+  if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
+  return VSLAM_OK;
+}
+static OrbUmax orb_umax_table(int half) {   // orb.cpp computeKeyPoints: row half-widths of the circular patch
+  OrbUmax t;
+  std::memset(&t, 0, sizeof t);
+  const int vmax = (int)std::floor(half * std::sqrt(2.f) / 2 + 1), vmin = (int)std::ceil(half * std::sqrt(2.f) / 2);
+  for (int v = 0; v <= vmax; ++v) t.v[v] = (int)std::lrint(std::sqrt((double)half * half - v * v));
+  for (int v = half, v0 = 0; v >= vmin; --v) { while (t.v[v0] == t.v[v0 + 1]) ++v0; t.v[v] = v0; ++v0; }
+  return t;
+}
+VS_API int vslam_harris_angle(vslam_ctx* c, const uint8_t* img, int32_t rows, int32_t cols, int32_t row_stride, int32_t n, const int16_t* xy,
+                              float* response, float* angle) {
+  if (!c) return VSLAM_ERR_INVALID;
+  if (c->sticky != VSLAM_OK) return c->sticky;
+  if (!img || n < 0 || rows < 33 || cols < 33 || row_stride < cols || (n && (!xy || !response || !angle))) return fail(c, VSLAM_ERR_INVALID, "harris_angle: bad argument");
+  for (int i = 0; i < n; ++i)
+    if (xy[2 * i] < 16 || xy[2 * i + 1] < 16 || xy[2 * i] >= cols - 16 || xy[2 * i + 1] >= rows - 16) return fail(c, VSLAM_ERR_INVALID, "harris_angle: keypoint closer than 16 px to the border");
+  if (n == 0) return VSLAM_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  uint8_t* di = nullptr; int16_t* dxy = nullptr; float *dr = nullptr, *da = nullptr; int32_t* dn = nullptr;
+  hipError_t e = hipMalloc((void**)&di, (size_t)rows * row_stride);
+  if (e == hipSuccess) e = hipMalloc((void**)&dxy, (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&dr, (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&da, (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&dn, 4);
+  if (e == hipSuccess) e = hipMemcpyAsync(di, img, (size_t)(rows - 1) * row_stride + cols, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dxy, xy, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dn, &n, 4, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    const int blocks = std::min(256, (n + 3) / 4);
+    hipLaunchKernelGGL(k_orb_harris, dim3(blocks), dim3(256), 0, c->stream, di, row_stride, dn, dxy, dr);
+    hipLaunchKernelGGL(k_orb_angle, dim3(blocks), dim3(256), 0, c->stream, di, row_stride, dn, dxy, dr, 15, orb_umax_table(15), da, (float*)nullptr,
+                       (const int32_t*)nullptr, 0, 1.f, 0, 31);
+    e = hipMemcpyAsync(response, dr, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(angle, da, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(di); (void)hipFree(dxy); (void)hipFree(dr); (void)hipFree(da); (void)hipFree(dn);
+  if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
+  return VSLAM_OK;
+}
+VS_API int vslam_orb_detect(vslam_ctx* c, const uint8_t* img, int32_t rows, int32_t cols, int32_t row_stride, int32_t nfeatures, float scale_factor,
+                            int32_t nlevels, int32_t edge, int32_t patch, int32_t fast_threshold, int32_t cap, int32_t* n, float* keypoints) {
+  if (!c) return VSLAM_ERR_INVALID;
+  if (c->sticky != VSLAM_OK) return c->sticky;
+  if (!img || !n || nlevels < 1 || nlevels > 16 || nfeatures < 0 || patch < 3 || patch > 63 || cap < 0 || (cap && !keypoints) || row_stride < cols ||
+      !(scale_factor > 1.f) || edge < patch / 2 + 1 || edge < 4 || rows < 2 * edge + 8 || cols < 2 * edge + 8 || rows > 32767 || cols > 32767)
+    return fail(c, VSLAM_ERR_INVALID, "orb_detect: bad argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  // features per level (orb.cpp computeKeyPoints), float arithmetic as upstream
+  std::vector<int> per(nlevels);
+  {
+    const float factor = (float)(1.0 / scale_factor);
+    float nd = nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int l = 0; l < nlevels - 1; ++l) { per[l] = (int)std::lrint(nd); sum += per[l]; nd *= factor; }
+    per[nlevels - 1] = std::max(nfeatures - sum, 0);
+  }
+  const int half = patch / 2;
+  const OrbUmax um = orb_umax_table(half);
+  hipStream_t st = c->stream;
+  std::vector<void*> tmp;
+  auto dmal = [&](size_t bytes) -> void* { void* q = nullptr; if (hipMalloc(&q, std::max<size_t>(bytes, 4)) != hipSuccess) return nullptr; tmp.push_back(q); return q; };
+  float* dout = (float*)dmal((size_t)std::max(cap, 1) * 6 * sizeof(float));
+  int32_t* dtotal = (int32_t*)dmal(4);
+  int rc = VSLAM_OK;
+  hipError_t e = (dout && dtotal) ? hipMemsetAsync(dtotal, 0, 4, st) : hipErrorOutOfMemory;
+  const uint8_t* lev = nullptr;
+  int lrows = rows, lcols = cols, lstride = (cols + 63) & ~63;
+  std::vector<vslam_ctx*> scratch;
+  if (e == hipSuccess) {
+    uint8_t* d0 = (uint8_t*)dmal((size_t)rows * lstride);
+    if (!d0) e = hipErrorOutOfMemory;
+    else e = hipMemcpy2DAsync(d0, lstride, img, row_stride, cols, rows, hipMemcpyHostToDevice, st);
+    lev = d0;
+  }
+  for (int l = 0; l < nlevels && e == hipSuccess && rc == VSLAM_OK; ++l) {
+    const float sc = (float)std::pow((double)scale_factor, (double)l);
+    if (l > 0) {
+      const int nr = (int)std::lrint(rows / sc), nc = (int)std::lrint(cols / sc);
+      if (nr < 2 * edge + 8 || nc < 2 * edge + 8) break;
+      const int ns = (nc + 63) & ~63;
+      uint8_t* dl = (uint8_t*)dmal((size_t)nr * ns);
+      if (!dl) { e = hipErrorOutOfMemory; break; }
+      hipLaunchKernelGGL(k_resize_linear_u8, dim3((nc + 255) / 256, nr), dim3(256), 0, st, lev, lrows, lcols, lstride, dl, nr, nc, ns);
+      lev = dl; lrows = nr; lcols = nc; lstride = ns;
+    }
+    // FAST-9/16 + NMS + border filter through the image pipeline's own kernels on a scratch context of the level's size
+    vslam_ctx* t = nullptr;
+    rc = make_scratch_ctx(c, lrows, lcols, 65535, 64, &t);
+    if (rc != VSLAM_OK) break;
+    scratch.push_back(t);
+    t->cfg.n_regions = 1;
+    t->cfg.regions[0].x = 0; t->cfg.regions[0].y = 0; t->cfg.regions[0].w = lcols; t->cfg.regions[0].h = lrows;
+    StreamState sst;
+    e = hipMemcpy(&sst, t->buf.st, sizeof sst, hipMemcpyDeviceToHost);
+    sst.thr[0] = fast_threshold;
+    if (e == hipSuccess) e = hipMemcpy(t->buf.st, &sst, sizeof sst, hipMemcpyHostToDevice);
+    if (e != hipSuccess) break;
+    rc = set_images_device(t, lev, lev, lstride, 0);
+    if (rc != VSLAM_OK) break;
+    const int N = t->cfg.NMAX;
+    int16_t* xy1 = (int16_t*)dmal((size_t)N * 4); int16_t* xy2 = (int16_t*)dmal((size_t)N * 4);
+    float* r1 = (float*)dmal((size_t)N * 4); float* r2 = (float*)dmal((size_t)N * 4); float* rh = (float*)dmal((size_t)N * 4);
+    int32_t* n1 = (int32_t*)dmal(4); int32_t* n2 = (int32_t*)dmal(4);
+    if (!xy1 || !xy2 || !r1 || !r2 || !rh || !n1 || !n2) { e = hipErrorOutOfMemory; break; }
+    dim3 g1(t->cfg.TX, (lrows + VS_TILE_H - 1) / VS_TILE_H, 1);
+    hipLaunchKernelGGL(k_fast_box, g1, dim3(256), 0, st, t->cfg, t->buf);
+    hipLaunchKernelGGL(k_emit, dim3(1, 1), dim3(512), 0, st, t->cfg, t->buf, edge, 0);                                  // runByImageBorder(edgeThreshold)
+    hipLaunchKernelGGL(k_orb_select<uint8_t>, dim3(1), dim3(1024), 0, st, t->buf.n_kp, t->buf.kp_xy, t->buf.kp_score, 2 * per[l], n1, xy1, r1, N);   // retainBest(2 n) on the FAST score
+    hipLaunchKernelGGL(k_orb_harris, dim3(256), dim3(256), 0, st, lev, lstride, n1, xy1, rh);
+    hipLaunchKernelGGL(k_orb_select<float>, dim3(1), dim3(1024), 0, st, n1, xy1, rh, per[l], n2, xy2, r2, N);            // retainBest(n) on the Harris response
+    hipLaunchKernelGGL(k_orb_angle, dim3(256), dim3(256), 0, st, lev, lstride, n2, xy2, r2, half, um, (float*)nullptr, dout, dtotal, cap, sc, l, patch);
+    hipLaunchKernelGGL(k_orb_advance, dim3(1), dim3(1), 0, st, dtotal, n2);
+    e = hipGetLastError();
+  }
+  int32_t total = 0;
+  if (e == hipSuccess && rc == VSLAM_OK) e = hipMemcpyAsync(&total, dtotal, 4, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e == hipSuccess && rc == VSLAM_OK) {
+    *n = total;
+    const int m = std::min(total, cap);
+    if (m) e = hipMemcpy(keypoints, dout, (size_t)m * 6 * sizeof(float), hipMemcpyDeviceToHost);
+    for (vslam_ctx* t : scratch) { int32_t cnt = 0; if (hipMemcpy(&cnt, t->buf.n_kp, 4, hipMemcpyDeviceToHost) == hipSuccess && cnt >= t->cfg.NMAX) rc = fail(c, VSLAM_ERR_CAPACITY, "orb_detect: more than 65535 FAST corners on a level"); }
+    if (rc == VSLAM_OK && total > cap) rc = fail(c, VSLAM_ERR_CAPACITY, "orb_detect: output capacity too small");
+  }
+  for (vslam_ctx* t : scratch) vslam_destroy(t);
+  for (void* q : tmp) (void)hipFree(q);
+  if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
+  return rc;
 }
 
 VS_API int vslam_get_poses(vslam_ctx* c, int s, int32_t first, int32_t nf, double* out) {
