@@ -54,7 +54,20 @@ __global__ __launch_bounds__(1024) void k_orb_select(const int32_t* n_in_p, cons
   const int n = *n_in_p;
   uint32_t thr_key = 0;                               // keep everything
   if (n_keep <= 0) thr_key = 0xffffffffu;             // keep nothing (keys never reach it: NaN-free responses)
-  else if (n_keep < n) {
+  else if (n_keep < n && sizeof(R) == 1) {
+    // FAST scores: one histogram over the 256 values
+    for (int i = tid; i < 256; i += 1024) hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) atomicAdd(&hist[(int)resp_in[i] & 255], 1);
+    __syncthreads();
+    if (tid == 0) {
+      int rank = n_keep, bin = 255;
+      for (; bin > 0; --bin) { if (hist[bin] >= rank) break; rank -= hist[bin]; }
+      s_prefix = orb_key((float)bin);
+    }
+    __syncthreads();
+    thr_key = s_prefix;
+  } else if (n_keep < n) {
     if (tid == 0) { s_prefix = 0; s_rank = n_keep; }  // looking for the s_rank-th largest among keys matching the prefix
     for (int pass = 0; pass < 4; ++pass) {
       const int shift = 24 - 8 * pass;
