@@ -1880,7 +1880,8 @@ template <typename KP> static void retain_best(std::vector<KP>& k, int n) {
 struct OrbKp { float x, y, response, angle; };
 ORC_API int orc_orb_detect(const uint8_t* img, int32_t rows, int32_t cols, int32_t stride, int32_t nfeatures, float scale_factor, int32_t nlevels,
                            int32_t edge, int32_t patch, int32_t fast_threshold, int32_t cap, int32_t* n, float* out) {
-  if (!img || !n || nlevels < 1 || nlevels > 16 || nfeatures < 0 || patch < 3) return VSLAM_ERR_INVALID;
+  if (!img || !n || nlevels < 1 || nlevels > 16 || nfeatures < 0 || patch < 3 || patch > 63 || !(scale_factor > 1.f) || edge < patch / 2 + 1 || edge < 4 ||
+      rows < 2 * edge + 8 || cols < 2 * edge + 8) return VSLAM_ERR_INVALID;
   /* features per level (orb.cpp computeKeyPoints) */
   std::vector<int> per(nlevels);
   {

@@ -68,6 +68,10 @@ def test_orb_components_golden(gpu, golden):
     pc.check_orb_components(gpu, golden["orb"])
 
 
+def test_orb_edge_cases(gpu, golden):
+    pc.check_orb_edge_cases(gpu, golden["orb"])
+
+
 def test_depth_recover_golden(gpu, golden):
     """DepthFramePointGenerator::recoverPoints (projection gates, BRIEF at the rounded ROI, descriptor gate)."""
     pc.check_depth_recover(gpu, golden["depth_recover"])

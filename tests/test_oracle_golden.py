@@ -48,6 +48,10 @@ def test_orb_components_known_answers(oracle, golden):
     pc.check_orb_components(oracle, golden["orb"])
 
 
+def test_orb_edge_cases(oracle, golden):
+    pc.check_orb_edge_cases(oracle, golden["orb"])
+
+
 def test_aligner_first_linearization(oracle, golden):
     g = golden["aligner"]
     for name in pc.ALIGNER_CASES:
