@@ -291,6 +291,17 @@ int vslam_stereo_match(vslam_ctx* ctx, double tau_tri, int32_t nL, const int32_t
                        int32_t nR, const int32_t* rc_right, const uint8_t* desc_right, int32_t cap, int32_t* n_out,
                        int32_t* out4);
 
+/* Landmark::update (types/landmark.cpp:66-167) for n landmarks, stand-alone (the fused tracker runs the same refinement inside
+ * its frame kernel): landmark i owns the measurements offsets[i] .. offsets[i+1]-1 in the caller's order, the LAST one being
+ * the new observation; measurement m was taken in frame frame_of[m] (pose tables world_to_camera / camera_to_world, 3x4 each)
+ * at left-camera coordinates cam[m] with information 1 / cam[m].z (landmark.h:22-36).  Gauss-Newton on the world position
+ * with the saturated kernel (landmark_maximum_error_squared_meters, landmark_maximum_number_of_iterations of ctx's config),
+ * 3x3 full-pivot LU; on convergence the estimate is taken if it has more inliers than the landmark had updates, reset to the
+ * mean of the measurements if inliers < outliers, kept otherwise.  world (n*3) and updates (n) are read and written. */
+int vslam_landmark_update(vslam_ctx* ctx, int32_t n, const int32_t* offsets, const int32_t* frame_of, int32_t n_frames,
+                          const double* world_to_camera, const double* camera_to_world, const double* cam, double* world,
+                          int32_t* updates);
+
 /* ---- RGB-D components: the pieces of DepthFramePointGenerator, stand-alone -----------------
  * Not wired into the fused stereo tracker; same role as vslam_align_points_uvd (the RGB-D aligner): the kernels a
  * depth-mode shim calls, each checked against the oracle and an independent fixture. */

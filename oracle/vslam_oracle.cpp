@@ -1537,6 +1537,39 @@ ORC_API int orc_track_match(const vslam_config* cfg, const double T[12], int32_t
   return VSLAM_OK;
 }
 
+/* Landmark::update (landmark.cpp:66-167) on caller-provided measurement lists (last measurement of a list = the new one) */
+ORC_API int orc_landmark_update(const vslam_config* cfg, int32_t n, const int32_t* offsets, const int32_t* frame_of, int32_t n_frames,
+                                const double* w2c, const double* c2w, const double* cam, double* world, int32_t* updates) {
+  Stream s;
+  s.configure(*cfg);
+  s.frames.resize(n_frames);
+  for (int f = 0; f < n_frames; ++f) {
+    std::memcpy(s.frames[f].world_to_cam.m, w2c + 12 * f, sizeof(double) * 12);
+    std::memcpy(s.frames[f].cam_to_world.m, c2w + 12 * f, sizeof(double) * 12);
+  }
+  for (int i = 0; i < n; ++i) {
+    const int a = offsets[i], b = offsets[i + 1];
+    if (b <= a) continue;
+    Landmark lm;
+    for (int k = 0; k < 3; ++k) lm.w[k] = world[3 * i + k];
+    lm.updates = (uint32_t)updates[i];
+    for (int m = a; m < b - 1; ++m) {
+      Meas q;
+      q.frame = frame_of[m];
+      for (int k = 0; k < 3; ++k) q.cam[k] = cam[3 * m + k];
+      q.inv_depth = 1 / cam[3 * m + 2];
+      lm.meas.push_back(q);
+    }
+    Point p;
+    std::memset(&p, 0, sizeof p);
+    for (int k = 0; k < 3; ++k) p.cam[k] = cam[3 * (b - 1) + k];
+    s.update_landmark(lm, frame_of[b - 1], p);
+    for (int k = 0; k < 3; ++k) world[3 * i + k] = lm.w[k];
+    updates[i] = (int32_t)lm.updates;
+  }
+  return VSLAM_OK;
+}
+
 /* ---- RGB-D components (DepthFramePointGenerator) ------------------------------------------ */
 /* _computeDepthMap (depth_framepoint_generator.cpp:410-485), bilateral filter off (configuration_{icl,tum,xtion}.yaml) */
 ORC_API int orc_depth_space_map(const vslam_depth_params* p, const uint16_t* depth, int32_t stride, float* space,

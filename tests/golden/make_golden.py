@@ -1141,6 +1141,82 @@ def gen_orb(rng):
     return len(out["orb_a"]), len(out["orb_b"])
 
 
+# ---------------------------------------------------------------------------------------------
+# Landmark::update (types/landmark.cpp:66-167) with numpy matrices and numpy.linalg.solve
+def landmark_update_ref(w2c, c2w, meas, world, updates, max_iter=100, kernel=25.0):
+    """meas: list of (frame, cam xyz); last = new observation.  Returns (world, updates)."""
+    w = np.array(world, float)
+    prev = 0.0
+    for it in range(max_iter):
+        H = np.zeros((3, 3)); b = np.zeros(3); err = 0.0; n_out = 0
+        for (f, mc) in meas:
+            R, t = w2c[f][:, :3], w2c[f][:, 3]
+            s_ = R @ w + t
+            if s_[2] <= 0:
+                n_out += 1
+                continue
+            e = s_ - mc
+            om = 1.0 / mc[2]
+            e2 = om * float(e @ e)
+            err += e2
+            if e2 > kernel:
+                om *= kernel / e2
+                n_out += 1
+            H += om * (R.T @ R); b += om * (R.T @ e)
+        if np.any(H != 0):              # H == 0 (every measurement skipped): fullPivLu().solve returns 0
+            w = w + np.linalg.solve(H, -b)
+        if abs(err - prev) < 1e-5 or it == 999:
+            n_in = len(meas) - n_out
+            if n_in > updates:
+                return w, n_in
+            if n_in < n_out:
+                acc = np.zeros(3)
+                for (f, mc) in meas:
+                    acc += c2w[f][:, :3] @ mc + c2w[f][:, 3]
+                return acc / len(meas), updates
+            return np.array(world, float), updates
+        prev = err
+    return np.array(world, float), updates
+
+
+def gen_landmark(rng):
+    n_frames = 24
+    w2c, c2w = [], []
+    for f in range(n_frames):
+        v = np.array([0.02 * f + rng.normal(0, 0.01), rng.normal(0, 0.01), 0.9 * f + rng.normal(0, 0.02), rng.normal(0, 0.004), 0.01 * np.sin(f / 5.0), rng.normal(0, 0.004)])
+        C = v2t(v)                      # camera to world
+        c2w.append(C[:3, :]); w2c.append(np.linalg.inv(C)[:3, :])
+    offsets, frame_of, cam, world, updates = [0], [], [], [], []
+    ref_world, ref_updates = [], []
+    for i in range(60):
+        f0 = int(rng.integers(0, n_frames - 4)); length = int(rng.integers(3, min(12, n_frames - f0)))
+        X = c2w[f0][:, :3] @ np.array([rng.uniform(-6, 6), rng.uniform(-2, 2), rng.uniform(4, 40)]) + c2w[f0][:, 3]
+        kind = i % 6
+        meas = []
+        for k in range(length):
+            f = f0 + k
+            pc = w2c[f][:, :3] @ X + w2c[f][:, 3]
+            noise = rng.normal(0, 0.02 * max(pc[2], 1.0) / 10, 3)
+            if kind == 3 and k % 2 == 0:
+                noise += rng.normal(0, 8.0, 3)                     # gross outliers: kernel saturation
+            mc = pc + noise
+            mc[2] = max(mc[2], 0.3)
+            meas.append((f, mc))
+        if kind == 4:
+            meas = meas[::-1]                                      # creation order (newest first) as the constructor leaves it
+        w0 = X + rng.normal(0, 0.3, 3)
+        up0 = length - 1 if kind != 5 else length + 5             # kind 5: already better supported, the estimate is not taken
+        if kind == 2:
+            w0 = X + np.array([0, 0, -200.0])                      # behind most cameras: outliers dominate -> reset to the mean
+        wr, ur = landmark_update_ref(w2c, c2w, meas, w0, up0)
+        offsets.append(offsets[-1] + len(meas)); frame_of += [m[0] for m in meas]; cam += [m[1] for m in meas]
+        world.append(w0); updates.append(up0); ref_world.append(wr); ref_updates.append(ur)
+    np.savez_compressed(os.path.join(HERE, "landmark.npz"), w2c=np.array(w2c), c2w=np.array(c2w), offsets=np.array(offsets, np.int32),
+                        frame_of=np.array(frame_of, np.int32), cam=np.array(cam), world=np.array(world), updates=np.array(updates, np.int32),
+                        ref_world=np.array(ref_world), ref_updates=np.array(ref_updates, np.int32))
+    return sum(1 for a, b in zip(updates, ref_updates) if a != b), len(updates)
+
+
 def main():
     rng = np.random.default_rng(20261003)
     gen_hamming(rng)
@@ -1155,6 +1231,7 @@ def main():
     gen_depth_track(np.random.default_rng(20261007))
     gen_depth_recover(np.random.default_rng(20261008))
     gen_orb(np.random.default_rng(20261009))
+    gen_landmark(np.random.default_rng(20261010))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

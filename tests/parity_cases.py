@@ -241,3 +241,14 @@ def check_orb_edge_cases(api, g):
         raise AssertionError("capacity overflow not reported")
     except VslamError as e:
         assert e.code == -4
+
+
+def check_landmark_update(api, g, cfg):
+    """Landmark::update against the numpy restatement (numpy.linalg.solve instead of the 3x3 full-pivot LU: 1e-9), update
+    counts exact; the fixture covers plain refinement, kernel saturation, the reset to the mean and the kept estimate."""
+    w, u = api.landmark_update(cfg, g["offsets"], g["frame_of"], g["w2c"], g["c2w"], g["cam"], g["world"], g["updates"])
+    np.testing.assert_array_equal(u, g["ref_updates"])
+    np.testing.assert_allclose(w, g["ref_world"], rtol=1e-9, atol=1e-9)
+    kept = np.all(g["ref_world"] == g["world"], axis=1)
+    np.testing.assert_array_equal(w[kept], g["world"][kept])      # an estimate that is not taken leaves the landmark untouched
+    return w, u

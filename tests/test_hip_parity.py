@@ -62,6 +62,15 @@ def test_depth_edge_cases(gpu, golden):
     pc.check_depth_edge_cases(gpu, golden["depth"])
 
 
+def test_landmark_update_golden(gpu, oracle, golden):
+    """Landmark::update stand-alone: the numpy fixture (1e-9) and the oracle (bit for bit: same arithmetic, same order)."""
+    g = golden["landmark"]
+    w, u = pc.check_landmark_update(gpu, g, gpu.cfg)
+    wo, uo = oracle.landmark_update(oracle.default_config("kitti"), g["offsets"], g["frame_of"], g["w2c"], g["c2w"], g["cam"], g["world"], g["updates"])
+    np.testing.assert_array_equal(u, uo)
+    np.testing.assert_array_equal(w, wo)
+
+
 def test_orb_components_golden(gpu, golden):
     """OrbDetector pieces (INTER_LINEAR pyramid level, Harris response, intensity-centroid angle, ORB::detect) against the
     numpy restatement: bytes exact, floats bit for bit."""

@@ -52,6 +52,10 @@ def test_orb_edge_cases(oracle, golden):
     pc.check_orb_edge_cases(oracle, golden["orb"])
 
 
+def test_landmark_update_known_answers(oracle, golden):
+    pc.check_landmark_update(oracle, golden["landmark"], oracle.default_config("kitti"))
+
+
 def test_aligner_first_linearization(oracle, golden):
     g = golden["aligner"]
     for name in pc.ALIGNER_CASES:

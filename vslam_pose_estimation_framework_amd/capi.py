@@ -412,6 +412,17 @@ class CApi(object):
         k = nr.value
         return idx[:k].copy(), xy[:k].copy(), desc[:k].copy(), xyz[:k].copy()
 
+    def landmark_update(self, cfg, offsets, frame_of, world_to_camera, camera_to_world, cam, world, updates):
+        """Landmark::update for a batch of landmarks (last measurement of each list = the new observation)."""
+        off = np.ascontiguousarray(offsets, np.int32); fo = np.ascontiguousarray(frame_of, np.int32)
+        w2c = np.ascontiguousarray(world_to_camera, np.float64).reshape(-1, 12); c2w = np.ascontiguousarray(camera_to_world, np.float64).reshape(-1, 12)
+        cm = np.ascontiguousarray(cam, np.float64).reshape(-1, 3)
+        w = np.array(world, np.float64).reshape(-1, 3).copy(); u = np.array(updates, np.int32).copy()
+        first = (self.ctx,) if self.prefix == "vslam_" else (C.byref(cfg),)
+        self.check(self.fn("landmark_update")(*first, C.c_int32(w.shape[0]), _p(off, C.c_int32), _p(fo, C.c_int32), C.c_int32(w2c.shape[0]),
+                                              _p(w2c, C.c_double), _p(c2w, C.c_double), _p(cm, C.c_double), _p(w, C.c_double), _p(u, C.c_int32)))
+        return w, u
+
     # -- OrbDetector components -------------------------------------------------------------------------------------
     def resize_linear_u8(self, image, dst_rows, dst_cols):
         img = np.ascontiguousarray(image, np.uint8)

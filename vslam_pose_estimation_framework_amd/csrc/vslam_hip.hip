@@ -12,6 +12,7 @@
 #include "kernels_frame2.h"
 #include "kernels_depth.h"
 #include "kernels_orb.h"
+#include "kernels_landmark.h"
 
 #define VS_API extern "C" __attribute__((visibility("default")))
 
@@ -879,6 +880,44 @@ VS_API int vslam_point_in_camera(vslam_ctx* c, int32_t n, const float* xp, const
   }
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   (void)hipFree(dp); (void)hipFree(dc); (void)hipFree(dT); (void)hipFree(dK); (void)hipFree(dout);
+  if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
+  return VSLAM_OK;
+}
+
+VS_API int vslam_landmark_update(vslam_ctx* c, int32_t n, const int32_t* offsets, const int32_t* frame_of, int32_t n_frames, const double* w2c,
+                                 const double* c2w, const double* cam, double* world, int32_t* updates) {
+  if (!c) return VSLAM_ERR_INVALID;
+  if (c->sticky != VSLAM_OK) return c->sticky;
+  if (n < 0 || n_frames < 0 || (n && (!offsets || !world || !updates))) return fail(c, VSLAM_ERR_INVALID, "landmark_update: bad argument");
+  if (n == 0) return VSLAM_OK;
+  const int M = offsets[n];
+  if (M < 0 || (M && (!frame_of || !w2c || !c2w || !cam))) return fail(c, VSLAM_ERR_INVALID, "landmark_update: bad argument");
+  for (int i = 0; i < n; ++i) if (offsets[i] > offsets[i + 1] || offsets[i] < 0) return fail(c, VSLAM_ERR_INVALID, "landmark_update: offsets not ascending");
+  for (int m = 0; m < M; ++m) if (frame_of[m] < 0 || frame_of[m] >= n_frames) return fail(c, VSLAM_ERR_INVALID, "landmark_update: frame index out of range");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int32_t *doff = nullptr, *dfo = nullptr, *dup = nullptr; double *dw2c = nullptr, *dc2w = nullptr, *dcam = nullptr, *dworld = nullptr;
+  hipError_t e = hipMalloc((void**)&doff, (size_t)(n + 1) * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&dfo, std::max<size_t>(M, 1) * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&dup, (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&dw2c, std::max<size_t>(n_frames, 1) * 96);
+  if (e == hipSuccess) e = hipMalloc((void**)&dc2w, std::max<size_t>(n_frames, 1) * 96);
+  if (e == hipSuccess) e = hipMalloc((void**)&dcam, std::max<size_t>(M, 1) * 24);
+  if (e == hipSuccess) e = hipMalloc((void**)&dworld, (size_t)n * 24);
+  if (e == hipSuccess) e = hipMemcpyAsync(doff, offsets, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess && M) e = hipMemcpyAsync(dfo, frame_of, (size_t)M * 4, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dup, updates, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess && n_frames) e = hipMemcpyAsync(dw2c, w2c, (size_t)n_frames * 96, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess && n_frames) e = hipMemcpyAsync(dc2w, c2w, (size_t)n_frames * 96, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess && M) e = hipMemcpyAsync(dcam, cam, (size_t)M * 24, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dworld, world, (size_t)n * 24, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_landmark_update, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, doff, dfo, dw2c, dc2w, dcam, dworld, dup,
+                       c->cfg.c.landmark_maximum_number_of_iterations, c->cfg.c.landmark_maximum_error_squared_meters);
+    e = hipMemcpyAsync(world, dworld, (size_t)n * 24, hipMemcpyDeviceToHost, c->stream);
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(updates, dup, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(doff); (void)hipFree(dfo); (void)hipFree(dup); (void)hipFree(dw2c); (void)hipFree(dc2w); (void)hipFree(dcam); (void)hipFree(dworld);
   if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   return VSLAM_OK;
 }
