@@ -1537,6 +1537,47 @@ ORC_API int orc_track_match(const vslam_config* cfg, const double T[12], int32_t
   return VSLAM_OK;
 }
 
+/* StereoFramePointGenerator::recoverPoints (:683-869) on caller-provided data: the lost points' landmarks (world), their last
+ * descriptors, the frame's world_to_camera_left and both images.  Test infrastructure for the independent fixture
+ * (tests/golden/stereo_recover.npz); the HIP path is compared with this code frame by frame in the pipeline tests. */
+ORC_API int orc_stereo_recover(const vslam_config* cfg, const uint8_t* imgL, const uint8_t* imgR, int32_t stride, const double w2c[12], int32_t n,
+                               const uint8_t* has_lm, const double* lmw, const uint8_t* pdL, const uint8_t* pdR, double tau_track, double tau_tri,
+                               int32_t* n_rec, int32_t* rec_index, int32_t* rec_xy4, int32_t* rec_dist, uint8_t* rec_desc, double* rec_xyz) {
+  Stream s;
+  s.configure(*cfg);
+  integral_image(imgL, cfg->rows, cfg->cols, stride, s.sumL);
+  integral_image(imgR, cfg->rows, cfg->cols, stride, s.sumR);
+  s.gen_tau_track = tau_track; s.tau_tri = tau_tri;
+  FrameRec prev, cur;
+  std::memcpy(cur.world_to_cam.m, w2c, sizeof(double) * 12);
+  cur.cam_to_world = tf_inverse(cur.world_to_cam);
+  prev.points.resize(n);
+  for (int i = 0; i < n; ++i) {
+    Point& p = prev.points[i];
+    std::memset(&p, 0, sizeof p);
+    std::memcpy(p.dL, pdL + 32 * i, 32); std::memcpy(p.dR, pdR + 32 * i, 32);
+    p.lm = -1; p.prev = -1;
+    if (has_lm[i]) {
+      Landmark L;
+      for (int k = 0; k < 3; ++k) L.w[k] = lmw[3 * i + k];
+      L.updates = 1;
+      s.landmarks.push_back(L);
+      p.lm = (int)s.landmarks.size() - 1;
+    }
+    s.lost.push_back(i);
+  }
+  *n_rec = s.recover(cur, prev);
+  for (size_t k = 0; k < cur.points.size(); ++k) {
+    const Point& q = cur.points[k];
+    rec_index[k] = q.prev;
+    rec_xy4[4 * k] = q.xL; rec_xy4[4 * k + 1] = q.yL; rec_xy4[4 * k + 2] = q.xR; rec_xy4[4 * k + 3] = q.yR;
+    rec_dist[k] = q.dist;
+    std::memcpy(rec_desc + 64 * k, q.dL, 32); std::memcpy(rec_desc + 64 * k + 32, q.dR, 32);
+    for (int j = 0; j < 3; ++j) rec_xyz[3 * k + j] = q.cam[j];
+  }
+  return VSLAM_OK;
+}
+
 /* Landmark::update (landmark.cpp:66-167) on caller-provided measurement lists (last measurement of a list = the new one) */
 ORC_API int orc_landmark_update(const vslam_config* cfg, int32_t n, const int32_t* offsets, const int32_t* frame_of, int32_t n_frames,
                                 const double* w2c, const double* c2w, const double* cam, double* world, int32_t* updates) {

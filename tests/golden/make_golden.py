@@ -1217,6 +1217,89 @@ def gen_landmark(rng):
     return sum(1 for a, b in zip(updates, ref_updates) if a != b), len(updates)
 
 
+# ---------------------------------------------------------------------------------------------
+# StereoFramePointGenerator::recoverPoints (stereo_framepoint_generator.cpp:683-869)
+def stereo_recover_ref(K, bh, rows, cols, imgL, imgR, pat, w2c, lost, kp_size, tau_track, tau_tri, min_depth, max_depth, min_disp):
+    """lost: (has_landmark, world xyz, descL, descR).  Returns [(index, xL, yL, xR, yR, dist, descL, descR, xyz)]."""
+    out = []
+    R, t = w2c[:, :3], w2c[:, 3]
+    f32 = np.float32
+    for i, (has_lm, X, pdL, pdR) in enumerate(lost):
+        if not has_lm:
+            continue
+        pc = np.array([((R[k, 0] * X[0] + R[k, 1] * X[1]) + R[k, 2] * X[2]) + t[k] for k in range(3)])
+        uL = np.array([(K[k, 0] * pc[0] + K[k, 1] * pc[1]) + K[k, 2] * pc[2] for k in range(3)])
+        uR = uL + bh
+        if uL[2] < min_depth or uL[2] > max_depth or uR[2] < min_depth or uR[2] > max_depth:
+            continue
+        pLx, pLy = f32(np.rint(uL[0] / uL[2])), f32(np.rint(uL[1] / uL[2]))
+        pRx, pRy = f32(np.rint(uR[0] / uR[2])), f32(np.rint(uR[1] / uR[2]))
+        rbc = f32(5) * f32(kp_size)
+        lo, hx, hy = rbc + f32(1), f32(cols) - rbc - f32(1), f32(rows) - rbc - f32(1)
+        if pLx < lo or pLx > hx or pRx < lo or pRx > hx or pLy < lo or pLy > hy or pRy < lo or pRy > hy:
+            continue
+        xL, yL, xR, yR = int(pLx), int(pLy), int(pRx), int(pRy)     # integer-valued: ROI corner and keypoint round trivially
+        dL = brief32(imgL, xL, yL, pat)
+        if hamming(pdL, dL) > tau_track:
+            continue
+        dR = brief32(imgR, xR, yR, pat)
+        if float(pLx - pRx) < min_disp:
+            continue
+        if hamming(pdR, dR) > tau_track:
+            continue
+        dist = hamming(dL, dR)
+        if dist > tau_tri:
+            continue
+        z = bh[0] / float(xR - xL)                                    # getPointInLeftCamera :871-895
+        xyz = np.array([1 / K[0, 0] * (xL - K[0, 2]) * z, 1 / K[1, 1] * ((yL + yR) / 2.0 - K[1, 2]) * z, z])
+        out.append((i, xL, yL, xR, yR, dist, dL, dR, xyz))
+    return out
+
+
+def gen_stereo_recover(rng):
+    pat = read_brief_pattern()
+    rows, cols = 150, 220
+    f_, cx, cy, base = 160.0, 109.5, 74.5, 0.5
+    K = np.array([[f_, 0, cx], [0, f_, cy], [0, 0, 1.0]])
+    bh = np.array([-f_ * base, 0.0, 0.0])
+    imgL = block_image(rng, rows, cols, 4)
+    imgR = np.roll(imgL, -6, axis=1)                                  # a fronto-parallel world at disparity 6 ...
+    imgR = np.clip(imgR.astype(np.int64) + rng.integers(-4, 5, imgR.shape), 0, 255).astype(np.uint8)   # ... plus sensor noise
+    ang = -0.015
+    w2c = np.hstack([np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]]), np.array([[-0.02], [0.01], [0.04]])])
+    c2w_R, c2w_t = w2c[:, :3].T, -w2c[:, :3].T @ w2c[:, 3]
+    lost = []
+    for i in range(160):
+        u = float(rng.uniform(30, cols - 30)); v = float(rng.uniform(30, rows - 30))
+        if i % 10 == 3:
+            u = float(rng.uniform(-5, cols + 5)); v = float(rng.uniform(-5, rows + 5))
+        z = f_ * base / 6.0 if i % 4 else float(rng.uniform(2.0, 60.0))   # most landmarks at the depth the right image shows
+        if i % 17 == 0:
+            z = 200.0                                                 # disparity below the minimum
+        pc = np.array([(u - cx) * z / f_, (v - cy) * z / f_, z])
+        X = c2w_R @ pc + c2w_t
+        bx, by = int(np.clip(round(u), 28, cols - 29)), int(np.clip(round(v), 28, rows - 29))
+        bxr = int(np.clip(round(u - f_ * base / z), 28, cols - 29))
+
+        def flip(d, k):
+            bits = np.unpackbits(d)
+            bits[rng.choice(256, size=k, replace=False)] ^= 1
+            return np.packbits(bits)
+        lost.append((int(rng.random() < 0.9), X, flip(brief32(imgL, bx, by, pat), int(rng.integers(0, 45))),
+                     flip(brief32(imgR, bxr, by, pat), int(rng.integers(0, 45)))))
+    tau_track, tau_tri = 35.0, 60.0
+    rec = stereo_recover_ref(K, bh, rows, cols, imgL, imgR, pat, w2c, lost, 7.0, tau_track, tau_tri, 0.1, 1000.0, 1.0)
+    out = {"K": K, "bh": bh, "imgL": imgL, "imgR": imgR, "w2c": w2c, "tau_track": np.float64(tau_track), "tau_tri": np.float64(tau_tri),
+           "has_lm": np.array([q[0] for q in lost], np.uint8), "lm": np.array([q[1] for q in lost]),
+           "pdL": np.array([q[2] for q in lost], np.uint8), "pdR": np.array([q[3] for q in lost], np.uint8),
+           "rec_index": np.array([r[0] for r in rec], np.int32), "rec_xy4": np.array([r[1:5] for r in rec], np.int32).reshape(-1, 4),
+           "rec_dist": np.array([r[5] for r in rec], np.int32),
+           "rec_desc": np.array([np.concatenate([r[6], r[7]]) for r in rec], np.uint8).reshape(-1, 64),
+           "rec_xyz": np.array([r[8] for r in rec], np.float64).reshape(-1, 3)}
+    np.savez_compressed(os.path.join(HERE, "stereo_recover.npz"), **out)
+    return len(rec)
+
+
 def main():
     rng = np.random.default_rng(20261003)
     gen_hamming(rng)
@@ -1232,6 +1315,7 @@ def main():
     gen_depth_recover(np.random.default_rng(20261008))
     gen_orb(np.random.default_rng(20261009))
     gen_landmark(np.random.default_rng(20261010))
+    gen_stereo_recover(np.random.default_rng(20261011))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

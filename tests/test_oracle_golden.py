@@ -164,3 +164,36 @@ def test_harness_regression_record(golden):
     np.testing.assert_array_equal(tau, g["tau_track"])
     np.testing.assert_allclose(poses, g["poses"], rtol=0, atol=1e-9)
     assert g["counters"][-1][0] == 1 and g["counters"][:, 6].max() > 30   # Tracking, real tracks
+
+
+def test_stereo_recover_known_answers(oracle, golden):
+    """StereoFramePointGenerator::recoverPoints against the pure-Python restatement (projection / depth / border / three descriptor
+    gates, minimum disparity, triangulation): indices, keypoints, descriptors exact; coordinates bit for bit."""
+    g = golden["stereo_recover"]
+    cfg = oracle.default_config("kitti")
+    rows, cols = g["imgL"].shape
+    cfg.rows, cfg.cols = rows, cols
+    for i in range(9):
+        cfg.K[i] = float(g["K"].ravel()[i])
+    for i in range(3):
+        cfg.baseline_h[i] = float(g["bh"][i])
+    n = len(g["has_lm"])
+    imgL = np.ascontiguousarray(g["imgL"]); imgR = np.ascontiguousarray(g["imgR"])
+    w2c = np.ascontiguousarray(g["w2c"], np.float64); hl = np.ascontiguousarray(g["has_lm"]); lm = np.ascontiguousarray(g["lm"], np.float64)
+    pdL = np.ascontiguousarray(g["pdL"]); pdR = np.ascontiguousarray(g["pdR"])
+    idx = np.zeros(n, np.int32); xy4 = np.zeros((n, 4), np.int32); dist = np.zeros(n, np.int32)
+    desc = np.zeros((n, 64), np.uint8); xyz = np.zeros((n, 3), np.float64)
+    nrec = C.c_int32()
+    p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    rc = oracle.lib.orc_stereo_recover(C.byref(cfg), p(imgL, C.c_uint8), p(imgR, C.c_uint8), C.c_int32(cols), p(w2c, C.c_double), C.c_int32(n),
+                                       p(hl, C.c_uint8), p(lm, C.c_double), p(pdL, C.c_uint8), p(pdR, C.c_uint8),
+                                       C.c_double(float(g["tau_track"])), C.c_double(float(g["tau_tri"])), C.byref(nrec), p(idx, C.c_int32),
+                                       p(xy4, C.c_int32), p(dist, C.c_int32), p(desc, C.c_uint8), p(xyz, C.c_double))
+    assert rc == 0
+    k = nrec.value
+    assert k == len(g["rec_index"]) and k > 20
+    np.testing.assert_array_equal(idx[:k], g["rec_index"])
+    np.testing.assert_array_equal(xy4[:k], g["rec_xy4"])
+    np.testing.assert_array_equal(dist[:k], g["rec_dist"])
+    np.testing.assert_array_equal(desc[:k], g["rec_desc"])
+    np.testing.assert_array_equal(xyz[:k], g["rec_xyz"])
