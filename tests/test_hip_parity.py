@@ -479,6 +479,21 @@ def test_rgbd_components_at_sensor_size_against_oracle(gpu, oracle):
         a = gpu.depth_track(p, None, np.eye(4)[:3], d, 35.0, by_app, cam, pdesc, flags, feats, fdesc)
         b = oracle.depth_track(p, so, np.eye(4)[:3], d, 35.0, by_app, cam, pdesc, flags, feats, fdesc)
         assert all(np.array_equal(x, y) for x, y in zip(a[:4], b[:4])) and a[4] == b[4] and len(a[0]) > 300
+    # rivals: many previous points want the same few features (candidate lists exhausted -> window rescans), and a block of
+    # 81 identical features (more candidates than a list holds -> incomplete lists), both search modes
+    D = rng.integers(0, 256, 32, dtype=np.uint8)
+    blk = np.array([(r, c) for r in range(200, 209) for c in range(300, 309)], np.int32)
+    few = np.array([(100, 100 + 2 * k) for k in range(10)], np.int32)
+    cfeat = np.vstack([few, blk]); cdesc = np.tile(D, (len(cfeat), 1))
+    zc = 2.0
+    def at(r, c): return [(c - Kl[0, 2]) * zc / Kl[0, 0], (r - Kl[1, 2]) * zc / Kl[1, 1], zc]
+    ccam = np.array([at(100.4, 109.3)] * 14 + [at(204.2, 304.6)] * 40)
+    cpd = np.tile(D, (len(ccam), 1)); cfl = np.ones(len(ccam), np.uint8)
+    for by_app, d in ((1, 10), (0, 10)):
+        a = gpu.depth_track(p, None, np.eye(4)[:3], d, 35.0, by_app, ccam, cpd, cfl, cfeat, cdesc)
+        b = oracle.depth_track(p, so, np.eye(4)[:3], d, 35.0, by_app, ccam, cpd, cfl, cfeat, cdesc)
+        assert all(np.array_equal(x, y) for x, y in zip(a[:4], b[:4])) and a[4] == b[4]
+        assert len(a[0]) + len(a[2]) + len(a[3]) >= 50          # every rival ends somewhere: tracked, temporary or lost
     img = rng.integers(0, 256, (rows, cols), dtype=np.uint8)
     lm = np.stack([rng.uniform(-2, 2, 300), rng.uniform(-1.5, 1.5, 300), rng.uniform(1.0, 6.0, 300)], axis=1)
     ld = rng.integers(0, 256, (300, 32), dtype=np.uint8)

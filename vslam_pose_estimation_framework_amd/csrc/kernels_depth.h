@@ -221,6 +221,7 @@ __global__ __launch_bounds__(256) void k_point_in_camera(int n, const float* xp,
 // point is the serial outcome; a handful of sweeps in practice).  One workgroup per image, one thread per previous point
 // and sweep; features row-major with a (row, 16-px cell) CSR, so a window scan reads only the cells it overlaps.
 // A match on a pixel below the minimum depth is dropped WITHOUT taking the feature (:238-240).
+#define VS_DT_K 6
 struct DepthTrack {
   vslam_depth_params p;
   double T[12];
@@ -234,10 +235,12 @@ struct DepthTrack {
   const float* space;
   int32_t* hold;             // [2][nL]
   int32_t* pick;             // [nP]  feature, -1 none, -2 projection outside
+  unsigned long long* cand;  // [nP][VS_DT_K + 1] the K best keys of the point's window (ascending) + the candidate count
   int32_t* counts;           // tracked, temporary, lost, tracked landmarks
   int32_t* out2; double* xyz; int32_t* temp2; int32_t* lost;
 };
 
+// full window scan of one point under the current holds (used when its candidate list is exhausted or incomplete)
 __device__ __forceinline__ int depth_track_best(const DepthTrack& a, int i, int row, int col, const uint32_t* pd, const int32_t* hold) {
   const int rows = a.p.rows, cols = a.p.cols;
   const int r0 = max(row - a.d, 0), r1 = min(row + a.d + 1, rows);                  // :214-217
@@ -266,6 +269,80 @@ __device__ __forceinline__ int depth_track_best(const DepthTrack& a, int i, int 
   return best == ~0ull ? -1 : (int)(best & 0xffffffffu);
 }
 
+// projection of previous point i (:197-208): false = outside / behind (neither tracked nor lost)
+__device__ __forceinline__ bool depth_track_project(const DepthTrack& a, int i, int* row, int* col) {
+  double q[3], uvw[3];
+  const double* cm = a.cam + 3 * (size_t)i;
+  for (int k = 0; k < 3; ++k) q[k] = ((a.T[4 * k] * cm[0] + a.T[4 * k + 1] * cm[1]) + a.T[4 * k + 2] * cm[2]) + a.T[4 * k + 3];   // :197
+  for (int k = 0; k < 3; ++k) uvw[k] = (a.p.K_left[3 * k] * q[0] + a.p.K_left[3 * k + 1] * q[1]) + a.p.K_left[3 * k + 2] * q[2];     // :200
+  if (!(uvw[2] > 0)) return false;
+  const double uc = uvw[0] / uvw[2], ur = uvw[1] / uvw[2];
+  if (!(uc > -2147483648.0 && uc < 2147483648.0 && ur > -2147483648.0 && ur < 2147483648.0)) return false;
+  *col = (int)uc; *row = (int)ur;                                                   // :201-202 (truncation)
+  return !(*col < 0 || *col > a.p.cols || *row < 0 || *row > a.p.rows);             // :205-208
+}
+
+// Wide first pass (nothing is held yet): one 16-lane group per previous point, the lanes split the window rows, every
+// candidate key goes to the group's LDS buffer, a rank sort orders them and the VS_DT_K best + the count are kept for the
+// sweeps of k_depth_track.  More than VS_DT_CAP candidates: the list is declared incomplete (count = huge, no keys), the
+// resolution kernel then rescans that window itself.
+#define VS_DT_CAP 32
+__global__ __launch_bounds__(256) void k_depth_track_candidates(const DepthTrack a) {
+  __shared__ unsigned long long keys[16][VS_DT_CAP];
+  __shared__ int cnt[16];
+  const int lane = threadIdx.x & 15, g = threadIdx.x >> 4;
+  for (int i = blockIdx.x * 16 + g; i < a.nP; i += gridDim.x * 16) {
+    unsigned long long* list = a.cand + (size_t)i * (VS_DT_K + 1);
+    int row = 0, col = 0;
+    const bool ok = depth_track_project(a, i, &row, &col);
+    if (lane == 0) cnt[g] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (ok) {
+      const int rows = a.p.rows, cols = a.p.cols;
+      const int r0 = max(row - a.d, 0), r1 = min(row + a.d + 1, rows);
+      const int c0 = max(col - a.d, 0), c1 = min(col + a.d + 1, cols);
+      if (c1 > c0) {
+        uint32_t pd[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pd[u] = reinterpret_cast<const uint32_t*>(a.pdesc + (size_t)32 * i)[u];
+        const int cl = c0 >> 4, ch = ((c1 - 1) >> 4) + 1;
+        for (int r = r0 + lane; r < r1; r += 16) {
+          const int lo = a.rowcell[(size_t)r * (a.CW + 1) + cl], hi = a.rowcell[(size_t)r * (a.CW + 1) + ch];
+          for (int k = lo; k < hi; ++k) {
+            const int x = a.kxy[2 * k];
+            if (x < c0 || x >= c1) continue;
+            const uint32_t* kd = reinterpret_cast<const uint32_t*>(a.desc + (size_t)32 * k);
+            int h = 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) h += __popc(pd[u] ^ kd[u]);
+            if (!((double)h < a.tau)) continue;
+            unsigned prim;
+            if (a.by_app) prim = (unsigned)h;
+            else { const int dr = row - r, dc = col - x; prim = (unsigned)(dr * dr + dc * dc); if (prim >= 10000u) continue; }
+            const int slot = atomicAdd(&cnt[g], 1);
+            if (slot < VS_DT_CAP) keys[g][slot] = ((unsigned long long)prim << 32) | (unsigned)k;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int n = __hip_atomic_load(&cnt[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (n <= VS_DT_CAP) {
+      for (int j = lane; j < n; j += 16) {
+        const unsigned long long mine = __hip_atomic_load(&keys[g][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        int rank = 0;
+        for (int u = 0; u < n; ++u) rank += __hip_atomic_load(&keys[g][u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < mine ? 1 : 0;
+        if (rank < VS_DT_K) list[rank] = mine;
+      }
+      if (lane == 0) list[VS_DT_K] = (unsigned long long)n;
+    } else if (lane == 0) {
+      list[VS_DT_K] = 0x7fffffffull;          // incomplete: k_depth_track rescans
+    }
+    if (lane == 0) a.pick[i] = ok ? -1 : -2;  // -2: projection outside
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 __global__ __launch_bounds__(1024) void k_depth_track(const DepthTrack a) {
   __shared__ int sh[17];
   __shared__ int changed;
@@ -279,21 +356,23 @@ __global__ __launch_bounds__(1024) void k_depth_track(const DepthTrack a) {
     if (tid == 0) changed = 0;
     __syncthreads();
     for (int i = tid; i < a.nP; i += 1024) {
-      double q[3], uvw[3];
-      const double* cm = a.cam + 3 * (size_t)i;
-      for (int k = 0; k < 3; ++k) q[k] = ((a.T[4 * k] * cm[0] + a.T[4 * k + 1] * cm[1]) + a.T[4 * k + 2] * cm[2]) + a.T[4 * k + 3];   // :197
-      for (int k = 0; k < 3; ++k) uvw[k] = (a.p.K_left[3 * k] * q[0] + a.p.K_left[3 * k + 1] * q[1]) + a.p.K_left[3 * k + 2] * q[2];     // :200
-      int f = -2;
-      if (uvw[2] > 0) {
-        const double uc = uvw[0] / uvw[2], ur = uvw[1] / uvw[2];
-        if (uc > -2147483648.0 && uc < 2147483648.0 && ur > -2147483648.0 && ur < 2147483648.0) {
-          const int col = (int)uc, row = (int)ur;                                   // :201-202 (truncation)
-          if (!(col < 0 || col > a.p.cols || row < 0 || row > a.p.rows)) {          // :205-208
-            uint32_t pd[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) pd[u] = reinterpret_cast<const uint32_t*>(a.pdesc + (size_t)32 * i)[u];
-            f = depth_track_best(a, i, row, col, pd, hold);
+      int f = a.pick[i] == -2 ? -2 : -1;
+      if (f != -2) {
+        const unsigned long long* list = a.cand + (size_t)i * (VS_DT_K + 1);
+        const int cnt = (int)list[VS_DT_K];
+        bool found = false;
+        if (cnt != 0x7fffffff)
+          for (int u = 0; u < VS_DT_K && u < cnt; ++u) {
+            const int k = (int)(list[u] & 0xffffffffu);
+            if (hold[k] >= i) { f = k; found = true; break; }      // the best candidate no earlier point holds
           }
+        if (!found && cnt > VS_DT_K) {                               // list exhausted or incomplete: scan the window
+          int row = 0, col = 0;
+          depth_track_project(a, i, &row, &col);
+          uint32_t pd[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) pd[u] = reinterpret_cast<const uint32_t*>(a.pdesc + (size_t)32 * i)[u];
+          f = depth_track_best(a, i, row, col, pd, hold);
         }
       }
       if (f >= 0) {

@@ -750,8 +750,10 @@ VS_API int vslam_depth_track(vslam_ctx* c, const vslam_depth_params* p, const fl
   a.p = *p; std::memcpy(a.T, T, sizeof a.T); a.d = d; a.by_app = by_appearance ? 1 : 0; a.tau = tau; a.nP = nP; a.nL = nL; a.CW = CW;
   float* dspace = nullptr; double *dcam = nullptr, *dxyz = nullptr; uint8_t *dpd = nullptr, *dpf = nullptr, *dds = nullptr; int16_t* dxy = nullptr;
   int32_t *drc = nullptr, *dhold = nullptr, *dpick = nullptr, *dcnt = nullptr, *dout2 = nullptr, *dtmp2 = nullptr, *dlost = nullptr;
+  unsigned long long* dcand = nullptr;
   hipError_t e = hipSuccess;
   if (space) { e = hipMalloc((void**)&dspace, n * 3 * sizeof(float)); if (e == hipSuccess) e = hipMemcpyAsync(dspace, space, n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream); }
+  if (e == hipSuccess) e = hipMalloc((void**)&dcand, P1 * (VS_DT_K + 1) * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMalloc((void**)&dcam, P1 * 3 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&dxyz, P1 * 3 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&dpd, P1 * 32);
@@ -774,7 +776,8 @@ VS_API int vslam_depth_track(vslam_ctx* c, const vslam_depth_params* p, const fl
   int32_t cnt[4] = {0, 0, 0, 0};
   if (e == hipSuccess) {
     a.cam = dcam; a.pdesc = dpd; a.pflags = dpf; a.kxy = dxy; a.desc = dds; a.rowcell = drc; a.space = space ? dspace : c->dm.space;
-    a.hold = dhold; a.pick = dpick; a.counts = dcnt; a.out2 = dout2; a.xyz = dxyz; a.temp2 = dtmp2; a.lost = dlost;
+    a.hold = dhold; a.pick = dpick; a.cand = dcand; a.counts = dcnt; a.out2 = dout2; a.xyz = dxyz; a.temp2 = dtmp2; a.lost = dlost;
+    if (nP) hipLaunchKernelGGL(k_depth_track_candidates, dim3(std::min(1024, (nP + 15) / 16)), dim3(256), 0, c->stream, a);
     hipLaunchKernelGGL(k_depth_track, dim3(1), dim3(1024), 0, c->stream, a);
     e = hipGetLastError();
   }
@@ -789,7 +792,7 @@ VS_API int vslam_depth_track(vslam_ctx* c, const vslam_depth_params* p, const fl
     for (int u = 0; u < cnt[1]; ++u) temp2[2 * u + 1] = ord[temp2[2 * u + 1]];
   }
   (void)hipFree(dspace); (void)hipFree(dcam); (void)hipFree(dxyz); (void)hipFree(dpd); (void)hipFree(dpf); (void)hipFree(dds); (void)hipFree(dxy);
-  (void)hipFree(drc); (void)hipFree(dhold); (void)hipFree(dpick); (void)hipFree(dcnt); (void)hipFree(dout2); (void)hipFree(dtmp2); (void)hipFree(dlost);
+  (void)hipFree(dcand); (void)hipFree(drc); (void)hipFree(dhold); (void)hipFree(dpick); (void)hipFree(dcnt); (void)hipFree(dout2); (void)hipFree(dtmp2); (void)hipFree(dlost);
   if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   return VSLAM_OK;
 }
