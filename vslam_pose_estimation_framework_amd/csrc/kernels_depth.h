@@ -218,8 +218,9 @@ __global__ __launch_bounds__(256) void k_point_in_camera(int n, const float* xp,
 // have picked it takes its next-best one (:243-244).  Order-exact in parallel, as in the stereo tracker: iterate
 //   pick(i) = best feature of point i's window among those no EARLIER point holds;  hold(f) = min { i : pick(i) = f }
 // from "nobody holds anything" until nothing changes (point 0 is final after one sweep, point 1 after two, ...: the fixed
-// point is the serial outcome; a handful of sweeps in practice).  One workgroup per image, one thread per previous point
-// and sweep; features row-major with a (row, 16-px cell) CSR, so a window scan reads only the cells it overlaps.
+// point is the serial outcome; a handful of sweeps in practice).  Two kernels: k_depth_track_candidates (wide) sorts every
+// point's window candidates once — features are row-major with a (row, 16-px cell) CSR, so a window scan reads only the cells
+// it overlaps —, k_depth_track (one workgroup per image, one thread per previous point and sweep) walks those lists.
 // A match on a pixel below the minimum depth is dropped WITHOUT taking the feature (:238-240).
 #define VS_DT_K 6
 struct DepthTrack {
