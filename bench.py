@@ -134,6 +134,7 @@ def main():
     api.synchronize()
     api.reset()
     pose_send = torch.zeros((B, K, 12), dtype=torch.float64, device=dev)
+    sharding.gather_poses(pose_send)              # untimed: RCCL sets its all-gather channels up on first use
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
