@@ -8,7 +8,8 @@ image), cut into B contiguous chunks that start `overlap` frames early (SURVEY.m
 rank owns B further chunks (weak scaling: per-GPU work fixed), no data-path collective; the only exchange
 is one all-gather of the per-frame 3x4 poses at the end of the timed region.
 
-Prints ONE JSON line on rank 0.  `value` counts unique frames only: B*N*K/t * L/(L+overlap).
+Prints ONE JSON line on rank 0.  `value` counts unique frames only: B*N*K/t * L/(L+overlap).  Exactly K steps are
+timed for any K: the job is L+overlap steps long (the default K) and starts over (reset, rewind) when K exceeds it.
 """
 import argparse
 import ctypes as C
@@ -94,7 +95,7 @@ def main():
     L = -(-SEQ_FRAMES // B)                      # unique frames per chunk
     job_steps = L + overlap
     K = args.steps if args.steps > 0 else job_steps
-    K = min(K, job_steps)
+    KB = min(K, job_steps)                       # frames held per chunk; K > job_steps: the job is run again (reset + rewind)
     W = max(0, args.warmup)
 
     api = hip.load()
@@ -108,14 +109,14 @@ def main():
     img_bytes = cfg.rows * stride
 
     # ---- inputs resident in HBM: [step][stream][rows][stride] --------------------------------------------
-    Lbuf = torch.empty((K, B, cfg.rows, stride), dtype=torch.uint8, device=dev)
-    Rbuf = torch.empty((K, B, cfg.rows, stride), dtype=torch.uint8, device=dev)
+    Lbuf = torch.empty((KB, B, cfg.rows, stride), dtype=torch.uint8, device=dev)
+    Rbuf = torch.empty((KB, B, cfg.rows, stride), dtype=torch.uint8, device=dev)
     starts = []
     for s in range(B):
         gc = rank * B + s                        # global chunk index; rank r continues the virtual sequence
         start = max(0, gc * L - overlap)
         starts.append(start)
-        sy.render_device(scene, start, K, Lbuf[0, s].data_ptr(), Rbuf[0, s].data_ptr(), stride, B * img_bytes,
+        sy.render_device(scene, start, KB, Lbuf[0, s].data_ptr(), Rbuf[0, s].data_ptr(), stride, B * img_bytes,
                          torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
 
@@ -123,7 +124,10 @@ def main():
 
     def run_steps(n):
         for k in range(n):
-            api.process_device(Lbuf[k].data_ptr(), Rbuf[k].data_ptr(), stride, img_bytes)
+            j = k % KB
+            if j == 0 and k > 0:
+                api.reset()                          # the whole job again: every chunk re-localises from its first frame
+            api.process_device(Lbuf[j].data_ptr(), Rbuf[j].data_ptr(), stride, img_bytes)
 
     def barrier():
         if world > 1:
@@ -133,13 +137,13 @@ def main():
     run_steps(min(W, K))
     api.synchronize()
     api.reset()
-    pose_send = torch.zeros((B, K, 12), dtype=torch.float64, device=dev)
+    pose_send = torch.zeros((B, KB, 12), dtype=torch.float64, device=dev)
     sharding.gather_poses(pose_send)              # untimed: RCCL sets its all-gather channels up on first use
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run_steps(K)
-    api.copy_poses_device(0, K, pose_send.data_ptr())
+    api.copy_poses_device(0, min(KB, ((K - 1) % KB) + 1), pose_send.data_ptr())
     api.synchronize()
     all_poses = sharding.gather_poses(pose_send)          # RCCL all-gather (no-op for one GPU)
     torch.cuda.synchronize()
@@ -220,8 +224,8 @@ def main():
     # ---- CPU baseline: the oracle (a port of the reference path) on a bounded sample, rank 0, N=1 only ---------
     if rank == 0 and world == 1 and not args.no_cpu:
         orc = load_oracle()
-        n_chunks = max(1, min(B, args.cpu_frames // K)) if K <= args.cpu_frames else 1
-        per_chunk = min(K, args.cpu_frames)
+        n_chunks = max(1, min(B, args.cpu_frames // KB)) if KB <= args.cpu_frames else 1
+        per_chunk = min(KB, args.cpu_frames)
         orc.create(cfg, 0, 1)
         chk = hip.load()
         chk.create(cfg, dev_index, 1)
