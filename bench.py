@@ -28,7 +28,7 @@ from vslam_pose_estimation_framework_amd import hip, sharding, synth  # noqa: E4
 
 SEQ_FRAMES = 4541          # KITTI odometry sequence 00
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PMC_SUMMARY = "r01_g_pmc_traffic.json"   # tools/pmc_traffic.sh of this build (rocprofv3 --pmc, separate passes)
+PMC_SUMMARY = "r01_h_pmc_traffic.json"   # tools/pmc_traffic.sh of this build (rocprofv3 --pmc, separate passes)
 
 
 def load_oracle():
