@@ -312,7 +312,14 @@ __global__ __launch_bounds__(256) void k_recover_brief(const DevCfg c, const Dev
 // landmark of framepoint i of the current frame: creation = mean of the track's world coordinates
 // (Landmark::Landmark, landmark.cpp:19-31), otherwise Gauss-Newton refinement over all measurements of the track
 // (Landmark::update, :66-167).  Returns true when the point carries an active landmark afterwards.
-__device__ __forceinline__ bool landmark_point(const DevCfg& c, const DevBuf& b, int s, const PtView& cv, int f, int i) {
+// LDS variant (fused frame kernel): the poses of the last VS_LM_CN frames are staged once per workgroup and the first
+// VS_LM_CN measurements of the point's track once per point (the chain walk is a chase of dependent HBM loads, and the
+// Gauss-Newton rounds would repeat it); longer tracks continue in HBM from where the cache ends.  Same order of accumulation,
+// same bits.
+#define VS_LM_CN 6
+struct LmCache { double pose[VS_LM_CN][24]; double cam[VS_WG][VS_LM_CN][3]; };
+template <bool LDS>
+__device__ __forceinline__ bool landmark_point_t(const DevCfg& c, const DevBuf& b, int s, const PtView& cv, int f, int i, LmCache* lc) {
   const double* w2c_cur = hpose_of(c, b, s, f) + 12;
   {
     int32_t* m = cv.meta + (size_t)i * META;
@@ -341,32 +348,54 @@ __device__ __forceinline__ bool landmark_point(const DevCfg& c, const DevBuf& b,
       for (int q = 0; q < 3; ++q) wpos[q] = wv[q];
       double err_prev = 0;
       const double kern = c.c.landmark_maximum_error_squared_meters;
+      // one measurement of the track: residual, saturated kernel, H += R^T om R, b += R^T om e
+      auto accumulate = [&](const double* W, const double* mc, double* H, double* bv, double& err, int& n_out) {
+        double sp[3];
+        tf_apply(W, wv, sp);
+        if (sp[2] <= 0) {
+          ++n_out;
+        } else {
+          const double e[3] = {sp[0] - mc[0], sp[1] - mc[1], sp[2] - mc[2]};
+          double om = 1 / mc[2];
+          const double e2 = om * ((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]);
+          err += e2;
+          if (e2 > kern) { om *= kern / e2; ++n_out; }
+          for (int r = 0; r < 3; ++r) {
+            for (int cc = 0; cc < 3; ++cc) H[3 * r + cc] += om * ((W[r] * W[cc] + W[4 + r] * W[4 + cc]) + W[8 + r] * W[8 + cc]);
+            bv[r] += om * ((W[r] * e[0] + W[4 + r] * e[1]) + W[8 + r] * e[2]);
+          }
+        }
+      };
+      // chain walk, once: the first VS_LM_CN measurements into the thread's LDS slots
+      int ncache = 0, ffc = f, iic = i;
+      bool ended = false;
+      if constexpr (LDS) {
+        double (*slot)[3] = lc->cam[threadIdx.x];
+        for (int k = 0; k < len && k < VS_LM_CN; ++k) {
+          const double* mc = hcam_of(c, b, s, ffc) + 3 * (size_t)iic;
+          slot[k][0] = mc[0]; slot[k][1] = mc[1]; slot[k][2] = mc[2];
+          ++ncache;
+          iic = hprev_of(c, b, s, ffc)[iic];
+          --ffc;
+          if (iic < 0) { ended = true; break; }
+        }
+      }
       for (int it = 0; it < c.c.landmark_maximum_number_of_iterations; ++it) {
         double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bv[3] = {0, 0, 0};
         double err = 0;
         int n_out = 0;
-        int ff = f, ii = i;
-        for (int k = 0; k < len; ++k) {
-          const double* W = hpose_of(c, b, s, ff) + 12;
-          const double* mc = hcam_of(c, b, s, ff) + 3 * (size_t)ii;
-          double sp[3];
-          tf_apply(W, wv, sp);
-          if (sp[2] <= 0) {
-            ++n_out;
-          } else {
-            const double e[3] = {sp[0] - mc[0], sp[1] - mc[1], sp[2] - mc[2]};
-            double om = 1 / mc[2];
-            const double e2 = om * ((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]);
-            err += e2;
-            if (e2 > kern) { om *= kern / e2; ++n_out; }
-            for (int r = 0; r < 3; ++r) {
-              for (int cc = 0; cc < 3; ++cc) H[3 * r + cc] += om * ((W[r] * W[cc] + W[4 + r] * W[4 + cc]) + W[8 + r] * W[8 + cc]);
-              bv[r] += om * ((W[r] * e[0] + W[4 + r] * e[1]) + W[8 + r] * e[2]);
-            }
+        if constexpr (LDS) {
+          const double (*slot)[3] = lc->cam[threadIdx.x];
+          for (int k = 0; k < ncache; ++k) accumulate(lc->pose[k] + 12, slot[k], H, bv, err, n_out);   // frame f - k
+        }
+        if (!ended) {
+          int ff = ffc, ii = iic;
+          for (int k = ncache; k < len; ++k) {
+            accumulate(hpose_of(c, b, s, ff) + 12, hcam_of(c, b, s, ff) + 3 * (size_t)ii, H, bv, err, n_out);
+            ii = hprev_of(c, b, s, ff)[ii];
+            --ff;
+            if (ii < 0) break;
           }
-          ii = hprev_of(c, b, s, ff)[ii];
-          --ff;
-          if (ii < 0) break;
         }
         double nb[3] = {-bv[0], -bv[1], -bv[2]}, dx[3];
         full_piv_solve<3>(H, nb, dx);
@@ -398,6 +427,10 @@ __device__ __forceinline__ bool landmark_point(const DevCfg& c, const DevBuf& b,
     tf_apply(w2c_cur, wpos, cv.camlm + 3 * (size_t)i);
   }
   return true;
+}
+
+__device__ __forceinline__ bool landmark_point(const DevCfg& c, const DevBuf& b, int s, const PtView& cv, int f, int i) {
+  return landmark_point_t<false>(c, b, s, cv, f, i, nullptr);
 }
 
 __device__ __forceinline__ void wg_publish_history(const DevCfg& c, const DevBuf& b, int s, int n, int pb_cur, int f) {
@@ -1031,7 +1064,11 @@ __global__ VS_FRAME_BOUNDS void k_frame(ConstDevCfg* cp, ConstDevBuf* bp, int ph
     const unsigned long long tu = wall_clock64();
     const PtView cvu = pts_of(c, b, s, pb_cur);
     int active = 0;
-    for (int i = tid; i < sh.n_cur; i += VS_WG) active += landmark_point(c, b, s, cvu, f, i) ? 1 : 0;
+    static_assert(sizeof(LmCache) <= VS_ARENA, "landmark measurement cache must fit the LDS arena");
+    LmCache* lc = reinterpret_cast<LmCache*>(arena);
+    for (int t = tid; t < VS_LM_CN * 24; t += VS_WG) { const int k = t / 24; if (f - k >= 0) lc->pose[k][t - 24 * k] = hpose_of(c, b, s, f - k)[t - 24 * k]; }
+    __syncthreads();
+    for (int i = tid; i < sh.n_cur; i += VS_WG) active += landmark_point_t<true>(c, b, s, cvu, f, i, lc) ? 1 : 0;
     int total;
     block_exclusive_scan(active, sh.scan, &total);
     if (tid == 0) { fc.n_active = total; st.ticks[3] += wall_clock64() - tu; }
