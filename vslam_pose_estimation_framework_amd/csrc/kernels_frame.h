@@ -716,10 +716,16 @@ __device__ __forceinline__ void align_rows(const DevCfg& c, const double* T, con
 #pragma unroll
       for (int j = 0; j < 6; ++j) KJ[2][j] = Jt[2][j];
     } else {
+      // general K: the products with the structural zeros of Jt are exact zeros and are left out (x + 0 == x), which also
+      // keeps a dozen loop-invariant K * 0 values from being hoisted in front of the round loop and held in registers
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) KJ[i][j] = (K[3 * i] * Jt[0][j] + K[3 * i + 1] * Jt[1][j]) + K[3 * i + 2] * Jt[2][j];
+      for (int i = 0; i < 3; ++i) {
+        const double k0 = K[3 * i], k1 = K[3 * i + 1], k2 = K[3 * i + 2];
+        KJ[i][0] = k0 * Jt[0][0]; KJ[i][1] = k1 * Jt[1][1]; KJ[i][2] = k2 * Jt[2][2];
+        KJ[i][3] = k1 * Jt[1][3] + k2 * Jt[2][3];
+        KJ[i][4] = k0 * Jt[0][4] + k2 * Jt[2][4];
+        KJ[i][5] = k0 * Jt[0][5] + k1 * Jt[1][5];
+      }
     }
     if constexpr (UVD) {
       const double iz = 1 / (use ? p[2] : 1.0), iz2 = iz * iz;
@@ -860,7 +866,11 @@ __device__ __forceinline__ void wg_one_round(const DevCfg& c, const DevBuf& b, i
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     double dx[6];
     VS_PHASE_STAMP(9, tp0);
-    if (!ldlt_solve6(sh.H, sh.bvec, dx)) wave_solve6(a, lane, dx, &sh.key);
+    if (!ldlt_solve6(sh.H, sh.bvec, dx)) {
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));   // opaque: the fallback's lane-index arithmetic stays here instead of being hoisted out of the round loop
+      wave_solve6(a, lane_o, dx, &sh.key);
+    }
     VS_PHASE_STAMP(10, tp0);
     if (lane == 0) {
       double D[12], Tn[12];
@@ -989,8 +999,13 @@ __device__ __forceinline__ void wg_align(const DevCfg& c, const DevBuf& b, int s
 }
 
 // stand-alone aligner on caller-provided correspondences (vslam_align_points, vslam_align_points_uvd)
+#ifdef VS_ALIGN_WAVES
+#define VS_ALIGN_BOUNDS __launch_bounds__(VS_WG, VS_ALIGN_WAVES)
+#else
+#define VS_ALIGN_BOUNDS __launch_bounds__(VS_WG)
+#endif
 template <bool UVD>
-__global__ __launch_bounds__(VS_WG) void k_align_points(const DevCfg c, const DevBuf b, int n, const double* T_init) {
+__global__ VS_ALIGN_BOUNDS void k_align_points(const DevCfg c, const DevBuf b, int n, const double* T_init) {
   __shared__ FrameShared sh;
   double T0[12];
   for (int k = 0; k < 12; ++k) T0[k] = T_init[k];
