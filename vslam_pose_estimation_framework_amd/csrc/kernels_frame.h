@@ -241,7 +241,7 @@ __device__ __forceinline__ void candidates_wave(const DevCfg& c, const DevBuf& b
   __builtin_amdgcn_wave_barrier();
 }
 
-__global__ __launch_bounds__(256) void k_track_candidates(const DevCfg c, const DevBuf b, int mode) {
+__global__ __launch_bounds__(256, 8) void k_track_candidates(const DevCfg c, const DevBuf b, int mode) {
   // mode < 0: fused path (appearance iff the tracker is Localizing, window forced to max in that case);
   // mode 0/1: stage path, window and distance exactly as set through vslam_set_tracker_state
   __shared__ CandWave cw[256 / VS_CGL];
