@@ -361,7 +361,7 @@ __global__ __launch_bounds__(512, 4) void k_emit(const DevCfg c, const DevBuf b,
   __syncthreads();
   const int nwords = rows * TX;
   // one 512-thread workgroup per image (blockIdx.y = side).
-  // Word order = keypoint order.  A pass covers 4096 consecutive mask words: wave w owns words [512 w, 512 w + 512)
+  // Word order = keypoint order.  A pass covers 512 * VS_EMIT_WPT consecutive mask words: wave w owns 64 * VS_EMIT_WPT of them, [256 w, 256 w + 256)
   // of the pass, lane l its words l, l + 64, ... — every load and store of a wave covers consecutive words (coalesced),
   // and the prefix over the words is 8 wave scans + one 8-entry scan across waves.
   const int side = blockIdx.y, lane = tid & 63, w = tid >> 6;
