@@ -965,7 +965,12 @@ struct Stream {
     gen_tau_track = tau_track; /* setMaximumDescriptorDistanceTracking (:238) */
     track(cur, prev, prior, by_appearance);
     n_tracked_points = (uint32_t)cur.points.size();
-    const real tracking_ratio = (real)n_tracked_points / (real)prev.points.size();
+    adapt_search(prev.points.size());
+    ++info.track_attempts;
+  }
+  /* the adaptive part of _track (:240-288): search window and descriptor distance from the tracking statistics */
+  void adapt_search(size_t n_previous_points) {
+    const real tracking_ratio = (real)n_tracked_points / (real)n_previous_points;
     const real landmark_per_point = (real)n_tracked_landmarks / (real)n_tracked_points;
     const real success_ratio = (real)n_tracked_points / (real)target_kp;
     const int wmax = cfg.maximum_projection_tracking_distance_pixels, wmin = cfg.minimum_projection_tracking_distance_pixels;
@@ -983,7 +988,6 @@ struct Stream {
       tau_track -= 5;
       if (tau_track < cfg.minimum_descriptor_distance_tracking) tau_track = cfg.minimum_descriptor_distance_tracking;
     }
-    ++info.track_attempts;
   }
   void fallback(FrameRec& cur, FrameRec& prev) { /* _fallbackEstimate (:551-566) */
     prior = tf_identity();
@@ -1040,15 +1044,18 @@ struct Stream {
   }
   int cur_status_at_start = VSLAM_LOCALIZING;
 
+  /* the selection rule of _prunePoints (:439-466) */
+  bool prune_keeps(real average_error, real error, uint8_t inlier) const {
+    if (average_error < cfg.aligner_maximum_error_kernel) return inlier != 0;
+    return error != -1 && error < 100 * cfg.aligner_maximum_error_kernel;
+  }
   /* _prunePoints (:437-472) */
   void prune(FrameRec& cur, FrameRec& prev) {
     std::vector<Point> kept;
     if (aligner_valid) {
       const real avg = al.total_error / (real)al.n;
       for (size_t i = 0; i < cur.points.size(); ++i) {
-        bool keep;
-        if (avg < cfg.aligner_maximum_error_kernel) keep = al.inliers[i] != 0;
-        else keep = (al.errors[i] != -1 && al.errors[i] < 100 * cfg.aligner_maximum_error_kernel);
+        const bool keep = prune_keeps(avg, al.errors[i], al.inliers[i]);
         if (keep) kept.push_back(cur.points[i]);
         else prev.points[cur.points[i].prev].has_next = false; /* FramePoint::clear (frame_point.cpp:57-82) */
       }
@@ -1575,6 +1582,30 @@ ORC_API int orc_stereo_recover(const vslam_config* cfg, const uint8_t* imgL, con
     std::memcpy(rec_desc + 64 * k, q.dL, 32); std::memcpy(rec_desc + 64 * k + 32, q.dR, 32);
     for (int j = 0; j < 3; ++j) rec_xyz[3 * k + j] = q.cam[j];
   }
+  return VSLAM_OK;
+}
+
+/* PoseTracker3D control arithmetic on scripted inputs (test infrastructure for tests/golden/tracker.npz): the search
+ * adaptation of _track (:240-288) over a sequence of (previous points, tracked points, tracked landmarks, by_appearance), and the
+ * selection rule of _prunePoints (:439-466). */
+ORC_API int orc_track_adapt(const vslam_config* cfg, int32_t n, const int32_t* n_prev, const int32_t* n_tracked, const int32_t* n_landmarks,
+                            const int32_t* by_appearance, int32_t win0, double tau0, int32_t* win_out, double* tau_out) {
+  Stream s;
+  s.configure(*cfg);
+  s.win = win0; s.tau_track = tau0;
+  for (int i = 0; i < n; ++i) {
+    if (by_appearance[i]) s.win = cfg->maximum_projection_tracking_distance_pixels;   /* :228-230 */
+    s.n_tracked_points = (uint32_t)n_tracked[i]; s.n_tracked_landmarks = (uint32_t)n_landmarks[i];
+    s.adapt_search((size_t)n_prev[i]);
+    win_out[i] = s.win; tau_out[i] = s.tau_track;
+  }
+  return VSLAM_OK;
+}
+ORC_API int orc_prune_select(const vslam_config* cfg, int32_t n, double total_error, const double* errors, const uint8_t* inliers, uint8_t* keep) {
+  Stream s;
+  s.configure(*cfg);
+  const real avg = total_error / (real)n;   /* averageError() = E / M (base_aligner.h) */
+  for (int i = 0; i < n; ++i) keep[i] = s.prune_keeps(avg, errors[i], inliers[i]) ? 1 : 0;
   return VSLAM_OK;
 }
 

@@ -1300,6 +1300,56 @@ def gen_stereo_recover(rng):
     return len(rec)
 
 
+# ---------------------------------------------------------------------------------------------
+# PoseTracker3D control arithmetic (pose_tracker_3d.cpp:240-288 and :439-466) on scripted inputs; configuration_kitti.yaml values
+def track_adapt_ref(steps, win, tau, target, wmin=15, wmax=50, tmin=25.6, tmax=51.2, good=0.2, tunnel=0.5, min_inliers=100):
+    out = []
+    for (n_prev, n_trk, n_lm, by_app) in steps:
+        if by_app:
+            win = wmax
+        ratio = n_trk / n_prev
+        lm_per_pt = n_lm / n_trk if n_trk else float("nan")
+        success = n_trk / target
+        if ratio < good / 2:
+            if win < wmax:
+                win = int(min(win * 1 / tunnel, float(wmax)))
+        else:
+            if win > wmin:
+                win = int(max(win * tunnel, float(wmin)))
+        if ratio < good or n_trk < min_inliers or (lm_per_pt < 0.5 and success < 0.25):
+            tau = min(tau + 5, tmax)
+        else:
+            tau = max(tau - 5, tmin)
+        out.append((win, tau))
+    return out
+
+
+def gen_tracker(rng):
+    target = (1241 // 15 + 1) * (376 // 15 + 1)          # base_framepoint_generator.cpp:304-308, bin 15
+    steps = []
+    for i in range(60):
+        n_prev = int(rng.integers(300, 2200))
+        mode = 0 if i < 6 else i % 6                     # six good frames first: the descriptor distance reaches its lower clamp
+        frac = [0.9, 0.5, 0.15, 0.05, 0.3, 0.19][mode] * float(rng.uniform(0.9, 1.1))
+        n_trk = max(1, int(n_prev * frac))
+        if mode == 4:
+            n_trk = int(rng.integers(40, 100))             # below the aligner's minimum number of inliers
+        n_lm = int(n_trk * float(rng.uniform(0.1, 0.95)))
+        steps.append((n_prev, n_trk, n_lm, int(i % 11 == 0)))
+    res = track_adapt_ref(steps, 20, 40.0, target)
+    n = 300
+    err = rng.uniform(0, 30, n); err[rng.random(n) < 0.1] = -1.0; err[rng.random(n) < 0.05] = rng.uniform(390, 420, 1)[0]
+    inl = ((err >= 0) & (err <= 4.0)).astype(np.uint8)
+    out = {"steps": np.array(steps, np.int32), "win": np.array([r[0] for r in res], np.int32), "tau": np.array([r[1] for r in res], np.float64),
+           "errors": err, "inliers": inl}
+    for name, total in (("low", 2.0 * n), ("high", 9.0 * n)):   # average error below / above the kernel (4)
+        avg = total / n
+        keep = inl.astype(bool) if avg < 4.0 else ((err != -1) & (err < 100 * 4.0))
+        out["total_" + name] = np.float64(total); out["keep_" + name] = keep.astype(np.uint8)
+    np.savez_compressed(os.path.join(HERE, "tracker.npz"), **out)
+    return len(steps)
+
+
 def main():
     rng = np.random.default_rng(20261003)
     gen_hamming(rng)
@@ -1316,6 +1366,7 @@ def main():
     gen_orb(np.random.default_rng(20261009))
     gen_landmark(np.random.default_rng(20261010))
     gen_stereo_recover(np.random.default_rng(20261011))
+    gen_tracker(np.random.default_rng(20261012))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

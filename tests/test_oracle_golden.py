@@ -197,3 +197,26 @@ def test_stereo_recover_known_answers(oracle, golden):
     np.testing.assert_array_equal(dist[:k], g["rec_dist"])
     np.testing.assert_array_equal(desc[:k], g["rec_desc"])
     np.testing.assert_array_equal(xyz[:k], g["rec_xyz"])
+
+
+def test_tracker_control_known_answers(oracle, golden):
+    """_track's window / descriptor-distance adaptation over 60 scripted frames and the _prunePoints selection rule against the
+    pure-Python restatement (configuration_kitti.yaml values)."""
+    g = golden["tracker"]
+    cfg = oracle.default_config("kitti")
+    st = np.ascontiguousarray(g["steps"], np.int32)
+    n = len(st)
+    cols = [np.ascontiguousarray(st[:, k]) for k in range(4)]
+    win = np.zeros(n, np.int32); tau = np.zeros(n, np.float64)
+    p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    assert oracle.lib.orc_track_adapt(C.byref(cfg), C.c_int32(n), p(cols[0], C.c_int32), p(cols[1], C.c_int32), p(cols[2], C.c_int32),
+                                      p(cols[3], C.c_int32), C.c_int32(20), C.c_double(40.0), p(win, C.c_int32), p(tau, C.c_double)) == 0
+    np.testing.assert_array_equal(win, g["win"])
+    np.testing.assert_array_equal(tau, g["tau"])
+    assert len(set(win.tolist())) >= 4 and tau.min() == 25.6 and tau.max() == 51.2        # the script reaches both clamps
+    err = np.ascontiguousarray(g["errors"], np.float64); inl = np.ascontiguousarray(g["inliers"], np.uint8)
+    for name in ("low", "high"):
+        keep = np.zeros(len(err), np.uint8)
+        assert oracle.lib.orc_prune_select(C.byref(cfg), C.c_int32(len(err)), C.c_double(float(g["total_" + name])), p(err, C.c_double),
+                                           p(inl, C.c_uint8), p(keep, C.c_uint8)) == 0
+        np.testing.assert_array_equal(keep, g["keep_" + name])
