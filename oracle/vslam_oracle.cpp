@@ -2041,6 +2041,12 @@ ORC_API void orc_synth_pose(const synth_scene* s, int k, double cam_to_world[12]
   synth_pose(s, k, R, t);
   for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) cam_to_world[4 * i + j] = R[3 * i + j]; cam_to_world[4 * i + 3] = t[i]; }
 }
+ORC_API void orc_synth_render_depth(const synth_scene* s, int frame, double unit_m, uint16_t* depth, int32_t stride) {
+  double R[9], t[3];
+  synth_pose(s, frame, R, t);
+  for (int y = 0; y < s->rows; ++y)
+    for (int x = 0; x < s->cols; ++x) depth[(size_t)y * stride + x] = synth_depth(s, R, t, x, y, unit_m);
+}
 ORC_API void orc_synth_render(const synth_scene* s, int frame, uint8_t* left, uint8_t* right, int32_t stride) {
   double R[9], t[3];
   synth_pose(s, frame, R, t);

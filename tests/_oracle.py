@@ -53,6 +53,11 @@ class Oracle(CApi):
                                   right.ctypes.data_as(C.c_void_p), C.c_int32(stride))
         return left, right
 
+    def render_depth(self, scene, frame, unit_m=2e-3):
+        depth = np.zeros((scene.rows, scene.cols), np.uint16)
+        self.lib.orc_synth_render_depth(C.byref(scene), C.c_int(frame), C.c_double(unit_m), depth.ctypes.data_as(C.c_void_p), C.c_int32(scene.cols))
+        return depth
+
     def gt_pose(self, scene, frame):
         out = np.zeros(12, np.float64)
         self.lib.orc_synth_pose(C.byref(scene), C.c_int(frame), out.ctypes.data_as(C.c_void_p))

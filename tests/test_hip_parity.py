@@ -513,3 +513,49 @@ def test_orb_detect_at_kitti_size_against_oracle(gpu, oracle):
         o = oracle.orb_detect(left, 5000, 1.2, 8, 31, 31, thr)
         assert g.shape == o.shape and np.array_equal(g.view(np.uint32), o.view(np.uint32))
         assert len(g) >= 4000 and set(np.unique(g[:, 5]).astype(int)) == set(range(8))
+
+
+def test_rgbd_chain_on_rendered_frames(gpu, oracle):
+    """Two consecutive rendered frames (left image + depth of the synthetic street scene, half KITTI size) through the RGB-D
+    entry points in the order a depth tracker calls them — space map, FAST + BRIEF, compute; next frame: track from the
+    ground-truth motion (both search modes), recovery of the lost points — GPU against oracle at every step, all exact."""
+    from vslam_pose_estimation_framework_amd.capi import DepthParams
+    from vslam_pose_estimation_framework_amd import evaluation as ev
+    scene = oracle.scene_kitti(scale=0.5)
+    rows, cols = scene.rows, scene.cols
+    K = np.array([[scene.fx, 0, scene.cx], [0, scene.fy, scene.cy], [0, 0, 1.0]])
+    p = DepthParams.make(rows, cols, K, np.linalg.inv(K), np.linalg.inv(K), np.eye(4)[:3], 2e-3, 0.1, 80.0, 1, 1, 15)
+    frames = []
+    for k in (40, 41):
+        left, _ = oracle.render(scene, k)
+        depth = oracle.render_depth(scene, k, 2e-3)
+        sg = gpu.depth_space_map(p, depth); so = oracle.depth_space_map(p, depth)
+        assert all(np.array_equal(a.view(np.uint8), b.view(np.uint8)) for a, b in zip(sg, so))
+        xy_g, sc_g = gpu.fast_detect(left, (0, 0, cols, rows), 20); xy_o, sc_o = oracle.fast_detect(left, (0, 0, cols, rows), 20)
+        assert np.array_equal(xy_g, xy_o) and np.array_equal(sc_g, sc_o) and len(xy_g) > 300
+        keep_g, d_g = gpu.brief_describe(left, xy_g); keep_o, d_o = oracle.brief_describe(left, xy_o)
+        assert np.array_equal(keep_g, keep_o) and np.array_equal(d_g, d_o)
+        sel = keep_g.astype(bool)
+        feats = np.stack([xy_g[sel, 1], xy_g[sel, 0]], axis=1).astype(np.int32)      # (row, col), row-major as FAST emits them
+        frames.append(dict(left=left, space=so[0], feats=feats, desc=d_g[sel], c2w=oracle.gt_pose(scene, k)))
+    f0, f1 = frames
+    new_g = gpu.depth_compute(p, f0["space"], f0["feats"], np.zeros((0, 2), np.int32))
+    new_o = oracle.depth_compute(p, f0["space"], f0["feats"], np.zeros((0, 2), np.int32))
+    assert all(np.array_equal(a, b) for a, b in zip(new_g, new_o)) and len(new_g[0]) > 100
+    idx, cam = new_g[0], new_g[1]                              # the previous frame's points: measured-depth points of frame 40
+    pdesc = f0["desc"][idx]
+    flags = np.ones(len(idx), np.uint8)
+    T = ev.mul34(ev.inv34(f1["c2w"]), f0["c2w"])               # previous -> current camera, ground truth
+    lost_all = None
+    for by_app, d in ((1, 20), (0, 10)):
+        a = gpu.depth_track(p, f1["space"], T, d, 40.0, by_app, cam, pdesc, flags, f1["feats"], f1["desc"])
+        b = oracle.depth_track(p, f1["space"], T, d, 40.0, by_app, cam, pdesc, flags, f1["feats"], f1["desc"])
+        assert all(np.array_equal(x, y) for x, y in zip(a[:4], b[:4])) and a[4] == b[4]
+        assert len(a[0]) > 0.3 * len(idx)                      # the scene is static and the motion exact: most points are found again
+        lost_all = a[3]
+    world = np.array([f0["c2w"][:, :3] @ c + f0["c2w"][:, 3] for c in cam[lost_all]]).reshape(-1, 3)
+    w2c1 = ev.inv34(f1["c2w"])
+    ra = gpu.depth_recover(p, f1["space"], f1["left"], w2c1, np.ones(len(lost_all), np.uint8), world, pdesc[lost_all], 7.0, 60.0)
+    rb = oracle.depth_recover(p, f1["space"], f1["left"], w2c1, np.ones(len(lost_all), np.uint8), world, pdesc[lost_all], 7.0, 60.0)
+    assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1].view(np.uint32), rb[1].view(np.uint32))
+    assert np.array_equal(ra[2], rb[2]) and np.array_equal(ra[3], rb[3])

@@ -96,6 +96,21 @@ SYNTH_HD double synth_sample(const synth_scene* s, const double R[9], const doub
   return acc < 0.0 ? 0.0 : (acc > 255.0 ? 255.0 : acc);
 }
 
+/* depth of the LEFT camera's pixel (x, y) along the optical axis, in units of `unit_m` metres (RGB-D tests: unit 2 mm keeps
+ * the 90 m scene inside 16 bits); 0 = no surface within max_depth_m.  The ray parameter of synth_sample IS the camera-frame z. */
+SYNTH_HD uint16_t synth_depth(const synth_scene* s, const double R[9], const double t[3], int x, int y, double unit_m) {
+  const double dx = ((double)x - s->cx) / s->fx, dy = ((double)y - s->cy) / s->fy;
+  const double Dx = R[0] * dx + R[1] * dy + R[2];
+  const double Dy = R[3] * dx + R[4] * dy + R[5];
+  double best = 1e30;
+  if (Dy > 1e-12) { const double q = (s->cam_height_m - t[1]) / Dy; if (q > 0 && q < best) best = q; }
+  if (Dx < -1e-12) { const double q = (-s->wall_half_m - t[0]) / Dx; if (q > 0 && q < best) best = q; }
+  if (Dx > 1e-12) { const double q = (s->wall_half_m - t[0]) / Dx; if (q > 0 && q < best) best = q; }
+  if (best > s->max_depth_m) return 0;
+  const double v = floor(best / unit_m + 0.5);
+  return v > 65535.0 ? 0 : (uint16_t)v;
+}
+
 /* one output pixel: 2x2 supersampling + +-2 grey levels of deterministic sensor noise */
 SYNTH_HD uint8_t synth_pixel(const synth_scene* s, const double R[9], const double t[3], int frame,
                              int side, int x, int y) {

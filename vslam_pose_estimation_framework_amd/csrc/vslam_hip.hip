@@ -1136,7 +1136,7 @@ VS_API int vslam_fast_detect(vslam_ctx* c, const uint8_t* img, int32_t rows, int
   if (!c || !img || !n) return VSLAM_ERR_INVALID;
   if (rx < 0 || ry < 0 || rw < 1 || rh < 1 || rx + rw > cols || ry + rh > rows) return fail(c, VSLAM_ERR_INVALID, "ROI outside the image");
   vslam_ctx* t = nullptr;
-  int rc = make_scratch_ctx(c, rows, cols, std::min(cap, rows * cols), 64, &t);
+  int rc = make_scratch_ctx(c, rows, cols, std::min(std::min(cap, rows * cols), 65535), 64, &t);   // 16-bit feature indices
   if (rc != VSLAM_OK) return rc;
   t->cfg.n_regions = 1;
   t->cfg.regions[0].x = rx; t->cfg.regions[0].y = ry; t->cfg.regions[0].w = rw; t->cfg.regions[0].h = rh;
