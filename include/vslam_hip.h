@@ -151,6 +151,14 @@ void vslam_default_config_kitti(vslam_config* cfg); /* configuration_kitti.yaml 
 void vslam_default_config_euroc(vslam_config* cfg); /* configuration_euroc.yaml values                */
 /* Restart every stream as a fresh sequence (PoseTracker3D::configure, WorldMap::clear). */
 int vslam_reset(vslam_ctx* ctx);
+/* Exact mode with whole sequences of different lengths per stream: a stream whose sequence has ended is
+ * switched off — every kernel skips it, its last frame's state, report and pose log stay readable — while the other
+ * streams of the context carry on; vslam_reset_stream restarts ONE stream as a fresh sequence (a new PoseTracker3D /
+ * generator / aligner / WorldMap: pose_tracker_3d.cpp:11-21) so that a stream can work through a queue of sequences.
+ * Both synchronise the context; neither may be called between vslam_frame_begin and the end of that frame.
+ * The images passed for an inactive stream are ignored (the pointer arithmetic still reserves its slot). */
+int vslam_set_stream_active(vslam_ctx* ctx, int stream, int active);
+int vslam_reset_stream(vslam_ctx* ctx, int stream);
 /* Use the caller's HIP stream (hipStream_t passed as void*) for all work of this context. */
 int vslam_set_hip_stream(vslam_ctx* ctx, void* hip_stream);
 
@@ -225,6 +233,11 @@ int vslam_get_points(vslam_ctx* ctx, int stream, int32_t cap, int32_t* n, int16_
                      int32_t* meta, double* cam, double* lm);
 int vslam_get_aligner_result(vslam_ctx* ctx, int stream, int32_t cap, int32_t* n, double* chi,
                              uint8_t* inlier, double T[12], double H[36]);
+/* StereoUVAligner::_weights_translation as the stream's last initialize() left it (stereouv_aligner.cpp:22,57-61): the
+ * vector is a MEMBER of the aligner, `resize(n, 1)` keeps the elements it already holds, and they are rewritten only while
+ * enable_inverse_depth_as_information is set — so Localizing frames (flag off, pose_tracker_3d.cpp:124) reuse the weights the
+ * last Tracking frame left at the same indices.  n = the vector's size. */
+int vslam_get_aligner_weights(vslam_ctx* ctx, int stream, int32_t cap, int32_t* n, double* weight);
 /* The 8 chronometers SLAMAssembly::printReport prints (slam_assembly.cpp:703-742), seconds of
  * device time accumulated per stage over all streams (HIP events): keypoint_detection,
  * descriptor_extraction, point_triangulation, tracking, track_creation, pose_optimization,
@@ -248,9 +261,9 @@ int vslam_fast_detect(vslam_ctx* ctx, const uint8_t* image_host, int32_t rows, i
  * integer keypoints; keypoints closer than 28 px to the border are removed (keep[i]=0). */
 int vslam_brief_describe(vslam_ctx* ctx, const uint8_t* image_host, int32_t rows, int32_t cols,
                          int32_t stride, int32_t n, const int16_t* xy, uint8_t* keep, uint8_t* desc);
-/* matcher->knnMatch(query, train, k=2) of the use_matches block
- * (stereo_framepoint_generator.cpp:168-206).  norm: 0 = NORM_HAMMING on the bytes,
- * 1 = NORM_L2 on the bytes converted to float (what convertTo(CV_32F)+BRUTEFORCE computes).
+/* matcher->knnMatch(query, train, k=2) of the use_matches block (stereo_framepoint_generator.cpp:168-206); the matcher type
+ * selects the norm (:175-197).  norm: 0 = NORM_HAMMING on the bits (BRUTEFORCE_HAMMING), 1 = NORM_L2 on the bytes converted
+ * to float (convertTo(CV_32F) + BRUTEFORCE), 2 = NORM_L1 (BRUTEFORCE_L1), 3 = squared L2 (BRUTEFORCE_SL2).
  * idx: nq*2 int32 (-1 if fewer than 2 train rows), dist: nq*2 float. Ties -> lowest index. */
 int vslam_knn2(vslam_ctx* ctx, int norm, int32_t nq, const uint8_t* query, int32_t nt,
                const uint8_t* train, int32_t* idx, float* dist);
@@ -260,6 +273,13 @@ int vslam_align_points(vslam_ctx* ctx, int32_t n, const double* moving, const do
                        const double* omega, const double* weight, const double T_init[12],
                        double T_out[12], double* chi, uint8_t* inlier, int32_t* n_inliers,
                        double* total_error, int32_t* iterations, double H_out[36]);
+
+/* The translation weights over a sequence of StereoUVAligner::initialize calls on ONE aligner object
+ * (stereouv_aligner.cpp:22,57-61), for known-answer tests: call k has n[k] measurements with depths depth[off_k ..]
+ * (off_k = n[0] + .. + n[k-1]) and the flag inverse_depth[k]; out receives the n[k] weights in effect after call k.
+ * Runs the weight rule of the fused tracker's aligner (maximum_reliable_depth_meters of ctx's config). */
+int vslam_aligner_weights(vslam_ctx* ctx, int32_t n_calls, const int32_t* n, const int32_t* inverse_depth,
+                          const double* depth, double* out);
 
 /* UVDAligner (RGB-D mode, uvd_aligner.cpp:72-232) on caller-provided correspondences: moving n*3 (previous camera
  * coordinates), fixed n*3 (u, v, depth), omega_uv n and omega_depth n (the diagonal of the information matrix:

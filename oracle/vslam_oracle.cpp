@@ -630,6 +630,7 @@ struct Stream {
     lost.clear();
     poses.clear();
     aligner_valid = false;
+    al.weight.clear();           /* a new StereoUVAligner: empty _weights_translation */
     std::memset(&info, 0, sizeof info);
   }
 
@@ -925,7 +926,12 @@ struct Stream {
   void align(FrameRec& cur, FrameRec& prev, bool inverse_depth) {
     const int n = (int)cur.points.size();
     al.n = n;
-    al.moving.resize(3 * n); al.fixed.resize(4 * n); al.omega.resize(n); al.weight.resize(n);
+    al.moving.resize(3 * n); al.fixed.resize(4 * n); al.omega.resize(n);
+    /* _weights_translation.resize(n, 1) (stereouv_aligner.cpp:22): a std::vector resize keeps the elements it already
+     * holds and gives 1 only to the ones it appends; they are rewritten only when inverse depth is enabled (:57-61).
+     * The vector is a member of the aligner, so the Localizing frames after a breakTrack (inverse depth off,
+     * pose_tracker_3d.cpp:124) run with the weights the last Tracking frame left at the same indices. */
+    aligner_resize_weights(n);
     for (int u = 0; u < n; ++u) {
       const Point& p = cur.points[u];
       const Point& pp = prev.points[p.prev];
@@ -938,7 +944,7 @@ struct Stream {
         for (int i = 0; i < 3; ++i) al.moving[3 * u + i] = pp.cam[i];
       }
       al.omega[u] = om;
-      al.weight[u] = inverse_depth ? std::min(cfg.maximum_reliable_depth_meters / p.cam[2], 1.0) : 1.0;
+      if (inverse_depth) aligner_set_weight(u, p.cam[2]);
     }
     al.T = prior;
     AlignerParams P = aligner_params();
@@ -946,6 +952,8 @@ struct Stream {
     for (int u = 0; u < n; ++u) { cur.points[u].chi = al.errors[u]; cur.points[u].inlier = al.inliers[u]; }
     aligner_valid = true;
   }
+  void aligner_resize_weights(int n) { al.weight.resize(n, 1.0); }                                   /* :22 */
+  void aligner_set_weight(int u, real depth) { al.weight[u] = std::min(cfg.maximum_reliable_depth_meters / depth, 1.0); } /* :60 */
   AlignerParams aligner_params() const {
     AlignerParams P;
     std::memcpy(P.K, cfg.K, sizeof P.K);
@@ -1231,6 +1239,7 @@ struct Stream {
 
 struct orc_ctx {
   std::vector<Stream> streams;
+  std::vector<uint8_t> active;   /* a stream whose sequence has ended is skipped (vslam_set_stream_active) */
   std::string err;
 };
 
@@ -1290,10 +1299,22 @@ ORC_API int orc_create(const vslam_config* cfg, int /*device*/, int n_streams, o
   return VSLAM_OK;
 }
 ORC_API void orc_destroy(orc_ctx* c) { delete c; }
-ORC_API int orc_reset(orc_ctx* c) { for (Stream& s : c->streams) s.reset(); return VSLAM_OK; }
+ORC_API int orc_reset(orc_ctx* c) { for (Stream& s : c->streams) s.reset(); c->active.clear(); return VSLAM_OK; }
 ORC_API int orc_process_host(orc_ctx* c, const uint8_t* L, const uint8_t* R, int32_t stride, size_t image_stride) {
   if (!c || !L || !R) return VSLAM_ERR_INVALID;
-  for (size_t s = 0; s < c->streams.size(); ++s) c->streams[s].process(L + s * image_stride, R + s * image_stride, stride);
+  for (size_t s = 0; s < c->streams.size(); ++s)
+    if (c->active.empty() || c->active[s]) c->streams[s].process(L + s * image_stride, R + s * image_stride, stride);
+  return VSLAM_OK;
+}
+ORC_API int orc_set_stream_active(orc_ctx* c, int s, int on) {
+  if (!c || s < 0 || s >= (int)c->streams.size()) return VSLAM_ERR_INVALID;
+  if (c->active.empty()) c->active.assign(c->streams.size(), 1);
+  c->active[s] = on ? 1 : 0;
+  return VSLAM_OK;
+}
+ORC_API int orc_reset_stream(orc_ctx* c, int s) {
+  if (!c || s < 0 || s >= (int)c->streams.size()) return VSLAM_ERR_INVALID;
+  c->streams[s].reset();
   return VSLAM_OK;
 }
 ORC_API int orc_get_frame_info(orc_ctx* c, int s, vslam_frame_info* out) {
@@ -1342,6 +1363,15 @@ ORC_API int orc_get_aligner_result(orc_ctx* c, int s, int32_t cap, int32_t* n, d
   if (H) std::memcpy(H, a.H, sizeof(double) * 36);
   return VSLAM_OK;
 }
+/* _weights_translation as the last StereoUVAligner::initialize of the stream left it */
+ORC_API int orc_get_aligner_weights(orc_ctx* c, int s, int32_t cap, int32_t* n, double* weight) {
+  if (!c || s < 0 || s >= (int)c->streams.size() || !n) return VSLAM_ERR_INVALID;
+  const AlignerIO& a = c->streams[s].al;
+  *n = (int32_t)a.weight.size();
+  if (*n > cap) return VSLAM_ERR_CAPACITY;
+  for (int i = 0; i < *n; ++i) if (weight) weight[i] = a.weight[i];
+  return VSLAM_OK;
+}
 ORC_API int orc_get_poses(orc_ctx* c, int s, int32_t first, int32_t nf, double* out) {
   if (!c || s < 0 || s >= (int)c->streams.size() || !out) return VSLAM_ERR_INVALID;
   const std::vector<Tf>& p = c->streams[s].poses;
@@ -1376,20 +1406,22 @@ ORC_API int orc_brief_describe(orc_ctx*, const uint8_t* img, int32_t rows, int32
 }
 /* knnMatch(k=2) of the use_matches block (stereo_framepoint_generator.cpp:168-206) */
 ORC_API int orc_knn2(orc_ctx*, int norm, int32_t nq, const uint8_t* q, int32_t nt, const uint8_t* t, int32_t* idx, float* dist) {
-  if (!q || !t || !idx || !dist) return VSLAM_ERR_INVALID;
+  if (!q || !t || !idx || !dist || norm < 0 || norm > 3) return VSLAM_ERR_INVALID;
   for (int i = 0; i < nq; ++i) {
     int64_t b0 = INT64_MAX, b1 = INT64_MAX;
     int i0 = -1, i1 = -1;
     for (int j = 0; j < nt; ++j) {
       int64_t d;
+      /* matcher type -> norm (stereo_framepoint_generator.cpp:175-197): 0 HAMMING, 1 L2, 2 L1, 3 SL2, on the bytes as floats */
       if (norm == 0) d = hamming32(q + 32 * i, t + 32 * j);
+      else if (norm == 2) { d = 0; for (int k = 0; k < 32; ++k) d += std::abs((int)q[32 * i + k] - (int)t[32 * j + k]); }
       else { d = 0; for (int k = 0; k < 32; ++k) { const int e = (int)q[32 * i + k] - (int)t[32 * j + k]; d += e * e; } }
       if (d < b0) { b1 = b0; i1 = i0; b0 = d; i0 = j; }
       else if (d < b1) { b1 = d; i1 = j; }
     }
     idx[2 * i] = i0; idx[2 * i + 1] = i1;
-    dist[2 * i] = i0 < 0 ? 0.f : (norm == 0 ? (float)b0 : std::sqrt((float)b0));
-    dist[2 * i + 1] = i1 < 0 ? 0.f : (norm == 0 ? (float)b1 : std::sqrt((float)b1));
+    dist[2 * i] = i0 < 0 ? 0.f : (norm != 1 ? (float)b0 : std::sqrt((float)b0));
+    dist[2 * i + 1] = i1 < 0 ? 0.f : (norm != 1 ? (float)b1 : std::sqrt((float)b1));
   }
   return VSLAM_OK;
 }
@@ -1598,6 +1630,22 @@ ORC_API int orc_track_adapt(const vslam_config* cfg, int32_t n, const int32_t* n
     s.n_tracked_points = (uint32_t)n_tracked[i]; s.n_tracked_landmarks = (uint32_t)n_landmarks[i];
     s.adapt_search((size_t)n_prev[i]);
     win_out[i] = s.win; tau_out[i] = s.tau_track;
+  }
+  return VSLAM_OK;
+}
+/* The translation weights over a sequence of StereoUVAligner::initialize calls on ONE aligner object
+ * (stereouv_aligner.cpp:22,57-61): call k has n[k] measurements with depths depth[off_k ..] and the
+ * enable_inverse_depth_as_information flag inverse_depth[k]; out receives the n[k] weights after each call. */
+ORC_API int orc_aligner_weights(const vslam_config* cfg, int32_t n_calls, const int32_t* n, const int32_t* inverse_depth,
+                                const double* depth, double* out) {
+  Stream s;
+  s.configure(*cfg);
+  size_t off = 0;
+  for (int k = 0; k < n_calls; ++k) {
+    s.aligner_resize_weights(n[k]);
+    if (inverse_depth[k]) for (int u = 0; u < n[k]; ++u) s.aligner_set_weight(u, depth[off + u]);
+    for (int u = 0; u < n[k]; ++u) out[off + u] = s.al.weight[u];
+    off += (size_t)n[k];
   }
   return VSLAM_OK;
 }
@@ -2036,6 +2084,7 @@ ORC_API int orc_orb_detect(const uint8_t* img, int32_t rows, int32_t cols, int32
 
 /* ---- synthetic data + trajectory error (test / bench infrastructure) ---------------------- */
 ORC_API void orc_synth_default_kitti(synth_scene* s) { synth_default_kitti(s); }
+ORC_API void orc_synth_default_euroc(synth_scene* s) { synth_default_euroc(s); }
 ORC_API void orc_synth_pose(const synth_scene* s, int k, double cam_to_world[12]) {
   double R[9], t[3];
   synth_pose(s, k, R, t);

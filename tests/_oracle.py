@@ -25,7 +25,8 @@ class SynthScene(C.Structure):
                 ("cx", C.c_double), ("cy", C.c_double), ("baseline_m", C.c_double),
                 ("cam_height_m", C.c_double), ("wall_half_m", C.c_double), ("max_depth_m", C.c_double),
                 ("cell_m", C.c_double), ("speed_m", C.c_double), ("sway_m", C.c_double),
-                ("sway_rate", C.c_double), ("seed", C.c_uint64)]
+                ("sway_rate", C.c_double), ("seed", C.c_uint64), ("bob_m", C.c_double), ("roll_amp", C.c_double),
+                ("pitch_amp", C.c_double), ("roll_rate", C.c_double), ("pitch_rate", C.c_double), ("contrast", C.c_double)]
 
 
 class Oracle(CApi):
@@ -42,6 +43,15 @@ class Oracle(CApi):
             s.fy *= scale
             s.cx *= scale
             s.cy *= scale
+        s.seed = seed
+        return s
+
+    def scene_euroc(self, scale=1.0, seed=7):
+        s = SynthScene()
+        self.lib.orc_synth_default_euroc(C.byref(s))
+        if scale != 1.0:
+            s.rows = int(round(s.rows * scale)); s.cols = int(round(s.cols * scale))
+            s.fx *= scale; s.fy *= scale; s.cx *= scale; s.cy *= scale
         s.seed = seed
         return s
 

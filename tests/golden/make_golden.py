@@ -1350,7 +1350,46 @@ def gen_tracker(rng):
     return len(steps)
 
 
+# ---------------------------------------------------------------------------------------------
+# StereoUVAligner::_weights_translation over a sequence of initialize() calls on ONE aligner (stereouv_aligner.cpp:22,57-61):
+# a Python list stands in for the std::vector member; `resize(n, 1)` truncates or appends ones, never touches what it keeps.
+def aligner_weights_ref(calls, max_reliable=15.0):
+    w = []                                              # the member vector, empty in a new aligner
+    out = []
+    for n, inverse_depth, depth in calls:
+        if n < len(w):
+            del w[n:]                                   # vector::resize shrinks ...
+        else:
+            w.extend([1.0] * (n - len(w)))              # ... or appends the fill value
+        if inverse_depth:
+            for u in range(n):
+                w[u] = min(max_reliable / depth[u], 1.0)
+        out.append(list(w))
+    return out
+
+
+def gen_aligner_weights(rng):
+    # Tracking frames (inverse depth on) with varying point counts, a track break, then Localizing frames (off) with FEWER and
+    # with MORE points than the last Tracking frame, Tracking again, a second break after a shrink (grow-back must give ones).
+    script = [(300, 1), (420, 1), (380, 1), (150, 0), (150, 0), (520, 0), (90, 0), (200, 0), (610, 1), (10, 1), (64, 0), (0, 0), (33, 0), (33, 1)]
+    calls = []
+    for n, inv in script:
+        depth = rng.uniform(1.5, 60.0, n)                # both sides of the 15 m reliable depth
+        calls.append((n, inv, depth))
+    res = aligner_weights_ref(calls)
+    out = {"sizes": np.array([c[0] for c in calls], np.int32), "inverse_depth": np.array([c[1] for c in calls], np.int32),
+           "depth": np.concatenate([c[2] for c in calls]), "weights": np.concatenate([np.array(r, np.float64) for r in res])}
+    np.savez_compressed(os.path.join(HERE, "aligner_weights.npz"), **out)
+    return len(calls)
+
+
 def main():
+    import sys
+    if len(sys.argv) > 1:                                 # regenerate selected fixtures only: make_golden.py aligner_weights ...
+        streams = {"aligner_weights": 20261013}
+        for name in sys.argv[1:]:
+            globals()["gen_" + name](np.random.default_rng(streams[name]))
+        return
     rng = np.random.default_rng(20261003)
     gen_hamming(rng)
     gen_fast(rng)
@@ -1367,6 +1406,7 @@ def main():
     gen_landmark(np.random.default_rng(20261010))
     gen_stereo_recover(np.random.default_rng(20261011))
     gen_tracker(np.random.default_rng(20261012))
+    gen_aligner_weights(np.random.default_rng(20261013))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

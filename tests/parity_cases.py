@@ -21,6 +21,14 @@ def check_hamming_knn(api, g):
     idx, dist = api.knn2(g["q"], g["t"], norm=1)
     np.testing.assert_array_equal(idx, g["idx_l2"])
     np.testing.assert_array_equal(dist, g["dist_l2"])
+    # BRUTEFORCE_L1 / BRUTEFORCE_SL2 (stereo_framepoint_generator.cpp:182-193): answers from numpy on the fixture's rows,
+    # stable sort = lowest index wins ties
+    qs, ts = g["q"].astype(np.int64), g["t"].astype(np.int64)
+    for norm, D in ((2, np.abs(qs[:, None, :] - ts[None, :, :]).sum(-1)), (3, ((qs[:, None, :] - ts[None, :, :]) ** 2).sum(-1))):
+        order = np.argsort(D, axis=1, kind="stable")[:, :2]
+        idx, dist = api.knn2(g["q"], g["t"], norm=norm)
+        np.testing.assert_array_equal(idx, order.astype(np.int32))
+        np.testing.assert_array_equal(dist, np.take_along_axis(D, order, 1).astype(np.float32))
     # ragged / empty
     idx, dist = api.knn2(g["q"][:5], g["t"][:1], norm=0)
     assert (idx[:, 0] == 0).all() and (idx[:, 1] == -1).all()
@@ -70,6 +78,22 @@ def check_aligner(api, g, rtol_pose=1e-9):
     assert np.linalg.norm(r["T"] - Tt) / np.linalg.norm(Tt) < 1e-4
     # skipped points (behind the camera / outside the image) keep error -1 and count as outliers
     assert r["chi"][-1] == -1 and r["chi"][-2] == -1 and r["inlier"][-1] == 0
+
+
+def check_aligner_weights(api, g, cfg):
+    """_weights_translation across a Tracking -> break -> Localizing script (fewer and more points than before): the stale
+    inverse-depth weights of stereouv_aligner.cpp:22,57-61, bit for bit against the Python-list restatement."""
+    w = api.aligner_weights(cfg, g["sizes"], g["inverse_depth"], g["depth"])
+    np.testing.assert_array_equal(w, g["weights"])
+    sizes, inv = g["sizes"], g["inverse_depth"]
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    k = 3                                               # first Localizing call: fewer points than the Tracking call before it
+    assert inv[k] == 0 and sizes[k] < sizes[k - 1]
+    np.testing.assert_array_equal(w[off[k]:off[k + 1]], w[off[k - 1]:off[k - 1] + sizes[k]])   # stale, not 1
+    assert (w[off[k]:off[k + 1]] != 1.0).any()
+    k = 5                                               # Localizing call that grows past the stale part: ones beyond it
+    assert inv[k] == 0 and sizes[k] > sizes[k - 1]
+    assert np.all(w[off[k] + sizes[k - 1]:off[k + 1]] == 1.0)
 
 
 def check_aligner_uvd(api, g, rtol_pose=1e-9):

@@ -1,0 +1,137 @@
+"""GPU parity on the BASELINE.json configurations that the other parity tests only cover at reduced size:
+#1 KITTI-shaped 1241x376 at bin 22 (~1026 keypoints), #5 at bin 11 (~3955), #4 an EuRoC-shaped 752x480 sequence with the
+EuRoC parameters (2x2 detector grid, 6-DoF motion) plus the L2 brute-force 2-NN on that frame's descriptors, and #3's
+per-GPU work: whole sequences of different lengths, one per stream (exact mode), as `sharding.plan_sequences` assigns them.
+The multi-rank halves of #3 / #5 (one process per GPU + the pose all-gather) are covered by tests/test_sharding.py."""
+import numpy as np
+import pytest
+
+from pipeline_compare import compare_frame, run_sequence
+from vslam_pose_estimation_framework_amd import hip, sharding
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config1_full_resolution_bin22():
+    # configuration_kitti.yaml with bin_size_pixels 22: target (1241/22+1)*(376/22+1) = 1026 keypoints ("ORB 1000 kp/frame")
+    from _oracle import Oracle
+
+    def edit(cfg):
+        cfg.bin_size_pixels = 22
+
+    def after(o, g):
+        fi = g.frame_info(0)
+        assert fi.status == 1 and 700 < fi.n_keypoints_left < 1500, (fi.status, fi.n_keypoints_left)
+    run_sequence(Oracle, dict(scale=1.0), 8, cfg_edit=edit, after=after)
+
+
+def test_config5_full_resolution_bin11():
+    # bin 11: target (1241/11+1)*(376/11+1) = 3955 keypoints per image ("4000 kp/frame")
+    from _oracle import Oracle
+
+    def edit(cfg):
+        cfg.bin_size_pixels = 11
+        cfg.max_keypoints, cfg.max_points = 16384, 8192
+
+    def after(o, g):
+        fi = g.frame_info(0)
+        assert fi.status == 1 and fi.n_keypoints_left > 2500 and fi.error_flags == 0, (fi.status, fi.n_keypoints_left)
+    run_sequence(Oracle, dict(scale=1.0), 6, cfg_edit=edit, after=after)
+
+
+def test_config4_euroc_shaped_sequence_and_l2_knn2():
+    """vslam_default_config_euroc (configuration_euroc.yaml:47-116: 2x2 detectors, thresholds 10..30 with 100 % change, bin 20,
+    track length 2, damping 0) on the EuRoC-shaped scene (752x480, f 458, baseline 0.11 m, 6-DoF motion <= 5 cm / 1 degree per
+    frame), 10 frames against the oracle; then the brute-force knnMatch(k=2) of the use_matches block
+    (stereo_framepoint_generator.cpp:199-206) with every matcher norm on the last frame's ~950 left x right descriptors."""
+    from _oracle import Oracle
+
+    def after(o, g):
+        fi = g.frame_info(0)
+        assert fi.status == 1 and fi.n_tracked > 40 and 600 < fi.n_keypoints_left < 1600, (fi.status, fi.n_tracked, fi.n_keypoints_left)
+        assert len(set(list(fi.thresholds)[:4])) > 1          # the four detectors run at different thresholds
+        dl, dr = g.keypoints(0, 0)[2], g.keypoints(0, 1)[2]
+        for norm in (1, 0, 2, 3):                             # L2 (the config's path), Hamming, L1, SL2
+            ig, dg = g.knn2(dl, dr, norm=norm)
+            io, do = o.knn2(dl, dr, norm=norm)
+            np.testing.assert_array_equal(ig, io)
+            np.testing.assert_array_equal(dg, do)
+        assert (ig[:, 0] >= 0).all() and (dg[:, 0] <= dg[:, 1]).all()
+    run_sequence(Oracle, dict(scale=1.0), 10, which="euroc", scene="euroc", after=after)
+
+
+def _run_exact(lengths, streams_of, n_streams, scale=0.5, ids=None):
+    """Whole sequences, one at a time per stream (the exact mode): stream r works through the sequences streams_of[r] in order;
+    a stream whose queue is empty is switched off.  Every frame of every stream is compared with the oracle."""
+    from _oracle import Oracle
+    o = Oracle()
+    ids = list(range(len(lengths))) if ids is None else ids  # which world / motion a sequence is
+    scenes = [o.scene_kitti(scale=scale, seed=100 + i) for i in ids]
+    for i, sc in zip(ids, scenes):
+        sc.speed_m = 0.6 + 0.04 * i                          # different motion per sequence
+    cfg = o.config_for_scene(scenes[0])
+    o.create(cfg, 0, n_streams)
+    g = hip.load()
+    g.create(cfg, 0, n_streams)
+    queue = [list(q) for q in streams_of]
+    cur = [q.pop(0) if q else -1 for q in queue]             # sequence a stream is working on
+    pos = [0] * n_streams
+    blank = np.zeros((cfg.rows, cfg.cols), np.uint8)
+    done_poses = {}
+    try:
+        for s in range(n_streams):
+            if cur[s] < 0:
+                o.set_stream_active(s, False); g.set_stream_active(s, False)
+        step = 0
+        while any(c >= 0 for c in cur):
+            imgs = [o.render(scenes[cur[s]], pos[s]) if cur[s] >= 0 else (blank, blank) for s in range(n_streams)]
+            L = np.stack([im[0] for im in imgs]); R = np.stack([im[1] for im in imgs])
+            o.process_host(L, R)
+            g.process_host(L, R)
+            for s in range(n_streams):
+                if cur[s] >= 0:
+                    compare_frame(o, g, s, step, "seq %d frame %d" % (cur[s], pos[s]))
+                    assert g.frame_info(s).frame_index == pos[s] + 1
+                    pos[s] += 1
+            for s in range(n_streams):
+                if cur[s] >= 0 and pos[s] == lengths[cur[s]]:          # sequence finished: keep its trajectory, take the next one
+                    pg, po = g.poses(s, 0, pos[s]), o.poses(s, 0, pos[s])
+                    assert np.abs(pg - po).max() <= 1e-9
+                    done_poses[cur[s]] = pg
+                    cur[s] = queue[s].pop(0) if queue[s] else -1
+                    pos[s] = 0
+                    if cur[s] >= 0:
+                        o.reset_stream(s); g.reset_stream(s)
+                    else:
+                        o.set_stream_active(s, False); g.set_stream_active(s, False)
+            step += 1
+        assert sorted(done_poses) == list(range(len(lengths)))
+        for i, n in enumerate(lengths):
+            assert done_poses[i].shape == (n, 3, 4)
+        # a finished stream keeps its last report while the others ran on
+        return done_poses, step
+    finally:
+        g.destroy()
+        o.destroy()
+
+
+def test_config3_four_sequences_one_per_stream_exact_mode():
+    # KITTI 00 / 02 / 05 / 06 have 4541 / 4661 / 2761 / 1101 frames; same proportions, 1/150 of the length
+    lengths = [30, 31, 18, 7]
+    ranks, load = sharding.plan_sequences(lengths, 4)
+    assert all(len(r) == 1 for r in ranks)
+    poses, steps = _run_exact(lengths, ranks, 4)
+    assert steps == max(lengths)
+
+
+def test_config5_sequences_queued_on_fewer_streams_exact_mode():
+    # eleven sequences (KITTI 00-10 proportions) on 4 streams, longest-processing-time first; streams restart with
+    # vslam_reset_stream between sequences and go idle when their queue is empty
+    kitti = [4541, 1101, 4661, 801, 271, 2761, 1101, 1101, 4071, 1591, 1201]
+    lengths = [max(3, n // 400) for n in kitti]
+    ranks, load = sharding.plan_sequences(lengths, 4)
+    poses, steps = _run_exact(lengths, ranks, 4, scale=0.4)
+    assert steps == max(load)
+    # the same sequence alone on a one-stream context gives the same trajectory (a queued stream carries nothing over)
+    single, _ = _run_exact([lengths[1]], [[0]], 1, scale=0.4, ids=[1])
+    np.testing.assert_array_equal(single[0], poses[1])

@@ -24,6 +24,10 @@ def test_aligner_known_answers(oracle, golden):
     pc.check_aligner(oracle, golden["aligner"])
 
 
+def test_aligner_stale_weights_known_answers(oracle, golden):
+    pc.check_aligner_weights(oracle, golden["aligner_weights"], oracle.default_config("kitti"))
+
+
 def test_aligner_uvd_known_answers(oracle, golden):
     pc.check_aligner_uvd(oracle, golden["aligner_uvd"])
 

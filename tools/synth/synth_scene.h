@@ -29,6 +29,10 @@ typedef struct synth_scene {
   double sway_m;         /* lateral sway amplitude                              */
   double sway_rate;      /* radians per frame of the sway                       */
   uint64_t seed;
+  double bob_m;          /* vertical bob amplitude (0.03 m in the KITTI-shaped scene)            */
+  double roll_amp, pitch_amp;   /* radians; 0 = planar motion (the KITTI-shaped scene)           */
+  double roll_rate, pitch_rate; /* radians per frame of the two oscillations                     */
+  double contrast;       /* texture amplitude factor (1 = the KITTI-shaped scene)                  */
 } synth_scene;
 
 SYNTH_HD uint32_t synth_hash(uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
@@ -39,8 +43,9 @@ SYNTH_HD uint32_t synth_hash(uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
   return (uint32_t)((z ^ (z >> 31)) >> 16);
 }
 
-/* camera-left-to-world pose of frame k: R (row-major 3x3), t.  Planar motion: forward along +z
- * with a sinusoidal lateral sway, heading tangent to the path, small vertical bob. */
+/* camera-left-to-world pose of frame k: R (row-major 3x3), t.  Forward along +z with a sinusoidal lateral
+ * sway, heading tangent to the path, small vertical bob; with roll_amp / pitch_amp != 0 the camera also rolls
+ * and pitches (6-DoF, the EuRoC-shaped scene): R = R_yaw * R_pitch * R_roll. */
 SYNTH_HD void synth_pose(const synth_scene* s, int k, double R[9], double t[3]) {
   const double a = s->sway_rate * (double)k;
   const double x = s->sway_m * sin(a);
@@ -51,8 +56,18 @@ SYNTH_HD void synth_pose(const synth_scene* s, int k, double R[9], double t[3]) 
   R[0] = cy; R[1] = 0; R[2] = sy;
   R[3] = 0;  R[4] = 1; R[5] = 0;
   R[6] = -sy; R[7] = 0; R[8] = cy;
+  if (s->roll_amp != 0.0 || s->pitch_amp != 0.0) {
+    const double pa = s->pitch_amp * sin(s->pitch_rate * (double)k), ra = s->roll_amp * sin(s->roll_rate * (double)k);
+    const double cp = cos(pa), sp = sin(pa), cr = cos(ra), sr = sin(ra);
+    /* pitch about x: [1 0 0; 0 cp -sp; 0 sp cp], roll about z: [cr -sr 0; sr cr 0; 0 0 1] */
+    const double P[9] = {1, 0, 0, 0, cp, -sp, 0, sp, cp};
+    const double Q[9] = {cr, -sr, 0, sr, cr, 0, 0, 0, 1};
+    double A[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) A[3 * i + j] = R[3 * i] * P[j] + R[3 * i + 1] * P[3 + j] + R[3 * i + 2] * P[6 + j];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[3 * i + j] = A[3 * i] * Q[j] + A[3 * i + 1] * Q[3 + j] + A[3 * i + 2] * Q[6 + j];
+  }
   t[0] = x;
-  t[1] = 0.03 * sin(0.37 * (double)k);
+  t[1] = s->bob_m * sin(0.37 * (double)k);
   t[2] = s->speed_m * (double)k;
 }
 
@@ -89,7 +104,7 @@ SYNTH_HD double synth_sample(const synth_scene* s, const double R[9], const doub
     if (w > 0.0) {
       const int64_t ia = (int64_t)floor(a / cell), ic = (int64_t)floor(c / cell);
       const uint32_t h = synth_hash(s->seed + 17 * (uint64_t)surf + 1000 * (uint64_t)o, (uint64_t)ia, (uint64_t)ic, 7);
-      acc += w * amp[o] * ((double)(h & 255u) - 127.5);
+      acc += s->contrast * (w * amp[o] * ((double)(h & 255u) - 127.5));
     }
     cell *= 2.0;
   }
@@ -133,5 +148,18 @@ SYNTH_HD void synth_default_kitti(synth_scene* s) {
   s->baseline_m = 0.5371657; /* 386.1448 / 718.856 */
   s->cam_height_m = 1.65; s->wall_half_m = 7.0; s->max_depth_m = 90.0; s->cell_m = 0.18;
   s->speed_m = 0.9; s->sway_m = 1.2; s->sway_rate = 0.05; s->seed = 7;
+  s->bob_m = 0.03; s->roll_amp = 0.0; s->pitch_amp = 0.0; s->roll_rate = 0.0; s->pitch_rate = 0.0; s->contrast = 1.0;
+}
+
+/* EuRoC-MH-shaped: 752x480, the cam0 intrinsics and 0.11 m baseline of configuration_euroc.yaml's data set, an indoor
+ * hall (walls 3 m either side, floor 1.2 m below, nothing beyond 25 m) and a slow 6-DoF MAV motion: <= 5 cm and
+ * <= 1 degree per frame (forward 4 cm, sway, bob, roll, pitch, heading along the path). */
+SYNTH_HD void synth_default_euroc(synth_scene* s) {
+  s->rows = 480; s->cols = 752;
+  s->fx = 458.654; s->fy = 457.296; s->cx = 367.215; s->cy = 248.375;
+  s->baseline_m = 0.11;
+  s->cam_height_m = 1.2; s->wall_half_m = 3.0; s->max_depth_m = 25.0; s->cell_m = 0.045;
+  s->speed_m = 0.04; s->sway_m = 0.2; s->sway_rate = 0.05; s->seed = 7;
+  s->bob_m = 0.02; s->roll_amp = 0.05; s->pitch_amp = 0.03; s->roll_rate = 0.11; s->pitch_rate = 0.07; s->contrast = 0.5;
 }
 #endif

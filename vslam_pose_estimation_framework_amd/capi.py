@@ -169,6 +169,12 @@ class CApi(object):
     def reset(self):
         self.check(self.fn("reset")(self.ctx))
 
+    def set_stream_active(self, stream, active=True):
+        self.check(self.fn("set_stream_active")(self.ctx, C.c_int(stream), C.c_int(1 if active else 0)))
+
+    def reset_stream(self, stream):
+        self.check(self.fn("reset_stream")(self.ctx, C.c_int(stream)))
+
     # -- whole frame --------------------------------------------------------------------------
     def process_host(self, left, right):
         """left/right: uint8 arrays [n_streams, rows, stride] (C-contiguous)."""
@@ -230,6 +236,24 @@ class CApi(object):
                                                  _p(H, C.c_double)))
         k = n.value
         return dict(chi=chi[:k].copy(), inlier=inl[:k].copy(), T=T.reshape(3, 4), H=H.reshape(6, 6))
+
+    def aligner_weights_of(self, stream=0):
+        """StereoUVAligner::_weights_translation as the stream's last initialize() left it."""
+        cap = int(self.cfg.max_points)
+        n = C.c_int32()
+        w = np.zeros(cap, np.float64)
+        self.check(self.fn("get_aligner_weights")(self.ctx, C.c_int(stream), C.c_int32(cap), C.byref(n), _p(w, C.c_double)))
+        return w[:n.value].copy()
+
+    def aligner_weights(self, cfg, sizes, inverse_depth, depth):
+        """Weights after each of a sequence of StereoUVAligner::initialize calls on one aligner (known-answer tests)."""
+        n = np.ascontiguousarray(sizes, np.int32); inv = np.ascontiguousarray(inverse_depth, np.int32)
+        d = np.ascontiguousarray(depth, np.float64)
+        out = np.zeros(max(int(n.sum()), 1), np.float64)
+        first = (self.ctx,) if self.prefix == "vslam_" else (C.byref(cfg),)
+        self.check(self.fn("aligner_weights")(*first, C.c_int32(n.shape[0]), _p(n, C.c_int32), _p(inv, C.c_int32), _p(d, C.c_double),
+                                              _p(out, C.c_double)))
+        return out[:int(n.sum())]
 
     def poses(self, stream, first, count):
         out = np.zeros((count, 12), np.float64)

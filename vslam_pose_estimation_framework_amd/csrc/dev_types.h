@@ -77,6 +77,7 @@ struct StreamState {
   int32_t by_appearance;                 // mode the candidate kernel must use for attempt 0
   int32_t n_trk, n_lost, n_tracked_landmarks;
   int32_t al_n, al_inliers, al_outliers, al_iterations, al_converged;
+  int32_t al_wsize;                      // size of StereoUVAligner::_weights_translation after the last initialize()
   double al_total_error;
   double al_T[12];
   double al_H[36];
@@ -98,8 +99,13 @@ struct ImgInfo {
   int32_t ticket;                         // k_emit: arrival counter of the stream's two per-image workgroups
 };
 
+#define VS_MAX_STREAMS 4096   // streams per context (one bit each in DevBuf::active)
 struct DevBuf {
   int32_t s0;          // first stream of the launch (streams are processed in independent groups)
+  // one bit per stream: a cleared bit makes every kernel skip the stream (its sequence has ended while other streams of
+  // the context still run: whole sequences of different lengths per stream, SURVEY.md 8e exact mode).  By value in the
+  // kernel arguments: a scalar load from the kernarg segment, no global round trip in the wide kernels.
+  uint32_t active[VS_MAX_STREAMS / 32];
   // current input images (device pointers)
   const uint8_t* img[2];
   int32_t img_row_stride;
@@ -158,3 +164,4 @@ struct DevBuf {
   double* h_cam;       // [..][MAXP][3]
   int32_t* h_prev;     // [..][MAXP]
 };
+__device__ __forceinline__ bool vs_active(const DevBuf& b, int s) { return (b.active[s >> 5] >> (s & 31)) & 1u; }

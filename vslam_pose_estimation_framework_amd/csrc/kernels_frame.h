@@ -246,6 +246,7 @@ __global__ __launch_bounds__(256, 8) void k_track_candidates(const DevCfg c, con
   // mode 0/1: stage path, window and distance exactly as set through vslam_set_tracker_state
   __shared__ CandWave cw[256 / VS_CGL];
   const int s = b.s0 + blockIdx.y;
+  if (!vs_active(b, s)) return;
   const StreamState& st = b.st[s];
   if (!st.has_prev) return;
   const int lane = threadIdx.x % VS_CGL, w = threadIdx.x / VS_CGL;
@@ -965,6 +966,16 @@ __device__ __forceinline__ void wg_align_converge(const DevCfg& c, const DevBuf&
   __syncthreads();
 }
 
+// _weights_translation of StereoUVAligner::initialize (stereouv_aligner.cpp:22,57-61).  The vector is a member of the aligner and
+// `resize(n, 1)` only initialises the elements it appends: with inverse depth enabled every weight is rewritten, without it the
+// first min(previous size, n) weights are whatever the previous initialize() left there — the Localizing frames after a
+// breakTrack (pose_tracker_3d.cpp:124) run with the inverse-depth weights of the last Tracking frame.  `old` is the stored
+// weight, `wprev` the vector's size before the call.
+__device__ __forceinline__ double al_weight_rule(bool inverse_depth, int u, int wprev, double old, double depth, double max_reliable) {
+  if (inverse_depth) return fmin(max_reliable / depth, 1.0);
+  return u < wprev ? old : 1.0;
+}
+
 // initialize (:10-69) on the tracked list, then converge
 __device__ __forceinline__ void wg_align(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_prev, bool inverse_depth,
                          const double* T_init) {
@@ -978,6 +989,9 @@ __device__ __forceinline__ void wg_align(const DevCfg& c, const DevBuf& b, int s
   double* fixed = b.al_fixed + (size_t)s * c.MAXP * 4;
   double* omega = b.al_omega + (size_t)s * c.MAXP;
   double* weight = b.al_weight + (size_t)s * c.MAXP;
+  const int wprev = b.st[s].al_wsize;
+  __syncthreads();
+  if (tid == 0) b.st[s].al_wsize = n;
   for (int u = tid; u < n; u += VS_WG) {
     const int ip = trk[4 * u], fl = trk[4 * u + 1], fr = trk[4 * u + 2];
     const int xL = kxyL[2 * fl], yL = kxyL[2 * fl + 1], xR = kxyR[2 * fr], yR = kxyR[2 * fr + 1];
@@ -993,7 +1007,7 @@ __device__ __forceinline__ void wg_align(const DevCfg& c, const DevBuf& b, int s
     omega[u] = om;
     double cam[3];
     triangulate(c, xL, yL, xR, yR, cam);
-    weight[u] = inverse_depth ? fmin(c.c.maximum_reliable_depth_meters / cam[2], 1.0) : 1.0;
+    weight[u] = al_weight_rule(inverse_depth, u, wprev, (!inverse_depth && u < wprev) ? weight[u] : 1.0, cam[2], c.c.maximum_reliable_depth_meters);
   }
   wg_align_converge(c, b, s, sh, n, T_init);
 }
@@ -1004,6 +1018,26 @@ __device__ __forceinline__ void wg_align(const DevCfg& c, const DevBuf& b, int s
 #else
 #define VS_ALIGN_BOUNDS __launch_bounds__(VS_WG)
 #endif
+// known-answer entry (vslam_aligner_weights): a sequence of initialize() calls on one aligner, weights after each call
+__global__ __launch_bounds__(256) void k_aligner_weights(int n_calls, const int32_t* n, const int32_t* inverse_depth, const double* depth,
+                                                          double max_reliable, double* weight, double* out) {
+  __shared__ int wsize;
+  if (threadIdx.x == 0) wsize = 0;
+  __syncthreads();
+  size_t off = 0;
+  for (int k = 0; k < n_calls; ++k) {
+    const int wprev = wsize, nk = n[k];
+    __syncthreads();
+    if (threadIdx.x == 0) wsize = nk;
+    for (int u = threadIdx.x; u < nk; u += blockDim.x) {
+      weight[u] = al_weight_rule(inverse_depth[k] != 0, u, wprev, weight[u], depth[off + u], max_reliable);
+      out[off + u] = weight[u];
+    }
+    off += (size_t)nk;
+    __syncthreads();
+  }
+}
+
 template <bool UVD>
 __global__ VS_ALIGN_BOUNDS void k_align_points(const DevCfg c, const DevBuf b, int n, const double* T_init) {
   __shared__ FrameShared sh;

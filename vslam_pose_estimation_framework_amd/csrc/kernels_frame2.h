@@ -298,6 +298,7 @@ __device__ __forceinline__ void wg_recover(const DevCfg& c, const DevBuf& b, int
 // fused path: BRIEF of the projected lost points of ALL streams, one wavefront each
 __global__ __launch_bounds__(256) void k_recover_brief(const DevCfg c, const DevBuf b) {
   const int s = b.s0 + blockIdx.y;
+  if (!vs_active(b, s)) return;
   const StreamState& st = b.st[s];
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
@@ -461,6 +462,7 @@ __device__ __forceinline__ void wg_update_points(const DevCfg& c, const DevBuf& 
 // fused path: one thread per framepoint of every stream
 __global__ __launch_bounds__(256) void k_update_landmarks(const DevCfg c, const DevBuf b) {
   const int s = b.s0 + blockIdx.y;
+  if (!vs_active(b, s)) return;
   StreamState& st = b.st[s];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = st.fc.n_cur;
@@ -824,6 +826,7 @@ __device__ __forceinline__ void wg_stereo(const DevCfg& c, const DevBuf& b, int 
 // wg_stereo's step A reads.  One thread per left feature.
 __global__ __launch_bounds__(256) void k_stereo_dist(const DevCfg c, const DevBuf b) {
   const int s = b.s0 + blockIdx.y;
+  if (!vs_active(b, s)) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int nL = b.n_kp[s * 2];
   if (i >= nL) return;
@@ -866,6 +869,7 @@ __global__ VS_FRAME_BOUNDS void k_frame(ConstDevCfg* cp, ConstDevBuf* bp, int ph
   __shared__ FrameShared sh;
   __shared__ __align__(16) unsigned char arena[VS_ARENA];
   const int s = b.s0 + blockIdx.x, tid = threadIdx.x;
+  if (!vs_active(b, s)) return;
   StreamState& st = b.st[s];
   vslam_frame_info& info = b.info[s];
   const int f = st.frame_count;             // index of the frame being processed
@@ -1113,6 +1117,7 @@ enum { VS_STAGE_TRACK = 1, VS_STAGE_ALIGN = 2, VS_STAGE_PRUNE_RECOVER = 3, VS_ST
 // WorldMap::createFrame + the bookkeeping PoseTracker3D::compute does before initialize() (:36-77)
 __global__ __launch_bounds__(256) void k_begin(const DevCfg c, const DevBuf b) {
   const int s = b.s0 + blockIdx.x, tid = threadIdx.x;
+  if (!vs_active(b, s)) return;
   StreamState& st = b.st[s];
   const int f = st.frame_count;
   if (st.has_prev) {
@@ -1135,6 +1140,7 @@ __global__ __launch_bounds__(VS_WG) void k_stage(const DevCfg c, const DevBuf b,
   __shared__ FrameShared sh;
   __shared__ __align__(16) unsigned char arena[VS_ARENA];
   const int s = b.s0 + blockIdx.x, tid = threadIdx.x;
+  if (!vs_active(b, s)) return;
   StreamState& st = b.st[s];
   vslam_frame_info& info = b.info[s];
   const int f = st.frame_count;

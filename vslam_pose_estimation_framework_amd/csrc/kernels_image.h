@@ -142,6 +142,7 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
   int tx, ty, tz;
   xcd_tile(&tx, &ty, &tz);
   const int s = b.s0 + (tz >> 1), side = tz & 1;
+  if (!vs_active(b, s)) return;
   const int x0 = tx * VS_TILE_W, y0 = ty * VS_TILE_H;
   const int rows = c.c.rows, cols = c.c.cols;
   const uint8_t* img = b.img[side] + (size_t)s * b.img_stream_stride;
@@ -355,6 +356,7 @@ __global__ __launch_bounds__(512, 4) void k_emit(const DevCfg c, const DevBuf b,
   __shared__ int sh_cnt[VSLAM_MAX_REGIONS];
   __shared__ int sh_last;
   const int s = b.s0 + blockIdx.x, tid = threadIdx.x;
+  if (!vs_active(b, s)) return;
   const int rows = c.c.rows, cols = c.c.cols, TX = c.TX, CW = c.CW;
   StreamState& st = b.st[s];
   if (tid < VSLAM_MAX_REGIONS) sh_cnt[tid] = 0;
@@ -539,6 +541,7 @@ __global__ __launch_bounds__(256) void k_brief(const DevCfg c, const DevBuf b) {
   int tx, ty, tz;
   xcd_tile(&tx, &ty, &tz);
   const int s = b.s0 + (tz >> 1), side = tz & 1;
+  if (!vs_active(b, s)) return;
   const int x0 = tx * VS_BT_W, y0 = ty * VS_BT_H;
   const int rows = c.c.rows;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -642,58 +645,106 @@ __global__ __launch_bounds__(256) void k_brief_at(const uint16_t* box, int bstri
 }
 
 // ==============================================================================================
-// K6: brute-force N x M 2-nearest-neighbours on 32-byte rows (Hamming on the bits, or squared L2 on
-// the bytes -> sqrt, which is what convertTo(CV_32F) + BFMatcher(NORM_L2) computes).  One query per
-// lane, 64-row train tiles broadcast from LDS, packed 64-bit keys (distance << 32 | index) keep
-// the "lowest index wins ties" order.  Distances are exact integers (L2: <= 32*255^2 < 2^24).
+// K6: brute-force N x M 2-nearest-neighbours on 32-byte rows — matcher->knnMatch(query, train, k = 2) of the use_matches block
+// (stereo_framepoint_generator.cpp:168-206).  The reference converts the descriptors to CV_32F and picks the norm with the
+// matcher type (:175-197): BRUTEFORCE = L2, BRUTEFORCE_L1, BRUTEFORCE_SL2 (squared L2), BRUTEFORCE_HAMMING on the bits.
+// All four distances are exact integers on bytes (L2^2 <= 32*255^2 < 2^24, so the float accumulation upstream is exact too);
+// L2 takes the float square root at the end.
+//
+// Layout: a workgroup owns 16 queries; every query is searched by a 16-lane group (four queries per wavefront), lane l of the
+// group taking train rows l, l+16, ... of each 256-row tile.  A tile is staged in LDS by one coalesced 32-byte row load per
+// thread (the next tile's loads are in flight while the current one is searched); the two 16-byte halves of a row are swapped
+// for rows 8..15 of every 16 so that the 16 lanes of a group read 16 rows from distinct banks, and the four groups of a
+// wavefront read the same addresses (broadcast).  Per pair: Hamming 8 x (xor, v_bcnt accumulate); L1 8 x v_sad_u8; L2 / SL2
+// ||q||^2 + ||t||^2 - 2 q.t with 8 x v_dot4_u32_u8 (the row norms are computed once while staging).  Each lane keeps its
+// best two as 64-bit keys (distance << 32 | row: the lowest index wins ties); the 16 lanes merge with 4 xor-shuffles.
 // ==============================================================================================
-__global__ __launch_bounds__(256) void k_knn2(int norm, int nq, const uint8_t* __restrict__ q, int nt,
-                                              const uint8_t* __restrict__ t, int32_t* idx, float* dist) {
-  __shared__ uint32_t tt[64][8];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+enum { VS_KNN_HAMMING = 0, VS_KNN_L2 = 1, VS_KNN_L1 = 2, VS_KNN_SL2 = 3 };
+#define VS_KNN_TILE 256
+__device__ __forceinline__ void knn_merge(unsigned long long& b0, unsigned long long& b1, unsigned long long c0, unsigned long long c1) {
+  const unsigned long long lo = b0 < c0 ? b0 : c0, hi = b0 < c0 ? c0 : b0, m = b1 < c1 ? b1 : c1;
+  b0 = lo; b1 = hi < m ? hi : m;
+}
+template <int NORM>
+__device__ __forceinline__ void knn2_body(int nq, const uint8_t* __restrict__ q, int nt, const uint8_t* __restrict__ t, int32_t* idx,
+                                          float* dist, uint4 (*tile)[2], uint32_t* tnorm) {
+  const int tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
+  const int i = blockIdx.x * 16 + grp;
+  const bool dotn = NORM == VS_KNN_L2 || NORM == VS_KNN_SL2;
   uint32_t qv[8];
-  if (i < nq) {
+  uint32_t qn = 0;
+  {
+    const uint4* qp = reinterpret_cast<const uint4*>(q + (size_t)32 * (i < nq ? i : nq - 1));
+    const uint4 a = qp[0], c = qp[1];
+    qv[0] = a.x; qv[1] = a.y; qv[2] = a.z; qv[3] = a.w; qv[4] = c.x; qv[5] = c.y; qv[6] = c.z; qv[7] = c.w;
+    if (dotn) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) qv[k] = reinterpret_cast<const uint32_t*>(q + (size_t)32 * i)[k];
+      for (int k = 0; k < 8; ++k) qn = __builtin_amdgcn_udot4(qv[k], qv[k], qn, false);
+    }
   }
   unsigned long long b0 = ~0ull, b1 = ~0ull;
-  for (int j0 = 0; j0 < nt; j0 += 64) {
-    __syncthreads();
-    for (int k = threadIdx.x; k < 64 * 8; k += blockDim.x) {
-      const int r = k >> 3, cc = k & 7;
-      tt[r][cc] = (j0 + r < nt) ? reinterpret_cast<const uint32_t*>(t + (size_t)32 * (j0 + r))[cc] : 0u;
-    }
-    __syncthreads();
-    if (i < nq) {
-      const int jn = min(64, nt - j0);
-      for (int r = 0; r < jn; ++r) {
-        uint32_t d = 0;
-        if (norm == 0) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) d += __popc(qv[k] ^ tt[r][k]);
-        } else {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const uint32_t a = qv[k], bb = tt[r][k];
-#pragma unroll
-            for (int sft = 0; sft < 32; sft += 8) {
-              const int e = (int)((a >> sft) & 255u) - (int)((bb >> sft) & 255u);
-              d += (uint32_t)(e * e);
-            }
-          }
-        }
-        const unsigned long long key = ((unsigned long long)d << 32) | (unsigned)(j0 + r);
-        if (key < b0) { b1 = b0; b0 = key; }
-        else if (key < b1) { b1 = key; }
+  uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0;
+  if (tid < nt) { const uint4* tp = reinterpret_cast<const uint4*>(t + (size_t)32 * tid); n0 = tp[0]; n1 = tp[1]; }
+  for (int j0 = 0; j0 < nt; j0 += VS_KNN_TILE) {
+    __syncthreads();                                   // the previous tile has been searched
+    {
+      const int sw = (tid >> 3) & 1;
+      tile[tid][sw] = n0; tile[tid][sw ^ 1] = n1;
+      if (dotn) {
+        uint32_t tn = 0;
+        tn = __builtin_amdgcn_udot4(n0.x, n0.x, tn, false); tn = __builtin_amdgcn_udot4(n0.y, n0.y, tn, false);
+        tn = __builtin_amdgcn_udot4(n0.z, n0.z, tn, false); tn = __builtin_amdgcn_udot4(n0.w, n0.w, tn, false);
+        tn = __builtin_amdgcn_udot4(n1.x, n1.x, tn, false); tn = __builtin_amdgcn_udot4(n1.y, n1.y, tn, false);
+        tn = __builtin_amdgcn_udot4(n1.z, n1.z, tn, false); tn = __builtin_amdgcn_udot4(n1.w, n1.w, tn, false);
+        tnorm[tid] = tn;
       }
     }
+    const int jn = j0 + VS_KNN_TILE;
+    if (jn + tid < nt) { const uint4* tp = reinterpret_cast<const uint4*>(t + (size_t)32 * (jn + tid)); n0 = tp[0]; n1 = tp[1]; }
+    __syncthreads();
+    const int cnt = min(VS_KNN_TILE, nt - j0);
+    for (int r = sub; r < cnt; r += 16) {
+      const int sw = (r >> 3) & 1;
+      const uint4 a = tile[r][sw], c = tile[r][sw ^ 1];
+      const uint32_t tv[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+      uint32_t d = 0;
+      if (NORM == VS_KNN_HAMMING) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d += __popc(qv[k] ^ tv[k]);
+      } else if (NORM == VS_KNN_L1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d = __builtin_amdgcn_sad_u8(qv[k], tv[k], d);
+      } else {
+        uint32_t dot = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dot = __builtin_amdgcn_udot4(qv[k], tv[k], dot, false);
+        d = qn + tnorm[r] - 2u * dot;
+      }
+      const unsigned long long key = ((unsigned long long)d << 32) | (unsigned)(j0 + r);
+      if (key < b0) { b1 = b0; b0 = key; }
+      else if (key < b1) { b1 = key; }
+    }
   }
-  if (i < nq) {
+#pragma unroll
+  for (int m = 1; m < 16; m <<= 1) {
+    const unsigned long long c0 = __shfl_xor(b0, m, 64), c1 = __shfl_xor(b1, m, 64);
+    knn_merge(b0, b1, c0, c1);
+  }
+  if (i < nq && sub == 0) {
     const bool h0 = b0 != ~0ull, h1 = b1 != ~0ull;
     idx[2 * i] = h0 ? (int32_t)(b0 & 0xFFFFFFFFull) : -1;
     idx[2 * i + 1] = h1 ? (int32_t)(b1 & 0xFFFFFFFFull) : -1;
     const float d0 = (float)(uint32_t)(b0 >> 32), d1 = (float)(uint32_t)(b1 >> 32);
-    dist[2 * i] = h0 ? (norm == 0 ? d0 : sqrtf(d0)) : 0.f;
-    dist[2 * i + 1] = h1 ? (norm == 0 ? d1 : sqrtf(d1)) : 0.f;
+    dist[2 * i] = h0 ? (NORM == VS_KNN_L2 ? sqrtf(d0) : d0) : 0.f;
+    dist[2 * i + 1] = h1 ? (NORM == VS_KNN_L2 ? sqrtf(d1) : d1) : 0.f;
   }
+}
+__global__ __launch_bounds__(256) void k_knn2(int norm, int nq, const uint8_t* __restrict__ q, int nt,
+                                              const uint8_t* __restrict__ t, int32_t* idx, float* dist) {
+  __shared__ uint4 tile[VS_KNN_TILE][2];
+  __shared__ uint32_t tnorm[VS_KNN_TILE];
+  if (norm == VS_KNN_HAMMING) knn2_body<VS_KNN_HAMMING>(nq, q, nt, t, idx, dist, tile, tnorm);
+  else if (norm == VS_KNN_L2) knn2_body<VS_KNN_L2>(nq, q, nt, t, idx, dist, tile, tnorm);
+  else if (norm == VS_KNN_L1) knn2_body<VS_KNN_L1>(nq, q, nt, t, idx, dist, tile, tnorm);
+  else knn2_body<VS_KNN_SL2>(nq, q, nt, t, idx, dist, tile, tnorm);
 }

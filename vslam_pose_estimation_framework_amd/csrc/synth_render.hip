@@ -25,6 +25,7 @@ extern "C" __attribute__((visibility("default"))) int synth_render_device(const 
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 extern "C" __attribute__((visibility("default"))) void synth_scene_default_kitti(synth_scene* s) { synth_default_kitti(s); }
+extern "C" __attribute__((visibility("default"))) void synth_scene_default_euroc(synth_scene* s) { synth_default_euroc(s); }
 extern "C" __attribute__((visibility("default"))) void synth_pose_host(const synth_scene* s, int k, double* c2w) {
   double R[9], t[3];
   synth_pose(s, k, R, t);

@@ -198,18 +198,34 @@ static void derive_cfg(const vslam_config& in, int n_streams, DevCfg* d) {
   d->n_streams = n_streams;
 }
 
+// PoseTracker3D::configure (pose_tracker_3d.cpp:11-21) + a fresh generator / aligner / world map for one stream
+static void fresh_stream_state(const vslam_ctx* c, StreamState& x) {
+  std::memset(&x, 0, sizeof x);
+  for (int r = 0; r < c->cfg.n_regions; ++r) x.thr[r] = c->cfg.c.detector_threshold_minimum;
+  x.status = VSLAM_LOCALIZING;
+  x.win = c->cfg.c.maximum_projection_tracking_distance_pixels;
+  x.tau_track = c->cfg.c.minimum_descriptor_distance_tracking;
+  x.tau_tri = 0.1 * 256;
+  tf_identity(x.prior);
+  tf_identity(x.pose);
+}
+static int upload_buffer_tables(vslam_ctx* c) {
+  const size_t G = c->groups.size();
+  std::vector<DevBuf> hb(2 * G);
+  for (int q = 0; q < 2; ++q) for (size_t g = 0; g < G; ++g) hb[q * G + g] = buf_set(c, q, c->groups[g].s0);
+  HIP_TRY(c, hipMemcpy(c->d_bufs, hb.data(), sizeof(DevBuf) * 2 * G, hipMemcpyHostToDevice));
+  return VSLAM_OK;
+}
 static int init_state(vslam_ctx* c) {
   std::vector<StreamState> st(c->B);
-  std::memset(st.data(), 0, sizeof(StreamState) * c->B);
-  for (int s = 0; s < c->B; ++s) {
-    StreamState& x = st[s];
-    for (int r = 0; r < c->cfg.n_regions; ++r) x.thr[r] = c->cfg.c.detector_threshold_minimum;
-    x.status = VSLAM_LOCALIZING;
-    x.win = c->cfg.c.maximum_projection_tracking_distance_pixels;
-    x.tau_track = c->cfg.c.minimum_descriptor_distance_tracking;
-    x.tau_tri = 0.1 * 256;
-    tf_identity(x.prior);
-    tf_identity(x.pose);
+  for (int s = 0; s < c->B; ++s) fresh_stream_state(c, st[s]);
+  bool all_active = true;
+  for (int s = 0; s < c->B; ++s) all_active = all_active && ((c->buf.active[s >> 5] >> (s & 31)) & 1u);
+  if (!all_active) {   // a reset of the whole context re-activates every stream
+    sync_all(c);
+    std::memset(c->buf.active, 0xff, sizeof c->buf.active);
+    int rc = upload_buffer_tables(c);
+    if (rc != VSLAM_OK) return rc;
   }
   HIP_TRY(c, hipMemcpyAsync(c->buf.st, st.data(), sizeof(StreamState) * c->B, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemsetAsync(c->buf.info, 0, sizeof(vslam_frame_info) * c->B, c->stream));
@@ -228,6 +244,7 @@ static int init_state(vslam_ctx* c) {
 
 static int create_internal(const vslam_config* cfg, int device, int n_streams, vslam_ctx** out) {
   if (!cfg || !out || n_streams < 1) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: null argument or n_streams < 1");
+  if (n_streams > VS_MAX_STREAMS) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: more than 4096 streams in one context");
   if (cfg->rows < 16 || cfg->cols < 16 || cfg->cols > 32767 || cfg->rows > 32767) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: invalid image dimensions");
   if (cfg->det_rows < 1 || cfg->det_cols < 1 || cfg->det_rows * cfg->det_cols > VSLAM_MAX_REGIONS) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: invalid detector grid");
   if (!(-cfg->baseline_h[0] / cfg->K[0] > 0)) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: invalid baseline (m), verify intrinsic camera parameters");
@@ -276,6 +293,7 @@ static int create_internal(const vslam_config* cfg, int device, int n_streams, v
   const DevCfg& d = c->cfg;
   DevBuf& b = c->buf;
   std::memset(&b, 0, sizeof b);
+  std::memset(b.active, 0xff, sizeof b.active);
   const size_t B = n_streams, S2 = B * 2, rows = cfg->rows, N = d.NMAX, P = d.MAXP, Hc = d.HCAP;
   hipError_t e = hipSuccess;
 #define A(field, count) if (e == hipSuccess) e = dalloc(c, &b.field, (count))
@@ -328,12 +346,10 @@ static int create_internal(const vslam_config* cfg, int device, int n_streams, v
   {
     // the frame kernel's view of the configuration and of the buffer table (image pointers excluded: it never reads them)
     const size_t G = c->groups.size();
-    std::vector<DevBuf> hb(2 * G);
-    for (int q = 0; q < 2; ++q) for (size_t g = 0; g < G; ++g) hb[q * G + g] = buf_set(c, q, c->groups[g].s0);
     e = dalloc(c, &c->d_cfg, 1);
     if (e == hipSuccess) e = dalloc(c, &c->d_bufs, 2 * G);
     if (e == hipSuccess) e = hipMemcpy(c->d_cfg, &c->cfg, sizeof(DevCfg), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(c->d_bufs, hb.data(), sizeof(DevBuf) * 2 * G, hipMemcpyHostToDevice);
+    if (e == hipSuccess && upload_buffer_tables(c) != VSLAM_OK) e = hipErrorUnknown;
     if (e != hipSuccess) {
       std::string msg = std::string("vslam_create: device tables: ") + hipGetErrorString(e);
       for (void* p : c->allocs) (void)hipFree(p);
@@ -376,6 +392,36 @@ VS_API int vslam_reset(vslam_ctx* c) {
   HIP_TRY(c, hipSetDevice(c->device));
   return init_state(c);
 }
+// ---- per-stream lifetime: whole sequences of different lengths on the streams of one context (exact mode) --------------
+VS_API int vslam_set_stream_active(vslam_ctx* c, int s, int active) {
+  if (!c) return VSLAM_ERR_INVALID;
+  if (s < 0 || s >= c->B) return fail(c, VSLAM_ERR_INVALID, "stream index out of range");
+  if (c->frame_begun) return fail(c, VSLAM_ERR_STATE, "vslam_set_stream_active called inside a frame (between vslam_frame_begin and vslam_stereo_new)");
+  const uint32_t bit = 1u << (s & 31);
+  const bool was = (c->buf.active[s >> 5] & bit) != 0;
+  if (was == (active != 0)) return VSLAM_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  sync_all(c);                       // the buffer tables in flight still carry the old mask
+  if (active) c->buf.active[s >> 5] |= bit; else c->buf.active[s >> 5] &= ~bit;
+  return upload_buffer_tables(c);
+}
+VS_API int vslam_reset_stream(vslam_ctx* c, int s) {
+  if (!c) return VSLAM_ERR_INVALID;
+  if (s < 0 || s >= c->B) return fail(c, VSLAM_ERR_INVALID, "stream index out of range");
+  if (c->frame_begun) return fail(c, VSLAM_ERR_STATE, "vslam_reset_stream called inside a frame");
+  HIP_TRY(c, hipSetDevice(c->device));
+  sync_all(c);
+  StreamState x;
+  fresh_stream_state(c, x);
+  HIP_TRY(c, hipMemcpy(c->buf.st + s, &x, sizeof x, hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemset(c->buf.info + s, 0, sizeof(vslam_frame_info)));
+  HIP_TRY(c, hipMemset(c->buf.n_points + s * 2, 0, sizeof(int32_t) * 2));
+  for (int q = 0; q < 2; ++q) {
+    HIP_TRY(c, hipMemset(c->sets[q].n_kp + s * 2, 0, sizeof(int32_t) * 2));
+    HIP_TRY(c, hipMemset(c->sets[q].iinfo + s, 0, sizeof(ImgInfo)));
+  }
+  return VSLAM_OK;
+}
 VS_API int vslam_set_hip_stream(vslam_ctx* c, void* s) {
   if (!c) return VSLAM_ERR_INVALID;
   sync_all(c);
@@ -394,9 +440,7 @@ VS_API int vslam_set_hip_stream(vslam_ctx* c, void* s) {
   c->stream = q.st_frm; c->stream_img = q.st_img;
   c->own_stream = false;
   // the frame kernel's buffer table for the single group
-  DevBuf hb[2] = {buf_set(c, 0, 0), buf_set(c, 1, 0)};
-  HIP_TRY(c, hipMemcpy(c->d_bufs, hb, sizeof hb, hipMemcpyHostToDevice));
-  return VSLAM_OK;
+  return upload_buffer_tables(c);
 }
 VS_API int vslam_synchronize(vslam_ctx* c) {
   if (!c) return VSLAM_ERR_INVALID;
@@ -611,6 +655,46 @@ VS_API int vslam_get_aligner_result(vslam_ctx* c, int s, int32_t cap, int32_t* n
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (T) std::memcpy(T, st.al_T, sizeof(double) * 12);
   if (H) std::memcpy(H, st.al_H, sizeof(double) * 36);
+  return VSLAM_OK;
+}
+VS_API int vslam_get_aligner_weights(vslam_ctx* c, int s, int32_t cap, int32_t* n, double* weight) {
+  int rc = check_stream(c, s);
+  if (rc) return rc;
+  if (!n) return fail(c, VSLAM_ERR_INVALID, "bad argument");
+  StreamState st;
+  HIP_TRY(c, d2h(c, &st, c->buf.st + s, 1));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  *n = st.al_wsize;
+  if (st.al_wsize > cap) return fail(c, VSLAM_ERR_CAPACITY, "aligner weight output capacity too small");
+  HIP_TRY(c, d2h(c, weight, c->buf.al_weight + (size_t)s * c->cfg.MAXP, (size_t)st.al_wsize));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return VSLAM_OK;
+}
+VS_API int vslam_aligner_weights(vslam_ctx* c, int32_t n_calls, const int32_t* n, const int32_t* inverse_depth, const double* depth, double* out) {
+  if (!c) return VSLAM_ERR_INVALID;
+  if (c->sticky != VSLAM_OK) return c->sticky;
+  if (n_calls < 0 || (n_calls && (!n || !inverse_depth))) return fail(c, VSLAM_ERR_INVALID, "aligner_weights: bad argument");
+  size_t total = 0; int nmax = 0;
+  for (int k = 0; k < n_calls; ++k) { if (n[k] < 0) return fail(c, VSLAM_ERR_INVALID, "aligner_weights: negative size"); total += (size_t)n[k]; nmax = std::max(nmax, n[k]); }
+  if (total && (!depth || !out)) return fail(c, VSLAM_ERR_INVALID, "aligner_weights: bad argument");
+  if (!n_calls || !total) return VSLAM_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  int32_t *dn = nullptr, *di = nullptr; double *dd = nullptr, *dw = nullptr, *dout = nullptr;
+  hipError_t e = hipMalloc((void**)&dn, (size_t)n_calls * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&di, (size_t)n_calls * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&dd, total * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&dw, (size_t)nmax * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&dout, total * 8);
+  if (e == hipSuccess) e = hipMemcpyAsync(dn, n, (size_t)n_calls * 4, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(di, inverse_depth, (size_t)n_calls * 4, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dd, depth, total * 8, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_aligner_weights, dim3(1), dim3(256), 0, c->stream, n_calls, dn, di, dd, c->cfg.c.maximum_reliable_depth_meters, dw, dout);
+    e = hipMemcpyAsync(out, dout, total * 8, hipMemcpyDeviceToHost, c->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(dn); (void)hipFree(di); (void)hipFree(dd); (void)hipFree(dw); (void)hipFree(dout);
+  if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   return VSLAM_OK;
 }
 // ---- RGB-D components (DepthFramePointGenerator pieces, stand-alone) ------------------------------------------------
@@ -1184,7 +1268,7 @@ VS_API int vslam_brief_describe(vslam_ctx* c, const uint8_t* img, int32_t rows, 
   return rc;
 }
 VS_API int vslam_knn2(vslam_ctx* c, int norm, int32_t nq, const uint8_t* q, int32_t nt, const uint8_t* t, int32_t* idx, float* dist) {
-  if (!c || !q || !t || !idx || !dist || nq < 0 || nt < 0 || norm < 0 || norm > 1) return VSLAM_ERR_INVALID;
+  if (!c || !q || !t || !idx || !dist || nq < 0 || nt < 0 || norm < 0 || norm > 3) return VSLAM_ERR_INVALID;
   if (nq == 0) return VSLAM_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   uint8_t *dq = nullptr, *dt = nullptr; int32_t* di = nullptr; float* dd = nullptr;
@@ -1195,7 +1279,7 @@ VS_API int vslam_knn2(vslam_ctx* c, int norm, int32_t nq, const uint8_t* q, int3
   if (e == hipSuccess) e = hipMemcpyAsync(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess && nt) e = hipMemcpyAsync(dt, t, (size_t)nt * 32, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_knn2, dim3((nq + 255) / 256), dim3(256), 0, c->stream, norm, nq, dq, nt, dt, di, dd);
+    hipLaunchKernelGGL(k_knn2, dim3((nq + 15) / 16), dim3(256), 0, c->stream, norm, nq, dq, nt, dt, di, dd);
     e = hipMemcpyAsync(idx, di, (size_t)nq * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
   }
   if (e == hipSuccess) e = hipMemcpyAsync(dist, dd, (size_t)nq * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream);

@@ -18,7 +18,8 @@ class SynthScene(C.Structure):
                 ("cx", C.c_double), ("cy", C.c_double), ("baseline_m", C.c_double),
                 ("cam_height_m", C.c_double), ("wall_half_m", C.c_double), ("max_depth_m", C.c_double),
                 ("cell_m", C.c_double), ("speed_m", C.c_double), ("sway_m", C.c_double),
-                ("sway_rate", C.c_double), ("seed", C.c_uint64)]
+                ("sway_rate", C.c_double), ("seed", C.c_uint64), ("bob_m", C.c_double), ("roll_amp", C.c_double),
+                ("pitch_amp", C.c_double), ("roll_rate", C.c_double), ("pitch_rate", C.c_double), ("contrast", C.c_double)]
 
 
 class Synth(object):
@@ -31,6 +32,12 @@ class Synth(object):
     def scene_kitti(self, seed=7):
         s = SynthScene()
         self.lib.synth_scene_default_kitti(C.byref(s))
+        s.seed = seed
+        return s
+
+    def scene_euroc(self, seed=7):
+        s = SynthScene()
+        self.lib.synth_scene_default_euroc(C.byref(s))
         s.seed = seed
         return s
 
