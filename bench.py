@@ -1,21 +1,28 @@
 #!/usr/bin/env python3
 """bench.py — stereo frames/s of the hot path (FAST+BRIEF+stereo/temporal matching+StereoUVAligner) on MI355X.
 
-One "step" = one pass of the whole per-frame hot path over a batch of B stereo pairs: one pair for each of
-the B streams (chunks of the sequence) a GPU owns.  Workload (BASELINE.json configs[1]): KITTI-00-shaped
-synthetic sequence (1241x376, 4541 frames), configuration_kitti.yaml values (bin 15 -> ~2158 keypoints per
-image), cut into B contiguous chunks that start `overlap` frames early.  With N GPUs every
-rank owns B further chunks (weak scaling: per-GPU work fixed), no data-path collective; the only exchange
-is one all-gather of the per-frame 3x4 poses at the end of the timed region.
+One "step" = one pass of the whole per-frame hot path over a batch of B stereo pairs: one pair for each of the B
+streams a GPU owns.
 
-Prints ONE JSON line on rank 0.  `value` counts unique frames only: B*N*K/t * L/(L+overlap).  Exactly K steps are
-timed for any K: the job is L+overlap steps long (the default K) and starts over (reset, rewind) when K exceeds it.
-"""
+--mode chunks (default; BASELINE.json configs[1]): KITTI-00-shaped synthetic sequence (1241x376, 4541 frames),
+  configuration_kitti.yaml values (bin 15 -> target 2158 keypoints per image), cut into B contiguous chunks that start
+  `overlap` frames early.  The chunks run as a steady-state pipeline: stream s is `phase_s` frames into
+  its chunk when the timed region starts and restarts (vslam_reset_stream, asynchronous) whenever its chunk ends, so ANY
+  window of K steps sees the stationary mix of warm-up and unique frames.  `value` counts only the unique frames
+  (frames inside their chunk's own range) produced inside the timed region.  With N GPUs every rank owns B further
+  chunks (weak scaling), no data-path collective; one all-gather of the per-step 3x4 poses ends the timed region.
+--mode sequences (configs[2] / configs[4], the exact mode): whole KITTI-shaped sequences, one per stream, assigned to
+  ranks longest first (sharding.plan_sequences); N = 4: 00+02+05+06, otherwise 00..10 (with --bin 11 for config #5).
+
+Prints ONE JSON line on rank 0.  At N = 1 the line also carries: `exact_mode` (whole sequences per stream),
+`pcie_inclusive` (host images through vslam_process_host), `cpu_baseline` (the oracle on the host cores)."""
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -26,22 +33,33 @@ import torch  # noqa: E402
 
 from vslam_pose_estimation_framework_amd import hip, sharding, synth  # noqa: E402
 
-SEQ_FRAMES = 4541          # KITTI odometry sequence 00
+KITTI_FRAMES = [4541, 1101, 4661, 801, 271, 2761, 1101, 1101, 4071, 1591, 1201]   # odometry sequences 00..10
+SEQ_FRAMES = KITTI_FRAMES[0]
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PMC_SUMMARY = "r01_h_pmc_traffic.json"   # tools/pmc_traffic.sh of this build (rocprofv3 --pmc, separate passes)
+PMC_SUMMARY = "r02_pmc_traffic.json"   # tools/pmc_traffic.sh of this build (rocprofv3 --pmc, separate passes)
+METRIC = "stereo frames/sec on KITTI-00 at 1/2/4/8 MI355X; ATE vs reference"
+KERNELS = ["k_fast_box", "k_emit", "k_brief", "k_track_candidates", "k_frame", "k_recover_brief", "k_update_landmarks", "k_stereo_dist"]
 
 
-def load_oracle():
-    """CPU oracle, used ONLY for the cpu_baseline leg (timing + sample parity check)."""
-    so = os.path.join(ROOT, "oracle", "libvslam_oracle.so")
+def load_oracle(native=False):
+    """CPU oracle, used ONLY for the cpu_baseline leg (timing + sample parity check).  native: a -march=native build made on
+    this host; falls back to the portable build that travelled with the repository."""
+    from vslam_pose_estimation_framework_amd.capi import CApi
+    odir = os.path.join(ROOT, "oracle")
+    if native:
+        so = os.path.join(odir, "libvslam_oracle_native.so")
+        try:
+            subprocess.check_call(["g++", "-O3", "-march=native", "-std=c++14", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
+                                   "-shared", "-o", so, os.path.join(odir, "vslam_oracle.cpp")], stderr=subprocess.DEVNULL, timeout=180)
+            return CApi(so, "orc_"), "-O3 -march=native"
+        except (OSError, subprocess.SubprocessError):
+            pass
+    so = os.path.join(odir, "libvslam_oracle.so")
     try:
-        from vslam_pose_estimation_framework_amd.capi import CApi
-        return CApi(so, "orc_")
+        return CApi(so, "orc_"), "-O3 -march=x86-64-v3"
     except OSError:
-        import subprocess
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "-B"])
-        from vslam_pose_estimation_framework_amd.capi import CApi
-        return CApi(so, "orc_")
+        subprocess.check_call(["make", "-C", odir, "-s", "-B"])
+        return CApi(so, "orc_"), "-O3 -march=x86-64-v3"
 
 
 def algorithmic_bytes(cfg, B, stats):
@@ -51,165 +69,197 @@ def algorithmic_bytes(cfg, B, stats):
     per_frame = {
         "k_fast_box": 2 * W * H,                                   # each image byte read once
         "k_emit": 2 * W * H / 8 + 2 * N * 5,                        # corner masks in, keypoints out
-        "k_brief": 2 * N * (4 + 32) + 2 * N * 512 * 2,             # keypoints in, descriptors out, 512 u16 taps
+        "k_brief": 2 * N * (4 + 32),                                # keypoints in, descriptors out (§8d: 2·N·36)
         "k_track_candidates": P * (24 + 32) + P * 32 * 4,           # previous points + in-window descriptors
         "k_frame": P * (24 + 64 + 8) + P * 64 + I * M * 64 + M * 9 + 2 * N * 32 + 96,
-        "k_recover_brief": P * 0.5 * (64 + 2 * 512 * 2),               # lost points: previous descriptors + 2 x 512 taps
+        "k_recover_brief": P * 0.5 * 64,                               # lost points: previous descriptors
         "k_update_landmarks": M * (24 + 8) * 4,                        # a few measurements per tracked point
         "k_stereo_dist": 2 * N * 32 + N * 16,                          # descriptors in, 16 distances per left feature out
     }
     return {k: v * B for k, v in per_frame.items()}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=0, help="timed steps (0 = the whole chunked job)")
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("VSLAM_BENCH_STREAMS", "160")))
-    ap.add_argument("--overlap", type=int, default=10, help="warm-up frames per chunk (SURVEY.md 8e default)")
-    ap.add_argument("--cpu-frames", type=int, default=240)
-    ap.add_argument("--no-cpu", action="store_true")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    # one rank per GPU (RCCL).  VSLAM_BENCH_BACKEND=gloo is a rehearsal aid only: several ranks on the one GPU of a
-    # test box, same code path, the single all-gather staged through the host
-    backend = os.environ.get("VSLAM_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    if world > 1:
-        import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-
-    B = args.streams
-    overlap = args.overlap
-    L = -(-SEQ_FRAMES // B)                      # unique frames per chunk
-    job_steps = L + overlap
-    K = args.steps if args.steps > 0 else job_steps
-    KB = min(K, job_steps)                       # frames held per chunk; K > job_steps: the job is run again (reset + rewind)
-    W = max(0, args.warmup)
-
-    api = hip.load()
-    sy = synth.Synth()
-    scene = sy.scene_kitti(seed=7)
-    cfg = synth.config_for_scene(api, scene, "kitti")
-    cfg.max_keypoints = 8192
-    cfg.max_points = 4096
-    cfg.max_history_frames = job_steps + 2
-    stride = ((cfg.cols + 63) // 64) * 64
-    img_bytes = cfg.rows * stride
-
-    # ---- inputs resident in HBM: [step][stream][rows][stride] --------------------------------------------
-    Lbuf = torch.empty((KB, B, cfg.rows, stride), dtype=torch.uint8, device=dev)
-    Rbuf = torch.empty((KB, B, cfg.rows, stride), dtype=torch.uint8, device=dev)
-    starts = []
-    for s in range(B):
-        gc = rank * B + s                        # global chunk index; rank r continues the virtual sequence
-        start = max(0, gc * L - overlap)
-        starts.append(start)
-        sy.render_device(scene, start, KB, Lbuf[0, s].data_ptr(), Rbuf[0, s].data_ptr(), stride, B * img_bytes,
-                         torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
-
-    api.create(cfg, dev_index, B)
-
-    def run_steps(n):
-        for k in range(n):
-            j = k % KB
-            if j == 0 and k > 0:
-                api.reset()                          # the whole job again: every chunk re-localises from its first frame
-            api.process_device(Lbuf[j].data_ptr(), Rbuf[j].data_ptr(), stride, img_bytes)
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-
-    # ---- warm-up (untimed), then the timed region ---------------------------------------------------------
-    run_steps(min(W, K))
-    api.synchronize()
-    api.reset()
-    pose_send = torch.zeros((B, KB, 12), dtype=torch.float64, device=dev)
-    sharding.gather_poses(pose_send)              # untimed: RCCL sets its all-gather channels up on first use
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(K)
-    api.copy_poses_device(0, min(KB, ((K - 1) % KB) + 1), pose_send.data_ptr())
-    api.synchronize()
-    all_poses = sharding.gather_poses(pose_send)          # RCCL all-gather (no-op for one GPU)
-    torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    # ---- frame statistics of the timed pass (sizes the algorithmic-byte figures) ----------------------------
-    infos = [api.frame_info(s) for s in range(B)]
-    flags = max(fi.error_flags for fi in infos)
-    stats = {
+def frame_stats(api, streams):
+    infos = [api.frame_info(s) for s in streams]
+    return {
         "N": float(np.mean([0.5 * (fi.n_keypoints_left + fi.n_keypoints_right) for fi in infos])),
         "P": float(np.mean([fi.n_points for fi in infos])),
         "M": float(np.mean([fi.n_tracked for fi in infos])),
         "I": float(np.mean([max(fi.aligner_iterations, 1) for fi in infos])),
-    }
+    }, max(fi.error_flags for fi in infos)
 
-    # ---- instrumented pass: per-kernel device time with HIP events on the context stream ----------------------
-    api.reset()
-    api.enable_timers(True)
-    run_steps(K)
-    api.synchronize()
+
+def kernel_report(api, cfg, B, stats, launches_per_step_hint):
     ktimes = api.kernel_times()
-    chrono = api.timers()
-    api.enable_timers(False)
+    groups = max(1, launches_per_step_hint)
+    abytes = algorithmic_bytes(cfg, B / groups, stats)
+    kern = {}
+    for name, (ms, n) in ktimes.items():
+        if n <= 0:
+            continue
+        avg_ms = ms / n
+        kern[name] = {"avg_ms": round(avg_ms, 4), "launches": n,
+                      "achieved_GBs": round(abytes[name] / (avg_ms * 1e-3) / 1e9, 2) if avg_ms > 0 else None}
+    dom = max(ktimes.items(), key=lambda kv: kv[1][0])[0]
+    dom_avg_s = ktimes[dom][0] / max(ktimes[dom][1], 1) * 1e-3
+    return kern, dom, dom_avg_s, abytes
 
-    out = None
-    if rank == 0:
-        frames_per_step = B * world
-        eff = L / float(L + overlap)
-        value = frames_per_step * K / elapsed * eff
-        # the context processes its streams in G independent groups: one launch covers B/G streams
-        groups = max(1, ktimes["k_frame"][1] // max(K, 1))
-        abytes = algorithmic_bytes(cfg, B / groups, stats)
-        kern = {}
-        for name, (ms, n) in ktimes.items():
-            avg_ms = ms / max(n, 1)
-            kern[name] = {"avg_ms": round(avg_ms, 4), "launches": n,
-                          "achieved_GBs": round(abytes[name] / (avg_ms * 1e-3) / 1e9, 2) if avg_ms > 0 else None}
-        kern = {k_: v_ for k_, v_ in kern.items() if v_["launches"] > 0}
-        dom = max(ktimes.items(), key=lambda kv: kv[1][0])[0]
-        # HBM traffic of the dominant kernel: PMC counters cannot be read in-process; taken from the committed
-        # rocprofv3 --pmc summary (separate FETCH_SIZE / WRITE_SIZE passes of this same command) when it matches B
+
+class Bench(object):
+    def __init__(self, args):
+        self.args = args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+        # one rank per GPU (RCCL).  VSLAM_BENCH_BACKEND=gloo is a rehearsal aid only: several ranks on the one GPU of a
+        # test box, same code path, the single all-gather staged through the host
+        self.backend = os.environ.get("VSLAM_BENCH_BACKEND", "nccl")
+        self.dev_index = local_rank if self.backend == "nccl" else local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(self.dev_index)
+        self.dev = torch.device("cuda", self.dev_index)
+        if self.world > 1:
+            import torch.distributed as dist
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend)
+        self.sy = synth.Synth()
+        self.scene = self.sy.scene_kitti(seed=7)
+        self.api = hip.load()
+        self.cfg = synth.config_for_scene(self.api, self.scene, "kitti")
+        self.cfg.bin_size_pixels = args.bin
+        self.cfg.max_keypoints = 8192 if args.bin >= 15 else 16384
+        self.cfg.max_points = 4096 if args.bin >= 15 else 8192
+        self.stride = ((self.cfg.cols + 63) // 64) * 64
+        self.img_bytes = self.cfg.rows * self.stride
+
+    def barrier(self):
+        if self.world > 1:
+            torch.distributed.barrier()
+
+    def max_over_ranks(self, seconds):
+        if self.world > 1:
+            tt = torch.tensor([seconds], dtype=torch.float64, device=self.dev)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            return float(tt.item())
+        return seconds
+
+    def sum_over_ranks(self, value):
+        if self.world > 1:
+            tt = torch.tensor([float(value)], dtype=torch.float64, device=self.dev)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.SUM)
+            return float(tt.item())
+        return float(value)
+
+    def render(self, scene, first, n, L, R, s, n_slots):
+        """frames first..first+n-1 of `scene` into slabs 0..n-1 of L/R [slab][stream] at stream slot s."""
+        self.sy.render_device(scene, first, n, L[0, s].data_ptr(), R[0, s].data_ptr(), self.stride, n_slots * self.img_bytes,
+                              torch.cuda.current_stream().cuda_stream)
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def run_chunks(self):
+        a, api, cfg = self.args, self.api, self.cfg
+        B, overlap, world, rank = a.streams, a.overlap, self.world, self.rank
+        L = -(-SEQ_FRAMES // B)                      # unique frames per chunk
+        J = L + overlap                              # steps of one chunk job
+        K = a.steps if a.steps > 0 else J
+        W = max(0, a.warmup)
+        cfg.max_history_frames = J + 2
+        # chunk of stream s: global chunk gc = rank*B + s (rank r continues the virtual sequence), frames start..start+J-1,
+        # of which [gc*L, (gc+1)*L) are its own.  phase_s staggers the streams over the job.
+        starts, first_unique, phase = [], [], []
+        for s in range(B):
+            gc = rank * B + s
+            starts.append(max(0, gc * L - overlap))
+            first_unique.append(gc * L)
+            phase.append((s * J) // B)
+        # inputs resident in HBM: slab j, stream s = chunk frame (j + phase_s) % J of stream s
+        Lbuf = torch.empty((J, B, cfg.rows, self.stride), dtype=torch.uint8, device=self.dev)
+        Rbuf = torch.empty_like(Lbuf)
+        for s in range(B):
+            p = phase[s]
+            self.render(self.scene, starts[s] + p, J - p, Lbuf, Rbuf, s, B)                    # slabs 0 .. J-p-1
+            if p:
+                self.render(self.scene, starts[s], p, Lbuf[J - p:], Rbuf[J - p:], s, B)        # slabs J-p .. J-1
+        torch.cuda.synchronize()
+        api.create(cfg, self.dev_index, B)
+        counter = [0]
+
+        def run_steps(n):
+            for _ in range(n):
+                k = counter[0]
+                j = k % J
+                for s in range(B):
+                    if (j + phase[s]) % J == 0 and k > 0:
+                        api.reset_stream(s)              # the stream's chunk starts over: a fresh sequence, queued asynchronously
+                api.process_device(Lbuf[j].data_ptr(), Rbuf[j].data_ptr(), self.stride, self.img_bytes)
+                counter[0] = k + 1
+
+        def unique_in(k0, n):
+            """frames inside their chunk's own range among steps k0 .. k0+n-1"""
+            cnt = 0
+            for k in range(k0, k0 + n):
+                for s in range(B):
+                    f = starts[s] + (k + phase[s]) % J
+                    if first_unique[s] <= f < min(first_unique[s] + L, SEQ_FRAMES * world):
+                        cnt += 1
+            return cnt
+
+        # pre-roll: every stream passes one restart so that the timed region starts in the pipeline's steady state
+        preroll = J
+        run_steps(preroll + W)
+        api.synchronize()
+        pose_send = torch.zeros((K, B, 12), dtype=torch.float64, device=self.dev)
+        sharding.gather_poses(pose_send)              # untimed: RCCL sets its all-gather channels up on first use
+        self.barrier()
+        torch.cuda.synchronize()
+        k_first = counter[0]
+        t0 = time.perf_counter()
+        for i in range(K):
+            run_steps(1)
+            api.copy_current_poses_device(pose_send[i].data_ptr())
+        api.synchronize()
+        sharding.gather_poses(pose_send)              # RCCL all-gather of the per-step poses (no-op for one GPU)
+        torch.cuda.synchronize()
+        self.barrier()
+        elapsed = self.max_over_ranks(time.perf_counter() - t0)
+        unique = self.sum_over_ranks(unique_in(k_first, K))
+        stats, flags = frame_stats(api, range(B))
+
+        # instrumented pass: per-kernel device time with HIP events on the context's HIP streams
+        api.enable_timers(True)
+        run_steps(K)
+        api.synchronize()
+        kern, dom, dom_avg_s, abytes = kernel_report(api, cfg, B, stats, 1)
+        chrono = api.timers()
+        api.enable_timers(False)
+        self.Lbuf, self.Rbuf, self.J, self.B = Lbuf, Rbuf, J, B
+        self.starts, self.phase = starts, phase
+        if rank != 0:
+            return None
         traffic = None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", PMC_SUMMARY)))
-            if B == 160 and groups == 1 and dom in pm["per_launch_KB"]:
+            if B == pm.get("streams", 160) and dom in pm["per_launch_KB"]:
                 traffic = int((pm["per_launch_KB"][dom]["FETCH_SIZE"] + pm["per_launch_KB"][dom]["WRITE_SIZE"]) * 1024)
         except (OSError, KeyError, ValueError):
             pass
-        dom_avg_s = ktimes[dom][0] / max(ktimes[dom][1], 1) * 1e-3
         achieved = abytes[dom] / dom_avg_s / 1e9
-        out = {
-            "metric": "stereo frames/sec on KITTI-00 at 1/2/4/8 MI355X; ATE vs reference",
-            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+        frames = B * world * K
+        return {
+            "metric": METRIC, "value": round(unique / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "frames_processed": frames, "unique_frames_timed": int(unique), "raw_pairs_per_s": round(frames / elapsed, 1),
             "config": {"workload": "KITTI-00-shaped synthetic stereo (1241x376, 4541 frames), configuration_kitti.yaml "
-                                   "values, bin 15 (target 2158 kp/image), FAST+BRIEF-32, open loop",
-                       "streams_per_gpu": B, "chunk_frames": L, "chunk_overlap": overlap,
-                       "frames_per_step": frames_per_step, "stream_groups": groups, "streams_per_launch": B // groups,
-                       "unique_frame_fraction": round(eff, 4),
+                                   "values, bin %d (target %d kp/image), FAST+BRIEF-32, open loop; chunks as a steady-state "
+                                   "pipeline (streams staggered over the %d-step chunk job, restart when a chunk ends)"
+                                   % (a.bin, (cfg.cols // a.bin + 1) * (cfg.rows // a.bin + 1), J),
+                       "mode": "chunks", "streams_per_gpu": B, "chunk_frames": L, "chunk_overlap": overlap, "chunk_job_steps": J,
+                       "preroll_steps": preroll, "frames_per_step": B * world,
+                       "unique_frame_fraction": round(unique / frames, 4),
                        "parallelism": "frame-sharded chunks, %d per GPU x %d GPU" % (B, world),
                        "mean_keypoints_per_image": round(stats["N"], 1), "mean_points_per_frame": round(stats["P"], 1),
                        "mean_tracked": round(stats["M"], 1), "mean_aligner_iterations": round(stats["I"], 1),
@@ -221,49 +271,252 @@ def main():
             "chronometers_s": {k: round(v, 4) for k, v in chrono.items()},
         }
 
-    # ---- CPU baseline: the oracle (a port of the reference path) on a bounded sample, rank 0, N=1 only ---------
-    if rank == 0 and world == 1 and not args.no_cpu:
-        orc = load_oracle()
-        n_chunks = max(1, min(B, args.cpu_frames // KB)) if KB <= args.cpu_frames else 1
-        per_chunk = min(KB, args.cpu_frames)
-        orc.create(cfg, 0, 1)
+    # ------------------------------------------------------------------------------------------------------------------
+    def run_sequences(self, seq_ids, steps, warmup, api=None, label=None):
+        """Exact mode: whole sequences, one per stream, longest first over the ranks; every stream runs start to end on its
+        own (results identical to the sequential run), shorter ones switch off when they end.  steps = 0: whole sequences."""
+        cfg, world, rank = self.cfg, self.world, self.rank
+        lengths = [KITTI_FRAMES[i] for i in seq_ids]
+        ranks, load = sharding.plan_sequences(lengths, world)
+        mine = ranks[rank]
+        B = max(1, max(len(r) for r in ranks))       # same stream count on every rank (idle slots switched off)
+        my_len = [lengths[i] for i in mine] + [0] * (B - len(mine))
+        total_steps = max(load) if max(len(r) for r in ranks) == 1 else max(lengths)
+        K = min(steps, total_steps) if steps > 0 else total_steps
+        Wm = min(max(0, warmup), 8)
+        KB = K
+        cfg.max_history_frames = min(K + Wm + 2, 512)
+        api = api or hip.load()
+        Lbuf = torch.empty((KB, B, cfg.rows, self.stride), dtype=torch.uint8, device=self.dev)
+        Rbuf = torch.empty_like(Lbuf)
+        scenes = []
+        for slot, i in enumerate(mine):
+            sc = self.sy.scene_kitti(seed=7 + 13 * seq_ids[i])       # one world per sequence
+            sc.speed_m = 0.7 + 0.05 * (seq_ids[i] % 5)
+            scenes.append(sc)
+            n = min(KB, my_len[slot])
+            for f0 in range(0, n, 512):
+                self.render(sc, f0, min(512, n - f0), Lbuf[f0:], Rbuf[f0:], slot, B)
+        torch.cuda.synchronize()
+        api.create(cfg, self.dev_index, B)
+
+        def run(n_steps):
+            live = [s for s in range(B) if my_len[s] > 0]
+            for s in range(B):
+                api.set_stream_active(s, my_len[s] > 0)
+            done = 0
+            for k in range(n_steps):
+                ended = [s for s in live if my_len[s] <= k]
+                for s in ended:
+                    api.set_stream_active(s, False)
+                    live.remove(s)
+                if not live:
+                    break
+                api.process_device(Lbuf[k].data_ptr(), Rbuf[k].data_ptr(), self.stride, self.img_bytes)
+                done += len(live)
+            return done
+
+        run(Wm)
+        api.synchronize()
+        api.reset()
+        pose_send = torch.zeros((B, K, 12), dtype=torch.float64, device=self.dev)
+        sharding.gather_poses(pose_send)
+        self.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        frames = run(K)
+        api.copy_poses_device(0, K, pose_send.data_ptr())
+        api.synchronize()
+        sharding.gather_poses(pose_send)
+        torch.cuda.synchronize()
+        self.barrier()
+        elapsed = self.max_over_ranks(time.perf_counter() - t0)
+        frames = self.sum_over_ranks(frames)
+        live = [s for s in range(B) if my_len[s] >= K] or [0]
+        stats, flags = frame_stats(api, live)
+        out = {"sequences": ["%02d" % i for i in seq_ids], "frames": int(frames), "seconds": round(elapsed, 4),
+               "frames_per_s": round(frames / elapsed, 2), "steps": K, "streams_per_gpu": B,
+               "rank_loads": load, "ms_per_step": round(elapsed / max(K, 1) * 1e3, 4),
+               "mean_keypoints_per_image": round(stats["N"], 1), "mean_tracked": round(stats["M"], 1), "error_flags": flags}
+        if label:
+            out["label"] = label
+        return out, api, (Lbuf, Rbuf)
+
+    def main_sequences(self):
+        a = self.args
+        seq_ids = [0, 2, 5, 6] if self.world == 4 else list(range(11))
+        if a.sequences:
+            seq_ids = [int(x) for x in a.sequences.split(",")]
+        res, api, _ = self.run_sequences(seq_ids, a.steps, a.warmup, api=self.api)
+        if self.rank != 0:
+            return None
+        K = res["steps"]
+        return {
+            "metric": METRIC, "value": res["frames_per_s"], "unit": "frames/s", "n_gpus": self.world, "steps": K, "warmup": max(0, a.warmup),
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic", "frames_processed": res["frames"], "unique_frames_timed": res["frames"],
+            "config": {"workload": "KITTI-shaped synthetic sequences %s (1241x376, KITTI odometry lengths), configuration_kitti.yaml values, "
+                                   "bin %d, whole sequences one per stream (exact mode)" % ("+".join(res["sequences"]), a.bin),
+                       "mode": "sequences", "streams_per_gpu": res["streams_per_gpu"], "rank_frame_loads": res["rank_loads"],
+                       "parallelism": "sequence-sharded, longest first, %d GPU" % self.world,
+                       "mean_keypoints_per_image": res["mean_keypoints_per_image"], "mean_tracked": res["mean_tracked"],
+                       "error_flags": res["error_flags"]},
+            "roofline": None,
+        }
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def pcie_leg(self, steps=16):
+        """The chunk job again with HOST images (vslam_process_host): every pair crosses PCIe first.  Never `value`."""
+        cfg, B, J = self.cfg, self.B, self.J
+        n = min(steps, J)
+        Lh = torch.empty((n, B, cfg.rows, self.stride), dtype=torch.uint8).pin_memory()
+        Rh = torch.empty_like(Lh).pin_memory()
+        Lh.copy_(self.Lbuf[:n]); Rh.copy_(self.Rbuf[:n])
+        torch.cuda.synchronize()
+        api = hip.load()
+        api.create(cfg, self.dev_index, B)
+        lp, rp = Lh.data_ptr(), Rh.data_ptr()
+        slab = B * self.img_bytes
+
+        def run():
+            for k in range(n):
+                api.check(api.fn("process_host")(api.ctx, C.c_void_p(lp + k * slab), C.c_void_p(rp + k * slab), C.c_int32(self.stride),
+                                                 C.c_size_t(self.img_bytes)))
+            api.synchronize()
+        run()
+        t0 = time.perf_counter()
+        run()
+        dt = time.perf_counter() - t0
+        api.destroy()
+        pairs = n * B / dt
+        L = -(-SEQ_FRAMES // B)
+        return {"pairs_per_s": round(pairs, 1), "unique_frames_per_s": round(pairs * L / J, 1), "steps": n,
+                "host_to_device_GBs": round(pairs * 2 * self.img_bytes / 1e9, 2),
+                "note": "pinned host images, one hipMemcpyAsync per side and step; PCIe-bound, never `value`"}
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def cpu_leg(self):
+        """The oracle (a port of the reference path) on bounded samples of the same images, on this host's cores."""
+        a, cfg, B, J = self.args, self.cfg, self.B, self.J
+        orc, flags = load_oracle(native=True)
+        # chunk frames in job order: stream s, slab j holds chunk frame (j + phase_s) % J -> undo the stagger
+        n_chunks = max(1, min(B, a.cpu_frames // J))
+
+        def chunk_images(s, count):
+            idx = [(f - self.phase[s]) % J for f in range(count)]
+            Lh = self.Lbuf[idx, s].cpu().numpy()
+            Rh = self.Rbuf[idx, s].cpu().numpy()
+            return Lh, Rh
         chk = hip.load()
-        chk.create(cfg, dev_index, 1)
-        cpu_t = 0.0
-        mism, max_rel, nfr = 0, 0.0, 0
+        chk.create(cfg, self.dev_index, 1)
+        orc.create(cfg, 0, 1)
+        cpu_t, knn_t, nfr, mism, max_rel = 0.0, 0.0, 0, 0, 0.0
+        samples = []
         for sidx in range(n_chunks):
-            orc.reset()
-            chk.reset()
-            Lh = Lbuf[:per_chunk, sidx].cpu().numpy()
-            Rh = Rbuf[:per_chunk, sidx].cpu().numpy()
-            for k in range(per_chunk):
-                a = time.perf_counter()
+            orc.reset(); chk.reset()
+            Lh, Rh = chunk_images(sidx, J)
+            samples.append((Lh, Rh))
+            for k in range(J):
+                t = time.perf_counter()
                 orc.process_host(Lh[k], Rh[k])
-                cpu_t += time.perf_counter() - a
+                cpu_t += time.perf_counter() - t
+                t = time.perf_counter()
+                orc.fn("dead_knn_match")(orc.ctx, C.c_int(0), C.c_int(1))      # use_matches: knnMatch(k=2), BRUTEFORCE (L2 on floats)
+                knn_t += time.perf_counter() - t
                 chk.process_host(Lh[k], Rh[k])
                 fo, fg = orc.frame_info(0), chk.frame_info(0)
                 for name in ("n_keypoints_left", "n_keypoints_right", "n_tracked", "n_inliers", "n_points", "status",
                              "n_recovered", "n_new_stereo", "window_pixels"):
                     if getattr(fo, name) != getattr(fg, name):
                         mism += 1
-                To = np.array(fo.camera_left_to_world)
-                Tg = np.array(fg.camera_left_to_world)
+                To, Tg = np.array(fo.camera_left_to_world), np.array(fg.camera_left_to_world)
                 max_rel = max(max_rel, float(np.linalg.norm(Tg - To) / np.linalg.norm(To)))
                 nfr += 1
+        sec = (C.c_double * 8)()
+        orc.fn("get_timers")(orc.ctx, sec)
+        names = ["keypoint_detection", "descriptor_extraction", "point_triangulation", "tracking", "track_creation",
+                 "pose_optimization", "landmark_optimization", "point_recovery"]
+        modules = {names[i]: round(sec[i] / nfr * 1e3, 4) for i in range(8)}
+        chk.destroy(); orc.destroy()
         cpu_fps = nfr / cpu_t
-        out["cpu_baseline"] = {"value": round(cpu_fps, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-                               "sample": "%d chunks x %d frames of the same synthetic sequence (oracle/libvslam_oracle.so, "
-                                         "g++ -O3, 1 thread, process() time only)" % (n_chunks, per_chunk),
-                               "parity_on_sample": {"frames": nfr, "int_field_mismatches": mism,
-                                                    "max_pose_rel_frobenius": max_rel}}
-        out["speedup_vs_cpu_port"] = round(out["value"] / cpu_fps, 1)
-        orc.destroy()
-        chk.destroy()
+        # all host cores: one independent chunk per thread (ctypes releases the GIL), each with its own oracle context
+        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        per = max(4, min(J, (a.cpu_frames * 2) // max(ncpu, 1)))
+        ctxs = []
+        from vslam_pose_estimation_framework_amd.capi import CApi
+        for t in range(ncpu):
+            o = CApi(orc.lib._name, "orc_")
+            o.create(cfg, 0, 1)
+            ctxs.append(o)
 
-    if rank == 0:
+        def work(t):
+            Lh, Rh = samples[t % len(samples)]
+            for k in range(per):
+                ctxs[t].process_host(Lh[k], Rh[k])
+        th = [threading.Thread(target=work, args=(t,)) for t in range(ncpu)]
+        t0 = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        all_dt = time.perf_counter() - t0
+        for o in ctxs:
+            o.destroy()
+        return {"value": round(cpu_fps, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+                "sample": "%d chunks x %d frames of the same synthetic sequence (oracle/vslam_oracle.cpp, g++ %s, 1 thread, "
+                          "process() time only)" % (n_chunks, J, flags),
+                "with_dead_knn_match": {"value": round(nfr / (cpu_t + knn_t), 2), "unit": "frames/s",
+                                        "note": "plus the reference's per-frame knnMatch(k=2) on CV_32F descriptors "
+                                                "(use_matches: true, results discarded); findHomography not emulated"},
+                "all_cores": {"value": round(ncpu * per / all_dt, 2), "unit": "frames/s", "cores": ncpu,
+                              "sample": "%d threads x %d frames, one independent chunk per thread" % (ncpu, per)},
+                "module_ms_per_frame": modules,
+                "parity_on_sample": {"frames": nfr, "int_field_mismatches": mism, "max_pose_rel_frobenius": max_rel}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (0 = one whole chunk job / whole sequences)")
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mode", choices=["chunks", "sequences"], default="chunks")
+    ap.add_argument("--sequences", default="", help="--mode sequences: comma-separated KITTI sequence numbers")
+    ap.add_argument("--bin", type=int, default=15, help="bin_size_pixels (15: ~2158 kp/image, 22: ~1026, 11: ~3955)")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("VSLAM_BENCH_STREAMS", "160")))
+    ap.add_argument("--overlap", type=int, default=10, help="warm-up frames per chunk (SURVEY.md 8e default)")
+    ap.add_argument("--cpu-frames", type=int, default=240)
+    ap.add_argument("--exact-frames", type=int, default=1200, help="frames per sequence of the exact-mode legs (0 = whole sequences)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-exact", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true")
+    args = ap.parse_args()
+    b = Bench(args)
+    if args.mode == "sequences":
+        out = b.main_sequences()
+    else:
+        out = b.run_chunks()
+        if b.rank == 0 and b.world == 1:
+            if not args.no_pcie:
+                out["pcie_inclusive"] = b.pcie_leg()
+            if not args.no_cpu:
+                out["cpu_baseline"] = b.cpu_leg()
+                out["speedup_vs_cpu_port"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+            b.Lbuf = b.Rbuf = None
+            b.api.destroy()
+            torch.cuda.empty_cache()
+            if not args.no_exact:
+                # exact mode (whole sequence per stream, results identical to the sequential reference run)
+                one, api1, _ = b.run_sequences([0], args.exact_frames, 2, label="KITTI-00-shaped alone: ONE stream, the literal drop-in")
+                api1.destroy()
+                torch.cuda.empty_cache()
+                allseq, api2, _ = b.run_sequences(list(range(11)), args.exact_frames, 2, label="KITTI 00-10 lengths as 11 streams")
+                api2.destroy()
+                out["exact_mode"] = {"single_sequence": one, "eleven_sequences": allseq}
+                if "cpu_baseline" in out:
+                    out["exact_mode"]["single_sequence_speedup_vs_cpu_port"] = round(one["frames_per_s"] / out["cpu_baseline"]["value"], 1)
+    if b.rank == 0:
         print(json.dumps(out))
-    api.destroy()
-    if world > 1:
+    if b.world > 1:
         torch.distributed.destroy_process_group()
 
 

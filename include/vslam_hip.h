@@ -155,7 +155,8 @@ int vslam_reset(vslam_ctx* ctx);
  * switched off — every kernel skips it, its last frame's state, report and pose log stay readable — while the other
  * streams of the context carry on; vslam_reset_stream restarts ONE stream as a fresh sequence (a new PoseTracker3D /
  * generator / aligner / WorldMap: pose_tracker_3d.cpp:11-21) so that a stream can work through a queue of sequences.
- * Both synchronise the context; neither may be called between vslam_frame_begin and the end of that frame.
+ * vslam_set_stream_active synchronises the context; vslam_reset_stream is asynchronous (queued between two frames on the
+ * context's HIP streams).  Neither may be called between vslam_frame_begin and the end of that frame.
  * The images passed for an inactive stream are ignored (the pointer arithmetic still reserves its slot). */
 int vslam_set_stream_active(vslam_ctx* ctx, int stream, int active);
 int vslam_reset_stream(vslam_ctx* ctx, int stream);
@@ -427,6 +428,10 @@ int vslam_get_poses(vslam_ctx* ctx, int stream, int32_t first_frame, int32_t n_f
 /* Same, for ALL streams, into DEVICE memory (dst[stream][frame][12], asynchronous on the context
  * stream): the send buffer of the RCCL all-gather. */
 int vslam_copy_poses_device(vslam_ctx* ctx, int32_t first_frame, int32_t n_frames, double* dst_device);
+
+/* The pose (camera_left_to_world) of the frame every stream processed last, into DEVICE memory dst[stream][12],
+ * asynchronous on the context stream: one row block of the all-gather's send buffer per step. */
+int vslam_copy_current_poses_device(vslam_ctx* ctx, double* dst_device);
 
 #ifdef __cplusplus
 }

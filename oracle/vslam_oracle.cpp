@@ -19,6 +19,7 @@
  * Every function cites the reference file:line it follows (paths relative to the reference root).
  */
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -582,6 +583,16 @@ struct Stream {
   std::vector<int> lost;       /* _lost_points: indices into the previous frame's points */
   AlignerIO al;
   bool aligner_valid = false;  /* aligner ran on the current frame->points() (quirk B.3) */
+  /* the 8 chronometers SLAMAssembly::printReport prints (slam_assembly.cpp:703-742; CREATE_CHRONOMETER in
+   * base_framepoint_generator.h:232-233, stereo_framepoint_generator.h:81, pose_tracker_3d.h:123-127), seconds:
+   * keypoint_detection, descriptor_extraction, point_triangulation, tracking, track_creation, pose_optimization,
+   * landmark_optimization, point_recovery */
+  double chrono[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  struct Chrono {
+    double* acc; std::chrono::steady_clock::time_point t0;
+    explicit Chrono(double* a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+    ~Chrono() { *acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+  };
   vslam_frame_info info;
   std::vector<Tf> poses;
 
@@ -686,11 +697,9 @@ struct Stream {
   void initialize(const uint8_t* L, const uint8_t* R, int stride, bool extract, int frame_status) {
     if (extract) {
       std::vector<Keypoint> kl, kr;
-      detect_keypoints(L, stride, kl, n_detected_left_raw);
-      detect_keypoints(R, stride, kr, n_detected_right_raw);
+      { Chrono t(&chrono[0]); detect_keypoints(L, stride, kl, n_detected_left_raw); detect_keypoints(R, stride, kr, n_detected_right_raw); }
       adjust_thresholds();
-      compute_descriptors(L, stride, kl, sumL, kpL);
-      compute_descriptors(R, stride, kr, sumR, kpR);
+      { Chrono t(&chrono[1]); compute_descriptors(L, stride, kl, sumL, kpL); compute_descriptors(R, stride, kr, sumR, kpR); }
       n_detected_left = (int)kpL.size();
       if (frame_status == VSLAM_LOCALIZING) {
         tau_tri = std::min(0.1 * 256, cfg.maximum_matching_distance_triangulation);
@@ -924,6 +933,7 @@ struct Stream {
 
   /* StereoUVAligner::initialize (stereouv_aligner.cpp:10-69) + converge */
   void align(FrameRec& cur, FrameRec& prev, bool inverse_depth) {
+    Chrono timer(&chrono[5]);
     const int n = (int)cur.points.size();
     al.n = n;
     al.moving.resize(3 * n); al.fixed.resize(4 * n); al.omega.resize(n);
@@ -968,6 +978,7 @@ struct Stream {
 
   /* PoseTracker3D::_track (pose_tracker_3d.cpp:225-298) */
   void tracker_track(FrameRec& cur, FrameRec& prev, bool by_appearance) {
+    Chrono timer(&chrono[3]);
     if (by_appearance) win = cfg.maximum_projection_tracking_distance_pixels;
     aligner_valid = false;
     gen_tau_track = tau_track; /* setMaximumDescriptorDistanceTracking (:238) */
@@ -1211,13 +1222,13 @@ struct Stream {
       prune(cur, prev);
       info.n_after_prune = (int)cur.points.size();
       if (cfg.enable_landmark_recovery) {
-        info.n_recovered = recover(cur, prev);
+        { Chrono t(&chrono[7]); info.n_recovered = recover(cur, prev); }
         n_tracked_points = (uint32_t)cur.points.size();
       }
     }
-    update_points(findex);
+    { Chrono t(&chrono[6]); update_points(findex); }
     if (n_active_landmarks > (uint32_t)cfg.minimum_number_of_landmarks_to_track) status = VSLAM_TRACKING;
-    info.n_new_stereo = compute(cur);
+    { const double before = chrono[2]; { Chrono t(&chrono[2]); info.n_new_stereo = compute(cur); } chrono[4] += chrono[2] - before; }
     n_tracked_landmarks_prev = n_active_landmarks;
     /* report */
     info.status = status;
@@ -1372,6 +1383,12 @@ ORC_API int orc_get_aligner_weights(orc_ctx* c, int s, int32_t cap, int32_t* n, 
   for (int i = 0; i < *n; ++i) if (weight) weight[i] = a.weight[i];
   return VSLAM_OK;
 }
+/* the reference's 8 chronometers, summed over the streams of the context (seconds of host time) */
+ORC_API int orc_get_timers(orc_ctx* c, double seconds[8]) {
+  if (!c || !seconds) return VSLAM_ERR_INVALID;
+  for (int k = 0; k < 8; ++k) { seconds[k] = 0; for (const Stream& s : c->streams) seconds[k] += s.chrono[k]; }
+  return VSLAM_OK;
+}
 ORC_API int orc_get_poses(orc_ctx* c, int s, int32_t first, int32_t nf, double* out) {
   if (!c || s < 0 || s >= (int)c->streams.size() || !out) return VSLAM_ERR_INVALID;
   const std::vector<Tf>& p = c->streams[s].poses;
@@ -1407,23 +1424,50 @@ ORC_API int orc_brief_describe(orc_ctx*, const uint8_t* img, int32_t rows, int32
 /* knnMatch(k=2) of the use_matches block (stereo_framepoint_generator.cpp:168-206) */
 ORC_API int orc_knn2(orc_ctx*, int norm, int32_t nq, const uint8_t* q, int32_t nt, const uint8_t* t, int32_t* idx, float* dist) {
   if (!q || !t || !idx || !dist || norm < 0 || norm > 3) return VSLAM_ERR_INVALID;
+  /* matcher type -> norm (stereo_framepoint_generator.cpp:175-197): 0 HAMMING on the bytes; 1 L2, 2 L1, 3 SL2 on the
+   * descriptors converted to CV_32F (:199-205).  The float sums are exact: integers below 2^24. */
+  std::vector<float> qf, tf;
+  if (norm != 0) {
+    qf.resize((size_t)nq * 32); tf.resize((size_t)nt * 32);
+    for (size_t k = 0; k < qf.size(); ++k) qf[k] = (float)q[k];   /* convertTo(temp_des, CV_32F) */
+    for (size_t k = 0; k < tf.size(); ++k) tf[k] = (float)t[k];
+  }
   for (int i = 0; i < nq; ++i) {
-    int64_t b0 = INT64_MAX, b1 = INT64_MAX;
+    float b0 = 3.0e38f, b1 = 3.0e38f;
     int i0 = -1, i1 = -1;
     for (int j = 0; j < nt; ++j) {
-      int64_t d;
-      /* matcher type -> norm (stereo_framepoint_generator.cpp:175-197): 0 HAMMING, 1 L2, 2 L1, 3 SL2, on the bytes as floats */
-      if (norm == 0) d = hamming32(q + 32 * i, t + 32 * j);
-      else if (norm == 2) { d = 0; for (int k = 0; k < 32; ++k) d += std::abs((int)q[32 * i + k] - (int)t[32 * j + k]); }
-      else { d = 0; for (int k = 0; k < 32; ++k) { const int e = (int)q[32 * i + k] - (int)t[32 * j + k]; d += e * e; } }
+      float d;
+      if (norm == 0) d = (float)hamming32(q + 32 * i, t + 32 * j);
+      else {
+        const float* a = &qf[(size_t)32 * i]; const float* c = &tf[(size_t)32 * j];
+        d = 0;
+        if (norm == 2) for (int k = 0; k < 32; ++k) d += std::fabs(a[k] - c[k]);
+        else for (int k = 0; k < 32; ++k) { const float e = a[k] - c[k]; d += e * e; }
+      }
       if (d < b0) { b1 = b0; i1 = i0; b0 = d; i0 = j; }
       else if (d < b1) { b1 = d; i1 = j; }
     }
     idx[2 * i] = i0; idx[2 * i + 1] = i1;
-    dist[2 * i] = i0 < 0 ? 0.f : (norm != 1 ? (float)b0 : std::sqrt((float)b0));
-    dist[2 * i + 1] = i1 < 0 ? 0.f : (norm != 1 ? (float)b1 : std::sqrt((float)b1));
+    dist[2 * i] = i0 < 0 ? 0.f : (norm != 1 ? b0 : std::sqrt(b0));
+    dist[2 * i + 1] = i1 < 0 ? 0.f : (norm != 1 ? b1 : std::sqrt(b1));
   }
   return VSLAM_OK;
+}
+/* The use_matches block (stereo_framepoint_generator.cpp:168-206) on the CURRENT frame of stream s: the knnMatch(k=2) of
+ * the left against the right descriptors with the given norm, results discarded — exactly the dead work the reference pays
+ * per frame when use_matches is true (configuration_kitti.yaml:95).  findHomography (:232-262) is not emulated.
+ * Used by bench.py's cpu_baseline leg only; returns the number of query rows. */
+ORC_API int orc_dead_knn_match(orc_ctx* c, int s, int norm) {
+  if (!c || s < 0 || s >= (int)c->streams.size()) return VSLAM_ERR_INVALID;
+  const Stream& st = c->streams[s];
+  const int nq = (int)st.kpL.size(), nt = (int)st.kpR.size();
+  std::vector<uint8_t> dq((size_t)std::max(nq, 1) * 32), dt((size_t)std::max(nt, 1) * 32);
+  for (int i = 0; i < nq; ++i) std::memcpy(&dq[(size_t)32 * i], st.kpL[i].desc, 32);
+  for (int i = 0; i < nt; ++i) std::memcpy(&dt[(size_t)32 * i], st.kpR[i].desc, 32);
+  std::vector<int32_t> idx((size_t)std::max(nq, 1) * 2);
+  std::vector<float> dist((size_t)std::max(nq, 1) * 2);
+  const int rc = orc_knn2(c, norm, nq, dq.data(), nt, dt.data(), idx.data(), dist.data());
+  return rc == VSLAM_OK ? nq : rc;
 }
 ORC_API int orc_align_points(orc_ctx* c, int32_t n, const double* moving, const double* fixed, const double* omega,
                              const double* weight, const double T_init[12], double T_out[12], double* chi, uint8_t* inlier,

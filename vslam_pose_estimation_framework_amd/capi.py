@@ -488,6 +488,9 @@ def _extra_methods():
     def copy_poses_device(self, first, count, dst_ptr):
         self.check(self.fn("copy_poses_device")(self.ctx, C.c_int32(first), C.c_int32(count), C.c_void_p(dst_ptr)))
 
+    def copy_current_poses_device(self, dst_ptr):
+        self.check(self.fn("copy_current_poses_device")(self.ctx, C.c_void_p(dst_ptr)))
+
     def enable_timers(self, on=True):
         self.check(self.fn("enable_timers")(self.ctx, C.c_int(1 if on else 0)))
 
@@ -509,7 +512,7 @@ def _extra_methods():
     def set_hip_stream(self, stream_ptr):
         self.check(self.fn("set_hip_stream")(self.ctx, C.c_void_p(stream_ptr)))
 
-    for f in (copy_poses_device, enable_timers, kernel_times, timers, set_hip_stream):
+    for f in (copy_poses_device, copy_current_poses_device, enable_timers, kernel_times, timers, set_hip_stream):
         setattr(CApi, f.__name__, f)
 
 

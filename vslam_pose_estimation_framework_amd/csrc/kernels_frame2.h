@@ -1209,6 +1209,34 @@ __global__ __launch_bounds__(VS_WG) void k_stage(const DevCfg c, const DevBuf b,
   }
 }
 
+// vslam_reset_stream, asynchronous: the stream state has an image-pipeline half (the detector thresholds, written by k_emit
+// and read by k_fast_box on the image stream) and a tracker half (everything else, frame stream); each half is reset by a
+// one-thread kernel queued on the HIP stream that owns it, so a stream restarts between two frames without a host sync.
+__global__ void k_reset_stream_img(const DevCfg c, const DevBuf b, int s) {
+  StreamState& st = b.st[s];
+  for (int r = 0; r < VSLAM_MAX_REGIONS; ++r) st.thr[r] = r < c.n_regions ? c.c.detector_threshold_minimum : 0;
+  atomicAnd(&st.error_flags, ~1);     // bit 0 (keypoint capacity) is raised by k_emit on this HIP stream
+}
+__global__ void k_reset_stream_trk(const DevCfg c, const DevBuf b, int s) {
+  StreamState& st = b.st[s];
+  st.status = VSLAM_LOCALIZING; st.win = c.c.maximum_projection_tracking_distance_pixels; st.frame_count = 0; st.has_prev = 0;
+  st.n_tracked_landmarks_prev = 0; st.cur = 0; st.aligner_valid = 0; atomicAnd(&st.error_flags, 1);
+  st.tau_track = c.c.minimum_descriptor_distance_tracking; st.tau_tri = 0.1 * 256;
+  tf_identity(st.prior); tf_identity(st.pose);
+  st.by_appearance = 0; st.n_trk = 0; st.n_lost = 0; st.n_tracked_landmarks = 0;
+  st.al_n = 0; st.al_inliers = 0; st.al_outliers = 0; st.al_iterations = 0; st.al_converged = 0; st.al_wsize = 0; st.al_total_error = 0;
+  st.tau_gen = 0; st.n_cur = 0; st.n_active = 0; st.n_after_prune = 0; st.n_recovered = 0; st.n_new = 0; st.track_calls = 0;
+  b.n_points[s * 2] = 0; b.n_points[s * 2 + 1] = 0;
+  vslam_frame_info& info = b.info[s];
+  unsigned char* p = reinterpret_cast<unsigned char*>(&info);
+  for (size_t k = 0; k < sizeof(vslam_frame_info); ++k) p[k] = 0;
+}
+// the current pose of every stream (camera_left_to_world of the frame just processed) -> dst[stream][12]
+__global__ void k_gather_poses(const DevBuf b, int n, double* dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n * 12) dst[i] = b.st[b.s0 + i / 12].pose[i % 12];
+}
+
 // setters of the tracker-owned state (one thread)
 struct D12 { double v[12]; };   // a transform passed by value as a kernel argument (no staging buffer)
 __global__ void k_set_tracker_state(const DevBuf b, int s, int status, int win, double tau, const D12 prior) {

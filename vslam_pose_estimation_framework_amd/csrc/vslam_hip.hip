@@ -410,16 +410,24 @@ VS_API int vslam_reset_stream(vslam_ctx* c, int s) {
   if (s < 0 || s >= c->B) return fail(c, VSLAM_ERR_INVALID, "stream index out of range");
   if (c->frame_begun) return fail(c, VSLAM_ERR_STATE, "vslam_reset_stream called inside a frame");
   HIP_TRY(c, hipSetDevice(c->device));
-  sync_all(c);
-  StreamState x;
-  fresh_stream_state(c, x);
-  HIP_TRY(c, hipMemcpy(c->buf.st + s, &x, sizeof x, hipMemcpyHostToDevice));
-  HIP_TRY(c, hipMemset(c->buf.info + s, 0, sizeof(vslam_frame_info)));
-  HIP_TRY(c, hipMemset(c->buf.n_points + s * 2, 0, sizeof(int32_t) * 2));
-  for (int q = 0; q < 2; ++q) {
-    HIP_TRY(c, hipMemset(c->sets[q].n_kp + s * 2, 0, sizeof(int32_t) * 2));
-    HIP_TRY(c, hipMemset(c->sets[q].iinfo + s, 0, sizeof(ImgInfo)));
+  // no host synchronisation: each half of the state is reset in order on the HIP stream(s) that own it
+  const vslam_ctx::Group& g = c->groups[group_of(c, s)];
+  hipLaunchKernelGGL(k_reset_stream_img, dim3(1), dim3(1), 0, g.st_img, c->cfg, c->buf, s);
+  if (g.st_img2 != g.st_img) {   // two image streams alternate: the second one must see the reset as well
+    hipEvent_t e = ev_get(c);
+    HIP_TRY(c, hipEventRecord(e, g.st_img));
+    HIP_TRY(c, hipStreamWaitEvent(g.st_img2, e, 0));
+    c->evpool.push_back(e);
   }
+  hipLaunchKernelGGL(k_reset_stream_trk, dim3(1), dim3(1), 0, g.st_frm, c->cfg, c->buf, s);
+  HIP_TRY(c, hipGetLastError());
+  return VSLAM_OK;
+}
+VS_API int vslam_copy_current_poses_device(vslam_ctx* c, double* dst) {
+  if (!c || !dst) return VSLAM_ERR_INVALID;
+  for (auto& g : c->groups)
+    hipLaunchKernelGGL(k_gather_poses, dim3((g.n * 12 + 255) / 256), dim3(256), 0, g.st_frm, buf_set(c, c->last_set, g.s0), g.n, dst + (size_t)g.s0 * 12);
+  HIP_TRY(c, hipGetLastError());
   return VSLAM_OK;
 }
 VS_API int vslam_set_hip_stream(vslam_ctx* c, void* s) {
