@@ -440,8 +440,9 @@ class Bench(object):
         chk.destroy(); orc.destroy()
         cpu_fps = nfr / cpu_t
         # all host cores: one independent chunk per thread (ctypes releases the GIL), each with its own oracle context
-        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        per = max(4, min(J, (a.cpu_frames * 2) // max(ncpu, 1)))
+        nproc = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        ncpu = a.cpu_threads if a.cpu_threads > 0 else min(nproc, 16)    # a one-GPU box owns a 16-CPU share of its host
+        per = min(J, 24)
         ctxs = []
         from vslam_pose_estimation_framework_amd.capi import CApi
         for t in range(ncpu):
@@ -468,7 +469,7 @@ class Bench(object):
                 "with_dead_knn_match": {"value": round(nfr / (cpu_t + knn_t), 2), "unit": "frames/s",
                                         "note": "plus the reference's per-frame knnMatch(k=2) on CV_32F descriptors "
                                                 "(use_matches: true, results discarded); findHomography not emulated"},
-                "all_cores": {"value": round(ncpu * per / all_dt, 2), "unit": "frames/s", "cores": ncpu,
+                "all_cores": {"value": round(ncpu * per / all_dt, 2), "unit": "frames/s", "cores": ncpu, "nproc_visible": nproc,
                               "sample": "%d threads x %d frames, one independent chunk per thread" % (ncpu, per)},
                 "module_ms_per_frame": modules,
                 "parity_on_sample": {"frames": nfr, "int_field_mismatches": mism, "max_pose_rel_frobenius": max_rel}}
@@ -485,6 +486,7 @@ def main():
     ap.add_argument("--streams", type=int, default=int(os.environ.get("VSLAM_BENCH_STREAMS", "160")))
     ap.add_argument("--overlap", type=int, default=10, help="warm-up frames per chunk (SURVEY.md 8e default)")
     ap.add_argument("--cpu-frames", type=int, default=240)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU leg (0 = min(nproc, 16): the box's CPU share)")
     ap.add_argument("--exact-frames", type=int, default=1200, help="frames per sequence of the exact-mode legs (0 = whole sequences)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-exact", action="store_true")
