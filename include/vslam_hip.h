@@ -234,6 +234,18 @@ int vslam_get_points(vslam_ctx* ctx, int stream, int32_t cap, int32_t* n, int16_
                      int32_t* meta, double* cam, double* lm);
 int vslam_get_aligner_result(vslam_ctx* ctx, int stream, int32_t cap, int32_t* n, double* chi,
                              uint8_t* inlier, double T[12], double H[36]);
+/* Stage-granular read-backs for a host that keeps the reference's object model (shim/proslam_hip_plugin.h).
+ * vslam_get_track_result: what the last vslam_track left — out4 = (index in frame_previous->points(), left feature,
+ *   right feature, Hamming L-R) per tracked point in the order of the previous points (feature = index in the row-major
+ *   keypoint list of vslam_get_keypoints), lost = indices of the previous points on the lost list
+ *   (stereo_framepoint_generator.cpp:659-665).  cap bounds both lists.
+ * vslam_get_frame_points: as vslam_get_points, plus the 64 descriptor bytes (left | right) of every point; in_progress = 1
+ *   reads the frame the stage calls are assembling (after vslam_prune_recover: survivors of _prunePoints followed by the
+ *   recovered points), 0 the finished frame. */
+int vslam_get_track_result(vslam_ctx* ctx, int stream, int32_t cap, int32_t* n_tracked, int32_t* out4, int32_t* n_lost,
+                           int32_t* lost);
+int vslam_get_frame_points(vslam_ctx* ctx, int stream, int in_progress, int32_t cap, int32_t* n, int16_t* kp, int32_t* meta,
+                           double* cam, double* lm, uint8_t* desc);
 /* StereoUVAligner::_weights_translation as the stream's last initialize() left it (stereouv_aligner.cpp:22,57-61): the
  * vector is a MEMBER of the aligner, `resize(n, 1)` keeps the elements it already holds, and they are rewritten only while
  * enable_inverse_depth_as_information is set — so Localizing frames (flag off, pose_tracker_3d.cpp:124) reuse the weights the

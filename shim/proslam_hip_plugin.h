@@ -1,17 +1,27 @@
 // proslam_hip_plugin.h — header-only C++ shim: the reference's plug-in classes on top of libvslam_hip.so.
 //
-// Compiles ONLY inside the reference tree (needs its headers: OpenCV 3, Eigen, srrg_core); it is not built in
-// this repository (those dependencies are absent here).  INTEGRATION.md shows the two lines of
-// SLAMAssembly::_createStereoTracker (src/system/slam_assembly.cpp:61-76) a maintainer changes.
+// Meant to be compiled inside the reference tree (its headers: OpenCV 3, Eigen, srrg_core); INTEGRATION.md shows the two
+// lines of SLAMAssembly::_createStereoTracker (src/system/slam_assembly.cpp:61-76) a maintainer changes.  Those
+// dependencies are absent from this repository's image, so here the header is compile- and run-checked against minimal
+// declaration stubs of the interfaces it touches (tests/shim_stubs/, test-only): a signature drift against
+// base_framepoint_generator.h:119-145 / base_aligner.h:26-48 / frame.h fails the CPU test suite.
 //
 // The classes derive from the CONCRETE reference classes because SLAMAssembly down-casts the generator
 // (slam_assembly.h:101, slam_assembly.cpp:690-691,717-719) and PoseTracker3D keeps its own control flow
-// (pose_tracker_3d.cpp:32-566): every virtual below is one C call; results are materialised into the host
-// objects the rest of the reference reads (Frame::keypoints/descriptors, FramePoint via Frame::createFramepoint,
-// BaseAligner's protected result members).
+// (pose_tracker_3d.cpp:32-566): every virtual below is one or two C calls; results are materialised into the host
+// objects the rest of the reference reads (Frame::keypoints/descriptors, FramePoint via Frame::createFramepoint —
+// its constructor is protected, types/frame_point.h:45-58 — and BaseAligner's protected result members).
+//
+// Host and device run the same frame side by side: the device keeps its own framepoints / landmarks (they feed its
+// tracker and aligner), the host keeps the reference's objects (they feed the map, relocalization, viewers).  Both
+// apply the same rules, so they stay index-aligned: Frame::points()[i] on the host is point i of the device's frame;
+// every materialisation step below checks the counts and throws on divergence.  Open loop only (loop closing rewrites
+// host poses the device does not see).
 #pragma once
+#include <cstring>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "aligners/stereouv_aligner.h"
@@ -24,11 +34,107 @@ inline void hipCheck(vslam_ctx* ctx, int rc, const char* where) {
   if (rc != VSLAM_OK) throw std::runtime_error(std::string(where) + "|" + vslam_last_error(ctx));
 }
 
+class HipStereoUVAligner;
+
 //! one device context shared by the generator and the aligner of a tracker (n_streams = 1)
 struct HipContext {
   vslam_ctx* ctx = nullptr;
   vslam_config config;
+  int device = 0;
+  //! parameters the generator / aligner objects do not own (set them before configure(); null: configuration_kitti.yaml values)
+  const PoseTracker3DParameters* tracker_parameters = nullptr;   // tracking: (parameters.h:262-300)
+  const LandmarkParameters* landmark_parameters = nullptr;       // world_map: landmark (parameters.h:97-112)
+  HipStereoUVAligner* aligner = nullptr;
+  //! tracker-owned state last pushed to the device (Frame::status, window, descriptor distance)
+  int status = VSLAM_LOCALIZING;
+  int32_t window_pixels = 0;
+  double tau_track = 0;
+  HipContext() { vslam_default_config_kitti(&config); }
   ~HipContext() { if (ctx) vslam_destroy(ctx); }
+  HipContext(const HipContext&) = delete;
+  HipContext& operator=(const HipContext&) = delete;
+};
+
+template <typename Transform>
+inline void hipToArray(const Transform& T, double* out) {
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) out[4 * i + j] = T.matrix()(i, j);
+}
+
+class HipStereoUVAligner : public StereoUVAligner {
+public:
+  HipStereoUVAligner(AlignerParameters* parameters_, HipContext* hip_) : StereoUVAligner(parameters_), _hip(hip_) { _hip->aligner = this; }
+
+  //! creates the device context once every parameter is known (call after the generator's configure)
+  void configure() override {
+    vslam_config& c = _hip->config;
+    c.aligner_error_delta_for_convergence = _parameters->error_delta_for_convergence;
+    c.aligner_maximum_error_kernel = _parameters->maximum_error_kernel;
+    c.aligner_damping = _parameters->damping;
+    c.aligner_maximum_number_of_iterations = (int32_t)_parameters->maximum_number_of_iterations;
+    c.aligner_minimum_number_of_inliers = (int32_t)_parameters->minimum_number_of_inliers;
+    c.minimum_depth_meters = _minimum_reliable_depth_meters;         // setMinimumReliableDepthMeters (slam_assembly.cpp:70)
+    c.maximum_reliable_depth_meters = _maximum_reliable_depth_meters;
+    if (const PoseTracker3DParameters* t = _hip->tracker_parameters) {
+      c.minimum_track_length_for_landmark_creation = (int32_t)t->minimum_track_length_for_landmark_creation;
+      c.minimum_number_of_landmarks_to_track = (int32_t)t->minimum_number_of_landmarks_to_track;
+      c.tunnel_vision_ratio = t->tunnel_vision_ratio;
+      c.good_tracking_ratio = t->good_tracking_ratio;
+      c.enable_landmark_recovery = t->enable_landmark_recovery ? 1 : 0;
+      c.minimum_delta_angular_for_movement = t->minimum_delta_angular_for_movement;
+      c.minimum_delta_translational_for_movement = t->minimum_delta_translational_for_movement;
+    }
+    if (const LandmarkParameters* l = _hip->landmark_parameters) {
+      c.landmark_maximum_error_squared_meters = l->maximum_error_squared_meters;
+      c.landmark_maximum_number_of_iterations = (int32_t)l->maximum_number_of_iterations;
+    }
+    if (!_hip->ctx) hipCheck(nullptr, vslam_create(&c, _hip->device, 1, &_hip->ctx), "HipStereoUVAligner::configure");
+  }
+
+  //! StereoUVAligner::initialize (stereouv_aligner.cpp:10-69): the correspondences are already on the device (the list
+  //! the last track() left); the motion prior travels with the tracker state
+  void initialize(const Frame* frame_previous_, const Frame* frame_current_, const TransformMatrix3D& previous_to_current_) override {
+    _frame_previous = frame_previous_; _frame_current = frame_current_; _previous_to_current = previous_to_current_;
+    _number_of_measurements = (Count)_frame_current->points().size();
+    double prior[12];
+    hipToArray(previous_to_current_, prior);
+    hipCheck(_hip->ctx, vslam_set_tracker_state(_hip->ctx, 0, _hip->status, prior, _hip->window_pixels, _hip->tau_track), "HipStereoUVAligner::initialize");
+  }
+  void linearize(const bool&) override {}   // folded into converge() on the device
+  void oneRound(const bool&) override {}
+
+  //! StereoUVAligner::converge (:210-264): one launch; results into the base-class members the tracker reads
+  //! (errors(), inliers(), numberOfInliers(), totalError(), previousToCurrent(): base_aligner.h:37-48)
+  void converge() override {
+    hipCheck(_hip->ctx, vslam_align(_hip->ctx, _parameters->enable_inverse_depth_as_information ? 1 : 0), "HipStereoUVAligner::converge");
+    std::vector<double> chi(_number_of_measurements + 1);
+    std::vector<uint8_t> inl(_number_of_measurements + 1);
+    double T[12], H[36];
+    int32_t n = 0;
+    hipCheck(_hip->ctx, vslam_get_aligner_result(_hip->ctx, 0, (int32_t)_number_of_measurements, &n, chi.data(), inl.data(), T, H), "HipStereoUVAligner::converge");
+    if (n != (int32_t)_number_of_measurements) throw std::runtime_error("HipStereoUVAligner::converge|host and device disagree on the number of measurements");
+    vslam_frame_info info;
+    hipCheck(_hip->ctx, vslam_get_frame_info(_hip->ctx, 0, &info), "HipStereoUVAligner::converge");
+    _errors.assign(chi.begin(), chi.begin() + n);
+    _inliers.resize(n);
+    for (int32_t u = 0; u < n; ++u) _inliers[u] = inl[u] != 0;
+    _number_of_inliers = (Count)info.n_inliers; _number_of_outliers = (Count)info.n_outliers; _total_error = info.total_error;
+    _has_system_converged = info.aligner_converged != 0;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) _previous_to_current.matrix()(i, j) = T[4 * i + j];
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) { _H(i, j) = H[6 * i + j]; _information_matrix(i, j) = H[6 * i + j]; }
+  }
+
+  //! a new track() invalidates the previous converge(): PoseTracker3D::_prunePoints would otherwise read the stale
+  //! errors()/inliers() of another point list (pose_tracker_3d.cpp:441-470).  Defined behaviour, same as the device
+  //!: without a fresh aligner result every tracked point is dropped — all outliers, zero error.
+  void invalidate(const Count& number_of_points_) {
+    _number_of_measurements = number_of_points_;
+    _errors.assign(number_of_points_, -1.0);
+    _inliers.assign(number_of_points_, false);
+    _number_of_inliers = 0; _number_of_outliers = number_of_points_; _total_error = 0; _has_system_converged = false;
+  }
+
+private:
+  HipContext* _hip;
 };
 
 class HipStereoFramePointGenerator : public StereoFramePointGenerator {
@@ -40,16 +146,15 @@ public:
   void configure() override {
     StereoFramePointGenerator::configure();  // keeps the inherited members (bins, targets, chronometers) valid
     vslam_config& c = _hip->config;
-    vslam_default_config_kitti(&c);
     c.rows = _number_of_rows_image; c.cols = _number_of_cols_image;
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) c.K[3 * i + j] = _camera_left->cameraMatrix()(i, j);
     for (int i = 0; i < 3; ++i) c.baseline_h[i] = _camera_right->baselineHomogeneous()(i);
-    StereoFramePointGeneratorParameters* p = static_cast<StereoFramePointGeneratorParameters*>(parameters());
-    c.det_rows = p->number_of_detectors_vertical; c.det_cols = p->number_of_detectors_horizontal;
-    c.detector_threshold_minimum = p->detector_threshold_minimum; c.detector_threshold_maximum = p->detector_threshold_maximum;
+    StereoFramePointGeneratorParameters* p = parameters();
+    c.det_rows = (int32_t)p->number_of_detectors_vertical; c.det_cols = (int32_t)p->number_of_detectors_horizontal;
+    c.detector_threshold_minimum = (int32_t)p->detector_threshold_minimum; c.detector_threshold_maximum = (int32_t)p->detector_threshold_maximum;
     c.detector_threshold_maximum_change = p->detector_threshold_maximum_change;
     c.target_number_of_keypoints_tolerance = p->target_number_of_keypoints_tolerance;
-    c.bin_size_pixels = p->bin_size_pixels; c.enable_keypoint_binning = p->enable_keypoint_binning;
+    c.bin_size_pixels = (int32_t)p->bin_size_pixels; c.enable_keypoint_binning = p->enable_keypoint_binning ? 1 : 0;
     c.minimum_projection_tracking_distance_pixels = p->minimum_projection_tracking_distance_pixels;
     c.maximum_projection_tracking_distance_pixels = p->maximum_projection_tracking_distance_pixels;
     c.minimum_descriptor_distance_tracking = p->minimum_descriptor_distance_tracking;
@@ -59,18 +164,28 @@ public:
     c.maximum_matching_distance_triangulation = p->maximum_matching_distance_triangulation;
     c.minimum_disparity_pixels = p->minimum_disparity_pixels;
     c.maximum_epipolar_search_offset_pixels = p->maximum_epipolar_search_offset_pixels;
-    // tracker / aligner / landmark values are filled by HipStereoUVAligner::configure before vslam_create
+    _hip->window_pixels = p->maximum_projection_tracking_distance_pixels;    // PoseTracker3D::configure (pose_tracker_3d.cpp:11-21)
+    _hip->tau_track = p->minimum_descriptor_distance_tracking;
+    // tracker / aligner / landmark values are filled by HipStereoUVAligner::configure, which creates the device context
   }
 
   //! StereoFramePointGenerator::initialize (stereo_framepoint_generator.cpp:73-133)
   void initialize(Frame* frame_, const bool& extract_features_ = true) override {
     if (!frame_) throw std::runtime_error("HipStereoFramePointGenerator::initialize|called with empty frame");
-    if (!extract_features_) { hipCheck(_hip->ctx, vslam_frame_restore(_hip->ctx), "initialize"); return; }
+    if (!_hip->ctx) throw std::runtime_error("HipStereoFramePointGenerator::initialize|no device context: configure the aligner first");
+    if (!extract_features_) { hipCheck(_hip->ctx, vslam_frame_restore(_hip->ctx), "HipStereoFramePointGenerator::initialize"); return; }
     const cv::Mat& L = frame_->intensityImageLeft();
     const cv::Mat& R = frame_->intensityImageRight();
-    // the tracker status of the frame and its pose enter through the setters
-    double prior[12]; toArray(TransformMatrix3D::Identity(), prior);
-    hipCheck(_hip->ctx, vslam_frame_begin(_hip->ctx, L.data, R.data, (int32_t)L.step, 0, 0), "initialize");
+    if (!L.data || !R.data) throw std::runtime_error("HipStereoFramePointGenerator::initialize|called with empty frame");
+    // the frame is created with the tracker's status and the world map's pose (pose_tracker_3d.cpp:66-74): both enter
+    // through the setters BEFORE the frame begins (the triangulation-distance rule of :109-125 reads the status)
+    _hip->status = frame_->status() == Frame::Localizing ? VSLAM_LOCALIZING : VSLAM_TRACKING;
+    pushState(TransformMatrix3D::Identity());
+    double pose[12];
+    hipToArray(frame_->cameraLeftToWorld(), pose);
+    hipCheck(_hip->ctx, vslam_set_pose(_hip->ctx, 0, pose), "HipStereoFramePointGenerator::initialize");
+    hipCheck(_hip->ctx, vslam_frame_begin(_hip->ctx, L.data, R.data, (int32_t)static_cast<size_t>(L.step), 0, 0), "HipStereoFramePointGenerator::initialize");
+    _pruned = false;
     downloadKeypoints(frame_);   // Frame::keypointsLeft/Right + descriptorsLeft/Right for downstream consumers
   }
 
@@ -78,96 +193,180 @@ public:
   void track(Frame* frame_, Frame* frame_previous_, const TransformMatrix3D& camera_left_previous_in_current_,
              FramePointPointerVector& lost_points_, const bool track_by_appearance_ = true) override {
     if (!frame_ || !frame_previous_) throw std::runtime_error("HipStereoFramePointGenerator::track|called with invalid frames");
-    double prior[12]; toArray(camera_left_previous_in_current_, prior);
-    hipCheck(_hip->ctx, vslam_set_tracker_state(_hip->ctx, 0, frame_->status() == Frame::Localizing ? VSLAM_LOCALIZING : VSLAM_TRACKING,
-                                                prior, _projection_tracking_distance_pixels, _maximum_descriptor_distance_tracking), "track");
-    hipCheck(_hip->ctx, vslam_track(_hip->ctx, track_by_appearance_ ? 1 : 0), "track");
-    vslam_frame_info info;
-    hipCheck(_hip->ctx, vslam_get_frame_info(_hip->ctx, 0, &info), "track");
-    _number_of_tracked_landmarks = info.n_tracked_landmarks;
-    materializeTrackedPoints(frame_, frame_previous_, lost_points_, info);  // Frame::createFramepoint(..., previous)
+    // setProjectionTrackingDistancePixels / setMaximumDescriptorDistanceTracking were called by the tracker (:237-238)
+    _hip->status = frame_->status() == Frame::Localizing ? VSLAM_LOCALIZING : VSLAM_TRACKING;
+    _hip->window_pixels = _projection_tracking_distance_pixels;
+    _hip->tau_track = _maximum_descriptor_distance_tracking;
+    pushState(camera_left_previous_in_current_);
+    hipCheck(_hip->ctx, vslam_track(_hip->ctx, track_by_appearance_ ? 1 : 0), "HipStereoFramePointGenerator::track");
+    materializeTrackedPoints(frame_, frame_previous_, lost_points_);
+    if (_hip->aligner) _hip->aligner->invalidate((Count)frame_->points().size());
   }
 
-  //! StereoFramePointGenerator::recoverPoints (:683-869) — runs together with the tracker's _prunePoints on the device
+  //! StereoFramePointGenerator::recoverPoints (:683-869).  PoseTracker3D::_prunePoints has just pruned the host list; the
+  //! device prunes its own by the same rule and recovers in the same launch
   void recoverPoints(Frame* current_frame_, const FramePointPointerVector& lost_points_) const override {
-    double pose[12]; toArray(current_frame_->cameraLeftToWorld(), pose);
-    hipCheck(_hip->ctx, vslam_set_pose(_hip->ctx, 0, pose), "recoverPoints");
-    hipCheck(_hip->ctx, vslam_prune_recover(_hip->ctx), "recoverPoints");
-    materializeRecoveredPoints(current_frame_, lost_points_);
+    (void)lost_points_;   // the device kept the lost list of its own track()
+    pruneOnDevice(current_frame_);
+    materializeRecoveredPoints(current_frame_);
   }
 
-  //! StereoFramePointGenerator::compute (:135-462); the landmark refinement of PoseTracker3D::_updatePoints has to
-  //! precede it on the device (it feeds the next frame's aligner), so it is issued here
+  //! StereoFramePointGenerator::compute (:135-462); PoseTracker3D::_updatePoints has just run on the host objects — the
+  //! device updates its landmarks here (they feed the next frame's aligner)
   void compute(Frame* frame_) override {
     if (!frame_) throw std::runtime_error("HipStereoFramePointGenerator::compute|called with empty frame");
-    hipCheck(_hip->ctx, vslam_update_points(_hip->ctx), "compute");
-    hipCheck(_hip->ctx, vslam_stereo_new(_hip->ctx), "compute");
+    if (!_pruned) pruneOnDevice(frame_);     // recovery disabled or no previous frame: _prunePoints alone
+    hipCheck(_hip->ctx, vslam_update_points(_hip->ctx), "HipStereoFramePointGenerator::compute");
+    hipCheck(_hip->ctx, vslam_stereo_new(_hip->ctx), "HipStereoFramePointGenerator::compute");
     materializeNewPoints(frame_);  // Frame::createFramepoint(feature_left, feature_right, distance, xyz)
   }
 
   HipContext* hip() { return _hip; }
+  //! the device's per-frame report of the frame last finished (counters the tests compare with the fused path)
+  vslam_frame_info frameInfo() const { vslam_frame_info info; hipCheck(_hip->ctx, vslam_get_frame_info(_hip->ctx, 0, &info), "frameInfo"); return info; }
 
 private:
-  static void toArray(const TransformMatrix3D& T, double* out) {
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) out[4 * i + j] = T.matrix()(i, j);
+  void pushState(const TransformMatrix3D& prior_) const {
+    double prior[12];
+    hipToArray(prior_, prior);
+    hipCheck(_hip->ctx, vslam_set_tracker_state(_hip->ctx, 0, _hip->status, prior, _hip->window_pixels, _hip->tau_track), "HipStereoFramePointGenerator|state");
   }
-  // The four helpers below copy SoA read-backs (vslam_get_keypoints / vslam_get_points) into the reference's host
-  // objects: cv::KeyPoint(x, y, 7.f, -1, score), 1x32 CV_8U descriptor rows, IntensityFeature pairs handed to
-  // Frame::createFramepoint (types/frame.cpp:61-84), FramePoint::setEpipolarOffset, lost list from previous points
-  // whose next() stayed null.  Bodies are mechanical; see INTEGRATION.md §3 for the field mapping.
-  void downloadKeypoints(Frame* frame_);
-  void materializeTrackedPoints(Frame* frame_, Frame* previous_, FramePointPointerVector& lost_, const vslam_frame_info& info_);
-  void materializeRecoveredPoints(Frame* frame_, const FramePointPointerVector& lost_) const;
-  void materializeNewPoints(Frame* frame_);
-  HipContext* _hip;
-};
-
-class HipStereoUVAligner : public StereoUVAligner {
-public:
-  HipStereoUVAligner(AlignerParameters* parameters_, HipContext* hip_) : StereoUVAligner(parameters_), _hip(hip_) {}
-
-  //! creates the device context once every parameter is known (called after the generator's configure)
-  void configure() override {
-    vslam_config& c = _hip->config;
-    c.aligner_error_delta_for_convergence = _parameters->error_delta_for_convergence;
-    c.aligner_maximum_error_kernel = _parameters->maximum_error_kernel;
-    c.aligner_damping = _parameters->damping;
-    c.aligner_maximum_number_of_iterations = _parameters->maximum_number_of_iterations;
-    c.aligner_minimum_number_of_inliers = _parameters->minimum_number_of_inliers;
-    c.minimum_depth_meters = _minimum_reliable_depth_meters;
-    c.maximum_reliable_depth_meters = _maximum_reliable_depth_meters;
-    if (!_hip->ctx) hipCheck(nullptr, vslam_create(&c, 0, 1, &_hip->ctx), "HipStereoUVAligner::configure");
+  //! getPointInLeftCamera (:871-895) from the configuration, the arithmetic of the device's triangulation
+  PointCoordinates pointInLeftCamera(const double xL, const double yL, const double xR, const double yR) const {
+    const vslam_config& c = _hip->config;
+    const double z = c.baseline_h[0] / (xR - xL);
+    return PointCoordinates(1 / c.K[0] * (xL - c.K[2]) * z, 1 / c.K[4] * ((yL + yR) / 2.0 - c.K[5]) * z, z);
+  }
+  void pruneOnDevice(Frame* frame_) const {
+    double pose[12];
+    hipToArray(frame_->cameraLeftToWorld(), pose);   // Frame::setRobotToWorld happened on the host (pose_tracker_3d.cpp:151-152,175)
+    hipCheck(_hip->ctx, vslam_set_pose(_hip->ctx, 0, pose), "HipStereoFramePointGenerator|prune");
+    hipCheck(_hip->ctx, vslam_prune_recover(_hip->ctx), "HipStereoFramePointGenerator|prune");
+    _pruned = true;
   }
 
-  //! StereoUVAligner::initialize (stereouv_aligner.cpp:10-69): the correspondences are already on the device
-  void initialize(const Frame* frame_previous_, const Frame* frame_current_, const TransformMatrix3D& previous_to_current_) override {
-    _frame_previous = frame_previous_; _frame_current = frame_current_; _previous_to_current = previous_to_current_;
-    _number_of_measurements = _frame_current->points().size();
-  }
-  void linearize(const bool&) override {}   // folded into converge() on the device
-  void oneRound(const bool&) override {}
-
-  //! StereoUVAligner::converge (:210-264): one launch; results into the base-class members the tracker reads
-  void converge() override {
-    hipCheck(_hip->ctx, vslam_align(_hip->ctx, _parameters->enable_inverse_depth_as_information ? 1 : 0), "converge");
-    std::vector<double> chi(_number_of_measurements);
-    std::vector<uint8_t> inl(_number_of_measurements);
-    double T[12], H[36];
+  //! vslam_get_keypoints -> cv::KeyPoint(x, y, 7, -1, score) + 1x32 CV_8U descriptor rows (frame.h:64-67) and the
+  //! IntensityFeature vectors (frame_point.h:18-35) the framepoints are created from
+  void downloadSide(int side_, std::vector<cv::KeyPoint>& keypoints_, cv::Mat& descriptors_, std::vector<IntensityFeature>& features_,
+                    std::unordered_map<uint32_t, uint32_t>& pixel_to_feature_) const {
+    const int32_t cap = _hip->config.max_keypoints;
+    std::vector<int16_t> xy((size_t)cap * 2);
+    std::vector<int32_t> score(cap);
+    std::vector<uint8_t> desc((size_t)cap * VSLAM_DESC_BYTES);
     int32_t n = 0;
-    hipCheck(_hip->ctx, vslam_get_aligner_result(_hip->ctx, 0, (int32_t)_number_of_measurements, &n, chi.data(), inl.data(), T, H), "converge");
-    vslam_frame_info info;
-    hipCheck(_hip->ctx, vslam_get_frame_info(_hip->ctx, 0, &info), "converge");
-    _errors.assign(chi.begin(), chi.end());
-    _inliers.resize(n);
-    for (int32_t u = 0; u < n; ++u) _inliers[u] = inl[u] != 0;
-    _number_of_inliers = info.n_inliers; _number_of_outliers = info.n_outliers; _total_error = info.total_error;
-    _has_system_converged = info.aligner_converged != 0;
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) _previous_to_current.matrix()(i, j) = T[4 * i + j];
-    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) { _H(i, j) = H[6 * i + j]; _information_matrix(i, j) = H[6 * i + j]; }
+    hipCheck(_hip->ctx, vslam_get_keypoints(_hip->ctx, 0, side_, cap, &n, xy.data(), score.data(), desc.data()), "HipStereoFramePointGenerator|keypoints");
+    keypoints_.resize(n);
+    descriptors_ = cv::Mat(n > 0 ? n : 1, VSLAM_DESC_BYTES, CV_8UC1);
+    features_.resize(n);
+    pixel_to_feature_.clear();
+    for (int32_t i = 0; i < n; ++i) {
+      keypoints_[i] = cv::KeyPoint((float)xy[2 * i], (float)xy[2 * i + 1], 7.f, -1.f, (float)score[i]);   // FAST: size 7, no angle
+      std::memcpy(descriptors_.ptr<uint8_t>(i), &desc[(size_t)VSLAM_DESC_BYTES * i], VSLAM_DESC_BYTES);
+      features_[i] = IntensityFeature(keypoints_[i], descriptors_.row(i), (size_t)i);
+      pixel_to_feature_[((uint32_t)(uint16_t)xy[2 * i + 1] << 16) | (uint16_t)xy[2 * i]] = (uint32_t)i;
+    }
+  }
+  void downloadKeypoints(Frame* frame_) {
+    downloadSide(0, frame_->keypointsLeft(), frame_->descriptorsLeft(), _features_left, _pixel_left);
+    downloadSide(1, frame_->keypointsRight(), frame_->descriptorsRight(), _features_right, _pixel_right);
+    _number_of_detected_keypoints = (Count)_features_left.size();
   }
 
-private:
+  //! the tracked list of the device -> Frame::createFramepoint(left, right, distance, xyz, previous) in the order of the
+  //! previous points, FramePoint::setEpipolarOffset, the lost list, the tracking statistics (:632-668)
+  void materializeTrackedPoints(Frame* frame_, Frame* previous_, FramePointPointerVector& lost_) {
+    FramePointPointerVector& previous_points(previous_->points());
+    const int32_t cap = (int32_t)previous_points.size() + 1;
+    std::vector<int32_t> out4((size_t)cap * 4), lost(cap);
+    int32_t n_tracked = 0, n_lost = 0;
+    hipCheck(_hip->ctx, vslam_get_track_result(_hip->ctx, 0, cap, &n_tracked, out4.data(), &n_lost, lost.data()), "HipStereoFramePointGenerator::track");
+    FramePointPointerVector& points(frame_->points());
+    points.resize(n_tracked);
+    _number_of_tracked_landmarks = 0;
+    real accumulated_descriptor_distance = 0;
+    for (int32_t u = 0; u < n_tracked; ++u) {
+      const int32_t ip = out4[4 * u], fl = out4[4 * u + 1], fr = out4[4 * u + 2], dist = out4[4 * u + 3];
+      if (ip < 0 || ip >= (int32_t)previous_points.size() || fl < 0 || fl >= (int32_t)_features_left.size() || fr < 0 || fr >= (int32_t)_features_right.size())
+        throw std::runtime_error("HipStereoFramePointGenerator::track|host and device frames diverged");
+      const IntensityFeature* feature_left = &_features_left[fl];
+      const IntensityFeature* feature_right = &_features_right[fr];
+      FramePoint* point_previous = previous_points[ip];
+      FramePoint* framepoint = frame_->createFramepoint(feature_left, feature_right, (real)dist,
+                                                        pointInLeftCamera(feature_left->keypoint.pt.x, feature_left->keypoint.pt.y,
+                                                                          feature_right->keypoint.pt.x, feature_right->keypoint.pt.y),
+                                                        point_previous);
+      framepoint->setEpipolarOffset(feature_right->row - feature_left->row);
+      accumulated_descriptor_distance += dist;
+      points[u] = framepoint;
+      if (point_previous->landmark()) ++_number_of_tracked_landmarks;
+    }
+    lost_.resize(n_lost);
+    for (int32_t u = 0; u < n_lost; ++u) lost_[u] = previous_points[lost[u]];
+    previous_->setAverageDescriptorDistanceTracking(accumulated_descriptor_distance / n_tracked);
+  }
+
+  //! after vslam_prune_recover the device's frame holds the survivors of _prunePoints followed by the recovered points
+  //! (:841-856: features owned by the framepoint, previous = the lost point)
+  void materializeRecoveredPoints(Frame* frame_) const {
+    Frame* previous = frame_->previous();
+    if (!previous) return;
+    const int32_t cap = _hip->config.max_points;
+    std::vector<int16_t> kp((size_t)cap * 4);
+    std::vector<int32_t> meta((size_t)cap * 6);
+    std::vector<double> cam((size_t)cap * 3);
+    std::vector<uint8_t> desc((size_t)cap * 64);
+    int32_t n = 0;
+    hipCheck(_hip->ctx, vslam_get_frame_points(_hip->ctx, 0, 1, cap, &n, kp.data(), meta.data(), cam.data(), nullptr, desc.data()), "HipStereoFramePointGenerator::recoverPoints");
+    FramePointPointerVector& points(frame_->points());
+    const int32_t n_kept = (int32_t)points.size();
+    if (n < n_kept) throw std::runtime_error("HipStereoFramePointGenerator::recoverPoints|host and device frames diverged (prune)");
+    for (int32_t i = 0; i < n_kept; ++i)
+      if (points[i]->keypointLeft().pt.x != (float)kp[4 * i] || points[i]->keypointLeft().pt.y != (float)kp[4 * i + 1])
+        throw std::runtime_error("HipStereoFramePointGenerator::recoverPoints|host and device frames diverged (prune order)");
+    points.resize(n);
+    for (int32_t i = n_kept; i < n; ++i) {
+      const int32_t ip = meta[6 * i + 2];
+      if (ip < 0 || ip >= (int32_t)previous->points().size()) throw std::runtime_error("HipStereoFramePointGenerator::recoverPoints|bad previous index");
+      FramePoint* point_previous = previous->points()[ip];
+      cv::Mat descriptor_left(1, VSLAM_DESC_BYTES, CV_8UC1), descriptor_right(1, VSLAM_DESC_BYTES, CV_8UC1);
+      std::memcpy(descriptor_left.ptr<uint8_t>(0), &desc[(size_t)64 * i], VSLAM_DESC_BYTES);
+      std::memcpy(descriptor_right.ptr<uint8_t>(0), &desc[(size_t)64 * i + VSLAM_DESC_BYTES], VSLAM_DESC_BYTES);
+      cv::KeyPoint keypoint_left(point_previous->keypointLeft()), keypoint_right(point_previous->keypointRight());
+      keypoint_left.pt.x = kp[4 * i]; keypoint_left.pt.y = kp[4 * i + 1];
+      keypoint_right.pt.x = kp[4 * i + 2]; keypoint_right.pt.y = kp[4 * i + 3];
+      const IntensityFeature feature_left(keypoint_left, descriptor_left, 0), feature_right(keypoint_right, descriptor_right, 0);
+      points[i] = frame_->createFramepoint(&feature_left, &feature_right, (real)meta[6 * i],
+                                           PointCoordinates(cam[3 * i], cam[3 * i + 1], cam[3 * i + 2]), point_previous);
+    }
+  }
+
+  //! the finished device frame = the host list so far + the new stereo points in emission order
+  void materializeNewPoints(Frame* frame_) {
+    const int32_t cap = _hip->config.max_points;
+    std::vector<int16_t> kp((size_t)cap * 4);
+    std::vector<int32_t> meta((size_t)cap * 6);
+    std::vector<double> cam((size_t)cap * 3);
+    int32_t n = 0;
+    hipCheck(_hip->ctx, vslam_get_frame_points(_hip->ctx, 0, 0, cap, &n, kp.data(), meta.data(), cam.data(), nullptr, nullptr), "HipStereoFramePointGenerator::compute");
+    FramePointPointerVector& points(frame_->points());
+    const int32_t n_old = (int32_t)points.size();
+    if (n < n_old) throw std::runtime_error("HipStereoFramePointGenerator::compute|host and device frames diverged");
+    points.resize(n);
+    for (int32_t i = n_old; i < n; ++i) {
+      const auto fl = _pixel_left.find(((uint32_t)(uint16_t)kp[4 * i + 1] << 16) | (uint16_t)kp[4 * i]);
+      const auto fr = _pixel_right.find(((uint32_t)(uint16_t)kp[4 * i + 3] << 16) | (uint16_t)kp[4 * i + 2]);
+      if (fl == _pixel_left.end() || fr == _pixel_right.end()) throw std::runtime_error("HipStereoFramePointGenerator::compute|new point without a feature");
+      FramePoint* framepoint = frame_->createFramepoint(&_features_left[fl->second], &_features_right[fr->second], (real)meta[6 * i],
+                                                        PointCoordinates(cam[3 * i], cam[3 * i + 1], cam[3 * i + 2]));
+      framepoint->setEpipolarOffset(meta[6 * i + 1]);
+      points[i] = framepoint;
+    }
+  }
+
   HipContext* _hip;
+  mutable bool _pruned = false;
+  std::vector<IntensityFeature> _features_left, _features_right;            // keypoints + descriptors of the current frame
+  std::unordered_map<uint32_t, uint32_t> _pixel_left, _pixel_right;        // (row << 16 | col) -> feature (one feature per pixel)
 };
 
 }  // namespace proslam

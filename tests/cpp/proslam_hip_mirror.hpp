@@ -1,4 +1,4 @@
-// proslam_hip.hpp — host side above the C ABI, in C++14, mirroring the reference's plug-in interface for the hot
+// proslam_hip_mirror.hpp — TEST-ONLY host mirror above the C ABI, in C++14, mirroring the reference's plug-in interface for the hot
 // path (same class and method names, argument meaning and error behaviour) without its OpenCV / Eigen / srrg
 // dependencies, which are absent from this image.  Inside the reference tree use shim/proslam_hip_plugin.h instead
 // (it derives from the reference's own classes).  Single sequence (n_streams = 1), as the reference.
@@ -14,7 +14,7 @@
 #include <string>
 #include <vector>
 
-#include "../include/vslam_hip.h"
+#include "../../include/vslam_hip.h"
 
 namespace proslam_hip {
 

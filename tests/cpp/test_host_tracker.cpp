@@ -1,4 +1,4 @@
-// test_host_tracker.cpp — the C++ host mirror of the reference's plug-in interface (host/proslam_hip.hpp) driving
+// test_host_tracker.cpp — the C++ host mirror of the reference's plug-in interface (tests/cpp/proslam_hip_mirror.hpp) driving
 // libvslam_hip.so call by call, checked frame by frame against the CPU oracle (test infrastructure) on a rendered
 // synthetic sequence.  Reads like the reference's own harness (executables/test_stereo_frontend.cpp: initialize ->
 // track -> compute per frame), with assertions instead of a display.  Exit code 0 = pass.
@@ -7,7 +7,7 @@
 #include <cstring>
 #include <vector>
 
-#include "../../host/proslam_hip.hpp"
+#include "proslam_hip_mirror.hpp"
 #include "../../tools/synth/synth_scene.h"
 
 extern "C" {

@@ -618,7 +618,8 @@ VS_API int vslam_get_keypoints(vslam_ctx* c, int s, int side, int32_t cap, int32
   if (score) for (int i = 0; i < cnt; ++i) score[i] = sc[i];
   return VSLAM_OK;
 }
-VS_API int vslam_get_points(vslam_ctx* c, int s, int32_t cap, int32_t* n, int16_t* kp, int32_t* meta, double* cam, double* lm) {
+static int get_points_impl(vslam_ctx* c, int s, int in_progress, int32_t cap, int32_t* n, int16_t* kp, int32_t* meta, double* cam, double* lm,
+                           uint8_t* desc) {
   int rc = check_stream(c, s);
   if (rc) return rc;
   if (!n) return fail(c, VSLAM_ERR_INVALID, "bad argument");
@@ -626,18 +627,23 @@ VS_API int vslam_get_points(vslam_ctx* c, int s, int32_t cap, int32_t* n, int16_
   HIP_TRY(c, d2h(c, &st, c->buf.st + s, 1));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   int32_t cnt = 0;
-  HIP_TRY(c, d2h(c, &cnt, c->buf.n_points + s * 2 + st.cur, 1));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (!st.has_prev) cnt = 0;
+  const int pb = in_progress ? (st.cur ^ 1) : st.cur;
+  if (in_progress) cnt = st.n_cur;
+  else {
+    HIP_TRY(c, d2h(c, &cnt, c->buf.n_points + s * 2 + st.cur, 1));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!st.has_prev) cnt = 0;
+  }
   *n = cnt;
   if (cnt > cap) return fail(c, VSLAM_ERR_CAPACITY, "point output capacity too small");
-  const size_t o = ((size_t)s * 2 + st.cur) * c->cfg.MAXP;
+  const size_t o = ((size_t)s * 2 + pb) * c->cfg.MAXP;
   std::vector<int32_t> m((size_t)cnt * META);
   std::vector<int16_t> k((size_t)cnt * 4);
   HIP_TRY(c, d2h(c, k.data(), c->buf.p_kp + o * 4, (size_t)cnt * 4));
   HIP_TRY(c, d2h(c, m.data(), c->buf.p_meta + o * META, (size_t)cnt * META));
   HIP_TRY(c, d2h(c, cam, c->buf.p_cam + o * 3, (size_t)cnt * 3));
   HIP_TRY(c, d2h(c, lm, c->buf.p_lm + o * 3, (size_t)cnt * 3));
+  HIP_TRY(c, d2h(c, desc, c->buf.p_desc + o * 64, (size_t)cnt * 64));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   for (int i = 0; i < cnt; ++i) {
     if (kp) for (int q = 0; q < 4; ++q) kp[4 * i + q] = k[4 * i + q];
@@ -647,6 +653,27 @@ VS_API int vslam_get_points(vslam_ctx* c, int s, int32_t cap, int32_t* n, int16_
     }
     if (lm && m[META * i + M_LMUP] == 0) { lm[3 * i] = lm[3 * i + 1] = lm[3 * i + 2] = 0; }
   }
+  return VSLAM_OK;
+}
+VS_API int vslam_get_points(vslam_ctx* c, int s, int32_t cap, int32_t* n, int16_t* kp, int32_t* meta, double* cam, double* lm) {
+  return get_points_impl(c, s, 0, cap, n, kp, meta, cam, lm, nullptr);
+}
+VS_API int vslam_get_frame_points(vslam_ctx* c, int s, int in_progress, int32_t cap, int32_t* n, int16_t* kp, int32_t* meta, double* cam,
+                                  double* lm, uint8_t* desc) {
+  return get_points_impl(c, s, in_progress, cap, n, kp, meta, cam, lm, desc);
+}
+VS_API int vslam_get_track_result(vslam_ctx* c, int s, int32_t cap, int32_t* n_tracked, int32_t* out4, int32_t* n_lost, int32_t* lost) {
+  int rc = check_stream(c, s);
+  if (rc) return rc;
+  if (!n_tracked || !n_lost) return fail(c, VSLAM_ERR_INVALID, "bad argument");
+  StreamState st;
+  HIP_TRY(c, d2h(c, &st, c->buf.st + s, 1));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  *n_tracked = st.n_trk; *n_lost = st.n_lost;
+  if (st.n_trk > cap || st.n_lost > cap) return fail(c, VSLAM_ERR_CAPACITY, "track output capacity too small");
+  HIP_TRY(c, d2h(c, out4, c->buf.trk + (size_t)s * c->cfg.MAXP * 4, (size_t)st.n_trk * 4));
+  HIP_TRY(c, d2h(c, lost, c->buf.lost + (size_t)s * c->cfg.MAXP, (size_t)st.n_lost));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return VSLAM_OK;
 }
 VS_API int vslam_get_aligner_result(vslam_ctx* c, int s, int32_t cap, int32_t* n, double* chi, uint8_t* inlier, double T[12], double H[36]) {
