@@ -128,7 +128,7 @@ struct Harness {
     generator->compute(current);
     current->setStatus(status);
     tracked_landmarks_previous = active_landmarks;
-    if (frames.size() > 3) frames.erase(frames.begin());   // keep the window the links reach into (previous of previous is only read through next/previous pointers)
+    // frames are kept for the whole run: origin() / previous() chains of the tracks reach back into them
     return current;
   }
 };
