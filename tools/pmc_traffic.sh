@@ -7,7 +7,7 @@ OUT=$PWD/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -- python3 bench.py --no-cpu --steps 8 > $OUT/$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -- python3 bench.py --no-cpu --no-exact --no-pcie --steps 8 > $OUT/$C.log 2>&1
 done
 python3 - "$OUT" << 'PY'
 import csv, glob, json, sys, collections

@@ -213,19 +213,25 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
       if (cand) queue[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)((r << 8) | cc);
     }
   };
+#ifndef VS_PROBE
+#define VS_PROBE 0
+#endif
+  if (VS_PROBE & 1) { /* probe build: no pretest, no candidates */ } else
   if (uni_thr != -2) {
     // uniform threshold (the usual tile): four pixels per lane from aligned dwords, the compass differences in packed
-    // i16 (v_perm_b32 unpacks, v_pk_sub/min/max_i16), one queue reservation per wave-pass
+    // i16 (v_perm_b32 unpacks, v_pk_sub/min/max_i16).  16 lanes per region row (dwords 1..16 = region columns 1..64), four rows
+    // per wavefront and pass: no division in the index arithmetic, the third pass (rows 32, 33) is one half wavefront while
+    // two other wavefronts test the halo columns 0 and 65.  The four candidate predicates are the sign bits of the packed
+    // differences, balloted as they are (v_cmp_lt_i16 / _i32): one queue reservation per wave-pass.
     const s16x2 thr2 = {(short)uni_thr, (short)uni_thr};
-    constexpr int NT = (VS_TILE_H + 2) * 18;
-    for (int t0 = 0; t0 < NT; t0 += 256) {
-      const int t = t0 + tid;
-      unsigned bits4 = 0;
-      int r = 0, q = 0;
-      if (t < NT) {
-        r = t / 18; q = t - 18 * r;
+#pragma unroll 1
+    for (int pass = 0; pass < (VS_TILE_H + 2 + 15) / 16; ++pass) {
+      if (pass * 16 + w * 4 >= VS_TILE_H + 2) continue;          // wave-uniform: nothing of this wavefront in the pass
+      const int r = pass * 16 + (tid >> 4), q = (tid & 15) + 1;
+      uint32_t ng0 = 0, ng1 = 0;
+      if (r < VS_TILE_H + 2) {
         const uint32_t* rowp = reinterpret_cast<const uint32_t*>(&tile[r + 3][0]);
-        const uint32_t C = rowp[q], C0 = q > 0 ? rowp[q - 1] : 0u, C2 = rowp[q + 1];
+        const uint32_t C = rowp[q], C0 = rowp[q - 1], C2 = rowp[q + 1];
         const uint32_t N = reinterpret_cast<const uint32_t*>(&tile[r][0])[q], S = reinterpret_cast<const uint32_t*>(&tile[r + 6][0])[q];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -233,32 +239,32 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
           const uint32_t vv = __builtin_amdgcn_perm(0u, C, sel), nn = __builtin_amdgcn_perm(0u, N, sel), ss = __builtin_amdgcn_perm(0u, S, sel);
           const uint32_t ee = __builtin_amdgcn_perm(C2, C, half ? 0x0c060c05u : 0x0c040c03u);
           const uint32_t ww = __builtin_amdgcn_perm(C, C0, half ? 0x0c040c03u : 0x0c020c01u);
-          const s16x2 v = __builtin_bit_cast(s16x2, vv);
-          const s16x2 d0 = v - __builtin_bit_cast(s16x2, ss), d8 = v - __builtin_bit_cast(s16x2, nn);
-          const s16x2 d4 = v - __builtin_bit_cast(s16x2, ee), d12 = v - __builtin_bit_cast(s16x2, ww);
-          const s16x2 dk = pk_min(pk_max(d0, d8), pk_max(d4, d12));
-          const s16x2 br = pk_max(pk_min(d0, d8), pk_min(d4, d12));
-          // dk > thr  <=>  thr - dk < 0 ;  br < -thr  <=>  br + thr < 0   (|values| <= 510: no i16 overflow)
-          const uint32_t neg = (__builtin_bit_cast(uint32_t, thr2 - dk) | __builtin_bit_cast(uint32_t, br + thr2)) & 0x80008000u;
-          bits4 |= (((neg >> 15) & 1u) | ((neg >> 30) & 2u)) << (2 * half);
+          // dark side: some of {N,S} and some of {E,W} darker than v - thr  <=>  max(min(n,s), min(e,w)) < v - thr
+          // bright side: min(max(n,s), max(e,w)) > v + thr                  (values 0..255 +- thr: no i16 overflow)
+          const s16x2 v = __builtin_bit_cast(s16x2, vv), n = __builtin_bit_cast(s16x2, nn), s_ = __builtin_bit_cast(s16x2, ss);
+          const s16x2 e = __builtin_bit_cast(s16x2, ee), w_ = __builtin_bit_cast(s16x2, ww);
+          const s16x2 lo = pk_max(pk_min(n, s_), pk_min(e, w_)), hi = pk_min(pk_max(n, s_), pk_max(e, w_));
+          const uint32_t neg = __builtin_bit_cast(uint32_t, (s16x2)(lo - (v - thr2))) | __builtin_bit_cast(uint32_t, (s16x2)((v + thr2) - hi));
+          if (half) ng1 = neg; else ng0 = neg;
         }
-        if (q == 0) bits4 &= 8u;     // region columns -3..0: only column 0 exists
-        if (q == 17) bits4 &= 1u;    // region columns 65..68: only column 65 exists
       }
-      const unsigned long long m0 = __ballot(bits4 & 1u), m1 = __ballot(bits4 & 2u), m2 = __ballot(bits4 & 4u), m3 = __ballot(bits4 & 8u);
+      const bool p0 = (short)(ng0 & 0xffffu) < 0, p1 = (int)ng0 < 0, p2 = (short)(ng1 & 0xffffu) < 0, p3 = (int)ng1 < 0;
+      const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1), m2 = __ballot(p2), m3 = __ballot(p3);
       const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
       if (n0 + n1 + n2 + n3) {
         int base = 0;
         if (lane == 0) base = atomicAdd(&qn, n0 + n1 + n2 + n3);
         base = __builtin_amdgcn_readfirstlane(base);
-        const int cc0 = 4 * q - 3, e = r << 8;
+        const int ent = (r << 8) | (4 * q - 3);
         auto below = [&](unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
-        if (bits4 & 1u) queue[base + below(m0)] = (uint16_t)(e | cc0);
-        if (bits4 & 2u) queue[base + n0 + below(m1)] = (uint16_t)(e | (cc0 + 1));
-        if (bits4 & 4u) queue[base + n0 + n1 + below(m2)] = (uint16_t)(e | (cc0 + 2));
-        if (bits4 & 8u) queue[base + n0 + n1 + n2 + below(m3)] = (uint16_t)(e | (cc0 + 3));
+        if (p0) queue[base + below(m0)] = (uint16_t)ent;
+        if (p1) queue[base + n0 + below(m1)] = (uint16_t)(ent + 1);
+        if (p2) queue[base + n0 + n1 + below(m2)] = (uint16_t)(ent + 2);
+        if (p3) queue[base + n0 + n1 + n2 + below(m3)] = (uint16_t)(ent + 3);
       }
     }
+    // region columns 0 and 65 (the NMS halo left and right of the tile): (H+2)*2 pixels on the wavefronts the last pass leaves idle
+    if (tid >= 64 && tid < 64 + (VS_TILE_H + 2) * 2) { const int i = tid - 64; pretest(i >> 1, (i & 1) ? 65 : 0); }
   } else {
     for (int r = w; r < VS_TILE_H + 2; r += 4) pretest(r, lane);
     // the two halo columns 64, 65 of every row: (H+2)*2 pixels, waves 0-1
@@ -268,6 +274,7 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
     }
   }
   // ---- horizontal 9-sums, four outputs per thread from three aligned dwords -----------------------------------------
+  if (!(VS_PROBE & 4))
   for (int i = tid; i < (VS_TILE_H + 8) * 16; i += 256) {
     const int r = i >> 4, q = i & 15;
     const uint32_t* p = reinterpret_cast<const uint32_t*>(&tile[r][4 * q]);
@@ -279,7 +286,7 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
     *reinterpret_cast<uint2*>(&hs[r][4 * q]) = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
   }
   __syncthreads();
-  {
+  if (!(VS_PROBE & 2)) {
     const int nq = qn;
     for (int q = tid; 2 * q < nq; q += 256) {
       const int e0 = queue[2 * q], e1 = (2 * q + 1 < nq) ? queue[2 * q + 1] : e0;
@@ -316,7 +323,7 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
   }
   // ---- vertical 9-sums (sliding), two pixels per lane in packed u16 -> u16 box image: lanes 0-31 own the upper half of
   // the wave's rows, lanes 32-63 the lower half --------------------------------------------------------------------------
-  {
+  if (!(VS_PROBE & 4)) {
     constexpr int RW = VS_TILE_H / 8;   // output rows per half-wave
     const int half = lane >> 5, px = 2 * (lane & 31);
     const int rbase = (w * 2 + half) * RW;

@@ -490,13 +490,22 @@ static int frame_done(vslam_ctx* c) {
   c->parity = set ^ 1;
   return VSLAM_OK;
 }
+// blocks per stream of the candidate kernel (16 point groups each).  Streams differ in cost by an order of magnitude (a
+// Localizing stream searches 101 x 101 windows by appearance, a Tracking stream ~31 x 31), so the points are spread over
+// many small blocks — about one previous point per 16-lane group at ~700 points — and the hardware scheduler balances
+// them: 0.154 -> 0.086 ms back to back at 160 streams of mixed phase against 12 blocks per stream (profiles/r02_*).
+static int cand_blocks(const vslam_ctx* c, int n_streams) {
+  if (const char* e = getenv("VSLAM_CAND_GX")) return std::max(1, atoi(e));
+  (void)c;
+  return std::max(4, std::min(128, 7040 / std::max(n_streams, 1)));
+}
 static int launch_frame(vslam_ctx* c) {
   size_t gi = 0;
   for (auto& g : c->groups) {
     const DevBuf bs = buf_set(c, c->last_set, g.s0);
     ConstDevCfg* kc = (ConstDevCfg*)c->d_cfg;
     ConstDevBuf* kb = (ConstDevBuf*)(c->d_bufs + c->last_set * c->groups.size() + gi++);
-    const int gx = std::max(4, std::min(128, 2048 / std::max(g.n, 1)));
+    const int gx = cand_blocks(c, g.n);
     { KernelTimer t(c, 3, g.st_frm); hipLaunchKernelGGL(k_track_candidates, dim3(gx, g.n), dim3(256), 0, g.st_frm, c->cfg, bs, -1); }
     if (!c->split) {
       KernelTimer t(c, 4, g.st_frm);
@@ -1558,7 +1567,7 @@ VS_API int vslam_frame_restore(vslam_ctx* c) {
 VS_API int vslam_track(vslam_ctx* c, int by_appearance) {
   NEED_FRAME("vslam_track");
   for (auto& g : c->groups) {
-    const int gx = std::max(4, std::min(128, 2048 / std::max(g.n, 1)));
+    const int gx = cand_blocks(c, g.n);
     hipLaunchKernelGGL(k_track_candidates, dim3(gx, g.n), dim3(256), 0, g.st_frm, c->cfg, buf_set(c, c->last_set, g.s0), by_appearance ? 1 : 0);
   }
   return launch_stage(c, VS_STAGE_TRACK, by_appearance ? 1 : 0);
