@@ -227,6 +227,27 @@ class Bench(object):
         elapsed = self.max_over_ranks(time.perf_counter() - t0)
         unique = self.sum_over_ranks(unique_in(k_first, K))
         stats, flags = frame_stats(api, range(B))
+        # untimed: the same all-gather through the C ABI (vslam_comm_init / vslam_allgather_poses, RCCL called by the library
+        # itself — what a C++ caller uses), compared with torch.distributed's result
+        c_abi = None
+        if world > 1 and os.environ.get("VSLAM_BENCH_C_ABI_COMM", "1") != "0":
+            box = {}
+
+            def c_abi_gather():
+                try:
+                    torch.cuda.set_device(self.dev_index)
+                    ref = sharding.gather_poses(pose_send)
+                    comm = sharding.PoseComm(api, rank, world, self.dev_index)
+                    got = comm.allgather(pose_send)
+                    comm.destroy()
+                    box["r"] = "identical to torch.distributed" if torch.equal(got, ref) else "MISMATCH"
+                except Exception as e:  # a rehearsal with several ranks on one GPU cannot build an RCCL communicator
+                    box["r"] = "unavailable: %s" % str(e)[:160]
+            th = threading.Thread(target=c_abi_gather, daemon=True)
+            th.start()
+            th.join(timeout=60)
+            c_abi = box.get("r", "timeout")
+            self.c_abi_hung = th.is_alive()
 
         # instrumented pass: per-kernel device time with HIP events on the context's HIP streams
         api.enable_timers(True)
@@ -269,6 +290,7 @@ class Bench(object):
                          "algorithmic_bytes_per_launch": int(abytes[dom]), "avg_launch_ms": round(dom_avg_s * 1e3, 4)},
             "kernels": kern,
             "chronometers_s": {k: round(v, 4) for k, v in chrono.items()},
+            "c_abi_allgather": c_abi,
         }
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -517,7 +539,9 @@ def main():
                 if "cpu_baseline" in out:
                     out["exact_mode"]["single_sequence_speedup_vs_cpu_port"] = round(one["frames_per_s"] / out["cpu_baseline"]["value"], 1)
     if b.rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if getattr(b, "c_abi_hung", False):
+        os._exit(0)      # a communicator that never formed must not keep the finished benchmark from exiting
     if b.world > 1:
         torch.distributed.destroy_process_group()
 

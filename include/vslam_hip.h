@@ -441,6 +441,21 @@ int vslam_get_poses(vslam_ctx* ctx, int stream, int32_t first_frame, int32_t n_f
  * stream): the send buffer of the RCCL all-gather. */
 int vslam_copy_poses_device(vslam_ctx* ctx, int32_t first_frame, int32_t n_frames, double* dst_device);
 
+/* ---- multi-GPU: the pose all-gather itself, on RCCL, for callers that are not Python ---------------
+ * One process per GPU.  Rank 0 asks for a unique id (128 bytes, ncclUniqueId) and hands it to the other ranks by whatever
+ * channel launched them (MPI, a file, torch.distributed's store); every rank then joins with vslam_comm_init.  RCCL
+ * (librccl.so) is loaded on first use: a single-GPU user of the library never needs it.
+ * vslam_allgather_poses: send_device holds this rank's count doubles (e.g. [streams][frames][12] as vslam_copy_poses_device
+ * leaves them), recv_device receives nranks * count doubles ordered by rank; one ncclAllGather (xGMI on one node), queued
+ * on hip_stream (NULL: the default stream), asynchronous — synchronise the stream before reading. */
+typedef struct vslam_comm vslam_comm;
+#define VSLAM_COMM_ID_BYTES 128
+int vslam_comm_unique_id(uint8_t id[VSLAM_COMM_ID_BYTES]);
+int vslam_comm_init(int rank, int nranks, const uint8_t id[VSLAM_COMM_ID_BYTES], int device, vslam_comm** out);
+int vslam_allgather_poses(vslam_comm* comm, const double* send_device, double* recv_device, size_t count, void* hip_stream);
+void vslam_comm_destroy(vslam_comm* comm);
+const char* vslam_comm_last_error(void);
+
 /* The pose (camera_left_to_world) of the frame every stream processed last, into DEVICE memory dst[stream][12],
  * asynchronous on the context stream: one row block of the all-gather's send buffer per step. */
 int vslam_copy_current_poses_device(vslam_ctx* ctx, double* dst_device);

@@ -104,6 +104,82 @@ def test_pose_allgather_two_ranks_gloo():
     np.testing.assert_array_equal(results[0], results[1])
 
 
+def _id_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    uid = np.zeros(128, np.uint8)
+    if rank == 0:
+        uid[:] = (np.arange(128) * 7 + 3) % 251          # stands in for ncclGetUniqueId's bytes (needs a GPU)
+    got = sharding.exchange_unique_id(uid, rank)
+    # the send buffer layout of vslam_copy_poses_device: [streams][frames][12], gathered rank-major
+    import torch
+    send = torch.arange(2 * 3 * 12, dtype=torch.float64).reshape(2, 3, 12) + 1000.0 * rank
+    allp = sharding.gather_poses(send).numpy()
+    q.put((rank, got, allp))
+    dist.destroy_process_group()
+
+
+def test_comm_id_exchange_and_pose_layout_two_ranks_gloo():
+    """What a two-process caller of the C-ABI collective does around it, on CPU: rank 0's 128-byte communicator id reaches rank 1
+    unchanged, and the [streams][frames][12] send blocks come back rank-major (the order ncclAllGather gives)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_id_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r: (u, a) for r, u, a in (q.get(timeout=60) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = ((np.arange(128) * 7 + 3) % 251).astype(np.uint8)
+    np.testing.assert_array_equal(res[0][0], want)
+    np.testing.assert_array_equal(res[1][0], want)
+    for r in range(2):
+        a = res[r][1]
+        assert a.shape == (4, 3, 12)
+        np.testing.assert_array_equal(a[:2].ravel(), np.arange(72.0))
+        np.testing.assert_array_equal(a[2:].ravel(), np.arange(72.0) + 1000.0)
+
+
+@pytest.mark.gpu
+def test_c_abi_pose_allgather_single_rank_rccl():
+    """vslam_comm_unique_id / vslam_comm_init / vslam_allgather_poses on the GPU: librccl.so is loaded by the library itself, a
+    one-rank communicator gathers the context's own pose block (vslam_copy_poses_device) bit for bit."""
+    import torch
+    from vslam_pose_estimation_framework_amd import hip, synth
+    api = hip.load()
+    sy = synth.Synth()
+    scene = sy.scene_kitti(seed=3)
+    cfg = synth.config_for_scene(api, scene)
+    cfg.max_keypoints, cfg.max_points, cfg.max_history_frames = 8192, 4096, 16
+    B, K = 3, 5
+    dev = torch.device("cuda", 0)
+    stride = 1280
+    L = torch.empty((K, B, cfg.rows, stride), dtype=torch.uint8, device=dev)
+    R = torch.empty_like(L)
+    for s in range(B):
+        sy.render_device(scene, 10 * s, K, L[0, s].data_ptr(), R[0, s].data_ptr(), stride, B * cfg.rows * stride, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    api.create(cfg, 0, B)
+    for k in range(K):
+        api.process_device(L[k].data_ptr(), R[k].data_ptr(), stride, cfg.rows * stride)
+    send = torch.zeros((B, K, 12), dtype=torch.float64, device=dev)
+    api.copy_poses_device(0, K, send.data_ptr())
+    api.synchronize()
+    comm = sharding.PoseComm(api, 0, 1, 0)
+    out = comm.allgather(send)
+    comm.destroy()
+    assert out.shape == (B, K, 12)
+    assert torch.equal(out, send)
+    host = np.stack([api.poses(s, 0, K).reshape(K, 12) for s in range(B)])
+    np.testing.assert_array_equal(out.cpu().numpy(), host)
+    api.destroy()
+
+
 def test_chunked_oracle_trajectory_matches_sequential(oracle):
     """Chunks with a warm-up overlap, chained by sharding.assemble_trajectory, against the sequential run and
     the synthetic ground truth (CPU oracle; the device runs the same chunks as independent streams)."""

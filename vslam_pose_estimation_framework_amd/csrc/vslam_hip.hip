@@ -1602,6 +1602,79 @@ VS_API int vslam_set_pose(vslam_ctx* c, int s, const double pose[12]) {
   return VSLAM_OK;
 }
 
+// ---- pose all-gather on RCCL (loaded lazily: the single-GPU path has no dependency on librccl.so) ----------------------------
+#include <dlfcn.h>
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, struct Id128, int) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+struct Id128 { char internal[VSLAM_COMM_ID_BYTES]; };   // ncclUniqueId: passed BY VALUE to ncclCommInitRank
+RcclApi g_rccl;
+thread_local std::string g_comm_error;
+int comm_fail(int code, const std::string& msg) { g_comm_error = msg; return code; }
+int rccl_load() {
+  if (g_rccl.lib) return VSLAM_OK;
+  void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return comm_fail(VSLAM_ERR_NO_DEVICE, std::string("librccl.so not found: ") + dlerror());
+  RcclApi a;
+  a.lib = h;
+  a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+  a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+  a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(h, "ncclAllGather"));
+  a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+  a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+  if (!a.GetUniqueId || !a.CommInitRank || !a.AllGather || !a.CommDestroy || !a.GetErrorString) return comm_fail(VSLAM_ERR_NO_DEVICE, "librccl.so lacks an expected symbol");
+  g_rccl = a;
+  return VSLAM_OK;
+}
+}  // namespace
+struct vslam_comm { void* comm = nullptr; int rank = 0, nranks = 1, device = 0; };
+VS_API const char* vslam_comm_last_error(void) { return g_comm_error.c_str(); }
+VS_API int vslam_comm_unique_id(uint8_t id[VSLAM_COMM_ID_BYTES]) {
+  if (!id) return comm_fail(VSLAM_ERR_INVALID, "null id");
+  int rc = rccl_load();
+  if (rc != VSLAM_OK) return rc;
+  Id128 u;
+  const int r = g_rccl.GetUniqueId(&u);
+  if (r != 0) return comm_fail(VSLAM_ERR_HIP, std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r));
+  std::memcpy(id, u.internal, VSLAM_COMM_ID_BYTES);
+  return VSLAM_OK;
+}
+VS_API int vslam_comm_init(int rank, int nranks, const uint8_t id[VSLAM_COMM_ID_BYTES], int device, vslam_comm** out) {
+  if (!out || !id || nranks < 1 || rank < 0 || rank >= nranks) return comm_fail(VSLAM_ERR_INVALID, "vslam_comm_init: bad argument");
+  int rc = rccl_load();
+  if (rc != VSLAM_OK) return rc;
+  if (hipSetDevice(device) != hipSuccess) return comm_fail(VSLAM_ERR_NO_DEVICE, "vslam_comm_init: hipSetDevice failed");
+  Id128 u;
+  std::memcpy(u.internal, id, VSLAM_COMM_ID_BYTES);
+  vslam_comm* c = new vslam_comm;
+  c->rank = rank; c->nranks = nranks; c->device = device;
+  const int r = g_rccl.CommInitRank(&c->comm, nranks, u, rank);
+  if (r != 0) { delete c; return comm_fail(VSLAM_ERR_HIP, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r)); }
+  *out = c;
+  return VSLAM_OK;
+}
+VS_API int vslam_allgather_poses(vslam_comm* c, const double* send, double* recv, size_t count, void* stream) {
+  if (!c || !send || !recv) return comm_fail(VSLAM_ERR_INVALID, "vslam_allgather_poses: bad argument");
+  if (count == 0) return VSLAM_OK;
+  if (hipSetDevice(c->device) != hipSuccess) return comm_fail(VSLAM_ERR_NO_DEVICE, "hipSetDevice failed");
+  const int r = g_rccl.AllGather(send, recv, count, /*ncclDouble*/ 8, c->comm, (hipStream_t)stream);
+  if (r != 0) return comm_fail(VSLAM_ERR_HIP, std::string("ncclAllGather: ") + g_rccl.GetErrorString(r));
+  return VSLAM_OK;
+}
+VS_API void vslam_comm_destroy(vslam_comm* c) {
+  if (!c) return;
+  if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+  delete c;
+}
+
 // profiling aid (not part of the ABI): mean per-stream ticks of the fine-grained phase stamps, in microseconds
 VS_API int vslam_debug_ticks(vslam_ctx* c, double us[12]) {
   if (!c || !us) return VSLAM_ERR_INVALID;

@@ -70,3 +70,60 @@ def gather_poses(local_poses, group=None):
                       device=local_poses.device)
     dist.all_gather_into_tensor(out, local_poses.contiguous(), group=group)
     return out
+
+
+def exchange_unique_id(unique_id, rank, group=None):
+    """Rank 0's 128-byte communicator id to every rank over the launcher's own channel (torch.distributed here; MPI or a
+    file work as well).  unique_id: numpy uint8[128], filled on rank 0."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return unique_id
+    t = torch.from_numpy(np.ascontiguousarray(unique_id, np.uint8).copy())
+    on_gpu = dist.get_backend(group) == "nccl"
+    if on_gpu:
+        t = t.cuda()
+    dist.broadcast(t, src=0, group=group)
+    return t.cpu().numpy()
+
+
+class PoseComm(object):
+    """The pose all-gather behind the C ABI (vslam_comm_init / vslam_allgather_poses: RCCL called by libvslam_hip.so itself),
+    what a C++ caller of the library uses; `gather_poses` above is the Python convenience over torch.distributed."""
+
+    def __init__(self, api, rank, world, device, group=None):
+        import ctypes as C
+        import numpy as np
+        self.api, self.rank, self.world = api, rank, world
+        lib = api.lib
+        lib.vslam_comm_last_error.restype = C.c_char_p
+        uid = np.zeros(128, np.uint8)
+        if rank == 0:
+            rc = lib.vslam_comm_unique_id(uid.ctypes.data_as(C.c_void_p))
+            if rc != 0:
+                raise RuntimeError("vslam_comm_unique_id: %d %s" % (rc, lib.vslam_comm_last_error().decode()))
+        uid = np.ascontiguousarray(exchange_unique_id(uid, rank, group), np.uint8)
+        self.comm = C.c_void_p()
+        rc = lib.vslam_comm_init(C.c_int(rank), C.c_int(world), uid.ctypes.data_as(C.c_void_p), C.c_int(device), C.byref(self.comm))
+        if rc != 0:
+            raise RuntimeError("vslam_comm_init: %d %s" % (rc, lib.vslam_comm_last_error().decode()))
+
+    def allgather(self, send):
+        """send: contiguous float64 CUDA tensor; returns [world * send.shape[0], ...] ordered by rank (synchronised)."""
+        import ctypes as C
+        import torch
+        send = send.contiguous()
+        out = torch.empty((self.world * send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        stream = torch.cuda.current_stream(send.device)
+        rc = self.api.lib.vslam_allgather_poses(self.comm, C.c_void_p(send.data_ptr()), C.c_void_p(out.data_ptr()), C.c_size_t(send.numel()),
+                                                C.c_void_p(stream.cuda_stream))
+        if rc != 0:
+            raise RuntimeError("vslam_allgather_poses: %d %s" % (rc, self.api.lib.vslam_comm_last_error().decode()))
+        stream.synchronize()
+        return out
+
+    def destroy(self):
+        if self.comm:
+            self.api.lib.vslam_comm_destroy(self.comm)
+            self.comm = None
