@@ -4,6 +4,7 @@ either side of the hot path; executables/test_stereo_frontend.cpp:106-111,256-31
 
     python tools/run_kitti.py <sequence dir with image_0/ image_1/ calib.txt [times.txt]> [--out traj.txt]
                               [--format kitti|tum] [--gt poses.txt] [--max-frames N] [--config kitti|euroc]
+    python tools/run_kitti.py <EuRoC dir with mav0/cam0 mav0/cam1> --format tum --out traj.txt   (ground truth found in mav0/)
 
 The sequence runs in exact mode (one stream, whole sequence, bit-for-bit the reference port's arithmetic); images are
 uploaded frame by frame through vslam_process_host.  With --gt (KITTI 3x4 rows) the ATE-RMSE after rigid alignment is
@@ -21,15 +22,23 @@ import numpy as np  # noqa: E402
 from vslam_pose_estimation_framework_amd import evaluation, hip, io_formats  # noqa: E402
 
 
-def run(seq_dir, out_path=None, fmt="kitti", gt_path=None, max_frames=0, which="kitti", device=0, log=print):
-    seq = io_formats.KittiSequence(seq_dir)
+def run(seq_dir, out_path=None, fmt="kitti", gt_path=None, max_frames=0, which="kitti", device=0, log=print, layout="kitti", asl_gt=None):
+    euroc = layout == "euroc" or os.path.isdir(os.path.join(seq_dir, "mav0"))
+    seq = io_formats.EurocSequence(seq_dir) if euroc else io_formats.KittiSequence(seq_dir)
     n = len(seq) if max_frames <= 0 else min(len(seq), max_frames)
     if n == 0:
-        raise SystemExit("no images under %s/image_0" % seq_dir)
+        raise SystemExit("no images under %s" % seq_dir)
     left, right = seq.pair(0)
     api = hip.load()
-    cfg = api.default_config(which)
-    io_formats.apply_calib(cfg, seq.K, seq.baseline, left.shape[0], left.shape[1])
+    cfg = api.default_config("euroc" if euroc and which == "kitti" else which)
+    if euroc:
+        cal = seq.calibration()       # a rectified export may carry its P0 / P1; otherwise the EuRoC values of the default config
+        if cal is not None:
+            io_formats.apply_calib(cfg, cal[0], cal[1], left.shape[0], left.shape[1])
+        else:
+            cfg.rows, cfg.cols = int(left.shape[0]), int(left.shape[1])
+    else:
+        io_formats.apply_calib(cfg, seq.K, seq.baseline, left.shape[0], left.shape[1])
     cfg.max_history_frames = 512
     api.create(cfg, device, 1)
     t0 = time.perf_counter()
@@ -58,6 +67,11 @@ def run(seq_dir, out_path=None, fmt="kitti", gt_path=None, max_frames=0, which="
         gt = io_formats.read_trajectory_kitti(gt_path)[:n]
         result["ate_rmse_aligned"] = evaluation.ate_rmse(poses[:len(gt)], gt)
         log("ATE-RMSE after rigid alignment: %.4f m over %d frames" % (result["ate_rmse_aligned"], len(gt)))
+    asl = asl_gt or (seq.ground_truth_path if euroc else None)
+    if asl and out_path and fmt == "tum":
+        r = evaluation.trajectory_analyzer(out_path, asl)     # executables/trajectory_analyzer.cpp: -tum <out> -asl <ground truth>
+        result["trajectory_analyzer"] = {k: r[k] for k in ("correspondences", "raw_rmse", "optimal_rmse")}
+        log("trajectory_analyzer: %d interpolated positions, raw RMSE %.4f m, optimal RMSE %.4f m" % (r["correspondences"], r["raw_rmse"], r["optimal_rmse"]))
     return result
 
 
@@ -70,8 +84,10 @@ def main():
     ap.add_argument("--max-frames", type=int, default=0)
     ap.add_argument("--config", choices=("kitti", "euroc"), default="kitti")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--layout", choices=("kitti", "euroc"), default="kitti", help="folder layout (a folder with mav0/ is taken as EuRoC / ASL)")
+    ap.add_argument("--asl-gt", default=None, help="ASL ground-truth csv for the trajectory_analyzer step (needs --format tum --out)")
     a = ap.parse_args()
-    run(a.sequence, a.out, a.format, a.gt, a.max_frames, a.config, a.device)
+    run(a.sequence, a.out, a.format, a.gt, a.max_frames, a.config, a.device, layout=a.layout, asl_gt=a.asl_gt)
 
 
 if __name__ == "__main__":

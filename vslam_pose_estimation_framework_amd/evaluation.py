@@ -1,8 +1,11 @@
-"""Trajectory error: ATE-RMSE of the translation after a rigid (SE3, no scale) alignment, and raw.
+"""Trajectory error.
 
-Follows what the reference's trajectory_analyzer prints (executables/trajectory_analyzer.cpp:207,284-309:
-RMSE of position differences, raw and after aligning the trajectories); the alignment is the closed-form
-least-squares solution (Kabsch/Umeyama without scale) instead of its 100-iteration robust ICP."""
+* `trajectory_analyzer(...)` restates the reference's tool (executables/trajectory_analyzer.cpp:59-309): TUM trajectory against
+  an ASL / EuRoC ground-truth csv — nearest ground-truth sample within 1 s, linear interpolation to the measurement's time
+  stamp, start-point shift, raw RMSE, then its iterative robust alignment (100 Gauss-Newton rounds on T in SE3, kernel
+  1 m^2, Jacobian [I | -2 skew(T p)], LDL^T solve, v2t update, re-orthonormalisation) and the RMSE after it.
+* `ate_rmse(...)` is the closed-form companion (Kabsch / Umeyama without scale) used by the benchmarks on trajectories that
+  are already sample-aligned (synthetic ground truth, KITTI pose files)."""
 import numpy as np
 
 
@@ -53,3 +56,138 @@ def write_trajectory_kitti(path, poses):
     with open(path, "w") as f:
         for T in np.asarray(poses).reshape(-1, 12):
             f.write(" ".join("%.9f" % v for v in T) + "\n")
+
+
+# ---- executables/trajectory_analyzer.cpp restated -----------------------------------------------------------------------
+def read_trajectory_tum(path, skip=0):
+    """(timestamps, positions) of a TUM file `t x y z qx qy qz qw` (:67-107); `skip` poses are cut from both ends (:95-107)."""
+    ts, xyz = [], []
+    skipped = 0
+    with open(path) as f:
+        for line in f:
+            v = line.split()
+            if len(v) < 8:
+                raise RuntimeError("unable to parse pose lines")
+            if skipped >= skip:
+                ts.append(float(v[0])); xyz.append([float(v[1]), float(v[2]), float(v[3])])
+            else:
+                skipped += 1
+    if skip >= len(ts):
+        raise RuntimeError("insufficient number of measurements for number_of_poses_to_skip: %d" % skip)
+    n = len(ts) - skip
+    return np.array(ts[:n]), np.array(xyz[:n]).reshape(-1, 3)
+
+
+def read_ground_truth_asl(path):
+    """(timestamps in seconds, positions) of an ASL / EuRoC ground-truth csv: `#` comment lines, then
+    `timestamp_ns, p_x, p_y, p_z, ...` (:117-146; only the position columns are read)."""
+    ts, xyz = [], []
+    with open(path) as f:
+        for line in f:
+            if not line.strip() or line[0] == "#":
+                continue
+            v = line.split(",")
+            ts.append(int(v[0]) / 1e9)
+            xyz.append([float(v[1]), float(v[2]), float(v[3])])
+    return np.array(ts), np.array(xyz).reshape(-1, 3)
+
+
+def _skew(p):
+    return np.array([[0.0, -p[2], p[1]], [p[2], 0.0, -p[0]], [-p[1], p[0], 0.0]])
+
+
+def _v2t(v):
+    """srrg_core::v2t: translation v[0:3], rotation from the vector part of a unit quaternion v[3:6]."""
+    q = np.array(v[3:6], float)
+    n2 = float(q @ q)
+    if n2 < 1:
+        w = np.sqrt(1 - n2)
+    else:
+        q = q / np.sqrt(n2); w = 0.0
+    x, y, z = q
+    T = np.eye(4)
+    T[:3, :3] = [[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                 [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                 [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]]
+    T[:3, 3] = v[0:3]
+    return T
+
+
+def interpolate_correspondences(t_slam, p_slam, t_gt, p_gt):
+    """:152-200.  For every measurement: the ground-truth sample closest in time (strictly closer than 1 s, first one wins);
+    measurements whose closest sample is index 0 are skipped ("until we arrive at the ground truth timestamp"); the ground
+    truth is interpolated linearly to the measurement's time stamp between that sample and its neighbour on the measurement's
+    side; the interpolated position at the FIRST measurement (if it is not skipped) shifts every measurement.  A closest
+    sample that is the last one and still earlier than the measurement has no right neighbour (an out-of-bounds read
+    upstream): the measurement is skipped.  Returns (measured positions incl. shift, interpolated ground truth)."""
+    meas, ref = [], []
+    shift = np.zeros(3)
+    for i in range(len(t_slam)):
+        d = np.abs(t_slam[i] - t_gt)
+        best, best_d = 0, 1.0
+        for j in range(len(t_gt)):
+            if d[j] < best_d:
+                best_d, best = d[j], j
+        if best == 0:
+            continue
+        if t_gt[best] < t_slam[i]:
+            if best + 1 >= len(t_gt):
+                continue
+            a, b = best, best + 1
+        else:
+            a, b = best - 1, best
+        g = p_gt[a] + (t_slam[i] - t_gt[a]) / (t_gt[b] - t_gt[a]) * (p_gt[b] - p_gt[a])
+        if i == 0:
+            shift = g.copy()
+        meas.append(p_slam[i] + shift)
+        ref.append(g)
+    return np.array(meas).reshape(-1, 3), np.array(ref).reshape(-1, 3)
+
+
+def rmse(a, b):
+    """getAbsoluteTranslationRootMeanSquaredError (:288-309)."""
+    return float(np.sqrt(((np.asarray(a) - np.asarray(b)) ** 2).sum(1).mean()))
+
+
+def align_robust_icp(meas, ref, iterations=100, kernel=1.0):
+    """:212-276: T (4x4) that moves the measured positions onto the reference, by the tool's own iteration."""
+    T = np.eye(4)
+    log = []
+    for _ in range(iterations):
+        H = np.zeros((6, 6)); b = np.zeros(6)
+        inliers, total = 0, 0.0
+        for p, g in zip(meas, ref):
+            s = T[:3, :3] @ p + T[:3, 3]
+            e = s - g
+            e2 = float(e @ e)
+            w = 1.0
+            if e2 > kernel:
+                w = kernel / e2
+            else:
+                inliers += 1
+            total += e2
+            J = np.hstack([np.eye(3), -2 * _skew(s)])
+            H += w * J.T @ J
+            b += w * J.T @ e
+        # Eigen's H.ldlt().solve(-b); the least-squares solve covers the rank-deficient start (all points coincide)
+        dx = np.linalg.lstsq(H, -b, rcond=None)[0]
+        T = _v2t(dx) @ T
+        R = T[:3, :3]
+        RtR = R.T @ R
+        RtR[np.diag_indices(3)] -= 1
+        T[:3, :3] = R - 0.5 * R @ RtR
+        log.append((total, inliers))
+    return T, log
+
+
+def trajectory_analyzer(tum_path, asl_path, skip=0):
+    """The tool end to end: {"correspondences", "raw_rmse", "optimal_rmse", "transform", "iterations"}."""
+    t_s, p_s = read_trajectory_tum(tum_path, skip)
+    t_g, p_g = read_ground_truth_asl(asl_path)
+    meas, ref = interpolate_correspondences(t_s, p_s, t_g, p_g)
+    if len(meas) == 0:
+        raise RuntimeError("no interpolated positions: the trajectories do not overlap in time")
+    raw = rmse(meas, ref)
+    T, log = align_robust_icp(meas, ref)
+    moved = meas @ T[:3, :3].T + T[:3, 3]
+    return {"correspondences": len(meas), "raw_rmse": raw, "optimal_rmse": rmse(moved, ref), "transform": T, "iterations": log}

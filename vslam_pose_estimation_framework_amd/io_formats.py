@@ -121,6 +121,61 @@ class KittiSequence(object):
         return left, right
 
 
+# ---- EuRoC / ASL folder (mav0/cam0|cam1/data.csv + data/<timestamp>.png) ----------------------------------------------------------
+class EurocSequence(object):
+    """`<root>/mav0/cam0/data.csv` and `cam1/data.csv` list `timestamp_ns,filename` (one `#` header line); images live in
+    `camN/data/`.  Pairs are formed on equal time stamps (the two cameras are hardware-synchronised); `times` in seconds.
+    Calibration: configuration_euroc.yaml's data set is rectified upstream by the message converter
+    (executables/srrg_proslam_synchronizer / ROS rectification), so K / baseline come from the caller or from
+    `vslam_default_config_euroc`; `calibration()` reads them from an optional `calib.txt` in KITTI P0/P1 form when a
+    rectified export carries one.  Ground truth for trajectory_analyzer: `mav0/state_groundtruth_estimate0/data.csv` or
+    `mav0/leica0/data.csv` (`ground_truth_path`)."""
+
+    def __init__(self, root):
+        self.root = root
+        base = os.path.join(root, "mav0") if os.path.isdir(os.path.join(root, "mav0")) else root
+        self.base = base
+        left = self._listing(os.path.join(base, "cam0"))
+        right = dict(self._listing(os.path.join(base, "cam1")))
+        self.stamps, self.left, self.right = [], [], []
+        for ts, name in left:
+            if ts in right:
+                self.stamps.append(ts); self.left.append(name); self.right.append(right[ts])
+        self.times = [ts / 1e9 for ts in self.stamps]
+
+    @staticmethod
+    def _listing(cam_dir):
+        path = os.path.join(cam_dir, "data.csv")
+        out = []
+        with open(path) as f:
+            for line in f:
+                line = line.strip()
+                if not line or line[0] == "#":
+                    continue
+                a = line.split(",")
+                out.append((int(a[0]), a[1].strip() if len(a) > 1 and a[1].strip() else a[0].strip() + ".png"))
+        return out
+
+    def __len__(self):
+        return len(self.stamps)
+
+    def pair(self, k):
+        return (read_png_gray8(os.path.join(self.base, "cam0", "data", self.left[k])),
+                read_png_gray8(os.path.join(self.base, "cam1", "data", self.right[k])))
+
+    def calibration(self):
+        path = os.path.join(self.root, "calib.txt")
+        return parse_kitti_calib(path) if os.path.exists(path) else None
+
+    @property
+    def ground_truth_path(self):
+        for sub in ("state_groundtruth_estimate0", "leica0"):
+            p = os.path.join(self.base, sub, "data.csv")
+            if os.path.exists(p):
+                return p
+        return None
+
+
 # ---- trajectory writers -----------------------------------------------------------------------------------------------
 def write_trajectory_kitti(path, poses):
     with open(path, "w") as f:
