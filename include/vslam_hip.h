@@ -102,7 +102,15 @@ typedef struct vslam_config {
   int32_t max_keypoints;       /* per image, 64..65535                                        */
   int32_t max_points;          /* framepoints per frame                                       */
   int32_t max_history_frames;  /* frames of per-point history kept for landmark refinement     */
+
+  /* descriptor extractor (base_framepoint_generator.cpp:184-224): 0 = BRIEF-32 (descriptor_type "BRIEF",
+   * configuration_kitti.yaml:60; 28 px border), 1 = ORB (cv::ORB::create() used as extractor on the detector's FAST
+   * keypoints: descriptor_type "ORB" and every unknown string, e.g. configuration_euroc.yaml:52 "ORB-256"; rBRIEF at
+   * level 0 of the 7x7 Gaussian-blurred image, steered by KeyPoint::angle = -1 as FAST leaves it, 31 px border) */
+  int32_t descriptor_type;
 } vslam_config;
+#define VSLAM_DESCRIPTOR_BRIEF 0
+#define VSLAM_DESCRIPTOR_ORB 1
 
 /* Per-frame, per-stream report: the scalars PoseTracker3D / SLAMAssembly read back from the
  * plug-ins (pose_tracker_3d.cpp:111,132,242-248,361; slam_assembly.cpp:644-742). */
@@ -406,6 +414,19 @@ int vslam_depth_recover(vslam_ctx* ctx, const vslam_depth_params* p, const float
  * xy_*: n*2 floats; out: n*3 doubles.  Floating point: agrees with the reference's JacobiSVD to rounding (tests: 1e-9). */
 int vslam_point_in_camera(vslam_ctx* ctx, int32_t n, const float* xy_previous, const float* xy_current,
                           const double T[12], const double K[9], double* out);
+
+/* ---- ORB as descriptor extractor (second half; base_framepoint_generator.cpp:190-196,219-224) -------
+ * cv::ORB::create()->compute(image, keypoints, descriptors) on provided keypoints, restated [recalled, OpenCV 3.x orb.cpp
+ * detectAndCompute with useProvidedKeypoints]: keypoints closer than 31 px to the border are removed, the image (level 0:
+ * FAST keypoints carry octave 0) is blurred with GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) — 8-bit fixed-point
+ * separable filter, kernel round(256 k) = {18, 34, 49, 55, 49, 34, 18}, result (sum + 2^15) >> 16 — and every keypoint gets
+ * 256 steered tests I(c + R p1) < I(c + R p2), R = rotation by KeyPoint::angle (degrees; float arithmetic, cvRound), bit k
+ * of byte i = test 8i + k.  The 256 pairs are REPO-DEFINED (include/vslam_orb_pattern.h; OpenCV's bit_pattern_31_ is not
+ * in the reference tree).  vslam_gaussian_blur7_u8: host image in, host image out (dense, cols bytes per row).
+ * vslam_orb_describe: n integer keypoints xy with one angle for all (FAST: -1), keep[i] = 0 for removed keypoints. */
+int vslam_gaussian_blur7_u8(vslam_ctx* ctx, const uint8_t* image, int32_t rows, int32_t cols, int32_t row_stride, uint8_t* blurred);
+int vslam_orb_describe(vslam_ctx* ctx, const uint8_t* image_host, int32_t rows, int32_t cols, int32_t stride, int32_t n,
+                       const int16_t* xy, float angle_degrees, uint8_t* keep, uint8_t* desc);
 
 /* ---- OrbDetector components (first half; base_framepoint_generator.cpp:52-70) ----------------------
  * The reference's OrbDetector is cv::ORB::create(5000, 1.2, 8, 31, 0, 2, HARRIS_SCORE, 31, threshold) used as a DETECTOR

@@ -31,6 +31,7 @@
 
 #include "../include/vslam_hip.h"
 #include "../include/vslam_brief_pattern.h"
+#include "../include/vslam_orb_pattern.h"
 #include "../tools/synth/synth_scene.h"
 
 #define ORC_API extern "C" __attribute__((visibility("default")))
@@ -249,6 +250,69 @@ void brief_at(const std::vector<int32_t>& sum, int cols, int x, int y, uint8_t d
     const int32_t a = smoothed_sum(sum, cols, y + kBriefPattern[i][0], x + kBriefPattern[i][1]);
     const int32_t b = smoothed_sum(sum, cols, y + kBriefPattern[i][2], x + kBriefPattern[i][3]);
     if (a < b) desc[i >> 3] |= (uint8_t)(0x80u >> (i & 7));
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * ORB as descriptor extractor: cv::ORB::create()->compute() on provided keypoints [recalled, OpenCV 3.x
+ * features2d/src/orb.cpp detectAndCompute(useProvidedKeypoints) + computeOrbDescriptors, imgproc smooth.cpp].
+ * Reference call sites: base_framepoint_generator.cpp:190-196,219-224 (extractor), :431-438 (compute).
+ * ---------------------------------------------------------------------------------------- */
+const int8_t kOrbPattern[256][4] = VSLAM_ORB_PATTERN_INIT;
+
+/* getGaussianKernel(7, 2, CV_32F) -> fixed point for 8-bit images: cvRound(k * 256) (createSeparableLinearFilter, bits = 8) */
+inline void gauss7_kernel_fixed(int32_t k[7]) {
+  float cf[7];
+  double sum = 0;
+  const double scale2x = -0.5 / (2.0 * 2.0);
+  for (int i = 0; i < 7; ++i) { const double x = i - 3.0; cf[i] = (float)std::exp(scale2x * x * x); sum += cf[i]; }
+  sum = 1. / sum;
+  for (int i = 0; i < 7; ++i) { cf[i] = (float)(cf[i] * sum); k[i] = (int32_t)std::lrint((double)cf[i] * 256.0); }
+}
+inline int reflect101(int p, int n) { return p < 0 ? -p : (p >= n ? 2 * n - 2 - p : p); }
+/* GaussianBlur(src, dst, Size(7,7), 2, 2, BORDER_REFLECT_101) for CV_8UC1: integer row pass, integer column pass,
+ * FixedPtCastEx<int, uchar>(16): (v + 2^15) >> 16, saturated */
+void gaussian_blur7_u8(const uint8_t* img, int rows, int cols, int stride, std::vector<uint8_t>& out) {
+  int32_t k[7];
+  gauss7_kernel_fixed(k);
+  std::vector<int32_t> tmp((size_t)rows * cols);
+  for (int y = 0; y < rows; ++y)
+    for (int x = 0; x < cols; ++x) {
+      int32_t acc = 0;
+      for (int i = 0; i < 7; ++i) acc += k[i] * (int32_t)img[(size_t)y * stride + reflect101(x + i - 3, cols)];
+      tmp[(size_t)y * cols + x] = acc;
+    }
+  out.assign((size_t)rows * cols, 0);
+  for (int y = 0; y < rows; ++y)
+    for (int x = 0; x < cols; ++x) {
+      int32_t acc = 0;
+      for (int i = 0; i < 7; ++i) acc += k[i] * tmp[(size_t)reflect101(y + i - 3, rows) * cols + x];
+      const int32_t v = (acc + (1 << 15)) >> 16;
+      out[(size_t)y * cols + x] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+}
+inline bool orb_inside(int rows, int cols, int x, int y) { /* runByImageBorder(edgeThreshold = 31) */
+  const int b = VSLAM_ORB_BORDER;
+  return x >= b && x < cols - b && y >= b && y < rows - b;
+}
+/* rotation of the pattern by KeyPoint::angle: float angle *= (float)(CV_PI/180.f); a = (float)cos(angle), b = (float)sin(angle) */
+inline void orb_rotation(float angle_degrees, float* a, float* b) {
+  float angle = angle_degrees;
+  angle *= (float)(3.1415926535897932384626433832795 / 180.f);
+  *a = (float)std::cos(angle); *b = (float)std::sin(angle);
+}
+/* computeOrbDescriptors, WTA_K = 2: GET_VALUE(p) = blurred[cy + cvRound(px*b + py*a)][cx + cvRound(px*a - py*b)] */
+void orb_at(const uint8_t* blur, int cols, int cx, int cy, float a, float b, uint8_t desc[32]) {
+  std::memset(desc, 0, 32);
+  for (int i = 0; i < 256; ++i) {
+    int v[2];
+    for (int h = 0; h < 2; ++h) {
+      const float px = (float)kOrbPattern[i][2 * h], py = (float)kOrbPattern[i][2 * h + 1];
+      const float xf = px * a - py * b, yf = px * b + py * a;
+      const int ix = (int)std::lrint((double)xf), iy = (int)std::lrint((double)yf);
+      v[h] = blur[(size_t)(cy + iy) * cols + (cx + ix)];
+    }
+    if (v[0] < v[1]) desc[i >> 3] |= (uint8_t)(1u << (i & 7));
   }
 }
 
@@ -567,6 +631,7 @@ struct Stream {
   uint32_t target_per_detector = 0;
   FeatureStore storeL, storeR;
   std::vector<int32_t> sumL, sumR; /* integral images of the current frame (recoverPoints) */
+  std::vector<uint8_t> blurL, blurR; /* 7x7 Gaussian-blurred images of the current frame (ORB extractor) */
   std::vector<Feature> kpL, kpR;   /* Frame::keypoints/descriptors after the border filter */
   int n_detected_left = 0, n_detected_right_raw = 0, n_detected_left_raw = 0;
   real tau_tri;                /* _current_maximum_descriptor_distance_triangulation */
@@ -681,15 +746,39 @@ struct Stream {
   }
   /* computeDescriptors (:431-438): border filter + BRIEF */
   void compute_descriptors(const uint8_t* img, int stride, const std::vector<Keypoint>& kps,
-                           std::vector<int32_t>& sum, std::vector<Feature>& out) {
-    integral_image(img, cfg.rows, cfg.cols, stride, sum);
+                           std::vector<int32_t>& sum, std::vector<uint8_t>& blur, std::vector<Feature>& out) {
     out.clear();
+    if (cfg.descriptor_type == VSLAM_DESCRIPTOR_ORB) {   /* cv::ORB::create() as extractor (:190-196,219-224) */
+      gaussian_blur7_u8(img, cfg.rows, cfg.cols, stride, blur);
+      float a, b;
+      orb_rotation(-1.f, &a, &b);                        /* FAST keypoints: KeyPoint::angle = -1, never recomputed */
+      for (const Keypoint& k : kps) {
+        if (!orb_inside(cfg.rows, cfg.cols, k.x, k.y)) continue;
+        Feature f;
+        f.row = k.y; f.col = k.x; f.score = k.score;
+        orb_at(blur.data(), cfg.cols, k.x, k.y, a, b, f.desc);
+        out.push_back(f);
+      }
+      return;
+    }
+    integral_image(img, cfg.rows, cfg.cols, stride, sum);
     for (const Keypoint& k : kps) {
       if (!brief_inside(cfg.rows, cfg.cols, k.x, k.y)) continue;
       Feature f;
       f.row = k.y; f.col = k.x; f.score = k.score;
       brief_at(sum, cfg.cols, k.x, k.y, f.desc);
       out.push_back(f);
+    }
+  }
+  /* the extractor on the 71 x 71 region around a projected landmark (stereo_framepoint_generator.cpp:773-812): the pattern
+   * stays 14 px and more inside the region, so its border handling never reaches a tap — same bytes as on the whole image */
+  void describe_at(bool right, int x, int y, uint8_t desc[32]) const {
+    if (cfg.descriptor_type == VSLAM_DESCRIPTOR_ORB) {
+      float a, b;
+      orb_rotation(-1.f, &a, &b);                        /* keypoint_buffer = the previous point's FAST keypoint: angle -1 */
+      orb_at((right ? blurR : blurL).data(), cfg.cols, x, y, a, b, desc);
+    } else {
+      brief_at(right ? sumR : sumL, cfg.cols, x, y, desc);
     }
   }
 
@@ -699,7 +788,7 @@ struct Stream {
       std::vector<Keypoint> kl, kr;
       { Chrono t(&chrono[0]); detect_keypoints(L, stride, kl, n_detected_left_raw); detect_keypoints(R, stride, kr, n_detected_right_raw); }
       adjust_thresholds();
-      { Chrono t(&chrono[1]); compute_descriptors(L, stride, kl, sumL, kpL); compute_descriptors(R, stride, kr, sumR, kpR); }
+      { Chrono t(&chrono[1]); compute_descriptors(L, stride, kl, sumL, blurL, kpL); compute_descriptors(R, stride, kr, sumR, blurR, kpR); }
       n_detected_left = (int)kpL.size();
       if (frame_status == VSLAM_LOCALIZING) {
         tau_tri = std::min(0.1 * 256, cfg.maximum_matching_distance_triangulation);
@@ -910,9 +999,9 @@ struct Stream {
           pLy < border + 1 || pLy > cfg.rows - border - 1 || pRy < border + 1 || pRy > cfg.rows - border - 1) continue;
       const int xL = (int)pLx, yL = (int)pLy, xR = (int)pRx, yR = (int)pRy;
       uint8_t dL[32], dR[32];
-      brief_at(sumL, cfg.cols, xL, yL, dL);
+      describe_at(false, xL, yL, dL);
       if (hamming32(pp.dL, dL) > gen_tau_track) continue;
-      brief_at(sumR, cfg.cols, xR, yR, dR);
+      describe_at(true, xR, yR, dR);
       if ((real)(pLx - pRx) < cfg.minimum_disparity_pixels) continue;
       if (hamming32(pp.dR, dR) > gen_tau_track) continue;
       const int dtri = hamming32(dL, dR);
@@ -1297,6 +1386,7 @@ ORC_API void orc_default_config_euroc(vslam_config* c) { /* configurations/confi
   c->maximum_matching_distance_triangulation = 50;
   c->minimum_track_length_for_landmark_creation = 2; c->good_tracking_ratio = 0.25;
   c->aligner_damping = 0;
+  c->descriptor_type = VSLAM_DESCRIPTOR_ORB; /* configuration_euroc.yaml:52 "ORB-256" -> cv::ORB::create() (:219-224) */
 }
 
 ORC_API int orc_create(const vslam_config* cfg, int /*device*/, int n_streams, orc_ctx** out) {
@@ -1417,6 +1507,28 @@ ORC_API int orc_brief_describe(orc_ctx*, const uint8_t* img, int32_t rows, int32
     const int x = xy[2 * i], y = xy[2 * i + 1];
     keep[i] = brief_inside(rows, cols, x, y) ? 1 : 0;
     if (keep[i]) brief_at(sum, cols, x, y, desc + 32 * i);
+    else std::memset(desc + 32 * i, 0, 32);
+  }
+  return VSLAM_OK;
+}
+ORC_API int orc_gaussian_blur7_u8(const uint8_t* img, int32_t rows, int32_t cols, int32_t stride, uint8_t* out) {
+  if (!img || !out || rows < 4 || cols < 4 || stride < cols) return VSLAM_ERR_INVALID;
+  std::vector<uint8_t> b;
+  gaussian_blur7_u8(img, rows, cols, stride, b);
+  std::memcpy(out, b.data(), b.size());
+  return VSLAM_OK;
+}
+ORC_API int orc_orb_describe(const uint8_t* img, int32_t rows, int32_t cols, int32_t stride, int32_t n, const int16_t* xy, float angle_degrees,
+                             uint8_t* keep, uint8_t* desc) {
+  if (!img || !xy || !keep || !desc || n < 0 || rows < 4 || cols < 4 || stride < cols) return VSLAM_ERR_INVALID;
+  std::vector<uint8_t> blur;
+  gaussian_blur7_u8(img, rows, cols, stride, blur);
+  float a, b;
+  orb_rotation(angle_degrees, &a, &b);
+  for (int i = 0; i < n; ++i) {
+    const int x = xy[2 * i], y = xy[2 * i + 1];
+    keep[i] = orb_inside(rows, cols, x, y) ? 1 : 0;
+    if (keep[i]) orb_at(blur.data(), cols, x, y, a, b, desc + 32 * i);
     else std::memset(desc + 32 * i, 0, 32);
   }
   return VSLAM_OK;

@@ -164,6 +164,9 @@ public:
     c.maximum_matching_distance_triangulation = p->maximum_matching_distance_triangulation;
     c.minimum_disparity_pixels = p->minimum_disparity_pixels;
     c.maximum_epipolar_search_offset_pixels = p->maximum_epipolar_search_offset_pixels;
+    // descriptor extractor as BaseFramePointGenerator::configure selects it (base_framepoint_generator.cpp:184-224): BRIEF only
+    // by name (and only in a build with opencv_contrib); "ORB" and every string the parser does not know end at cv::ORB::create()
+    c.descriptor_type = p->descriptor_type == "BRIEF" ? VSLAM_DESCRIPTOR_BRIEF : VSLAM_DESCRIPTOR_ORB;
     _hip->window_pixels = p->maximum_projection_tracking_distance_pixels;    // PoseTracker3D::configure (pose_tracker_3d.cpp:11-21)
     _hip->tau_track = p->minimum_descriptor_distance_tracking;
     // tracker / aligner / landmark values are filled by HipStereoUVAligner::configure, which creates the device context

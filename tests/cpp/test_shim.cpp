@@ -146,6 +146,7 @@ int main(int argc, char** argv) {
   camera_right.setBaselineHomogeneous(Vector3(-scene.fx * scene.baseline_m, 0, 0));
   // configuration_kitti.yaml values (the structs default to parameters.h)
   StereoFramePointGeneratorParameters generator_parameters;
+  generator_parameters.descriptor_type = (argc > 3 && std::atoi(argv[3]) == 1) ? "ORB-256" : "BRIEF";   // configuration_kitti.yaml:60 / _euroc.yaml:52
   AlignerParameters aligner_parameters; aligner_parameters.error_delta_for_convergence = 1e-3; aligner_parameters.maximum_error_kernel = 4; aligner_parameters.damping = 5;
   PoseTracker3DParameters tracker_parameters; tracker_parameters.aligner = &aligner_parameters;
   tracker_parameters.minimum_track_length_for_landmark_creation = 1; tracker_parameters.minimum_number_of_landmarks_to_track = 5;
@@ -229,6 +230,7 @@ int main(int argc, char** argv) {
     std::fprintf(stderr, "exception at frame %d: %s\n", k, e.what());
     return 3;
   }
-  std::printf("shim ok: %d frames, host objects and counters identical to the fused device path (recovery %s)\n", n_frames, recovery ? "on" : "off");
+  std::printf("shim ok: %d frames, host objects and counters identical to the fused device path (recovery %s, descriptor %s)\n", n_frames,
+              recovery ? "on" : "off", hip.config.descriptor_type == VSLAM_DESCRIPTOR_ORB ? "ORB" : "BRIEF");
   return 0;
 }

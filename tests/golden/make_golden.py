@@ -1383,10 +1383,79 @@ def gen_aligner_weights(rng):
     return len(calls)
 
 
+# ---------------------------------------------------------------------------------------------
+# cv::ORB::create()->compute() on provided keypoints [recalled]: GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) in the 8-bit
+# fixed-point form of OpenCV's separable filter, then 256 steered intensity tests per keypoint (WTA_K = 2) with the
+# repo-defined pair table of include/vslam_orb_pattern.h.
+def read_orb_pattern():
+    text = open(os.path.join(ROOT, "include", "vslam_orb_pattern.h")).read()
+    body = text[text.index("VSLAM_ORB_PATTERN_INIT"):]
+    q = re.findall(r"\{(-?\d+),(-?\d+),(-?\d+),(-?\d+)\}", body)
+    assert len(q) == 256
+    return np.array(q, np.int32)
+
+
+def gauss7_fixed():
+    x = np.arange(7, dtype=np.float64) - 3.0
+    cf = np.exp(-0.5 / 4.0 * x * x).astype(np.float32)          # stored as float (CV_32F kernel)
+    s = 1.0 / float(np.sum(cf.astype(np.float64)))
+    cf = (cf.astype(np.float64) * s).astype(np.float32)
+    return np.rint(cf.astype(np.float64) * 256.0).astype(np.int64)
+
+
+def gaussian_blur7_ref(img):
+    k = gauss7_fixed()
+    p = np.pad(img.astype(np.int64), 3, mode="reflect")          # numpy 'reflect' == BORDER_REFLECT_101
+    rows, cols = img.shape
+    h = sum(k[i] * p[3:3 + rows, i:i + cols] for i in range(7))   # row pass on the image rows only
+    hp = np.pad(h, ((3, 3), (0, 0)), mode="reflect")
+    v = sum(k[i] * hp[i:i + rows, :] for i in range(7))
+    return np.clip((v + (1 << 15)) >> 16, 0, 255).astype(np.uint8)
+
+
+def orb_describe_ref(blur, x, y, angle_degrees, pat):
+    ang = np.float32(angle_degrees) * np.float32(np.pi / np.float32(180.0))
+    a, b = np.float32(np.cos(np.float64(ang))), np.float32(np.sin(np.float64(ang)))
+    d = np.zeros(32, np.uint8)
+    for i in range(256):
+        v = []
+        for h in range(2):
+            px, py = np.float32(pat[i][2 * h]), np.float32(pat[i][2 * h + 1])
+            xf = np.float32(px * a) - np.float32(py * b)
+            yf = np.float32(px * b) + np.float32(py * a)
+            v.append(int(blur[y + int(np.rint(yf)), x + int(np.rint(xf))]))
+        if v[0] < v[1]:
+            d[i >> 3] |= 1 << (i & 7)
+    return d
+
+
+def gen_orb_descriptor(rng):
+    pat = read_orb_pattern()
+    img = block_image(rng, 150, 190, 7)
+    img = np.clip(img.astype(np.int32) + rng.integers(-12, 13, img.shape), 0, 255).astype(np.uint8)
+    flat = np.full((40, 52), 201, np.uint8)                       # constant image: the 257/256 kernel gain shows (201 -> 203)
+    out = {"img": img, "blur": gaussian_blur7_ref(img), "flat": flat, "flat_blur": gaussian_blur7_ref(flat), "kernel": gauss7_fixed().astype(np.int32)}
+    pts = [(31, 31), (158, 118), (30, 60), (159, 60), (60, 119), (95, 75), (100, 31), (31, 118)]
+    pts += [(int(rng.integers(31, 159)), int(rng.integers(31, 119))) for _ in range(40)]
+    xy = np.array(pts, np.int16)
+    out["xy"] = xy
+    for name, ang in (("fast", -1.0), ("a0", 0.0), ("a37", 37.25), ("a180", 180.0), ("a301", 301.5)):
+        keep = np.array([1 if (31 <= x < 190 - 31 and 31 <= y < 150 - 31) else 0 for x, y in pts], np.uint8)
+        desc = np.zeros((len(pts), 32), np.uint8)
+        for i, (x, y) in enumerate(pts):
+            if keep[i]:
+                desc[i] = orb_describe_ref(out["blur"], x, y, ang, pat)
+        out["keep"] = keep
+        out["desc_" + name] = desc
+        out["angle_" + name] = np.float32(ang)
+    np.savez_compressed(os.path.join(HERE, "orb_descriptor.npz"), **out)
+    return len(pts)
+
+
 def main():
     import sys
     if len(sys.argv) > 1:                                 # regenerate selected fixtures only: make_golden.py aligner_weights ...
-        streams = {"aligner_weights": 20261013}
+        streams = {"aligner_weights": 20261013, "orb_descriptor": 20261014}
         for name in sys.argv[1:]:
             globals()["gen_" + name](np.random.default_rng(streams[name]))
         return
@@ -1407,6 +1476,7 @@ def main():
     gen_stereo_recover(np.random.default_rng(20261011))
     gen_tracker(np.random.default_rng(20261012))
     gen_aligner_weights(np.random.default_rng(20261013))
+    gen_orb_descriptor(np.random.default_rng(20261014))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

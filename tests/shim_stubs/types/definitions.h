@@ -102,6 +102,7 @@ struct AlignerParameters {
 };
 struct LandmarkParameters { real maximum_error_squared_meters = 25; Count maximum_number_of_iterations = 100; };
 struct BaseFramePointGeneratorParameters {
+  std::string detector_type = "FAST", descriptor_type = "ORB";
   real target_number_of_keypoints_tolerance = 0.1; uint32_t detector_threshold_minimum = 20, detector_threshold_maximum = 100;
   real detector_threshold_maximum_change = 0.1; uint32_t number_of_detectors_vertical = 1, number_of_detectors_horizontal = 1;
   int32_t minimum_projection_tracking_distance_pixels = 15, maximum_projection_tracking_distance_pixels = 50;

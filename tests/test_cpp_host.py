@@ -52,12 +52,12 @@ def test_cpp_host_tracker_matches_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("recovery", [1, 0])
-def test_shim_reproduces_fused_path(recovery):
+@pytest.mark.parametrize("recovery,orb", [(1, 0), (0, 0), (1, 1)])
+def test_shim_reproduces_fused_path(recovery, orb):
     """Both shim classes through the C ABI, driven like PoseTracker3D drives its plug-ins: 16 frames, counters, poses and the
     materialised host objects (points, links, descriptors) equal to the fused device path; with and without recovery (the
     device prune must not depend on recoverPoints being called)."""
     exe = _build("test_shim")
-    out = subprocess.run([exe, "16", str(recovery)], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([exe, "16", str(recovery), str(orb)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "identical to the fused device path" in out.stdout
+    assert "identical to the fused device path" in out.stdout and ("descriptor ORB" if orb else "descriptor BRIEF") in out.stdout

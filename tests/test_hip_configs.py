@@ -41,13 +41,14 @@ def test_config5_full_resolution_bin11():
 
 def test_config4_euroc_shaped_sequence_and_l2_knn2():
     """vslam_default_config_euroc (configuration_euroc.yaml:47-116: 2x2 detectors, thresholds 10..30 with 100 % change, bin 20,
-    track length 2, damping 0) on the EuRoC-shaped scene (752x480, f 458, baseline 0.11 m, 6-DoF motion <= 5 cm / 1 degree per
+    track length 2, damping 0, descriptor "ORB-256" = cv::ORB::create() as extractor on the FAST keypoints) on the EuRoC-shaped scene (752x480, f 458, baseline 0.11 m, 6-DoF motion <= 5 cm / 1 degree per
     frame), 10 frames against the oracle; then the brute-force knnMatch(k=2) of the use_matches block
     (stereo_framepoint_generator.cpp:199-206) with every matcher norm on the last frame's ~950 left x right descriptors."""
     from _oracle import Oracle
 
     def after(o, g):
         fi = g.frame_info(0)
+        assert g.cfg.descriptor_type == 1
         assert fi.status == 1 and fi.n_tracked > 40 and 600 < fi.n_keypoints_left < 1600, (fi.status, fi.n_tracked, fi.n_keypoints_left)
         assert len(set(list(fi.thresholds)[:4])) > 1          # the four detectors run at different thresholds
         dl, dr = g.keypoints(0, 0)[2], g.keypoints(0, 1)[2]
@@ -58,6 +59,30 @@ def test_config4_euroc_shaped_sequence_and_l2_knn2():
             np.testing.assert_array_equal(dg, do)
         assert (ig[:, 0] >= 0).all() and (dg[:, 0] <= dg[:, 1]).all()
     run_sequence(Oracle, dict(scale=1.0), 10, which="euroc", scene="euroc", after=after)
+
+
+@pytest.mark.parametrize("recovery,epi", [(1, 0), (0, 2)])
+def test_orb_extractor_in_the_tracker_kitti_scene(recovery, epi):
+    """descriptor_type ORB on the KITTI-shaped scene (what the reference does for every descriptor string it does not know, and
+    for "ORB"): Gaussian image + steered tests for the keypoints and for the recovered landmarks, 31 px border — frame by frame
+    against the oracle, with recovery (projected landmarks described on the blurred images) and without."""
+    from _oracle import Oracle
+
+    def edit(cfg):
+        cfg.descriptor_type = 1
+        cfg.enable_landmark_recovery = recovery
+        cfg.maximum_epipolar_search_offset_pixels = epi
+
+    seen = {"rec": 0}
+
+    def after(o, g):
+        fi = g.frame_info(0)
+        assert fi.status == 1 and fi.n_tracked > 50
+        xy = g.keypoints(0, 0)[0]
+        assert xy[:, 0].min() >= 31 and xy[:, 1].min() >= 31 and xy[:, 0].max() < g.cfg.cols - 31 and xy[:, 1].max() < g.cfg.rows - 31
+        seen["rec"] = fi.n_recovered
+    run_sequence(Oracle, dict(scale=0.6), 12, cfg_edit=edit, seeds=[77], after=after)
+    assert (seen["rec"] > 0) == bool(recovery)
 
 
 def _run_exact(lengths, streams_of, n_streams, scale=0.5, ids=None):

@@ -76,6 +76,11 @@ def test_orb_components_golden(gpu, golden):
     pc.check_orb_components(gpu, golden["orb"])
 
 
+def test_orb_descriptor_golden(gpu, golden):
+    """ORB as descriptor extractor (fixed-point Gaussian + steered rBRIEF) against the numpy restatement, bytes exact."""
+    pc.check_orb_descriptor(gpu, golden["orb_descriptor"])
+
+
 def test_orb_edge_cases(gpu, golden):
     pc.check_orb_edge_cases(gpu, golden["orb"])
 

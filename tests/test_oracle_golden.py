@@ -52,6 +52,10 @@ def test_orb_components_known_answers(oracle, golden):
     pc.check_orb_components(oracle, golden["orb"])
 
 
+def test_orb_descriptor_known_answers(oracle, golden):
+    pc.check_orb_descriptor(oracle, golden["orb_descriptor"])
+
+
 def test_orb_edge_cases(oracle, golden):
     pc.check_orb_edge_cases(oracle, golden["orb"])
 

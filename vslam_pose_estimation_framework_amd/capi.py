@@ -48,6 +48,7 @@ class Config(C.Structure):
         ("landmark_maximum_error_squared_meters", C.c_double),
         ("landmark_maximum_number_of_iterations", C.c_int32),
         ("max_keypoints", C.c_int32), ("max_points", C.c_int32), ("max_history_frames", C.c_int32),
+        ("descriptor_type", C.c_int32),
     ]
 
     def copy(self):
@@ -474,6 +475,25 @@ class CApi(object):
                                          C.c_int32(int(edge_threshold)), C.c_int32(int(patch_size)), C.c_int32(int(fast_threshold)),
                                          C.c_int32(cap), C.byref(n), _p(out, C.c_float)))
         return out[:n.value].copy()
+
+    def gaussian_blur7_u8(self, image):
+        img = np.ascontiguousarray(image, np.uint8)
+        out = np.zeros_like(img)
+        self.check(self.fn("gaussian_blur7_u8")(*self._ctx_args(), _p(img, C.c_uint8), C.c_int32(img.shape[0]), C.c_int32(img.shape[1]),
+                                                C.c_int32(img.shape[1]), _p(out, C.c_uint8)))
+        return out
+
+    def orb_describe(self, image, xy, angle_degrees=-1.0):
+        """cv::ORB::create()->compute() at integer keypoints with one angle: (keep, descriptors)."""
+        img = np.ascontiguousarray(image, np.uint8)
+        pts = np.ascontiguousarray(xy, np.int16).reshape(-1, 2)
+        n = pts.shape[0]
+        keep = np.zeros(n, np.uint8)
+        desc = np.zeros((n, 32), np.uint8)
+        self.check(self.fn("orb_describe")(*self._ctx_args(), _p(img, C.c_uint8), C.c_int32(img.shape[0]), C.c_int32(img.shape[1]),
+                                           C.c_int32(img.shape[1]), C.c_int32(n), _p(pts, C.c_int16), C.c_float(float(angle_degrees)),
+                                           _p(keep, C.c_uint8), _p(desc, C.c_uint8)))
+        return keep, desc
 
     def point_in_camera(self, xy_previous, xy_current, T, K):
         xp = np.ascontiguousarray(xy_previous, np.float32).reshape(-1, 2)

@@ -47,6 +47,10 @@ struct DevCfg {
   int32_t offsets[2 * VSLAM_MAX_EPI + 1];
   int32_t NMAX, MAXP, HCAP;
   int32_t n_streams;
+  // ORB extractor: the rotation of the pattern by the FAST keypoints' angle (-1 degree), evaluated on the host exactly as
+  // OpenCV does — angle *= (float)(CV_PI/180.f); (float)cos(angle), (float)sin(angle) — and the fixed-point Gaussian taps
+  float orb_cos, orb_sin;
+  int32_t gauss7[4];
 };
 
 // scalars of the frame in flight, handed from one phase kernel of the frame to the next

@@ -152,6 +152,36 @@ __device__ __forceinline__ void recover_brief_wave(const DevCfg& c, const DevBuf
   }
 }
 
+// recoverPoints with the ORB extractor (descriptor_type 1): the steered tests of both projections straight from the
+// Gaussian-blurred images (the extractor runs on the 71 x 71 region around the projection upstream,
+// stereo_framepoint_generator.cpp:773-812; the pattern stays >= 14 px inside it, so the region's own border handling never
+// reaches a tap).  Gates as in recover_brief_wave.
+__device__ __forceinline__ void recover_orb_wave(const DevCfg& c, const DevBuf& b, int s, int pb_prev, int q, int ip, int xL, int yL, int xR, int yR,
+                                                 int lane, double tau_track, double tau_tri, const OrbTaps& taps) {
+  int32_t* rec = b.rec + (size_t)s * c.MAXP * 6;
+  const PtView pv = pts_of(c, b, s, pb_prev);
+  unsigned long long dL[4], dR[4];
+  orb_wave(blur_of(c, b, s, 0) + (size_t)yL * c.bstride + xL, taps, dL);
+  orb_wave(blur_of(c, b, s, 1) + (size_t)yR * c.bstride + xR, taps, dR);
+  const unsigned long long* pd = reinterpret_cast<const unsigned long long*>(pv.desc + (size_t)64 * ip);
+  int hL = 0, hR = 0, dist = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { hL += __popcll(dL[j] ^ pd[j]); hR += __popcll(dR[j] ^ pd[4 + j]); dist += __popcll(dL[j] ^ dR[j]); }
+  int ok = 1;
+  if ((double)hL > tau_track) ok = 0;
+  if (ok && (double)((float)xL - (float)xR) < c.c.minimum_disparity_pixels) ok = 0;
+  if (ok && (double)hR > tau_track) ok = 0;
+  if (ok && (double)dist > tau_tri) ok = 0;
+  if (lane == 0) {
+    rec[6 * q] = ok; rec[6 * q + 5] = dist;
+    if (ok) {
+      unsigned long long* dl = reinterpret_cast<unsigned long long*>(b.rec_desc + ((size_t)s * c.MAXP + q) * 64);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { dl[j] = dL[j]; dl[4 + j] = dR[j]; }
+    }
+  }
+}
+
 // Same computation with the two 49 x 49 box patches staged in LDS by coalesced 16-byte row loads (7 lanes per row):
 // the 1024 scattered 2-byte gathers per point of recover_brief_wave keep the CU's texture-address unit busy for ~1000
 // cycles; 12 wide loads take a fraction of that.  `patch` = this wavefront's LDS area, VS_RPATCH bytes.
@@ -229,6 +259,16 @@ __device__ __forceinline__ void wg_recover_brief(const DevCfg& c, const DevBuf& 
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   uint16_t* patch = reinterpret_cast<uint16_t*>(arena + (size_t)w * VS_RPATCH);
   const int32_t* list = reinterpret_cast<const int32_t*>(arena + VS_RLIST_OFF);
+  if (c.c.descriptor_type == VSLAM_DESCRIPTOR_ORB) {
+    const OrbTaps taps = orb_taps(lane, c.orb_cos, c.orb_sin, c.bstride);
+    const int32_t* rec = b.rec + (size_t)s * c.MAXP * 6;
+    const int32_t* lost = b.lost + (size_t)s * c.MAXP;
+    for (int q = w; q < n_lost; q += VS_WG / 64) {
+      if (rec[6 * q] != 2) continue;   // wave-uniform
+      recover_orb_wave(c, b, s, pb_prev, q, lost[q], rec[6 * q + 1], rec[6 * q + 2], rec[6 * q + 3], rec[6 * q + 4], lane, tau_track, tau_tri, taps);
+    }
+    return;
+  }
   if (n_list <= VS_RLIST_CAP) {
     for (int k = w; k < n_list; k += VS_WG / 64) {
       const int32_t* e = list + 6 * k;
@@ -303,6 +343,16 @@ __global__ __launch_bounds__(256) void k_recover_brief(const DevCfg c, const Dev
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
   const int nl = st.fc.n_lost;
+  if (c.c.descriptor_type == VSLAM_DESCRIPTOR_ORB) {
+    const OrbTaps taps = orb_taps(lane, c.orb_cos, c.orb_sin, c.bstride);
+    const int32_t* rec = b.rec + (size_t)s * c.MAXP * 6;
+    const int32_t* lost = b.lost + (size_t)s * c.MAXP;
+    for (int q = wave; q < nl; q += nwaves) {
+      if (rec[6 * q] != 2) continue;   // wave-uniform
+      recover_orb_wave(c, b, s, st.cur, q, lost[q], rec[6 * q + 1], rec[6 * q + 2], rec[6 * q + 3], rec[6 * q + 4], lane, st.fc.tau_gen, st.fc.tau_tri, taps);
+    }
+    return;
+  }
   for (int q = wave; q < nl; q += nwaves) recover_brief_wave(c, b, s, st.cur, q, lane, st.fc.tau_gen, st.fc.tau_tri);
 }
 

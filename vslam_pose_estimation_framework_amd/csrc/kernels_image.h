@@ -11,8 +11,10 @@
 #include <hip/hip_runtime.h>
 #include "dev_types.h"
 #include "../../include/vslam_brief_pattern.h"
+#include "../../include/vslam_orb_pattern.h"
 
 __constant__ int8_t c_brief[256][4] = VSLAM_BRIEF_PATTERN_INIT;
+__constant__ int8_t c_orb[256][4] = VSLAM_ORB_PATTERN_INIT;
 
 // ---- indexing helpers ------------------------------------------------------------------------
 __device__ __forceinline__ size_t ix_side(const DevCfg& c, int s, int d) { return (size_t)s * 2 + d; }
@@ -274,7 +276,8 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
     }
   }
   // ---- horizontal 9-sums, four outputs per thread from three aligned dwords -----------------------------------------
-  if (!(VS_PROBE & 4))
+  const bool want_box = !(VS_PROBE & 4) && c.c.descriptor_type == VSLAM_DESCRIPTOR_BRIEF;   // ORB samples the Gaussian image instead
+  if (want_box)
   for (int i = tid; i < (VS_TILE_H + 8) * 16; i += 256) {
     const int r = i >> 4, q = i & 15;
     const uint32_t* p = reinterpret_cast<const uint32_t*>(&tile[r][4 * q]);
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
   }
   // ---- vertical 9-sums (sliding), two pixels per lane in packed u16 -> u16 box image: lanes 0-31 own the upper half of
   // the wave's rows, lanes 32-63 the lower half --------------------------------------------------------------------------
-  if (!(VS_PROBE & 4)) {
+  if (want_box) {
     constexpr int RW = VS_TILE_H / 8;   // output rows per half-wave
     const int half = lane >> 5, px = 2 * (lane & 31);
     const int rbase = (w * 2 + half) * RW;
@@ -648,6 +651,114 @@ __global__ __launch_bounds__(256) void k_brief_at(const uint16_t* box, int bstri
     if (lane == 0) keep[i] = in ? 1 : 0;
     if (in) brief_wave(box, bstride, x, y, lane, desc + (size_t)32 * i);
     else if (lane < 4) reinterpret_cast<unsigned long long*>(desc + (size_t)32 * i)[lane] = 0ull;
+  }
+}
+
+// ==============================================================================================
+// ORB as descriptor extractor (cv::ORB::create()->compute on the detector's keypoints; base_framepoint_generator.cpp:190-196,
+// 219-224, 431-438): 7x7 Gaussian (sigma 2, BORDER_REFLECT_101) in OpenCV's 8-bit fixed-point form — integer row pass with
+// round(256 k), integer column pass, (v + 2^15) >> 16 — then 256 steered intensity tests per keypoint on the blurred image.
+// The blurred u8 image lives in the memory of the (unused) box image, row stride c.bstride bytes.
+// ==============================================================================================
+struct Gauss7 { int32_t k[4]; };   // k[0] = centre tap ... k[3] = outermost (symmetric kernel)
+__device__ __forceinline__ int reflect101(int p, int n) { return p < 0 ? -p : (p >= n ? 2 * n - 2 - p : p); }
+__device__ __forceinline__ uint8_t* blur_of(const DevCfg& c, const DevBuf& b, int s, int d) { return reinterpret_cast<uint8_t*>(box_of(c, b, s, d)); }
+
+// one 64 x 32 tile per workgroup: (64+6) x (32+6) source pixels staged in LDS (reflected at the image border), row sums as
+// u16 (255 * 257 < 2^16), column sums in registers
+__device__ __forceinline__ void gauss7_tile(const uint8_t* img, int stride, int rows, int cols, int x0, int y0, const Gauss7& g, uint8_t* out, int ostride,
+                                            uint8_t (*src)[72], uint16_t (*hs)[VS_TILE_W]) {
+  const int tid = threadIdx.x;
+  for (int i = tid; i < (VS_TILE_H + 6) * 70; i += 256) {
+    const int r = i / 70, q = i - 70 * r;
+    src[r][q] = img[(size_t)reflect101(min(y0 - 3 + r, rows + 2), rows) * stride + reflect101(min(x0 - 3 + q, cols + 2), cols)];
+  }
+  __syncthreads();
+  for (int i = tid; i < (VS_TILE_H + 6) * VS_TILE_W; i += 256) {
+    const int r = i >> 6, x = i & 63;
+    const uint8_t* p = &src[r][x];
+    hs[r][x] = (uint16_t)(g.k[0] * p[3] + g.k[1] * (p[2] + p[4]) + g.k[2] * (p[1] + p[5]) + g.k[3] * (p[0] + p[6]));
+  }
+  __syncthreads();
+  for (int i = tid; i < VS_TILE_H * VS_TILE_W; i += 256) {
+    const int r = i >> 6, x = i & 63;
+    if (y0 + r >= rows || x0 + x >= cols) continue;
+    const int v = g.k[0] * hs[r + 3][x] + g.k[1] * (hs[r + 2][x] + hs[r + 4][x]) + g.k[2] * (hs[r + 1][x] + hs[r + 5][x]) + g.k[3] * (hs[r][x] + hs[r + 6][x]);
+    out[(size_t)(y0 + r) * ostride + x0 + x] = (uint8_t)min(max((v + (1 << 15)) >> 16, 0), 255);
+  }
+}
+__global__ __launch_bounds__(256) void k_gauss7(const DevCfg c, const DevBuf b, const Gauss7 g) {
+  __shared__ uint8_t src[VS_TILE_H + 6][72];
+  __shared__ uint16_t hs[VS_TILE_H + 6][VS_TILE_W];
+  int tx, ty, tz;
+  xcd_tile(&tx, &ty, &tz);
+  const int s = b.s0 + (tz >> 1), side = tz & 1;
+  if (!vs_active(b, s)) return;
+  gauss7_tile(b.img[side] + (size_t)s * b.img_stream_stride, b.img_row_stride, c.c.rows, c.c.cols, tx * VS_TILE_W, ty * VS_TILE_H, g,
+              blur_of(c, b, s, side), c.bstride, src, hs);
+}
+// stand-alone form on an explicit image (vslam_gaussian_blur7_u8, vslam_orb_describe)
+__global__ __launch_bounds__(256) void k_gauss7_plain(const uint8_t* img, int stride, int rows, int cols, const Gauss7 g, uint8_t* out, int ostride) {
+  __shared__ uint8_t src[VS_TILE_H + 6][72];
+  __shared__ uint16_t hs[VS_TILE_H + 6][VS_TILE_W];
+  gauss7_tile(img, stride, rows, cols, blockIdx.x * VS_TILE_W, blockIdx.y * VS_TILE_H, g, out, ostride, src, hs);
+}
+
+// computeOrbDescriptors (WTA_K = 2) for one keypoint by one wavefront: lane l evaluates tests l, 64+l, 128+l, 192+l; the
+// rotated, rounded tap offsets depend on the angle only (one angle per launch: the FAST keypoints all carry -1)
+struct OrbTaps { int off[4][2]; };
+__device__ __forceinline__ OrbTaps orb_taps(int lane, float a, float bsin, int stride) {
+  OrbTaps t;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = j * 64 + lane;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float px = (float)c_orb[i][2 * h], py = (float)c_orb[i][2 * h + 1];
+      const float xf = px * a - py * bsin, yf = px * bsin + py * a;
+      t.off[j][h] = (int)rintf(yf) * stride + (int)rintf(xf);
+    }
+  }
+  return t;
+}
+__device__ __forceinline__ void orb_wave(const uint8_t* centre, const OrbTaps& t, unsigned long long d[4]) {
+  int v[4][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { v[j][0] = centre[t.off[j][0]]; v[j][1] = centre[t.off[j][1]]; }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) d[j] = __ballot(v[j][0] < v[j][1]);   // bit l of word j = test 64 j + l: bytes LSB first
+}
+__global__ __launch_bounds__(256) void k_orb_describe(const DevCfg c, const DevBuf b, float a, float bsin) {
+  const int s = b.s0 + blockIdx.y, side = blockIdx.z;
+  if (!vs_active(b, s)) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = gridDim.x * (blockDim.x >> 6);
+  const int n = min(b.n_kp[s * 2 + side], c.NMAX);
+  const int16_t* xy = kpxy_of(c, b, s, side);
+  uint8_t* desc = desc_of(c, b, s, side);
+  const uint8_t* blur = blur_of(c, b, s, side);
+  const OrbTaps t = orb_taps(lane, a, bsin, c.bstride);
+  for (int i = wave; i < n; i += nwaves) {
+    unsigned long long d[4];
+    orb_wave(blur + (size_t)xy[2 * i + 1] * c.bstride + xy[2 * i], t, d);
+    const unsigned long long dv = lane == 0 ? d[0] : (lane == 1 ? d[1] : (lane == 2 ? d[2] : d[3]));
+    if (lane < 4) reinterpret_cast<unsigned long long*>(desc + (size_t)32 * i)[lane] = dv;
+  }
+}
+// stand-alone ORB at caller keypoints (vslam_orb_describe): keep[] = inside the 31 px border
+__global__ __launch_bounds__(256) void k_orb_at(const uint8_t* blur, int stride, int rows, int cols, int n, const int16_t* xy, float a, float bsin,
+                                                uint8_t* keep, uint8_t* desc) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = gridDim.x * (blockDim.x >> 6);
+  const OrbTaps t = orb_taps(lane, a, bsin, stride);
+  for (int i = wave; i < n; i += nwaves) {
+    const int x = xy[2 * i], y = xy[2 * i + 1];
+    const bool in = x >= VSLAM_ORB_BORDER && x < cols - VSLAM_ORB_BORDER && y >= VSLAM_ORB_BORDER && y < rows - VSLAM_ORB_BORDER;
+    if (lane == 0) keep[i] = in ? 1 : 0;
+    unsigned long long d[4] = {0ull, 0ull, 0ull, 0ull};
+    if (in) orb_wave(blur + (size_t)y * stride + x, t, d);
+    const unsigned long long dv = lane == 0 ? d[0] : (lane == 1 ? d[1] : (lane == 2 ? d[2] : d[3]));
+    if (lane < 4) reinterpret_cast<unsigned long long*>(desc + (size_t)32 * i)[lane] = dv;
   }
 }
 

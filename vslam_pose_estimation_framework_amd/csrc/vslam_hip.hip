@@ -159,10 +159,24 @@ VS_API void vslam_default_config_euroc(vslam_config* c) {
   c->maximum_matching_distance_triangulation = 50;
   c->minimum_track_length_for_landmark_creation = 2; c->good_tracking_ratio = 0.25;
   c->aligner_damping = 0;
+  c->descriptor_type = VSLAM_DESCRIPTOR_ORB;   // configuration_euroc.yaml:52 "ORB-256": unknown to the parser -> cv::ORB::create() (:219-224)
 }
 
 VS_API const char* vslam_last_error(const vslam_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
+// ---- ORB extractor constants, computed on the host with OpenCV's own expressions [recalled: orb.cpp, smooth.cpp] --------------
+static void orb_rotation_host(float angle_degrees, float* a, float* b) {
+  float angle = angle_degrees;
+  angle *= (float)(3.1415926535897932384626433832795 / 180.f);
+  *a = (float)std::cos(angle); *b = (float)std::sin(angle);
+}
+static void gauss7_kernel_host(int32_t k4[4]) {   // getGaussianKernel(7, 2, CV_32F) -> cvRound(k * 256): centre .. outermost tap
+  float cf[7];
+  double sum = 0;
+  for (int i = 0; i < 7; ++i) { const double x = i - 3.0; cf[i] = (float)std::exp(-0.5 / 4.0 * x * x); sum += cf[i]; }
+  sum = 1. / sum;
+  for (int i = 0; i < 4; ++i) k4[i] = (int32_t)std::lrint((double)(float)(cf[3 + i] * sum) * 256.0);
+}
 // ---- configure (BaseFramePointGenerator::configure, base_framepoint_generator.cpp:229-329) ----------
 static void derive_cfg(const vslam_config& in, int n_streams, DevCfg* d) {
   std::memset(d, 0, sizeof *d);
@@ -192,6 +206,8 @@ static void derive_cfg(const vslam_config& in, int n_streams, DevCfg* d) {
   d->n_offsets = 0;
   d->offsets[d->n_offsets++] = 0;
   for (int u = 1; u <= in.maximum_epipolar_search_offset_pixels; ++u) { d->offsets[d->n_offsets++] = u; d->offsets[d->n_offsets++] = -u; }
+  orb_rotation_host(-1.f, &d->orb_cos, &d->orb_sin);   // FAST keypoints: KeyPoint::angle = -1, never recomputed by ORB::compute
+  gauss7_kernel_host(d->gauss7);
   d->NMAX = in.max_keypoints;
   d->MAXP = in.max_points;
   d->HCAP = in.max_history_frames;
@@ -249,6 +265,7 @@ static int create_internal(const vslam_config* cfg, int device, int n_streams, v
   if (cfg->det_rows < 1 || cfg->det_cols < 1 || cfg->det_rows * cfg->det_cols > VSLAM_MAX_REGIONS) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: invalid detector grid");
   if (!(-cfg->baseline_h[0] / cfg->K[0] > 0)) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: invalid baseline (m), verify intrinsic camera parameters");
   if (cfg->maximum_epipolar_search_offset_pixels < 0 || cfg->maximum_epipolar_search_offset_pixels > VSLAM_MAX_EPI) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: epipolar offset out of range");
+  if (cfg->descriptor_type != VSLAM_DESCRIPTOR_BRIEF && cfg->descriptor_type != VSLAM_DESCRIPTOR_ORB) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: unknown descriptor_type");
   if (cfg->max_keypoints < 64 || cfg->max_keypoints > 65535 || cfg->max_points < 64 || cfg->max_history_frames < 2 || cfg->bin_size_pixels < 1) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: invalid capacities");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, VSLAM_ERR_NO_DEVICE, "vslam_create: no HIP device available (the HIP path has no CPU fallback)");
@@ -470,10 +487,18 @@ static int launch_image_pipeline(vslam_ctx* c) {
     if (g.emit_pending[set ^ 1] && g.st_img != g.st_img2) HIP_TRY(c, hipStreamWaitEvent(st, g.ev_emit[set ^ 1], 0));
     dim3 g1(d.TX, (d.c.rows + VS_TILE_H - 1) / VS_TILE_H, 2 * g.n);
     { KernelTimer t(c, 0, st); hipLaunchKernelGGL(k_fast_box, g1, dim3(256), 0, st, c->cfg, bs); }
-    { KernelTimer t(c, 1, st); hipLaunchKernelGGL(k_emit, dim3(g.n, 2), dim3(512), 0, st, c->cfg, bs, (int)VSLAM_BRIEF_BORDER, 1); }
+    const bool orb = d.c.descriptor_type == VSLAM_DESCRIPTOR_ORB;
+    { KernelTimer t(c, 1, st); hipLaunchKernelGGL(k_emit, dim3(g.n, 2), dim3(512), 0, st, c->cfg, bs, orb ? (int)VSLAM_ORB_BORDER : (int)VSLAM_BRIEF_BORDER, 1); }
     if (g.st_img != g.st_img2) { HIP_TRY(c, hipEventRecord(g.ev_emit[set], st)); g.emit_pending[set] = true; }
-    dim3 g3((d.c.cols + VS_BT_W - 1) / VS_BT_W, (d.c.rows + VS_BT_H - 1) / VS_BT_H, 2 * g.n);
-    { KernelTimer t(c, 2, st); hipLaunchKernelGGL(k_brief, g3, dim3(256), 0, st, c->cfg, bs); }
+    if (orb) {   // cv::ORB::create() as extractor: Gaussian image (in the box image's memory), steered tests per keypoint
+      KernelTimer t(c, 2, st);
+      Gauss7 gk; for (int i = 0; i < 4; ++i) gk.k[i] = d.gauss7[i];
+      hipLaunchKernelGGL(k_gauss7, g1, dim3(256), 0, st, c->cfg, bs, gk);
+      hipLaunchKernelGGL(k_orb_describe, dim3(std::max(4, std::min(64, 4096 / std::max(g.n, 1))), g.n, 2), dim3(256), 0, st, c->cfg, bs, d.orb_cos, d.orb_sin);
+    } else {
+      dim3 g3((d.c.cols + VS_BT_W - 1) / VS_BT_W, (d.c.rows + VS_BT_H - 1) / VS_BT_H, 2 * g.n);
+      KernelTimer t(c, 2, st); hipLaunchKernelGGL(k_brief, g3, dim3(256), 0, st, c->cfg, bs);
+    }
     // left-right descriptor distances of the first epipolar pass: a product of the images alone, so it is computed
     // here, wide, instead of inside the per-stream frame workgroup
     { KernelTimer t(c, 7, st); hipLaunchKernelGGL(k_stereo_dist, dim3((d.NMAX + 255) / 256, g.n), dim3(256), 0, st, c->cfg, bs); }
@@ -1254,6 +1279,7 @@ VS_API int vslam_enable_timers(vslam_ctx* c, int on) {
 static int make_scratch_ctx(vslam_ctx* parent, int rows, int cols, int nmax, int maxp, vslam_ctx** out) {
   vslam_config cfg = parent->cfg.c;
   cfg.rows = rows; cfg.cols = cols; cfg.det_rows = 1; cfg.det_cols = 1;
+  cfg.descriptor_type = VSLAM_DESCRIPTOR_BRIEF;   // the stand-alone FAST / BRIEF entries need the box image whatever the parent uses
   cfg.max_keypoints = std::max(64, nmax); cfg.max_points = std::max(64, maxp); cfg.max_history_frames = 2;
   int rc = create_internal(&cfg, parent->device, 1, out);
   if (rc != VSLAM_OK) parent->err = g_create_error;
@@ -1310,6 +1336,60 @@ VS_API int vslam_brief_describe(vslam_ctx* c, const uint8_t* img, int32_t rows, 
   }
   vslam_destroy(t);
   return rc;
+}
+// cv::ORB::create()->compute() pieces, stand-alone (known-answer tests)
+static int orb_blur_device(vslam_ctx* c, const uint8_t* img, int32_t rows, int32_t cols, int32_t stride, uint8_t** dimg, uint8_t** dblur) {
+  hipError_t e = hipMalloc((void**)dimg, (size_t)rows * stride);
+  if (e == hipSuccess) e = hipMalloc((void**)dblur, (size_t)rows * cols);
+  if (e == hipSuccess) e = hipMemcpyAsync(*dimg, img, (size_t)(rows - 1) * stride + cols, hipMemcpyHostToDevice, c->stream);
+  if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
+  Gauss7 gk; for (int i = 0; i < 4; ++i) gk.k[i] = c->cfg.gauss7[i];
+  hipLaunchKernelGGL(k_gauss7_plain, dim3((cols + VS_TILE_W - 1) / VS_TILE_W, (rows + VS_TILE_H - 1) / VS_TILE_H), dim3(256), 0, c->stream, *dimg, stride, rows, cols, gk, *dblur, cols);
+  return VSLAM_OK;
+}
+VS_API int vslam_gaussian_blur7_u8(vslam_ctx* c, const uint8_t* img, int32_t rows, int32_t cols, int32_t stride, uint8_t* out) {
+  if (!c) return VSLAM_ERR_INVALID;
+  if (c->sticky != VSLAM_OK) return c->sticky;
+  if (!img || !out || rows < 8 || cols < 8 || stride < cols) return fail(c, VSLAM_ERR_INVALID, "gaussian_blur7: bad argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  uint8_t *dimg = nullptr, *dblur = nullptr;
+  int rc = orb_blur_device(c, img, rows, cols, stride, &dimg, &dblur);
+  hipError_t e = hipSuccess;
+  if (rc == VSLAM_OK) e = hipMemcpyAsync(out, dblur, (size_t)rows * cols, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(dimg); (void)hipFree(dblur);
+  if (rc != VSLAM_OK) return rc;
+  if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
+  return VSLAM_OK;
+}
+VS_API int vslam_orb_describe(vslam_ctx* c, const uint8_t* img, int32_t rows, int32_t cols, int32_t stride, int32_t n, const int16_t* xy,
+                              float angle_degrees, uint8_t* keep, uint8_t* desc) {
+  if (!c) return VSLAM_ERR_INVALID;
+  if (c->sticky != VSLAM_OK) return c->sticky;
+  if (!img || n < 0 || rows < 2 * VSLAM_ORB_BORDER + 1 || cols < 2 * VSLAM_ORB_BORDER + 1 || stride < cols || (n && (!xy || !keep || !desc))) return fail(c, VSLAM_ERR_INVALID, "orb_describe: bad argument");
+  if (n == 0) return VSLAM_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  uint8_t *dimg = nullptr, *dblur = nullptr, *dkeep = nullptr, *ddesc = nullptr; int16_t* dxy = nullptr;
+  int rc = orb_blur_device(c, img, rows, cols, stride, &dimg, &dblur);
+  hipError_t e = hipSuccess;
+  if (rc == VSLAM_OK) {
+    e = hipMalloc((void**)&dxy, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&dkeep, (size_t)n);
+    if (e == hipSuccess) e = hipMalloc((void**)&ddesc, (size_t)n * 32);
+    if (e == hipSuccess) e = hipMemcpyAsync(dxy, xy, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+      float a, b;
+      orb_rotation_host(angle_degrees, &a, &b);
+      hipLaunchKernelGGL(k_orb_at, dim3(std::min(64, (n + 3) / 4)), dim3(256), 0, c->stream, dblur, cols, rows, cols, n, dxy, a, b, dkeep, ddesc);
+      e = hipMemcpyAsync(keep, dkeep, (size_t)n, hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(desc, ddesc, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  }
+  (void)hipFree(dimg); (void)hipFree(dblur); (void)hipFree(dxy); (void)hipFree(dkeep); (void)hipFree(ddesc);
+  if (rc != VSLAM_OK) return rc;
+  if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
+  return VSLAM_OK;
 }
 VS_API int vslam_knn2(vslam_ctx* c, int norm, int32_t nq, const uint8_t* q, int32_t nt, const uint8_t* t, int32_t* idx, float* dist) {
   if (!c || !q || !t || !idx || !dist || nq < 0 || nt < 0 || norm < 0 || norm > 3) return VSLAM_ERR_INVALID;
