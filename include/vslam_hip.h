@@ -356,6 +356,8 @@ typedef struct vslam_depth_params {
   double minimum_depth_meters, maximum_depth_meters;    /* parameters.h:197-198                                   */
   int32_t enable_point_triangulation;                   /* parameters.h:256                                       */
   int32_t enable_keypoint_binning, bin_size_pixels;     /* base generator parameters                              */
+  int32_t descriptor_type;                              /* extractor of recoverPoints: VSLAM_DESCRIPTOR_BRIEF / _ORB (the RGB-D
+                                                           configurations say "ORB-256", i.e. cv::ORB::create())   */
 } vslam_depth_params;
 
 /* DepthFramePointGenerator::_computeDepthMap (depth_framepoint_generator.cpp:410-485) without the optional bilateral
@@ -427,6 +429,28 @@ int vslam_point_in_camera(vslam_ctx* ctx, int32_t n, const float* xy_previous, c
 int vslam_gaussian_blur7_u8(vslam_ctx* ctx, const uint8_t* image, int32_t rows, int32_t cols, int32_t row_stride, uint8_t* blurred);
 int vslam_orb_describe(vslam_ctx* ctx, const uint8_t* image_host, int32_t rows, int32_t cols, int32_t stride, int32_t n,
                        const int16_t* xy, float angle_degrees, uint8_t* keep, uint8_t* desc);
+
+/* ---- RGB-D mode end to end: PoseTracker3D with DepthFramePointGenerator + UVDAligner ---------------
+ * (slam_assembly.cpp _createDepthTracker; configuration_{icl,tum,xtion}.yaml).  A host-driven loop inside the library
+ * (csrc/rgbd_tracker.h): the tracker's control flow and the framepoint / temporary-point / landmark bookkeeping run on the
+ * host, every data-parallel step is one of the entry points above on the device.  One sequence per object, detector grid
+ * 1 x 1.  cfg carries the tracker / aligner / landmark / detector values, p the depth camera (p->descriptor_type selects the
+ * extractor: the RGB-D configurations say "ORB-256").
+ * vslam_rgbd_process_host = PoseTracker3D::compute for one frame: left = 8-bit image, depth = 16-bit depth image (row
+ * strides in bytes / in elements).  vslam_rgbd_get_frame_info fills the counters that exist in this mode (n_keypoints_left,
+ * n_detected_left, thresholds[0], track_attempts, n_tracked, n_lost, n_tracked_landmarks, aligner_*, n_inliers, n_after_prune,
+ * n_recovered, n_active_landmarks, n_new_stereo = new points with measured depth, n_points, window_pixels, tau_track, status,
+ * poses) and the number of temporary points of the frame.  vslam_rgbd_get_points: Frame::points() as xy (float: recovered
+ * points sit at sub-pixel projections), cam, meta = (index of the predecessor in the previous frame's points followed by its
+ * temporary points or -1, track length, landmark updates or 0, hasUnreliableDepth), 32 descriptor bytes. */
+typedef struct vslam_rgbd vslam_rgbd;
+int vslam_rgbd_create(const vslam_config* cfg, const vslam_depth_params* p, int device, vslam_rgbd** out);
+void vslam_rgbd_destroy(vslam_rgbd* t);
+int vslam_rgbd_reset(vslam_rgbd* t);
+const char* vslam_rgbd_last_error(const vslam_rgbd* t);
+int vslam_rgbd_process_host(vslam_rgbd* t, const uint8_t* left, int32_t left_row_stride, const uint16_t* depth, int32_t depth_row_stride);
+int vslam_rgbd_get_frame_info(vslam_rgbd* t, vslam_frame_info* out, int32_t* n_temporary);
+int vslam_rgbd_get_points(vslam_rgbd* t, int32_t cap, int32_t* n, float* xy, double* cam, int32_t* meta4, uint8_t* desc);
 
 /* ---- OrbDetector components (first half; base_framepoint_generator.cpp:52-70) ----------------------
  * The reference's OrbDetector is cv::ORB::create(5000, 1.2, 8, 31, 0, 2, HARRIS_SCORE, 31, threshold) used as a DETECTOR

@@ -1996,8 +1996,12 @@ ORC_API int orc_depth_recover(const vslam_depth_params* p, const float* space, c
                               int32_t n, const uint8_t* has_lm, const double* lm, const uint8_t* pdesc, float kp_size, double tau,
                               int32_t* n_rec, int32_t* rec_index, float* rec_xy, uint8_t* rec_desc, double* rec_xyz) {
   const int rows = p->rows, cols = p->cols;
+  const bool orb = p->descriptor_type == VSLAM_DESCRIPTOR_ORB;   /* the configured _descriptor_extractor (:369-373) */
   std::vector<int32_t> sum;
-  integral_image(img, rows, cols, stride, sum);
+  std::vector<uint8_t> blur;
+  float oa = 1, ob = 0;
+  if (orb) { gaussian_blur7_u8(img, rows, cols, stride, blur); orb_rotation(-1.f, &oa, &ob); }   /* the lost point's FAST keypoint: angle -1 */
+  else integral_image(img, rows, cols, stride, sum);
   Tf W;
   std::memcpy(W.m, w2c, sizeof W.m);
   int nr = 0;
@@ -2018,9 +2022,10 @@ ORC_API int orc_depth_recover(const vslam_depth_params* p, const float* space, c
     const float cxf = px - rbc, cyf = py - rbc;                                   /* :362 */
     const int ox = (int)std::lrint(cxf), oy = (int)std::lrint(cyf);               /* cv::Rect_<float> -> cv::Rect: saturate_cast = cvRound */
     const int bx = ox + (int)(rbc + 0.5f), by = oy + (int)(rbc + 0.5f);           /* BRIEF rounds the keypoint (rbc, rbc) of the ROI */
-    if (!brief_inside(rows, cols, bx, by)) continue;                              /* :376-378 (cannot happen behind the border gate) */
+    if (!(orb ? orb_inside(rows, cols, bx, by) : brief_inside(rows, cols, bx, by))) continue;   /* :376-378 (cannot happen behind the border gate) */
     uint8_t d[32];
-    brief_at(sum, cols, bx, by, d);                                               /* :369-373 */
+    if (orb) orb_at(blur.data(), cols, bx, by, oa, ob, d);                        /* ORB::compute rounds the keypoint of the region the same way */
+    else brief_at(sum, cols, bx, by, d);                                          /* :369-373 */
     if (hamming32(pdesc + 32 * i, d) > tau) continue;                             /* :381-383 */
     rec_index[nr] = i;
     rec_xy[2 * nr] = rbc + cxf; rec_xy[2 * nr + 1] = rbc + cyf;                   /* :384 keypoint.pt += corner_left */

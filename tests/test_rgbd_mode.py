@@ -1,0 +1,122 @@
+"""RGB-D mode end to end: PoseTracker3D with a DepthFramePointGenerator and a UVDAligner.
+
+Two independent statements of the same tracker are compared on rendered image + depth sequences:
+  * the product: the C++ host loop inside libvslam_hip.so (csrc/rgbd_tracker.h, vslam_rgbd_*) over the device entry points;
+  * the checker: tests/rgbd_loop.py, a plain Python loop, run over the CPU oracle's stand-alone functions.
+Counters and point lists must agree exactly, poses within 1e-4 relative Frobenius (north_star).  The Python loop is also run
+over the HIP entry points (same control flow, device kernels), which separates a kernel difference from a loop difference."""
+import numpy as np
+import pytest
+
+from rgbd_loop import RgbdTracker as PyLoop
+from vslam_pose_estimation_framework_amd import hip
+from vslam_pose_estimation_framework_amd.capi import DepthParams, RgbdTracker
+
+POSE_RTOL = 1e-4
+
+
+def setup(o, scale=0.5, max_depth=40.0, descriptor=1, seed=23):
+    """TUM-style values (configuration_tum.yaml:27-79) on the synthetic street scene; depth beyond `max_depth` reads as "no
+    measurement", so far features become temporary points."""
+    scene = o.scene_kitti(scale=scale, seed=seed)
+    scene.speed_m = 0.25; scene.sway_m = 0.4
+    cfg = o.config_for_scene(scene)
+    cfg.detector_threshold_minimum = 10; cfg.detector_threshold_maximum = 100; cfg.detector_threshold_maximum_change = 0.5
+    cfg.minimum_projection_tracking_distance_pixels = 10
+    cfg.minimum_descriptor_distance_tracking = 40; cfg.maximum_descriptor_distance_tracking = 40
+    cfg.maximum_reliable_depth_meters = 12.0; cfg.maximum_depth_meters = max_depth
+    cfg.minimum_track_length_for_landmark_creation = 2; cfg.tunnel_vision_ratio = 0.75; cfg.good_tracking_ratio = 0.25
+    cfg.aligner_error_delta_for_convergence = 1e-5; cfg.aligner_maximum_error_kernel = 10; cfg.aligner_damping = 0
+    cfg.aligner_minimum_number_of_inliers = 0
+    cfg.landmark_maximum_error_squared_meters = 1.0
+    cfg.descriptor_type = descriptor
+    K = np.array([[scene.fx, 0, scene.cx], [0, scene.fy, scene.cy], [0, 0, 1.0]])
+    p = DepthParams.make(scene.rows, scene.cols, K, np.linalg.inv(K), np.linalg.inv(K), np.eye(4)[:3], 2e-3, 0.1, max_depth, 1, 1, 15, descriptor)
+    return scene, cfg, p
+
+
+def test_python_loop_over_the_oracle_tracks_the_scene():
+    """CPU: the checker loop itself locks on, keeps landmarks, recovers points, carries temporary points and follows the ground
+    truth (so that agreeing with it means something)."""
+    from _oracle import Oracle
+    o = Oracle()
+    scene, cfg, p = setup(o)
+    o.create(cfg, 0, 1)
+    tr = PyLoop(o, cfg, p)
+    g0 = o.gt_pose(scene, 0)
+    rec = tmp = 0
+    for k in range(10):
+        L, _ = o.render(scene, k)
+        info = tr.process(L, o.render_depth(scene, k, 2e-3))
+        rec += info["n_recovered"]; tmp += info["n_temporary"]
+    G = o.gt_pose(scene, 9)
+    Grel = np.hstack([g0[:, :3].T @ G[:, :3], (g0[:, :3].T @ (G[:, 3] - g0[:, 3]))[:, None]])
+    assert info["status"] == 1 and info["n_tracked"] > 50 and info["n_active_landmarks"] > 50
+    assert rec > 20 and tmp > 5
+    assert np.abs(info["pose"] - Grel).max() < 0.1          # 2.25 m of path
+    o.destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("descriptor,max_depth,seed", [(1, 40.0, 23), (0, 25.0, 31)])
+def test_rgbd_tracker_matches_the_checker_loop(descriptor, max_depth, seed):
+    from _oracle import Oracle
+    o = Oracle()
+    scene, cfg, p = setup(o, descriptor=descriptor, max_depth=max_depth, seed=seed)
+    o.create(cfg, 0, 1)
+    g = hip.load()
+    g.create(cfg, 0, 1)
+    ref = PyLoop(o, cfg, p)                 # Python loop over the oracle
+    mid = PyLoop(g, cfg, p)                 # Python loop over the HIP entry points
+    prod = RgbdTracker(g, cfg, p)           # the product: C++ loop inside libvslam_hip.so
+    try:
+        seen_temp = seen_rec = 0
+        for k in range(12):
+            L, _ = o.render(scene, k)
+            D = o.render_depth(scene, k, 2e-3)
+            a = ref.process(L, D)
+            b = mid.process(L, D)
+            fi, n_temp = prod.process(L, D)
+            for name, field in (("status", "status"), ("n_keypoints", "n_keypoints_left"), ("n_tracked", "n_tracked"), ("n_lost", "n_lost"),
+                                ("n_tracked_landmarks", "n_tracked_landmarks"), ("aligner_ran", "aligner_ran"), ("n_inliers", "n_inliers"),
+                                ("aligner_iterations", "aligner_iterations"), ("n_after_prune", "n_after_prune"), ("n_recovered", "n_recovered"),
+                                ("n_active_landmarks", "n_active_landmarks"), ("n_new", "n_new_stereo"), ("n_points", "n_points"),
+                                ("window_pixels", "window_pixels"), ("track_attempts", "track_attempts"), ("fallback", "fallback"),
+                                ("track_broken", "track_broken"), ("status_at_start", "status_at_start")):
+                assert a[name] == b[name] == getattr(fi, field), (k, name, a[name], b[name], getattr(fi, field))
+            assert a["threshold"] == b["threshold"] == fi.thresholds[0] and a["n_temporary"] == b["n_temporary"] == n_temp
+            assert a["tau_track"] == fi.tau_track
+            To, Tg = a["pose"], np.array(fi.camera_left_to_world).reshape(3, 4)
+            assert np.linalg.norm(Tg - To) / np.linalg.norm(To) <= POSE_RTOL
+            assert np.linalg.norm(b["pose"] - To) / np.linalg.norm(To) <= POSE_RTOL
+            pts = prod.points()
+            cur = ref.frames[-1]
+            assert len(pts["xy"]) == len(cur.points)
+            prevlist = (ref.frames[-2].points + ref.frames[-2].temps) if k else []
+            for i, q in enumerate(cur.points):
+                assert np.array_equal(pts["xy"][i].view(np.uint32), q.xy.view(np.uint32)), (k, i)
+                np.testing.assert_array_equal(pts["desc"][i], q.desc)
+                np.testing.assert_allclose(pts["cam"][i], q.cam, rtol=1e-12, atol=0)
+                want_prev = prevlist.index(q.previous) if q.previous is not None else -1
+                assert pts["meta"][i, 0] == want_prev and pts["meta"][i, 1] == q.track_len and pts["meta"][i, 3] == int(q.unreliable)
+                assert pts["meta"][i, 2] == (q.landmark.updates if q.landmark is not None else 0)
+            seen_temp += n_temp; seen_rec += fi.n_recovered
+        assert fi.status == 1 and fi.n_tracked > 40 and seen_temp > 0 and seen_rec > 0
+    finally:
+        prod.destroy(); g.destroy(); o.destroy()
+
+
+@pytest.mark.gpu
+def test_rgbd_tracker_argument_errors():
+    from _oracle import Oracle
+    from vslam_pose_estimation_framework_amd.capi import VslamError
+    o = Oracle()
+    scene, cfg, p = setup(o)
+    g = hip.load()
+    bad = cfg.copy(); bad.det_rows = 2
+    with pytest.raises(VslamError):
+        RgbdTracker(g, bad, p)
+    t = RgbdTracker(g, cfg, p)
+    rc = g.lib.vslam_rgbd_process_host(t.h, None, 0, None, 0)
+    assert rc == -1 and b"empty frame" in g.lib.vslam_rgbd_last_error(t.h)
+    t.destroy()

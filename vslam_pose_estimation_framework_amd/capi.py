@@ -89,11 +89,11 @@ class DepthParams(C.Structure):
                 ("K_right_inverse", C.c_double * 9), ("right_to_left", C.c_double * 12),
                 ("depth_scale_factor_intensity_to_meters", C.c_double), ("minimum_depth_meters", C.c_double),
                 ("maximum_depth_meters", C.c_double), ("enable_point_triangulation", C.c_int32),
-                ("enable_keypoint_binning", C.c_int32), ("bin_size_pixels", C.c_int32)]
+                ("enable_keypoint_binning", C.c_int32), ("bin_size_pixels", C.c_int32), ("descriptor_type", C.c_int32)]
 
     @staticmethod
     def make(rows, cols, K_left, K_left_inverse, K_right_inverse, right_to_left, scale=1e-3, min_depth=0.1, max_depth=10.0,
-             triangulation=1, binning=1, bin_px=6):
+             triangulation=1, binning=1, bin_px=6, descriptor=0):
         p = DepthParams()
         p.rows, p.cols = int(rows), int(cols)
         for name, a in (("K_left", K_left), ("K_left_inverse", K_left_inverse), ("K_right_inverse", K_right_inverse), ("right_to_left", right_to_left)):
@@ -102,6 +102,7 @@ class DepthParams(C.Structure):
         p.depth_scale_factor_intensity_to_meters = scale
         p.minimum_depth_meters, p.maximum_depth_meters = min_depth, max_depth
         p.enable_point_triangulation, p.enable_keypoint_binning, p.bin_size_pixels = int(triangulation), int(binning), int(bin_px)
+        p.descriptor_type = int(descriptor)
         return p
 
 
@@ -537,3 +538,41 @@ def _extra_methods():
 
 
 _extra_methods()
+
+
+class RgbdTracker(object):
+    """ctypes view of vslam_rgbd_* (RGB-D mode end to end, host-driven loop inside libvslam_hip.so)."""
+
+    def __init__(self, api, cfg, params, device=0):
+        self.lib = api.lib
+        self.cfg = cfg.copy()
+        self.lib.vslam_rgbd_last_error.restype = C.c_char_p
+        self.h = C.c_void_p()
+        rc = self.lib.vslam_rgbd_create(C.byref(cfg), C.byref(params), C.c_int(device), C.byref(self.h))
+        if rc != OK:
+            raise VslamError(rc, self.lib.vslam_rgbd_last_error(None).decode())
+
+    def _check(self, rc):
+        if rc != OK:
+            raise VslamError(rc, self.lib.vslam_rgbd_last_error(self.h).decode())
+
+    def process(self, left, depth):
+        left = np.ascontiguousarray(left, np.uint8); depth = np.ascontiguousarray(depth, np.uint16)
+        self._check(self.lib.vslam_rgbd_process_host(self.h, _p(left, C.c_uint8), C.c_int32(left.shape[1]), _p(depth, C.c_uint16), C.c_int32(depth.shape[1])))
+        fi = FrameInfo()
+        nt = C.c_int32()
+        self._check(self.lib.vslam_rgbd_get_frame_info(self.h, C.byref(fi), C.byref(nt)))
+        return fi, nt.value
+
+    def points(self):
+        cap = int(self.cfg.max_points) * 4
+        n = C.c_int32()
+        xy = np.zeros((cap, 2), np.float32); cam = np.zeros((cap, 3), np.float64); meta = np.zeros((cap, 4), np.int32); desc = np.zeros((cap, 32), np.uint8)
+        self._check(self.lib.vslam_rgbd_get_points(self.h, C.c_int32(cap), C.byref(n), _p(xy, C.c_float), _p(cam, C.c_double), _p(meta, C.c_int32), _p(desc, C.c_uint8)))
+        k = n.value
+        return dict(xy=xy[:k].copy(), cam=cam[:k].copy(), meta=meta[:k].copy(), desc=desc[:k].copy())
+
+    def destroy(self):
+        if self.h:
+            self.lib.vslam_rgbd_destroy(self.h)
+            self.h = None

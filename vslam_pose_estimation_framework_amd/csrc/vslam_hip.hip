@@ -993,10 +993,19 @@ VS_API int vslam_depth_recover(vslam_ctx* c, const vslam_depth_params* p, const 
     if (!space) (void)hipStreamSynchronize(c->stream);   // the resident map was written on the parent's stream
     a.has_lm = dhl; a.lm = dlm; a.pdesc = dpd; a.space = space ? dspace : c->dm.space; a.bxy = dbxy; a.kxy = dkxy; a.cell = dcell;
     a.keep = dkeep; a.desc = ddesc; a.count = dcnt; a.rec_index = dridx; a.rec_xy = drxy; a.rec_desc = drdesc; a.rec_xyz = drxyz;
-    dim3 g1(t->cfg.TX, (p->rows + VS_TILE_H - 1) / VS_TILE_H, 2);
-    hipLaunchKernelGGL(k_fast_box, g1, dim3(256), 0, t->stream_img, t->cfg, t->buf);
     hipLaunchKernelGGL(k_depth_recover_project, dim3((n + 255) / 256), dim3(256), 0, t->stream_img, a);
-    hipLaunchKernelGGL(k_brief_at, dim3(std::min(64, (n + 3) / 4)), dim3(256), 0, t->stream_img, t->buf.box, t->cfg.bstride, p->rows, p->cols, n, dbxy, dkeep, ddesc);
+    if (p->descriptor_type == VSLAM_DESCRIPTOR_ORB) {
+      // cv::ORB::create() as extractor: Gaussian image (in the scratch context's box memory), steered tests at the rounded pixels
+      uint8_t* dblur = reinterpret_cast<uint8_t*>(t->buf.box);
+      Gauss7 gk; for (int i = 0; i < 4; ++i) gk.k[i] = t->cfg.gauss7[i];
+      hipLaunchKernelGGL(k_gauss7_plain, dim3((p->cols + VS_TILE_W - 1) / VS_TILE_W, (p->rows + VS_TILE_H - 1) / VS_TILE_H), dim3(256), 0, t->stream_img,
+                         t->buf.img[0], t->buf.img_row_stride, p->rows, p->cols, gk, dblur, t->cfg.bstride);
+      hipLaunchKernelGGL(k_orb_at, dim3(std::min(64, (n + 3) / 4)), dim3(256), 0, t->stream_img, dblur, t->cfg.bstride, p->rows, p->cols, n, dbxy, t->cfg.orb_cos, t->cfg.orb_sin, dkeep, ddesc);
+    } else {
+      dim3 g1(t->cfg.TX, (p->rows + VS_TILE_H - 1) / VS_TILE_H, 2);
+      hipLaunchKernelGGL(k_fast_box, g1, dim3(256), 0, t->stream_img, t->cfg, t->buf);
+      hipLaunchKernelGGL(k_brief_at, dim3(std::min(64, (n + 3) / 4)), dim3(256), 0, t->stream_img, t->buf.box, t->cfg.bstride, p->rows, p->cols, n, dbxy, dkeep, ddesc);
+    }
     hipLaunchKernelGGL(k_depth_recover_finish, dim3(1), dim3(1024), 0, t->stream_img, a);
     e = hipGetLastError();
     int32_t cnt = 0;
@@ -1679,6 +1688,48 @@ VS_API int vslam_set_pose(vslam_ctx* c, int s, const double pose[12]) {
   std::memcpy(p.v, pose, sizeof p.v);
   hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(1), 0, c->groups[group_of(c, s)].st_frm, c->buf, s, p);
   HIP_TRY(c, hipGetLastError());
+  return VSLAM_OK;
+}
+
+// ---- RGB-D mode: host-driven tracker over the device entry points (csrc/rgbd_tracker.h) -----------------------------------------
+#include "rgbd_tracker.h"
+struct vslam_rgbd { vs_rgbd::Tracker t; };
+static thread_local std::string g_rgbd_error;
+VS_API const char* vslam_rgbd_last_error(const vslam_rgbd* r) { return r ? r->t.err.c_str() : g_rgbd_error.c_str(); }
+VS_API int vslam_rgbd_create(const vslam_config* cfg, const vslam_depth_params* p, int device, vslam_rgbd** out) {
+  if (!cfg || !p || !out) { g_rgbd_error = "vslam_rgbd_create: null argument"; return VSLAM_ERR_INVALID; }
+  vslam_rgbd* r = new vslam_rgbd;
+  const int rc = r->t.create(*cfg, *p, device);
+  if (rc != VSLAM_OK) { g_rgbd_error = r->t.err; delete r; return rc; }
+  *out = r;
+  return VSLAM_OK;
+}
+VS_API void vslam_rgbd_destroy(vslam_rgbd* r) { delete r; }
+VS_API int vslam_rgbd_reset(vslam_rgbd* r) { if (!r) return VSLAM_ERR_INVALID; r->t.reset(); return VSLAM_OK; }
+VS_API int vslam_rgbd_process_host(vslam_rgbd* r, const uint8_t* left, int32_t lstride, const uint16_t* depth, int32_t dstride) {
+  if (!r) return VSLAM_ERR_INVALID;
+  if (lstride < r->t.cfg.cols || dstride < r->t.cfg.cols) { r->t.err = "row stride smaller than image width"; return VSLAM_ERR_INVALID; }
+  return r->t.process(left, lstride, depth, dstride);
+}
+VS_API int vslam_rgbd_get_frame_info(vslam_rgbd* r, vslam_frame_info* out, int32_t* n_temporary) {
+  if (!r || !out) return VSLAM_ERR_INVALID;
+  *out = r->t.info;
+  if (n_temporary) *n_temporary = r->t.n_temporary;
+  return VSLAM_OK;
+}
+VS_API int vslam_rgbd_get_points(vslam_rgbd* r, int32_t cap, int32_t* n, float* xy, double* cam, int32_t* meta4, uint8_t* desc) {
+  if (!r || !n) return VSLAM_ERR_INVALID;
+  if (r->t.info.frame_index == 0) { *n = 0; return VSLAM_OK; }
+  const vs_rgbd::Fr& f = r->t.current();
+  *n = (int32_t)f.points.size();
+  if (*n > cap) { r->t.err = "point output capacity too small"; return VSLAM_ERR_CAPACITY; }
+  for (int i = 0; i < *n; ++i) {
+    const vs_rgbd::Pt& q = r->t.point(f.points[i]);
+    if (xy) { xy[2 * i] = q.xy[0]; xy[2 * i + 1] = q.xy[1]; }
+    if (cam) for (int k = 0; k < 3; ++k) cam[3 * i + k] = q.cam[k];
+    if (meta4) { meta4[4 * i] = r->t.previous_index(q); meta4[4 * i + 1] = q.track_len; meta4[4 * i + 2] = q.landmark >= 0 ? r->t.landmarks()[q.landmark].updates : 0; meta4[4 * i + 3] = q.unreliable ? 1 : 0; }
+    if (desc) std::memcpy(desc + (size_t)32 * i, q.desc, 32);
+  }
   return VSLAM_OK;
 }
 
