@@ -1708,6 +1708,7 @@ VS_API void vslam_rgbd_destroy(vslam_rgbd* r) { delete r; }
 VS_API int vslam_rgbd_reset(vslam_rgbd* r) { if (!r) return VSLAM_ERR_INVALID; r->t.reset(); return VSLAM_OK; }
 VS_API int vslam_rgbd_process_host(vslam_rgbd* r, const uint8_t* left, int32_t lstride, const uint16_t* depth, int32_t dstride) {
   if (!r) return VSLAM_ERR_INVALID;
+  if (!left || !depth) { r->t.err = "called with empty frame"; return VSLAM_ERR_INVALID; }   // depth_framepoint_generator.cpp:48-50
   if (lstride < r->t.cfg.cols || dstride < r->t.cfg.cols) { r->t.err = "row stride smaller than image width"; return VSLAM_ERR_INVALID; }
   return r->t.process(left, lstride, depth, dstride);
 }
