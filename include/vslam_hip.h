@@ -43,7 +43,11 @@ typedef enum {
   VSLAM_ERR_NO_DEVICE = -2, /* HIP device or kernel image missing: the product path never   */
                             /* falls back to a CPU implementation                           */
   VSLAM_ERR_HIP = -3,       /* a HIP runtime call failed                                    */
-  VSLAM_ERR_CAPACITY = -4,  /* a fixed-capacity device buffer overflowed (keypoints/points) */
+  VSLAM_ERR_CAPACITY = -4,  /* an output array of the caller, or the scratch buffers of a stand-alone entry, are too
+                               small.  Overflow of a context's device-resident buffers inside vslam_process_* / the
+                               stage calls is NOT a return code: processing continues on the truncated lists and the
+                               frame's vslam_frame_info.error_flags reports it per stream (bit 0 keypoints, bit 1 points,
+                               bit 2 history) */
   VSLAM_ERR_STATE = -5      /* call sequence violated (e.g. track before frame_begin)       */
 } vslam_status;
 
@@ -185,7 +189,8 @@ int vslam_process_device(vslam_ctx* ctx, const uint8_t* left, const uint8_t* rig
                          int32_t row_stride_bytes, size_t image_stride_bytes);
 int vslam_process_host(vslam_ctx* ctx, const uint8_t* left, const uint8_t* right,
                        int32_t row_stride_bytes, size_t image_stride_bytes);
-/* Block until all queued work of the context is done; returns the sticky error state. */
+/* Block until all queued work of the context is done; returns the sticky HIP error state (VSLAM_ERR_HIP once a runtime
+ * call has failed, else VSLAM_OK; capacity overflows are reported in vslam_frame_info.error_flags, see VSLAM_ERR_CAPACITY). */
 int vslam_synchronize(vslam_ctx* ctx);
 
 /* ---- stage entry points (the reference's plug-in virtuals, one call each) ------------------

@@ -258,6 +258,13 @@ static int init_state(vslam_ctx* c) {
   return VSLAM_OK;
 }
 
+static void destroy_streams(vslam_ctx* c) {
+  for (auto& g : c->groups) {
+    for (int q = 0; q < 2; ++q) { if (g.ev_img[q]) (void)hipEventDestroy(g.ev_img[q]); if (g.ev_frm[q]) (void)hipEventDestroy(g.ev_frm[q]); if (g.ev_emit[q]) (void)hipEventDestroy(g.ev_emit[q]); }
+    if (c->own_stream) { if (g.st_img != g.st_frm) (void)hipStreamDestroy(g.st_img); if (g.st_img2 != g.st_img) (void)hipStreamDestroy(g.st_img2); (void)hipStreamDestroy(g.st_frm); }
+  }
+  c->groups.clear();
+}
 static int create_internal(const vslam_config* cfg, int device, int n_streams, vslam_ctx** out) {
   if (!cfg || !out || n_streams < 1) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: null argument or n_streams < 1");
   if (n_streams > VS_MAX_STREAMS) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: more than 4096 streams in one context");
@@ -284,6 +291,7 @@ static int create_internal(const vslam_config* cfg, int device, int n_streams, v
     G = std::max(1, std::min(std::min(G, 16), n_streams));
     for (int g = 0; g < G; ++g) {
       vslam_ctx::Group q;
+      for (int k = 0; k < 2; ++k) { q.ev_img[k] = nullptr; q.ev_frm[k] = nullptr; q.ev_emit[k] = nullptr; }
       q.s0 = (int)((long long)n_streams * g / G);
       q.n = (int)((long long)n_streams * (g + 1) / G) - q.s0;
       bool ok = hipStreamCreateWithFlags(&q.st_frm, hipStreamNonBlocking) == hipSuccess &&
@@ -299,7 +307,7 @@ static int create_internal(const vslam_config* cfg, int device, int n_streams, v
              hipEventCreateWithFlags(&q.ev_emit[k], hipEventDisableTiming) == hipSuccess;
       q.frm_pending[0] = q.frm_pending[1] = false;
       q.emit_pending[0] = q.emit_pending[1] = false;
-      if (!ok) { delete c; return fail(nullptr, VSLAM_ERR_HIP, "hipStreamCreate failed"); }
+      if (!ok) { c->own_stream = true; destroy_streams(c); delete c; return fail(nullptr, VSLAM_ERR_HIP, "hipStreamCreate failed"); }
       c->groups.push_back(q);
     }
     c->stream = c->groups[0].st_frm;
@@ -353,7 +361,7 @@ static int create_internal(const vslam_config* cfg, int device, int n_streams, v
   if (e != hipSuccess) {
     std::string msg = std::string("vslam_create: hipMalloc failed: ") + hipGetErrorString(e);
     for (void* p : c->allocs) (void)hipFree(p);
-    (void)hipStreamDestroy(c->stream);
+    destroy_streams(c);     // every group's streams and events, not only the first group's
     delete c;
     return fail(nullptr, VSLAM_ERR_HIP, msg);
   }
@@ -370,12 +378,21 @@ static int create_internal(const vslam_config* cfg, int device, int n_streams, v
     if (e != hipSuccess) {
       std::string msg = std::string("vslam_create: device tables: ") + hipGetErrorString(e);
       for (void* p : c->allocs) (void)hipFree(p);
+      for (int i = 0; i < 6; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+      destroy_streams(c);
       delete c;
       return fail(nullptr, VSLAM_ERR_HIP, msg);
     }
   }
   int rc = init_state(c);
-  if (rc != VSLAM_OK) { g_create_error = c->err; for (void* p : c->allocs) (void)hipFree(p); delete c; return rc; }
+  if (rc != VSLAM_OK) {
+    g_create_error = c->err;
+    for (void* p : c->allocs) (void)hipFree(p);
+    for (int i = 0; i < 6; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    destroy_streams(c);
+    delete c;
+    return rc;
+  }
   *out = c;
   return VSLAM_OK;
 }
@@ -1297,7 +1314,9 @@ static int make_scratch_ctx(vslam_ctx* parent, int rows, int cols, int nmax, int
 VS_API int vslam_fast_detect(vslam_ctx* c, const uint8_t* img, int32_t rows, int32_t cols, int32_t stride, int32_t rx, int32_t ry,
                              int32_t rw, int32_t rh, int32_t threshold, int32_t cap, int32_t* n, int16_t* xy, int32_t* score) {
   if (!c || !img || !n) return VSLAM_ERR_INVALID;
-  if (rx < 0 || ry < 0 || rw < 1 || rh < 1 || rx + rw > cols || ry + rh > rows) return fail(c, VSLAM_ERR_INVALID, "ROI outside the image");
+  if (c->sticky != VSLAM_OK) return c->sticky;
+  if (rx < 0 || ry < 0 || rw < 1 || rh < 1 || rx + rw > cols || ry + rh > rows || cap < 0 || (cap && (!xy))) return fail(c, VSLAM_ERR_INVALID, "ROI outside the image");
+  HIP_TRY(c, hipSetDevice(c->device));
   vslam_ctx* t = nullptr;
   int rc = make_scratch_ctx(c, rows, cols, std::min(std::min(cap, rows * cols), 65535), 64, &t);   // 16-bit feature indices
   if (rc != VSLAM_OK) return rc;
@@ -1315,8 +1334,16 @@ VS_API int vslam_fast_detect(vslam_ctx* c, const uint8_t* img, int32_t rows, int
     int32_t cnt = 0;
     rc = vslam_get_keypoints(t, 0, 0, cap, &cnt, xy, score, nullptr);
     *n = cnt;
+    if (rc == VSLAM_OK) {
+      // more corners in the ROI than the scratch buffers hold (k_emit clamps and raises error bit 0): not a silent truncation
+      ImgInfo ii;
+      if (hipMemcpy(&ii, t->sets[t->last_set].iinfo, sizeof ii, hipMemcpyDeviceToHost) == hipSuccess && ii.raw_count[0][0] > cnt) {
+        *n = ii.raw_count[0][0];
+        rc = fail(c, VSLAM_ERR_CAPACITY, "fast_detect: more corners than the output capacity (65535 at most)");
+      }
+    }
     if (rc == VSLAM_OK) for (int i = 0; i < cnt; ++i) { xy[2 * i] = (int16_t)(xy[2 * i] - rx); xy[2 * i + 1] = (int16_t)(xy[2 * i + 1] - ry); }
-    if (rc != VSLAM_OK) c->err = t->err;
+    else if (rc != VSLAM_ERR_CAPACITY || c->err.empty()) c->err = t->err;
   }
   vslam_destroy(t);
   return rc;
