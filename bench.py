@@ -72,10 +72,14 @@ def algorithmic_bytes(cfg, B, stats):
         "k_brief": 2 * N * (4 + 32),                                # keypoints in, descriptors out (§8d: 2·N·36)
         "k_track_candidates": P * (24 + 32) + P * 32 * 4,           # previous points + in-window descriptors
         "k_frame": P * (24 + 64 + 8) + P * 64 + I * M * 64 + M * 9 + 2 * N * 32 + 96,
-        "k_recover_brief": P * 0.5 * 64,                               # lost points: previous descriptors
+        "k_recover_brief": stats.get("R", 0.0) * (64 + 2 * 512 * 2),   # projected lost landmarks: previous descriptors + 2 x 512 box taps
         "k_update_landmarks": M * (24 + 8) * 4,                        # a few measurements per tracked point
         "k_stereo_dist": 2 * N * 32 + N * 16,                          # descriptors in, 16 distances per left feature out
     }
+    if stats.get("fused", True):
+        # one launch of the fused frame kernel also does the recovery descriptors and the landmark refinement (their own rows
+        # above when the frame is split into phase launches)
+        per_frame["k_frame"] += per_frame["k_recover_brief"] + per_frame["k_update_landmarks"]
     return {k: v * B for k, v in per_frame.items()}
 
 
@@ -86,6 +90,7 @@ def frame_stats(api, streams):
         "P": float(np.mean([fi.n_points for fi in infos])),
         "M": float(np.mean([fi.n_tracked for fi in infos])),
         "I": float(np.mean([max(fi.aligner_iterations, 1) for fi in infos])),
+        "R": float(np.mean([fi.n_recovered for fi in infos])) / 0.87,     # projected landmarks: 87 % of them pass the descriptor gates
     }, max(fi.error_flags for fi in infos)
 
 
