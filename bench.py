@@ -196,9 +196,8 @@ class Bench(object):
             for _ in range(n):
                 k = counter[0]
                 j = k % J
-                for s in range(B):
-                    if (j + phase[s]) % J == 0 and k > 0:
-                        api.reset_stream(s)              # the stream's chunk starts over: a fresh sequence, queued asynchronously
+                if k > 0:                                # streams whose chunk starts over: fresh sequences, queued asynchronously
+                    api.reset_streams([s for s in range(B) if (j + phase[s]) % J == 0])
                 api.process_device(Lbuf[j].data_ptr(), Rbuf[j].data_ptr(), self.stride, self.img_bytes)
                 counter[0] = k + 1
 

@@ -172,6 +172,7 @@ int vslam_reset(vslam_ctx* ctx);
  * The images passed for an inactive stream are ignored (the pointer arithmetic still reserves its slot). */
 int vslam_set_stream_active(vslam_ctx* ctx, int stream, int active);
 int vslam_reset_stream(vslam_ctx* ctx, int stream);
+int vslam_reset_streams(vslam_ctx* ctx, int32_t n, const int32_t* streams);   /* several streams, one launch per state half */
 /* Use the caller's HIP stream (hipStream_t passed as void*) for all work of this context. */
 int vslam_set_hip_stream(vslam_ctx* ctx, void* hip_stream);
 

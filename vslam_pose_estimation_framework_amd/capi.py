@@ -177,6 +177,11 @@ class CApi(object):
     def reset_stream(self, stream):
         self.check(self.fn("reset_stream")(self.ctx, C.c_int(stream)))
 
+    def reset_streams(self, streams):
+        ids = np.ascontiguousarray(streams, np.int32)
+        if len(ids):
+            self.check(self.fn("reset_streams")(self.ctx, C.c_int32(len(ids)), _p(ids, C.c_int32)))
+
     # -- whole frame --------------------------------------------------------------------------
     def process_host(self, left, right):
         """left/right: uint8 arrays [n_streams, rows, stride] (C-contiguous)."""

@@ -1262,12 +1262,17 @@ __global__ __launch_bounds__(VS_WG) void k_stage(const DevCfg c, const DevBuf b,
 // vslam_reset_stream, asynchronous: the stream state has an image-pipeline half (the detector thresholds, written by k_emit
 // and read by k_fast_box on the image stream) and a tracker half (everything else, frame stream); each half is reset by a
 // one-thread kernel queued on the HIP stream that owns it, so a stream restarts between two frames without a host sync.
-__global__ void k_reset_stream_img(const DevCfg c, const DevBuf b, int s) {
+struct ResetList { int32_t n; int32_t ids[63]; };   // streams restarted between two frames, one launch per half of the state
+__global__ void k_reset_stream_img(const DevCfg c, const DevBuf b, const ResetList l) {
+  if ((int)threadIdx.x >= l.n) return;
+  const int s = l.ids[threadIdx.x];
   StreamState& st = b.st[s];
   for (int r = 0; r < VSLAM_MAX_REGIONS; ++r) st.thr[r] = r < c.n_regions ? c.c.detector_threshold_minimum : 0;
   atomicAnd(&st.error_flags, ~1);     // bit 0 (keypoint capacity) is raised by k_emit on this HIP stream
 }
-__global__ void k_reset_stream_trk(const DevCfg c, const DevBuf b, int s) {
+__global__ void k_reset_stream_trk(const DevCfg c, const DevBuf b, const ResetList l) {
+  if ((int)threadIdx.x >= l.n) return;
+  const int s = l.ids[threadIdx.x];
   StreamState& st = b.st[s];
   st.status = VSLAM_LOCALIZING; st.win = c.c.maximum_projection_tracking_distance_pixels; st.frame_count = 0; st.has_prev = 0;
   st.n_tracked_landmarks_prev = 0; st.cur = 0; st.aligner_valid = 0; atomicAnd(&st.error_flags, 1);

@@ -138,7 +138,11 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
   __shared__ __align__(4) uint8_t sc[VS_TILE_H + 2][68];
   __shared__ __align__(8) uint16_t hs[VS_TILE_H + 8][VS_TILE_W];
   __shared__ int32_t s_thr[VSLAM_MAX_REGIONS];
-  __shared__ uint16_t queue[(VS_TILE_H + 2) * 66];
+  // candidate queue of the tile (packed: the scoring pass fills whole wavefronts — per-wavefront queues were measured slower,
+  // they leave every wavefront a partly filled scoring pass); the 256 slots behind it take the stores of lanes without a
+  // candidate, so that the four queue writes of a pretest pass need no exec-mask branches
+  constexpr int QCAP = (VS_TILE_H + 2) * 66;
+  __shared__ uint16_t queue[QCAP + 256];
   __shared__ unsigned long long lmask[VS_TILE_H];
   __shared__ int qn;
   int tx, ty, tz;
@@ -259,10 +263,11 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
         base = __builtin_amdgcn_readfirstlane(base);
         const int ent = (r << 8) | (4 * q - 3);
         auto below = [&](unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
-        if (p0) queue[base + below(m0)] = (uint16_t)ent;
-        if (p1) queue[base + n0 + below(m1)] = (uint16_t)(ent + 1);
-        if (p2) queue[base + n0 + n1 + below(m2)] = (uint16_t)(ent + 2);
-        if (p3) queue[base + n0 + n1 + n2 + below(m3)] = (uint16_t)(ent + 3);
+        const int trash = QCAP + tid;
+        queue[p0 ? base + below(m0) : trash] = (uint16_t)ent;
+        queue[p1 ? base + n0 + below(m1) : trash] = (uint16_t)(ent + 1);
+        queue[p2 ? base + n0 + n1 + below(m2) : trash] = (uint16_t)(ent + 2);
+        queue[p3 ? base + n0 + n1 + n2 + below(m3) : trash] = (uint16_t)(ent + 3);
       }
     }
     // region columns 0 and 65 (the NMS halo left and right of the tile): (H+2)*2 pixels on the wavefronts the last pass leaves idle

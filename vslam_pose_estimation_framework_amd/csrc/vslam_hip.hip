@@ -439,24 +439,42 @@ VS_API int vslam_set_stream_active(vslam_ctx* c, int s, int active) {
   if (active) c->buf.active[s >> 5] |= bit; else c->buf.active[s >> 5] &= ~bit;
   return upload_buffer_tables(c);
 }
-VS_API int vslam_reset_stream(vslam_ctx* c, int s) {
-  if (!c) return VSLAM_ERR_INVALID;
-  if (s < 0 || s >= c->B) return fail(c, VSLAM_ERR_INVALID, "stream index out of range");
+VS_API int vslam_reset_streams(vslam_ctx* c, int32_t n, const int32_t* streams) {
+  if (!c || n < 0 || (n && !streams)) return VSLAM_ERR_INVALID;
+  for (int i = 0; i < n; ++i) if (streams[i] < 0 || streams[i] >= c->B) return fail(c, VSLAM_ERR_INVALID, "stream index out of range");
   if (c->frame_begun) return fail(c, VSLAM_ERR_STATE, "vslam_reset_stream called inside a frame");
+  if (n == 0) return VSLAM_OK;
   HIP_TRY(c, hipSetDevice(c->device));
-  // no host synchronisation: each half of the state is reset in order on the HIP stream(s) that own it
-  const vslam_ctx::Group& g = c->groups[group_of(c, s)];
-  hipLaunchKernelGGL(k_reset_stream_img, dim3(1), dim3(1), 0, g.st_img, c->cfg, c->buf, s);
-  if (g.st_img2 != g.st_img) {   // two image streams alternate: the second one must see the reset as well
-    hipEvent_t e = ev_get(c);
-    HIP_TRY(c, hipEventRecord(e, g.st_img));
-    HIP_TRY(c, hipStreamWaitEvent(g.st_img2, e, 0));
-    c->evpool.push_back(e);
+  // no host synchronisation: each half of the state is reset in order on the HIP stream(s) that own it, one launch per
+  // half for up to 63 streams of a group
+  for (auto& g : c->groups) {
+    ResetList l;
+    l.n = 0;
+    auto flush = [&]() -> int {
+      if (!l.n) return VSLAM_OK;
+      hipLaunchKernelGGL(k_reset_stream_img, dim3(1), dim3(64), 0, g.st_img, c->cfg, c->buf, l);
+      if (g.st_img2 != g.st_img) {   // two image streams alternate: the second one must see the reset as well
+        hipEvent_t e = ev_get(c);
+        HIP_TRY(c, hipEventRecord(e, g.st_img));
+        HIP_TRY(c, hipStreamWaitEvent(g.st_img2, e, 0));
+        c->evpool.push_back(e);
+      }
+      hipLaunchKernelGGL(k_reset_stream_trk, dim3(1), dim3(64), 0, g.st_frm, c->cfg, c->buf, l);
+      l.n = 0;
+      return VSLAM_OK;
+    };
+    for (int i = 0; i < n; ++i) {
+      if (streams[i] < g.s0 || streams[i] >= g.s0 + g.n) continue;
+      l.ids[l.n++] = streams[i];
+      if (l.n == 63) { int rc = flush(); if (rc) return rc; }
+    }
+    int rc = flush();
+    if (rc) return rc;
   }
-  hipLaunchKernelGGL(k_reset_stream_trk, dim3(1), dim3(1), 0, g.st_frm, c->cfg, c->buf, s);
   HIP_TRY(c, hipGetLastError());
   return VSLAM_OK;
 }
+VS_API int vslam_reset_stream(vslam_ctx* c, int s) { const int32_t id = s; return vslam_reset_streams(c, 1, &id); }
 VS_API int vslam_copy_current_poses_device(vslam_ctx* c, double* dst) {
   if (!c || !dst) return VSLAM_ERR_INVALID;
   for (auto& g : c->groups)
