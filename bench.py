@@ -509,7 +509,7 @@ def main():
     ap.add_argument("--mode", choices=["chunks", "sequences"], default="chunks")
     ap.add_argument("--sequences", default="", help="--mode sequences: comma-separated KITTI sequence numbers")
     ap.add_argument("--bin", type=int, default=15, help="bin_size_pixels (15: ~2158 kp/image, 22: ~1026, 11: ~3955)")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("VSLAM_BENCH_STREAMS", "160")))
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("VSLAM_BENCH_STREAMS", "144")))
     ap.add_argument("--overlap", type=int, default=10, help="warm-up frames per chunk (SURVEY.md 8e default)")
     ap.add_argument("--cpu-frames", type=int, default=240)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU leg (0 = min(nproc, 16): the box's CPU share)")

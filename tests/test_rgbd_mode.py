@@ -120,3 +120,45 @@ def test_rgbd_tracker_argument_errors():
     rc = g.lib.vslam_rgbd_process_host(t.h, None, 0, None, 0)
     assert rc == -1 and b"empty frame" in g.lib.vslam_rgbd_last_error(t.h)
     t.destroy()
+
+
+@pytest.mark.gpu
+def test_rgbd_degenerate_inputs():
+    """Featureless frames, a depth image without a single measurement (every feature becomes a temporary point), a depth image
+    that comes back, a scene cut: product loop and checker loop stay identical and nothing raises."""
+    from _oracle import Oracle
+    o = Oracle()
+    scene, cfg, p = setup(o, descriptor=0, max_depth=30.0, seed=41)
+    scene2 = o.scene_kitti(scale=0.5, seed=977)
+    o.create(cfg, 0, 1)
+    g = hip.load()
+    g.create(cfg, 0, 1)
+    ref = PyLoop(o, cfg, p)
+    prod = RgbdTracker(g, cfg, p)
+    blank = np.full((cfg.rows, cfg.cols), 90, np.uint8)
+    nodepth = np.zeros((cfg.rows, cfg.cols), np.uint16)
+    frames = [(blank, nodepth)]
+    for k in range(3):
+        frames.append((o.render(scene, k)[0], o.render_depth(scene, k, 2e-3)))
+    frames.append((o.render(scene, 3)[0], nodepth))                      # images go on, the depth sensor drops out
+    frames.append((o.render(scene, 4)[0], o.render_depth(scene, 4, 2e-3)))
+    for k in range(3):
+        frames.append((o.render(scene2, 50 + k)[0], o.render_depth(scene2, 50 + k, 2e-3)))   # another world: the track is lost
+    frames.append((blank, nodepth))
+    try:
+        temps = 0
+        for k, (L, D) in enumerate(frames):
+            a = ref.process(L, D)
+            fi, n_temp = prod.process(L, D)
+            for name, field in (("status", "status"), ("n_keypoints", "n_keypoints_left"), ("n_tracked", "n_tracked"), ("n_inliers", "n_inliers"),
+                                ("n_after_prune", "n_after_prune"), ("n_recovered", "n_recovered"), ("n_active_landmarks", "n_active_landmarks"),
+                                ("n_new", "n_new_stereo"), ("n_points", "n_points"), ("track_attempts", "track_attempts"),
+                                ("track_broken", "track_broken"), ("fallback", "fallback")):
+                assert a[name] == getattr(fi, field), (k, name, a[name], getattr(fi, field))
+            assert a["n_temporary"] == n_temp
+            To, Tg = a["pose"], np.array(fi.camera_left_to_world).reshape(3, 4)
+            assert np.linalg.norm(Tg - To) / np.linalg.norm(To) <= POSE_RTOL
+            temps = max(temps, n_temp)
+        assert temps > 100          # the frame without depth: features without a measurement are carried as temporary points
+    finally:
+        prod.destroy(); g.destroy(); o.destroy()
