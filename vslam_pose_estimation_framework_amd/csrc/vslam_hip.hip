@@ -55,6 +55,11 @@ struct vslam_ctx {
   // RGB-D components: the space map of the last vslam_depth_space_map call stays resident for vslam_depth_compute
   struct DepthMap { int rows = 0, cols = 0; uint16_t* depth = nullptr; unsigned long long* key = nullptr; int32_t* last = nullptr;
                     float* space = nullptr; int16_t* row_map = nullptr; int16_t* col_map = nullptr; bool valid = false; } dm;
+  // scratch contexts of the stand-alone entry points (one per distinct configuration), kept for reuse: creating one costs
+  // ~45 device allocations plus streams and events — several milliseconds, which the host-driven RGB-D loop would pay
+  // five times per frame
+  struct Scratch { vslam_ctx* t; vslam_config cfg; bool busy; size_t base_allocs; };
+  std::vector<Scratch> scratch;
   int split = 0;   // 1: frame processed by phase launches with wide kernels in between (measured slower); 0: one launch
   int sticky = VSLAM_OK;
 };
@@ -265,6 +270,43 @@ static void destroy_streams(vslam_ctx* c) {
   }
   c->groups.clear();
 }
+static int create_internal(const vslam_config* cfg, int device, int n_streams, vslam_ctx** out);
+static int init_state(vslam_ctx* c);
+// check a scratch context of configuration `cfg` out of the parent's pool (fresh stream state, pristine DevCfg) / back in
+static int scratch_get(vslam_ctx* parent, const vslam_config& cfg, vslam_ctx** out) {
+  for (auto& e : parent->scratch)
+    if (!e.busy && std::memcmp(&e.cfg, &cfg, sizeof cfg) == 0) {
+      derive_cfg(cfg, 1, &e.t->cfg);            // stand-alone entries edit the detector regions of their scratch DevCfg
+      e.t->err.clear(); e.t->sticky = VSLAM_OK; e.t->timers = false;
+      const int rc = init_state(e.t);
+      if (rc != VSLAM_OK) { parent->err = e.t->err; return rc; }
+      e.busy = true;
+      *out = e.t;
+      return VSLAM_OK;
+    }
+  vslam_ctx* t = nullptr;
+  const int rc = create_internal(&cfg, parent->device, 1, &t);
+  if (rc != VSLAM_OK) { parent->err = g_create_error; return rc; }
+  if (parent->scratch.size() >= 12) {           // bound the pool: drop an idle entry
+    for (size_t i = 0; i < parent->scratch.size(); ++i)
+      if (!parent->scratch[i].busy) { vslam_destroy(parent->scratch[i].t); parent->scratch.erase(parent->scratch.begin() + i); break; }
+  }
+  parent->scratch.push_back({t, cfg, true, t->allocs.size()});
+  *out = t;
+  return VSLAM_OK;
+}
+static void scratch_put(vslam_ctx* parent, vslam_ctx* t) {
+  if (!t) return;
+  for (auto& e : parent->scratch)
+    if (e.t == t) {
+      sync_all(t);
+      for (size_t i = e.base_allocs; i < t->allocs.size(); ++i) (void)hipFree(t->allocs[i]);   // per-call extras (dalloc on the scratch)
+      t->allocs.resize(e.base_allocs);
+      e.busy = false;
+      return;
+    }
+  vslam_destroy(t);
+}
 static int create_internal(const vslam_config* cfg, int device, int n_streams, vslam_ctx** out) {
   if (!cfg || !out || n_streams < 1) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: null argument or n_streams < 1");
   if (n_streams > VS_MAX_STREAMS) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: more than 4096 streams in one context");
@@ -410,6 +452,8 @@ VS_API void vslam_destroy(vslam_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   sync_all(c);
+  for (auto& e : c->scratch) vslam_destroy(e.t);
+  c->scratch.clear();
   for (void* p : c->allocs) (void)hipFree(p);
   depth_map_free(c);
   for (int i = 0; i < 6; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -1055,7 +1099,7 @@ VS_API int vslam_depth_recover(vslam_ctx* c, const vslam_depth_params* p, const 
     if (e == hipSuccess) *n_rec = cnt;
     else rc = fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   }
-  vslam_destroy(t);
+  scratch_put(c, t);
   return rc;
 }
 VS_API int vslam_point_in_camera(vslam_ctx* c, int32_t n, const float* xp, const float* xc, const double T[12], const double K[9], double* out) {
@@ -1266,7 +1310,7 @@ VS_API int vslam_orb_detect(vslam_ctx* c, const uint8_t* img, int32_t rows, int3
     for (vslam_ctx* t : scratch) { int32_t cnt = 0; if (hipMemcpy(&cnt, t->buf.n_kp, 4, hipMemcpyDeviceToHost) == hipSuccess && cnt >= t->cfg.NMAX) rc = fail(c, VSLAM_ERR_CAPACITY, "orb_detect: more than 65535 FAST corners on a level"); }
     if (rc == VSLAM_OK && total > cap) rc = fail(c, VSLAM_ERR_CAPACITY, "orb_detect: output capacity too small");
   }
-  for (vslam_ctx* t : scratch) vslam_destroy(t);
+  for (vslam_ctx* t : scratch) scratch_put(c, t);
   for (void* q : tmp) (void)hipFree(q);
   if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   return rc;
@@ -1325,9 +1369,7 @@ static int make_scratch_ctx(vslam_ctx* parent, int rows, int cols, int nmax, int
   cfg.rows = rows; cfg.cols = cols; cfg.det_rows = 1; cfg.det_cols = 1;
   cfg.descriptor_type = VSLAM_DESCRIPTOR_BRIEF;   // the stand-alone FAST / BRIEF entries need the box image whatever the parent uses
   cfg.max_keypoints = std::max(64, nmax); cfg.max_points = std::max(64, maxp); cfg.max_history_frames = 2;
-  int rc = create_internal(&cfg, parent->device, 1, out);
-  if (rc != VSLAM_OK) parent->err = g_create_error;
-  return rc;
+  return scratch_get(parent, cfg, out);
 }
 VS_API int vslam_fast_detect(vslam_ctx* c, const uint8_t* img, int32_t rows, int32_t cols, int32_t stride, int32_t rx, int32_t ry,
                              int32_t rw, int32_t rh, int32_t threshold, int32_t cap, int32_t* n, int16_t* xy, int32_t* score) {
@@ -1363,7 +1405,7 @@ VS_API int vslam_fast_detect(vslam_ctx* c, const uint8_t* img, int32_t rows, int
     if (rc == VSLAM_OK) for (int i = 0; i < cnt; ++i) { xy[2 * i] = (int16_t)(xy[2 * i] - rx); xy[2 * i + 1] = (int16_t)(xy[2 * i + 1] - ry); }
     else if (rc != VSLAM_ERR_CAPACITY || c->err.empty()) c->err = t->err;
   }
-  vslam_destroy(t);
+  scratch_put(c, t);
   return rc;
 }
 VS_API int vslam_brief_describe(vslam_ctx* c, const uint8_t* img, int32_t rows, int32_t cols, int32_t stride, int32_t n,
@@ -1388,7 +1430,7 @@ VS_API int vslam_brief_describe(vslam_ctx* c, const uint8_t* img, int32_t rows, 
     if (e == hipSuccess) e = hipStreamSynchronize(t->stream_img);
     if (e != hipSuccess) rc = fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   }
-  vslam_destroy(t);
+  scratch_put(c, t);
   return rc;
 }
 // cv::ORB::create()->compute() pieces, stand-alone (known-answer tests)
@@ -1471,9 +1513,9 @@ static int align_points_impl(vslam_ctx* c, bool uvd, int32_t n, const double* mo
                              int32_t* n_inliers, double* total_error, int32_t* iterations, double H_out[36]) {
   vslam_ctx* t = nullptr;
   vslam_config cfg = c->cfg.c;
-  cfg.max_points = std::max(64, n); cfg.max_keypoints = 64; cfg.max_history_frames = 2;
-  int rc = create_internal(&cfg, c->device, 1, &t);
-  if (rc != VSLAM_OK) { c->err = g_create_error; return rc; }
+  cfg.max_points = (std::max(64, n) + 1023) / 1024 * 1024; cfg.max_keypoints = 64; cfg.max_history_frames = 2;   // rounded: one pooled scratch context serves every call
+  int rc = scratch_get(c, cfg, &t);
+  if (rc != VSLAM_OK) return rc;
   double* dT = nullptr;
   hipError_t e = dalloc(t, &dT, 12);
   if (e == hipSuccess) e = hipMemcpyAsync(dT, T_init, 12 * sizeof(double), hipMemcpyHostToDevice, t->stream);
@@ -1498,7 +1540,7 @@ static int align_points_impl(vslam_ctx* c, bool uvd, int32_t n, const double* mo
     }
   }
   if (e != hipSuccess) rc = fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
-  vslam_destroy(t);
+  scratch_put(c, t);
   return rc;
 }
 VS_API int vslam_align_points(vslam_ctx* c, int32_t n, const double* moving, const double* fixed, const double* omega,
@@ -1562,8 +1604,8 @@ VS_API int vslam_track_match(vslam_ctx* c, const double T[12], int32_t d, double
   vslam_ctx* t = nullptr;
   vslam_config cfg = c->cfg.c;
   cfg.max_points = std::max(64, nP); cfg.max_keypoints = std::max(64, std::max(nL, nR)); cfg.max_history_frames = 2;
-  int rc = create_internal(&cfg, c->device, 1, &t);
-  if (rc != VSLAM_OK) { c->err = g_create_error; return rc; }
+  int rc = scratch_get(c, cfg, &t);
+  if (rc != VSLAM_OK) return rc;
   std::vector<int> order[2];
   rc = upload_features(c, t, 0, nL, rcL, dL, order[0]);
   if (rc == VSLAM_OK) rc = upload_features(c, t, 1, nR, rcR, dR, order[1]);
@@ -1609,7 +1651,7 @@ VS_API int vslam_track_match(vslam_ctx* c, const double T[12], int32_t d, double
     }
     if (e != hipSuccess) rc = fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   }
-  vslam_destroy(t);
+  scratch_put(c, t);
   return rc;
 }
 
@@ -1619,8 +1661,8 @@ VS_API int vslam_stereo_match(vslam_ctx* c, double tau_tri, int32_t nL, const in
   vslam_ctx* t = nullptr;
   vslam_config cfg = c->cfg.c;
   cfg.max_keypoints = std::max(64, std::max(nL, nR)); cfg.max_points = std::max(64, nL); cfg.max_history_frames = 2;
-  int rc = create_internal(&cfg, c->device, 1, &t);
-  if (rc != VSLAM_OK) { c->err = g_create_error; return rc; }
+  int rc = scratch_get(c, cfg, &t);
+  if (rc != VSLAM_OK) return rc;
   std::vector<int> order[2];
   rc = upload_features(c, t, 0, nL, rcL, dL, order[0]);
   if (rc == VSLAM_OK) rc = upload_features(c, t, 1, nR, rcR, dR, order[1]);
@@ -1659,7 +1701,7 @@ VS_API int vslam_stereo_match(vslam_ctx* c, double tau_tri, int32_t nL, const in
     }
     if (e != hipSuccess) rc = fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   }
-  vslam_destroy(t);
+  scratch_put(c, t);
   return rc;
 }
 
