@@ -338,6 +338,19 @@ int vslam_stereo_match(vslam_ctx* ctx, double tau_tri, int32_t nL, const int32_t
                        int32_t nR, const int32_t* rc_right, const uint8_t* desc_right, int32_t cap, int32_t* n_out,
                        int32_t* out4);
 
+/* StereoFramePointGenerator::recoverPoints (stereo_framepoint_generator.cpp:683-869) on caller-provided data, for known-answer
+ * tests: n lost points (landmark flag, landmark world coordinates n*3, last left / right descriptors n*32), the frame's
+ * world_to_camera_left and both images (ctx's image size, geometry, depth and disparity limits, descriptor type).  Per lost point
+ * in list order: projection into both cameras (:704-745), depth and 5 * keypoint.size border gates (:746-764), descriptors at the
+ * rounded projections, the three descriptor gates and the minimum disparity (:773-842).  Outputs (cap n) in list order:
+ * rec_index = position in the lost list, rec_xy4 = (xL, yL, xR, yR), rec_dist = left-right distance, rec_desc = left | right
+ * descriptor (64 B), rec_xyz = triangulated left-camera coordinates (:871-895). */
+int vslam_stereo_recover(vslam_ctx* ctx, const uint8_t* image_left, const uint8_t* image_right, int32_t row_stride,
+                         const double world_to_camera[12], int32_t n, const uint8_t* has_landmark, const double* landmark_world,
+                         const uint8_t* prev_desc_left, const uint8_t* prev_desc_right, double tau_track, double tau_tri,
+                         int32_t* n_recovered, int32_t* rec_index, int32_t* rec_xy4, int32_t* rec_dist, uint8_t* rec_desc,
+                         double* rec_xyz);
+
 /* Landmark::update (types/landmark.cpp:66-167) for n landmarks, stand-alone (the fused tracker runs the same refinement inside
  * its frame kernel): landmark i owns the measurements offsets[i] .. offsets[i+1]-1 in the caller's order, the LAST one being
  * the new observation; measurement m was taken in frame frame_of[m] (pose tables world_to_camera / camera_to_world, 3x4 each)

@@ -1742,6 +1742,10 @@ ORC_API int orc_stereo_recover(const vslam_config* cfg, const uint8_t* imgL, con
   s.configure(*cfg);
   integral_image(imgL, cfg->rows, cfg->cols, stride, s.sumL);
   integral_image(imgR, cfg->rows, cfg->cols, stride, s.sumR);
+  if (cfg->descriptor_type == VSLAM_DESCRIPTOR_ORB) {
+    gaussian_blur7_u8(imgL, cfg->rows, cfg->cols, stride, s.blurL);
+    gaussian_blur7_u8(imgR, cfg->rows, cfg->cols, stride, s.blurR);
+  }
   s.gen_tau_track = tau_track; s.tau_tri = tau_tri;
   FrameRec prev, cur;
   std::memcpy(cur.world_to_cam.m, w2c, sizeof(double) * 12);

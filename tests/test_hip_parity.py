@@ -136,6 +136,69 @@ def test_stereo_sweep_golden(golden):
             api.destroy()
 
 
+def _recover_ctx(load, g, descriptor_type=0):
+    api = load()
+    cfg = api.default_config("kitti")
+    cfg.rows, cfg.cols = g["imgL"].shape
+    for i in range(9):
+        cfg.K[i] = float(g["K"].ravel()[i])
+    for i in range(3):
+        cfg.baseline_h[i] = float(g["bh"][i])
+    cfg.descriptor_type = descriptor_type
+    cfg.max_keypoints, cfg.max_points, cfg.max_history_frames = 256, 256, 2
+    api.create(cfg, 0, 1)
+    return api
+
+
+def test_stereo_recover_golden(golden):
+    """vslam_stereo_recover (wg_recover of the frame kernel: projection, depth / border gates, BRIEF from LDS-staged box patches,
+    three descriptor gates, minimum disparity, triangulation) against the fixture of the independent pure-Python restatement of
+    StereoFramePointGenerator::recoverPoints: exact rows, coordinates bit for bit."""
+    g = golden["stereo_recover"]
+    api = _recover_ctx(hip.load, g)
+    for rep in range(2):   # second call: pooled scratch context
+        r = api.stereo_recover(g["imgL"], g["imgR"], g["w2c"], g["has_lm"], g["lm"], g["pdL"], g["pdR"], float(g["tau_track"]), float(g["tau_tri"]))
+        assert len(r["index"]) == len(g["rec_index"]) > 20
+        np.testing.assert_array_equal(r["index"], g["rec_index"])
+        np.testing.assert_array_equal(r["xy4"], g["rec_xy4"])
+        np.testing.assert_array_equal(r["dist"], g["rec_dist"])
+        np.testing.assert_array_equal(r["desc"], g["rec_desc"])
+        np.testing.assert_array_equal(r["xyz"], g["rec_xyz"])
+    # nothing to recover / no landmark at all
+    none = api.stereo_recover(g["imgL"], g["imgR"], g["w2c"], np.zeros(0, np.uint8), np.zeros((0, 3)), np.zeros((0, 32), np.uint8),
+                              np.zeros((0, 32), np.uint8), 35.0, 60.0)
+    assert len(none["index"]) == 0
+    nolm = api.stereo_recover(g["imgL"], g["imgR"], g["w2c"], np.zeros_like(g["has_lm"]), g["lm"], g["pdL"], g["pdR"], 35.0, 60.0)
+    assert len(nolm["index"]) == 0
+    api.destroy()
+
+
+def test_stereo_recover_orb_vs_oracle(golden):
+    """The same entry with the ORB extractor (steered tests on the 7 x 7 Gaussian image, keypoint angle -1): HIP against the
+    oracle on the fixture's scene with descriptors re-made for ORB; loose gates so that every geometric survivor is compared."""
+    from _oracle import Oracle
+    g = golden["stereo_recover"]
+    hp = _recover_ctx(hip.load, g, 1)
+    orc = _recover_ctx(Oracle, g, 1)
+    rng = np.random.default_rng(5)
+    # previous descriptors: ORB descriptors of the true projections, a few bits flipped
+    first = orc.stereo_recover(g["imgL"], g["imgR"], g["w2c"], g["has_lm"], g["lm"], g["pdL"], g["pdR"], 256.0, 256.0)
+    assert len(first["index"]) > 60
+    pdL, pdR = np.array(g["pdL"]), np.array(g["pdR"])
+    for k, i in enumerate(first["index"]):
+        for side, dst in ((0, pdL), (1, pdR)):
+            bits = np.unpackbits(first["desc"][k, 32 * side:32 * side + 32])
+            bits[rng.choice(256, size=int(rng.integers(0, 50)), replace=False)] ^= 1
+            dst[i] = np.packbits(bits)
+    for tau_track, tau_tri in ((35.0, 70.0), (256.0, 256.0), (20.0, 40.0)):
+        a = hp.stereo_recover(g["imgL"], g["imgR"], g["w2c"], g["has_lm"], g["lm"], pdL, pdR, tau_track, tau_tri)
+        b = orc.stereo_recover(g["imgL"], g["imgR"], g["w2c"], g["has_lm"], g["lm"], pdL, pdR, tau_track, tau_tri)
+        for key in ("index", "xy4", "dist", "desc", "xyz"):
+            np.testing.assert_array_equal(a[key], b[key], err_msg="%s at tau %g" % (key, tau_track))
+    assert 5 < len(hp.stereo_recover(g["imgL"], g["imgR"], g["w2c"], g["has_lm"], g["lm"], pdL, pdR, 35.0, 70.0)["index"]) < len(first["index"])
+    hp.destroy(); orc.destroy()
+
+
 def test_harness_record(golden):
     """The committed 30-frame record of the whole harness (per-frame counters, thresholds, descriptor distance, poses):
     the HIP path against fixture DATA, no oracle in the loop (the oracle library only renders the images)."""

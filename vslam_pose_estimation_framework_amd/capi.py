@@ -380,6 +380,25 @@ class CApi(object):
                                            C.c_int32(cap), C.byref(n), _p(out, C.c_int32)))
         return out[:n.value].copy()
 
+    def stereo_recover(self, image_left, image_right, w2c, has_landmark, landmark_world, prev_desc_left, prev_desc_right, tau_track, tau_tri):
+        """StereoFramePointGenerator::recoverPoints on caller-provided lost points (known-answer tests): dict of
+        index / xy4 / dist / desc / xyz rows of the recovered points in lost-list order."""
+        L = np.ascontiguousarray(image_left, np.uint8); R = np.ascontiguousarray(image_right, np.uint8)
+        w = np.ascontiguousarray(w2c, np.float64).reshape(12)
+        hl = np.ascontiguousarray(has_landmark, np.uint8); lm = np.ascontiguousarray(landmark_world, np.float64)
+        pdl = np.ascontiguousarray(prev_desc_left, np.uint8); pdr = np.ascontiguousarray(prev_desc_right, np.uint8)
+        n = hl.shape[0]
+        idx = np.zeros(max(n, 1), np.int32); xy4 = np.zeros((max(n, 1), 4), np.int32); dist = np.zeros(max(n, 1), np.int32)
+        desc = np.zeros((max(n, 1), 64), np.uint8); xyz = np.zeros((max(n, 1), 3), np.float64)
+        k = C.c_int32()
+        head = (self.ctx,) if self.prefix == "vslam_" else (C.byref(self.cfg),)
+        self.check(self.fn("stereo_recover")(*head, _p(L, C.c_uint8), _p(R, C.c_uint8), C.c_int32(L.shape[1]), _p(w, C.c_double), C.c_int32(n),
+                                             _p(hl, C.c_uint8), _p(lm, C.c_double), _p(pdl, C.c_uint8), _p(pdr, C.c_uint8),
+                                             C.c_double(float(tau_track)), C.c_double(float(tau_tri)), C.byref(k), _p(idx, C.c_int32),
+                                             _p(xy4, C.c_int32), _p(dist, C.c_int32), _p(desc, C.c_uint8), _p(xyz, C.c_double)))
+        k = k.value
+        return dict(index=idx[:k].copy(), xy4=xy4[:k].copy(), dist=dist[:k].copy(), desc=desc[:k].copy(), xyz=xyz[:k].copy())
+
     # -- RGB-D components.  The oracle's entry points (prefix orc_) take no context. --------------------------------
     def _ctx_args(self):
         return (self.ctx,) if self.prefix == "vslam_" else ()

@@ -1158,6 +1158,21 @@ __global__ VS_FRAME_BOUNDS void k_frame(ConstDevCfg* cp, ConstDevBuf* bp, int ph
   }
 }
 
+// recoverPoints on caller-provided lost points (vslam_stereo_recover): previous buffer 0 holds the lost points' descriptors,
+// landmarks and landmark flags, the lost list is 0..n-1, survivors are appended to buffer 1 from its start.
+struct RecoverAlone { double w2c[12]; double tau_track, tau_tri; int n; };
+__global__ __launch_bounds__(VS_WG) void k_recover_alone(const DevCfg c, const DevBuf b, const RecoverAlone a) {
+  __shared__ FrameShared sh;
+  __shared__ __align__(16) unsigned char arena[VS_ARENA];
+  __shared__ double w2c[12];
+  const int s = b.s0, tid = threadIdx.x;
+  if (tid < 12) w2c[tid] = a.w2c[tid];
+  if (tid == 0) { sh.n_lost = a.n; sh.n_cur = 0; sh.flag = 0; }
+  __syncthreads();
+  wg_recover(c, b, s, sh, 0, 1, w2c, a.tau_track, a.tau_tri, arena);
+  if (tid == 0) { b.st[s].n_cur = sh.n_cur; b.st[s].n_recovered = sh.flag; }
+}
+
 // ==============================================================================================
 // Stage-granular entry points: the same device functions, one reference virtual per launch, with the
 // control flow left to the caller (shim/proslam_hip_plugin.h keeps the reference's PoseTracker3D logic).

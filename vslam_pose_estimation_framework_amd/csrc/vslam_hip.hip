@@ -1705,6 +1705,73 @@ VS_API int vslam_stereo_match(vslam_ctx* c, double tau_tri, int32_t nL, const in
   return rc;
 }
 
+VS_API int vslam_stereo_recover(vslam_ctx* c, const uint8_t* imgL, const uint8_t* imgR, int32_t row_stride, const double w2c[12], int32_t n,
+                                const uint8_t* has_lm, const double* lm, const uint8_t* pdL, const uint8_t* pdR, double tau_track, double tau_tri,
+                                int32_t* n_rec, int32_t* rec_index, int32_t* rec_xy4, int32_t* rec_dist, uint8_t* rec_desc, double* rec_xyz) {
+  if (!c) return VSLAM_ERR_INVALID;
+  if (c->sticky != VSLAM_OK) return c->sticky;
+  if (!imgL || !imgR || !w2c || n < 0 || !n_rec || (n && (!has_lm || !lm || !pdL || !pdR || !rec_index || !rec_xy4 || !rec_dist || !rec_desc || !rec_xyz)))
+    return fail(c, VSLAM_ERR_INVALID, "stereo_recover: bad argument");
+  if (row_stride < c->cfg.c.cols) return fail(c, VSLAM_ERR_INVALID, "row stride smaller than image width");
+  *n_rec = 0;
+  if (n == 0) return VSLAM_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  vslam_ctx* t = nullptr;
+  vslam_config cfg = c->cfg.c;
+  cfg.det_rows = 1; cfg.det_cols = 1; cfg.max_keypoints = 64; cfg.max_points = (std::max(64, n) + 1023) & ~1023; cfg.max_history_frames = 2;
+  int rc = scratch_get(c, cfg, &t);
+  if (rc != VSLAM_OK) return rc;
+  const size_t P = t->cfg.MAXP;
+  std::vector<uint8_t> desc((size_t)n * 64);
+  std::vector<int32_t> meta((size_t)n * META, 0), lost((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    std::memcpy(&desc[(size_t)64 * i], pdL + (size_t)32 * i, 32);
+    std::memcpy(&desc[(size_t)64 * i + 32], pdR + (size_t)32 * i, 32);
+    meta[(size_t)i * META + M_LMUP] = has_lm[i] ? 1 : 0;
+    meta[(size_t)i * META + M_PREV] = -1;
+    lost[i] = i;
+  }
+  hipStream_t q = t->stream_img;
+  hipError_t e = hipMemcpyAsync(t->buf.p_desc, desc.data(), desc.size(), hipMemcpyHostToDevice, q);
+  if (e == hipSuccess) e = hipMemcpyAsync(t->buf.p_meta, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, q);
+  if (e == hipSuccess) e = hipMemcpyAsync(t->buf.p_lm, lm, (size_t)n * 24, hipMemcpyHostToDevice, q);
+  if (e == hipSuccess) e = hipMemcpyAsync(t->buf.lost, lost.data(), (size_t)n * 4, hipMemcpyHostToDevice, q);
+  rc = e == hipSuccess ? upload_images(t, imgL, imgR, row_stride, 0) : fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
+  if (rc == VSLAM_OK) {
+    const int rows = t->cfg.c.rows;
+    if (t->cfg.c.descriptor_type == VSLAM_DESCRIPTOR_ORB) {
+      Gauss7 gk; for (int i = 0; i < 4; ++i) gk.k[i] = t->cfg.gauss7[i];
+      hipLaunchKernelGGL(k_gauss7, dim3(t->cfg.TX, (rows + VS_TILE_H - 1) / VS_TILE_H, 2), dim3(256), 0, q, t->cfg, t->buf, gk);
+    } else {
+      hipLaunchKernelGGL(k_fast_box, dim3(t->cfg.TX, (rows + VS_TILE_H - 1) / VS_TILE_H, 2), dim3(256), 0, q, t->cfg, t->buf);
+    }
+    RecoverAlone a;
+    std::memcpy(a.w2c, w2c, sizeof a.w2c); a.tau_track = tau_track; a.tau_tri = tau_tri; a.n = n;
+    hipLaunchKernelGGL(k_recover_alone, dim3(1), dim3(VS_WG), 0, q, t->cfg, t->buf, a);
+    e = hipGetLastError();
+    StreamState st;
+    if (e == hipSuccess) e = hipMemcpyAsync(&st, t->buf.st, sizeof st, hipMemcpyDeviceToHost, q);
+    if (e == hipSuccess) e = hipStreamSynchronize(q);
+    if (e == hipSuccess && st.n_cur > 0) {
+      const int k = st.n_cur;
+      std::vector<int16_t> kp((size_t)k * 4);
+      std::vector<int32_t> m((size_t)k * META);
+      e = hipMemcpy(kp.data(), t->buf.p_kp + P * 4, (size_t)k * 8, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(m.data(), t->buf.p_meta + P * META, (size_t)k * META * 4, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(rec_desc, t->buf.p_desc + P * 64, (size_t)k * 64, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(rec_xyz, t->buf.p_cam + P * 3, (size_t)k * 24, hipMemcpyDeviceToHost);
+      for (int i = 0; i < k && e == hipSuccess; ++i) {
+        rec_index[i] = m[(size_t)i * META + M_PREV]; rec_dist[i] = m[(size_t)i * META + M_DIST];
+        for (int j = 0; j < 4; ++j) rec_xy4[4 * i + j] = kp[4 * (size_t)i + j];
+      }
+      if (e == hipSuccess) *n_rec = k;
+    }
+    if (e != hipSuccess) rc = fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
+  } else if (c->err.empty()) c->err = t->err;
+  scratch_put(c, t);
+  return rc;
+}
+
 // ---- stage entry points (the reference's plug-in virtuals; control flow stays with the caller) ----------
 static int launch_begin(vslam_ctx* c) {
   for (auto& g : c->groups) hipLaunchKernelGGL(k_begin, dim3(g.n), dim3(256), 0, g.st_frm, c->cfg, buf_set(c, c->last_set, g.s0));
