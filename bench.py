@@ -132,6 +132,8 @@ class Bench(object):
                 dist.init_process_group(self.backend)
         self.sy = synth.Synth()
         self.scene = self.sy.scene_kitti(seed=7)
+        if args.speed > 0:
+            self.scene.speed_m = args.speed
         self.api = hip.load()
         self.cfg = synth.config_for_scene(self.api, self.scene, "kitti")
         self.cfg.bin_size_pixels = args.bin
@@ -288,7 +290,7 @@ class Bench(object):
                        "parallelism": "frame-sharded chunks, %d per GPU x %d GPU" % (B, world),
                        "mean_keypoints_per_image": round(stats["N"], 1), "mean_points_per_frame": round(stats["P"], 1),
                        "mean_tracked": round(stats["M"], 1), "mean_aligner_iterations": round(stats["I"], 1),
-                       "error_flags": flags},
+                       "scene_speed_m_per_frame": round(float(self.scene.speed_m), 3), "error_flags": flags},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(abytes[dom]), "avg_launch_ms": round(dom_avg_s * 1e3, 4)},
@@ -318,6 +320,8 @@ class Bench(object):
         scenes = []
         for slot, i in enumerate(mine):
             sc = self.sy.scene_kitti(seed=7 + 13 * seq_ids[i])       # one world per sequence
+            if self.args.speed > 0:
+                sc.speed_m = self.args.speed
             sc.speed_m = 0.7 + 0.05 * (seq_ids[i] % 5)
             scenes.append(sc)
             n = min(KB, my_len[slot])
@@ -510,6 +514,7 @@ def main():
     ap.add_argument("--sequences", default="", help="--mode sequences: comma-separated KITTI sequence numbers")
     ap.add_argument("--bin", type=int, default=15, help="bin_size_pixels (15: ~2158 kp/image, 22: ~1026, 11: ~3955)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("VSLAM_BENCH_STREAMS", "144")))
+    ap.add_argument("--speed", type=float, default=0.0, help="camera speed of the synthetic scene in m/frame (0 = the scene's default 0.9; slower = more of the points tracked)")
     ap.add_argument("--overlap", type=int, default=10, help="warm-up frames per chunk (SURVEY.md 8e default)")
     ap.add_argument("--cpu-frames", type=int, default=240)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU leg (0 = min(nproc, 16): the box's CPU share)")

@@ -336,9 +336,14 @@ static int create_internal(const vslam_config* cfg, int device, int n_streams, v
       for (int k = 0; k < 2; ++k) { q.ev_img[k] = nullptr; q.ev_frm[k] = nullptr; q.ev_emit[k] = nullptr; }
       q.s0 = (int)((long long)n_streams * g / G);
       q.n = (int)((long long)n_streams * (g + 1) / G) - q.s0;
-      bool ok = hipStreamCreateWithFlags(&q.st_frm, hipStreamNonBlocking) == hipSuccess &&
-                hipStreamCreateWithFlags(&q.st_img, hipStreamNonBlocking) == hipSuccess &&
-                hipStreamCreateWithFlags(&q.st_img2, hipStreamNonBlocking) == hipSuccess;
+      // VSLAM_PRIO (measurement aid): 1 = frame stream at the highest queue priority, image stream at the lowest; 2 = the reverse
+      int p_lo = 0, p_hi = 0, prio = 0;
+      if (const char* e = getenv("VSLAM_PRIO")) prio = atoi(e);
+      (void)hipDeviceGetStreamPriorityRange(&p_lo, &p_hi);
+      const int pf = prio == 1 ? p_hi : (prio == 2 ? p_lo : 0), pi = prio == 1 ? p_lo : (prio == 2 ? p_hi : 0);
+      bool ok = hipStreamCreateWithPriority(&q.st_frm, hipStreamNonBlocking, pf) == hipSuccess &&
+                hipStreamCreateWithPriority(&q.st_img, hipStreamNonBlocking, pi) == hipSuccess &&
+                hipStreamCreateWithPriority(&q.st_img2, hipStreamNonBlocking, pi) == hipSuccess;
       // a second image stream (BRIEF(t) overlapping FAST(t+1)) measured slower on MI355X: opt-in only
       if (ok && !(getenv("VSLAM_IMG_STREAMS") && atoi(getenv("VSLAM_IMG_STREAMS")) == 2)) { (void)hipStreamDestroy(q.st_img2); q.st_img2 = q.st_img; }
       // VSLAM_IMG_STREAMS=0: everything on one HIP stream (no overlap) — measurement aid for stand-alone kernel times
