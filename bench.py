@@ -320,9 +320,7 @@ class Bench(object):
         scenes = []
         for slot, i in enumerate(mine):
             sc = self.sy.scene_kitti(seed=7 + 13 * seq_ids[i])       # one world per sequence
-            if self.args.speed > 0:
-                sc.speed_m = self.args.speed
-            sc.speed_m = 0.7 + 0.05 * (seq_ids[i] % 5)
+            sc.speed_m = self.args.speed if self.args.speed > 0 else 0.7 + 0.05 * (seq_ids[i] % 5)
             scenes.append(sc)
             n = min(KB, my_len[slot])
             for f0 in range(0, n, 512):

@@ -39,6 +39,26 @@ def test_config5_full_resolution_bin11():
     run_sequence(Oracle, dict(scale=1.0), 6, cfg_edit=edit, after=after)
 
 
+def test_capacity_fallback_paths_19k_keypoints():
+    """FAST threshold floor 1 and a 4 px bin grid: ~18.8 k keypoints per image, ~5.7 k stereo points, ~3.5 k lost points per
+    frame.  The per-stream tables no longer fit the frame workgroup's LDS arena, so the HBM forms of the track tables
+    (kernels_frame.h: in_lds false), of the stereo sweep's staged rows / distance cache / bin table (kernels_frame2.h: staged,
+    sd_lds, bl false) and the recovery work-list overflow (n_list > VS_RLIST_CAP) run — every frame compared with the oracle."""
+    from _oracle import Oracle
+
+    def edit(cfg):
+        cfg.bin_size_pixels = 4
+        cfg.detector_threshold_minimum = 1
+        cfg.detector_threshold_maximum_change = 0.9
+        cfg.max_keypoints, cfg.max_points = 32768, 16384
+
+    def after(o, g):
+        fi = g.frame_info(0)
+        assert fi.status == 1 and fi.n_keypoints_left > 15000 and fi.n_points > 5000 and fi.n_lost > 1900 and fi.error_flags == 0, \
+            (fi.status, fi.n_keypoints_left, fi.n_points, fi.n_lost, fi.error_flags)
+    run_sequence(Oracle, dict(scale=1.0), 5, cfg_edit=edit, after=after)
+
+
 def test_config4_euroc_shaped_sequence_and_l2_knn2():
     """vslam_default_config_euroc (configuration_euroc.yaml:47-116: 2x2 detectors, thresholds 10..30 with 100 % change, bin 20,
     track length 2, damping 0, descriptor "ORB-256" = cv::ORB::create() as extractor on the FAST keypoints) on the EuRoC-shaped scene (752x480, f 458, baseline 0.11 m, 6-DoF motion <= 5 cm / 1 degree per
