@@ -55,11 +55,22 @@ def test_assembly_is_exact_for_exact_chunks():
     for (start, first, end) in plan:
         W = random_se3(rng)                        # every chunk lives in its own world frame
         chunks.append(np.array([ev.mul34(W, G[f]) for f in range(start, end)]))
-    A = sharding.assemble_trajectory(chunks, plan)
-    rel = ev.mul34(G[0], ev.inv34(A[0]))           # assembled trajectory is in chunk 0's frame
+    for seam in (1, 3, 9):                         # seam transform from 1, 3 or all (4) warm-up frames: exact data, same answer
+        A = sharding.assemble_trajectory(chunks, plan, seam_frames=seam)
+        rel = ev.mul34(G[0], ev.inv34(A[0]))       # assembled trajectory is in chunk 0's frame
+        for f in range(total):
+            np.testing.assert_allclose(ev.mul34(rel, A[f]), G[f], atol=1e-9)
+        assert ev.ate_rmse(A, G) < 1e-9
+    # noisy warm-up estimates: the seam from several frames is a proper rigid transform and averages the noise
+    noisy = [c.copy() for c in chunks]
+    for c in noisy[1:]:
+        c[:4, :, 3] += rng.normal(scale=0.05, size=(4, 3))
+    e1 = ev.ate_rmse(sharding.assemble_trajectory(noisy, plan, seam_frames=1), G)
+    e4 = ev.ate_rmse(sharding.assemble_trajectory(noisy, plan, seam_frames=4), G)
+    A4 = sharding.assemble_trajectory(noisy, plan, seam_frames=4)
     for f in range(total):
-        np.testing.assert_allclose(ev.mul34(rel, A[f]), G[f], atol=1e-9)
-    assert ev.ate_rmse(A, G) < 1e-9
+        np.testing.assert_allclose(A4[f][:, :3] @ A4[f][:, :3].T, np.eye(3), atol=1e-9)
+    assert e4 < e1
 
 
 def _free_port():

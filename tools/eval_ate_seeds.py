@@ -50,11 +50,14 @@ for seed in seeds:
     chunks = [api.poses(s_, 0, en - st) for s_, (st, fi, en) in enumerate(plan)]
     api.destroy(); del Lb, Rb
     a_chk = ev.ate_rmse(sharding.assemble_trajectory(chunks, plan), gt)
-    rows_out.append({"seed": seed, "ate_sequential": a_seq, "ate_chunked": a_chk, "ratio": a_chk / a_seq, "error_flags": int(flags | flags_c)})
+    seam = {str(k): ev.ate_rmse(sharding.assemble_trajectory(chunks, plan, seam_frames=k), gt) / a_seq for k in (2, 3, 5) if k <= ov}
+    rows_out.append({"seed": seed, "ate_sequential": a_seq, "ate_chunked": a_chk, "ratio": a_chk / a_seq, "ratio_by_seam_frames": seam,
+                     "error_flags": int(flags | flags_c)})
     print(json.dumps(rows_out[-1]), flush=True)
 r = np.array([x["ratio"] for x in rows_out]); lr = np.log(r)
 print(json.dumps({"streams": B, "overlap": ov, "frames": total, "seeds": seeds, "ratio_mean": float(r.mean()), "ratio_geomean": float(np.exp(lr.mean())),
                   "ratio_min": float(r.min()), "ratio_max": float(r.max()), "log_ratio_std": float(lr.std(ddof=1)) if len(r) > 1 else None,
                   "log_ratio_stderr": float(lr.std(ddof=1) / np.sqrt(len(r))) if len(r) > 1 else None,
                   "ate_sequential_mean": float(np.mean([x["ate_sequential"] for x in rows_out])),
-                  "ate_chunked_mean": float(np.mean([x["ate_chunked"] for x in rows_out]))}))
+                  "ate_chunked_mean": float(np.mean([x["ate_chunked"] for x in rows_out])),
+                  "ratio_geomean_by_seam_frames": {k: float(np.exp(np.mean([np.log(x["ratio_by_seam_frames"][k]) for x in rows_out]))) for k in rows_out[0]["ratio_by_seam_frames"]}}))

@@ -38,9 +38,27 @@ def plan_sequences(lengths, world):
     return ranks, load
 
 
-def assemble_trajectory(chunk_poses, plan):
+def _seam_anchor(G, P, start, first, seam_frames):
+    """Rigid transform chunk-world -> global from the last `seam_frames` warm-up frames, which both the preceding range (G) and
+    this chunk (P) estimate: chordal mean of the rotations G_f P_f^-1, then the translation that fits the camera centres."""
+    k = max(1, min(seam_frames, first - start))
+    fs = range(first - k, first)
+    if k == 1:
+        return mul34(G[first - 1], inv34(P[first - 1 - start]))
+    M = np.zeros((3, 3))
+    for f in fs:
+        M += G[f][:, :3] @ P[f - start][:, :3].T
+    U, _, Vt = np.linalg.svd(M)
+    D = np.diag([1.0, 1.0, np.sign(np.linalg.det(U @ Vt))])
+    Rm = U @ D @ Vt
+    t = np.mean([G[f][:, 3] - Rm @ P[f - start][:, 3] for f in fs], axis=0)
+    return np.hstack([Rm, t.reshape(3, 1)])
+
+
+def assemble_trajectory(chunk_poses, plan, seam_frames=1):
     """chunk_poses[c]: array [n_processed_c, 3, 4] (camera-to-chunk-world), plan from plan_chunks.
-    Returns [total, 3, 4] in the first chunk's world frame."""
+    Returns [total, 3, 4] in the first chunk's world frame.  seam_frames: how many of the chunk's last warm-up frames the
+    seam transform is estimated from (1 = the frame before the chunk's own range alone)."""
     total = plan[-1][2]
     G = np.zeros((total, 3, 4))
     anchor = np.hstack([np.eye(3), np.zeros((3, 1))])
@@ -49,8 +67,7 @@ def assemble_trajectory(chunk_poses, plan):
         if end <= first:
             continue
         if c > 0 and first > start:
-            f0 = first - 1
-            anchor = mul34(G[f0], inv34(P[f0 - start]))
+            anchor = _seam_anchor(G, P, start, first, seam_frames)
         elif c > 0:
             anchor = mul34(G[first - 1], inv34(P[0])) if first > 0 else anchor
         for f in range(first, end):
