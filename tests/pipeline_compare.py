@@ -47,6 +47,24 @@ def compare_frame(o, g, s, k, tag=""):
     np.testing.assert_array_equal(o.aligner_weights_of(s), g.aligner_weights_of(s))   # persistent _weights_translation
 
 
+def create_hip(cfg, n_streams, split=None):
+    """HIP context; split: value of VSLAM_SPLIT while the context is created (None = the library's own choice)."""
+    import os
+    old = os.environ.get("VSLAM_SPLIT")
+    if split is not None:
+        os.environ["VSLAM_SPLIT"] = str(split)
+    try:
+        g = hip.load()
+        g.create(cfg, 0, n_streams)
+    finally:
+        if split is not None:
+            if old is None:
+                del os.environ["VSLAM_SPLIT"]
+            else:
+                os.environ["VSLAM_SPLIT"] = old
+    return g
+
+
 def run_sequence(oracle_cls, scene_kw, n_frames, n_streams=1, which="kitti", cfg_edit=None, seeds=None, scene="kitti", after=None):
     """scene: "kitti" (street canyon, planar motion) or "euroc" (752x480 hall, 6-DoF motion); which: the default
     configuration the run starts from; after(o, g): called with both contexts still alive after the last frame."""
@@ -63,21 +81,25 @@ def run_sequence(oracle_cls, scene_kw, n_frames, n_streams=1, which="kitti", cfg
     if cfg_edit:
         cfg_edit(cfg)
     o.create(cfg, 0, n_streams)
-    g = hip.load()
-    g.create(cfg, 0, n_streams)
+    # both launch sequences of the frame: the library's choice for this stream count (two launches around the wide recovery
+    # kernel up to 4 streams, one fused launch above) and the other one forced through VSLAM_SPLIT
+    g = create_hip(cfg, n_streams)
+    g2 = create_hip(cfg, n_streams, split=0 if n_streams <= 4 else 2)
     try:
         for k in range(n_frames):
             imgs = [o.render(sc, k) for sc in scenes]
             L = np.stack([im[0] for im in imgs])
             R = np.stack([im[1] for im in imgs])
             o.process_host(L, R)
-            g.process_host(L, R)
-            for s in range(n_streams):
-                compare_frame(o, g, s, k)
+            for h in (g, g2):
+                h.process_host(L, R)
+                for s in range(n_streams):
+                    compare_frame(o, h, s, k)
         if after:
             after(o, g)
     finally:
         g.destroy()
+        g2.destroy()
         o.destroy()
 
 

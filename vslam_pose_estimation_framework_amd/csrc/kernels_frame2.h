@@ -907,6 +907,9 @@ __device__ __forceinline__ void set_pose(const DevCfg& c, const DevBuf& b, int s
 //   [k_update_landmarks] landmark creation / refinement, one thread per framepoint; [k_stereo_dist] L-R distances
 //   phase 2  status switch, stereo sweep + binning + emission, report
 // phase < 0 runs everything in one launch (the wide steps inside the workgroup).
+// phase 3 = phases 1 and 2 in one launch with the landmark refinement inside the workgroup: with phase 0 and the wide recovery
+// kernel in front this is the two-launch sequence used for few streams (the ~140 recovery patches of a frame spread over the
+// idle CUs: 67 -> 9 us; the wide landmark kernel, one thread per track, is slower than the workgroup's LDS-cached one).
 // The configuration and the buffer table arrive as pointers into the CONSTANT address space (device-resident copies the
 // context uploads once): passed by value, the ~60 pointers of DevBuf are all loaded in the prologue, cannot stay in the
 // 100-odd SGPRs and are parked in VGPR lanes — 1900 v_readlane instructions kernel-wide, ~190 in every aligner round.
@@ -1093,7 +1096,7 @@ __global__ VS_FRAME_BOUNDS void k_frame(ConstDevCfg* cp, ConstDevBuf* bp, int ph
   if (phase == 0) return;
   }  // phase 0
 
-  if (phase == 1 || phase < 0) {   // ========================== phase 1 ==========================
+  if (phase == 1 || phase < 0 || phase == 3) {   // ========================== phase 1 ==========================
     if (tid == 0) { sh.n_cur = fc.n_cur; sh.n_lost = fc.n_lost; sh.flag = 0; }
     __syncthreads();
     if (has_prev && c.c.enable_landmark_recovery) {
@@ -1114,7 +1117,7 @@ __global__ VS_FRAME_BOUNDS void k_frame(ConstDevCfg* cp, ConstDevBuf* bp, int ph
   // ============================================== phase 2 ==============================================
   if (tid == 0) { sh.n_cur = fc.n_cur; sh.n_cand = 0; }
   __syncthreads();
-  if (phase < 0) {
+  if (phase < 0 || phase == 3) {
     const unsigned long long tu = wall_clock64();
     const PtView cvu = pts_of(c, b, s, pb_cur);
     int active = 0;

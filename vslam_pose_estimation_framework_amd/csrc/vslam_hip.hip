@@ -18,6 +18,9 @@
 
 static thread_local std::string g_create_error;
 
+#ifndef VS_SPLIT2_MAX_STREAMS
+#define VS_SPLIT2_MAX_STREAMS 4   // up to this many streams the frame runs as two launches around the wide recovery kernel
+#endif
 struct vslam_ctx {
   DevCfg cfg;
   DevBuf buf;
@@ -60,7 +63,8 @@ struct vslam_ctx {
   // five times per frame
   struct Scratch { vslam_ctx* t; vslam_config cfg; bool busy; size_t base_allocs; };
   std::vector<Scratch> scratch;
-  int split = 0;   // 1: frame processed by phase launches with wide kernels in between (measured slower); 0: one launch
+  int split = 0;   // 0: one frame launch; 1: three phase launches with wide recovery / landmark kernels in between (measured slower);
+                   // 2: two phase launches around the wide recovery kernel (faster for few streams: VS_SPLIT2_MAX_STREAMS)
   int sticky = VSLAM_OK;
 };
 
@@ -360,7 +364,8 @@ static int create_internal(const vslam_config* cfg, int device, int n_streams, v
     c->stream = c->groups[0].st_frm;
     c->stream_img = c->groups[0].st_img;
     c->own_stream = true;
-    if (const char* e = getenv("VSLAM_SPLIT")) c->split = atoi(e) != 0;
+    c->split = n_streams <= VS_SPLIT2_MAX_STREAMS ? 2 : 0;
+    if (const char* e = getenv("VSLAM_SPLIT")) c->split = std::max(0, std::min(2, atoi(e)));
   }
   const DevCfg& d = c->cfg;
   DevBuf& b = c->buf;
@@ -616,9 +621,13 @@ static int launch_frame(vslam_ctx* c) {
     ConstDevBuf* kb = (ConstDevBuf*)(c->d_bufs + c->last_set * c->groups.size() + gi++);
     const int gx = cand_blocks(c, g.n);
     { KernelTimer t(c, 3, g.st_frm); hipLaunchKernelGGL(k_track_candidates, dim3(gx, g.n), dim3(256), 0, g.st_frm, c->cfg, bs, -1); }
-    if (!c->split) {
+    if (!c->split || (c->split == 2 && !c->cfg.c.enable_landmark_recovery)) {
       KernelTimer t(c, 4, g.st_frm);
       hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, kc, kb, -1);
+    } else if (c->split == 2) {
+      { KernelTimer t(c, 4, g.st_frm, false); hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, kc, kb, 0); }
+      { KernelTimer t(c, 5, g.st_frm); hipLaunchKernelGGL(k_recover_brief, dim3(std::max(4, std::min(64, 1024 / std::max(g.n, 1))), g.n), dim3(256), 0, g.st_frm, c->cfg, bs); }
+      { KernelTimer t(c, 4, g.st_frm); hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, kc, kb, 3); }
     } else {
       { KernelTimer t(c, 4, g.st_frm, false); hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, kc, kb, 0); }
       if (c->cfg.c.enable_landmark_recovery) { KernelTimer t(c, 5, g.st_frm); hipLaunchKernelGGL(k_recover_brief, dim3(std::max(4, std::min(64, 1024 / std::max(g.n, 1))), g.n), dim3(256), 0, g.st_frm, c->cfg, bs); }
