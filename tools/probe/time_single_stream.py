@@ -32,5 +32,6 @@ for timers in (False, True):
     out = {"streams": B, "split": os.environ.get("VSLAM_SPLIT", "0"), "timers": timers, "ms_per_frame": round(dt / (N - 40) * 1e3, 4)}
     if timers:
         out["kernels_ms"] = {k: round(ms / max(n, 1), 4) for k, (ms, n) in api.kernel_times().items() if n > 0}
+        out["chronometers_us_per_frame"] = {k: round(v / N * 1e6, 1) for k, v in api.timers().items()}
     print(json.dumps(out), flush=True)
 api.destroy()
