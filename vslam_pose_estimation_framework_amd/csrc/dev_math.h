@@ -88,6 +88,95 @@ VS_HD void full_piv_solve(const double* A_in, const double* b_in, double* x) {
   }
   for (int i = 0; i < N; ++i) x[perm[i]] = y[i];
 }
+#ifdef __HIPCC__
+// The same elimination with every index static: rows, columns and the permutation are exchanged through selects, so the
+// matrix lives in registers (the generic form above indexes its arrays with the pivot position, which puts them into
+// scratch memory on the device: a memory round trip per access).  Same operands, same operations, same order: same bits.
+template <int N>
+__device__ __forceinline__ void full_piv_solve_regs(const double* A_in, const double* b_in, double* x) {
+  double A[N][N], b[N], y[N];
+  int perm[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) A[i][j] = A_in[i * N + j];
+    b[i] = b_in[i]; perm[i] = i; y[i] = 0;
+  }
+  int rank = N;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    if (k < rank) {
+      int pr = k, pc = k;
+      double best = 0;
+#pragma unroll
+      for (int j = k; j < N; ++j)
+#pragma unroll
+        for (int i = k; i < N; ++i) {
+          const double a = fabs(A[i][j]);
+          if (a > best) { best = a; pr = i; pc = j; }
+        }
+      if (best == 0) {
+        rank = k;
+      } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {   // rows k <-> pr
+          const double t = A[k][j];
+          double src = t;
+#pragma unroll
+          for (int r = k + 1; r < N; ++r) { if (pr == r) { src = A[r][j]; A[r][j] = t; } }
+          A[k][j] = src;
+        }
+        {
+          const double t = b[k];
+          double src = t;
+#pragma unroll
+          for (int r = k + 1; r < N; ++r) { if (pr == r) { src = b[r]; b[r] = t; } }
+          b[k] = src;
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) {   // columns k <-> pc
+          const double t = A[i][k];
+          double src = t;
+#pragma unroll
+          for (int cc = k + 1; cc < N; ++cc) { if (pc == cc) { src = A[i][cc]; A[i][cc] = t; } }
+          A[i][k] = src;
+        }
+        {
+          const int t = perm[k];
+          int src = t;
+#pragma unroll
+          for (int cc = k + 1; cc < N; ++cc) { if (pc == cc) { src = perm[cc]; perm[cc] = t; } }
+          perm[k] = src;
+        }
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) {
+          const double f = A[i][k] / A[k][k];
+          A[i][k] = 0;
+#pragma unroll
+          for (int j = k + 1; j < N; ++j) A[i][j] -= f * A[k][j];
+          b[i] -= f * b[k];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    if (i < rank) {
+      double sv = b[i];
+#pragma unroll
+      for (int j = i + 1; j < N; ++j) if (j < rank) sv -= A[i][j] * y[j];
+      y[i] = sv / A[i][i];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    double v = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) if (perm[i] == q) v = y[i];
+    x[q] = v;
+  }
+}
+#endif
 // |cv::Rodrigues(R)| : rotation angle (WorldMap::toOrientationRodrigues(...).norm())
 VS_HD double rotation_angle(const double* T) {
   const double rx = T[9] - T[6], ry = T[2] - T[8], rz = T[4] - T[1];

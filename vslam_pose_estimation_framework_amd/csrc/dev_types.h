@@ -30,6 +30,7 @@
 #else
 #define VS_FRAME_BOUNDS __launch_bounds__(VS_WG)
 #endif
+#define VS_TRAIL 32           // predecessors a framepoint knows by index (64 B per point): the landmark refinement reads its measurements without chasing the per-frame `prev` links
 #ifndef VS_ARENA
 #define VS_ARENA (128 * 1024) // bytes of LDS scratch the frame kernel stages hot index arrays in (one frame workgroup per CU)
 #endif
@@ -46,6 +47,7 @@ struct DevCfg {
   int32_t n_offsets;
   int32_t offsets[2 * VSLAM_MAX_EPI + 1];
   int32_t NMAX, MAXP, HCAP;
+  int32_t trail;           // 1: framepoints carry the indices of their track's last VS_TRAIL predecessors (MAXP <= 65535)
   int32_t n_streams;
   // ORB extractor: the rotation of the pattern by the FAST keypoints' angle (-1 degree), evaluated on the host exactly as
   // OpenCV does — angle *= (float)(CV_PI/180.f); (float)cos(angle), (float)sin(angle) — and the fixed-point Gaussian taps
@@ -137,6 +139,7 @@ struct DevBuf {
   double* p_cam;       // [..][3]
   double* p_camlm;     // [..][3]
   double* p_lm;        // [..][3]
+  uint16_t* p_trail;   // [..][VS_TRAIL] index of the track's point in frame f-1, f-2, ... (0xFFFF: the track starts before); see wg_publish_history
   int32_t* n_points;   // [B][2]
   // track candidates / resolution  [B][MAXP]
   int32_t* proj;       // [..][8] row, col, candidate count (-1 = projection outside the image), |epipolar offset|,

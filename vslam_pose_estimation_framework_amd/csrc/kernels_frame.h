@@ -38,13 +38,14 @@
 #define M_NEXT 5
 
 struct PtView {  // frame points of stream s, buffer pb
-  int16_t* kp; uint8_t* desc; int32_t* meta; double* cam; double* camlm; double* lm; int32_t* n;
+  int16_t* kp; uint8_t* desc; int32_t* meta; double* cam; double* camlm; double* lm; int32_t* n; uint16_t* trail;
 };
 __device__ __forceinline__ PtView pts_of(const DevCfg& c, const DevBuf& b, int s, int pb) {
   const size_t o = ((size_t)s * 2 + pb) * c.MAXP;
   PtView v;
   v.kp = b.p_kp + o * 4; v.desc = b.p_desc + o * 64; v.meta = b.p_meta + o * META;
   v.cam = b.p_cam + o * 3; v.camlm = b.p_camlm + o * 3; v.lm = b.p_lm + o * 3; v.n = b.n_points + s * 2 + pb;
+  v.trail = b.p_trail + (c.trail ? o * VS_TRAIL : (size_t)0);
   return v;
 }
 __device__ __forceinline__ double* hpose_of(const DevCfg& c, const DevBuf& b, int s, int f) {

@@ -368,7 +368,8 @@ __global__ __launch_bounds__(256) void k_recover_brief(const DevCfg c, const Dev
 // Gauss-Newton rounds would repeat it); longer tracks continue in HBM from where the cache ends.  Same order of accumulation,
 // same bits.
 #define VS_LM_CN 6
-struct LmCache { double pose[VS_LM_CN][24]; double cam[VS_WG][VS_LM_CN][3]; };
+#define VS_LM_NP 48   // world_to_camera of the last VS_LM_NP frames staged in LDS (one copy for all points of the frame)
+struct LmCache { double w2c[VS_LM_NP][12]; double cam[VS_WG][VS_LM_CN][3]; };
 template <bool LDS>
 __device__ __forceinline__ bool landmark_point_t(const DevCfg& c, const DevBuf& b, int s, const PtView& cv, int f, int i, LmCache* lc) {
   const double* w2c_cur = hpose_of(c, b, s, f) + 12;
@@ -417,19 +418,54 @@ __device__ __forceinline__ bool landmark_point_t(const DevCfg& c, const DevBuf& 
           }
         }
       };
-      // chain walk, once: the first VS_LM_CN measurements into the thread's LDS slots
-      int ncache = 0, ffc = f, iic = i;
+      // Measurement k of the track (frame f - k): index i for k = 0, the trail's entry k - 1 up to k = VS_TRAIL, then the
+      // `prev` links of the history ring.  n_direct = measurements addressed without a link walk; a 0xFFFF entry (the track
+      // starts there) ends the list like a negative `prev` link does.
+      const uint16_t* tr = cv.trail + (size_t)i * VS_TRAIL;
+      int n_direct = 1;
       bool ended = false;
+      if (c.trail) {
+        const int want = min(len, VS_TRAIL + 1);
+        for (int q0 = 0; q0 < VS_TRAIL && n_direct < want && !ended; q0 += 8) {
+          const uint4 v = *reinterpret_cast<const uint4*>(tr + q0);
+          const uint32_t wv4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const uint32_t ent = (wv4[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+            if (!ended && n_direct < want) { if (ent == 0xFFFFu) ended = true; else ++n_direct; }
+          }
+        }
+      }
+      auto index_at = [&](int k) -> int { return k == 0 ? i : (int)tr[k - 1]; };   // k < n_direct
+      // the first VS_LM_CN measurements into the thread's LDS slots, once
+      int ncache = 0, ffc = f, iic = i;
       if constexpr (LDS) {
         double (*slot)[3] = lc->cam[threadIdx.x];
-        for (int k = 0; k < len && k < VS_LM_CN; ++k) {
-          const double* mc = hcam_of(c, b, s, ffc) + 3 * (size_t)iic;
-          slot[k][0] = mc[0]; slot[k][1] = mc[1]; slot[k][2] = mc[2];
-          ++ncache;
-          iic = hprev_of(c, b, s, ffc)[iic];
-          --ffc;
-          if (iic < 0) { ended = true; break; }
+        if (c.trail) {
+          const int nc = min(min(len, VS_LM_CN), n_direct);
+          double mv[VS_LM_CN][3];
+#pragma unroll
+          for (int k = 0; k < VS_LM_CN; ++k)
+            if (k < nc) { const double* mc = hcam_of(c, b, s, f - k) + 3 * (size_t)index_at(k); mv[k][0] = mc[0]; mv[k][1] = mc[1]; mv[k][2] = mc[2]; }
+#pragma unroll
+          for (int k = 0; k < VS_LM_CN; ++k)
+            if (k < nc) { slot[k][0] = mv[k][0]; slot[k][1] = mv[k][1]; slot[k][2] = mv[k][2]; }
+          ncache = nc;
+        } else {
+          for (int k = 0; k < len && k < VS_LM_CN; ++k) {
+            const double* mc = hcam_of(c, b, s, ffc) + 3 * (size_t)iic;
+            slot[k][0] = mc[0]; slot[k][1] = mc[1]; slot[k][2] = mc[2];
+            ++ncache;
+            iic = hprev_of(c, b, s, ffc)[iic];
+            --ffc;
+            if (iic < 0) { ended = true; break; }
+          }
         }
+      }
+      if (c.trail) {
+        // where the link walk continues after the directly addressed measurements (only tracks longer than VS_TRAIL + 1)
+        if (!ended && n_direct < len) { ffc = f - (n_direct - 1); iic = hprev_of(c, b, s, ffc)[index_at(n_direct - 1)]; --ffc; if (iic < 0) ended = true; }
+        else ended = true;
       }
       for (int it = 0; it < c.c.landmark_maximum_number_of_iterations; ++it) {
         double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bv[3] = {0, 0, 0};
@@ -437,11 +473,35 @@ __device__ __forceinline__ bool landmark_point_t(const DevCfg& c, const DevBuf& 
         int n_out = 0;
         if constexpr (LDS) {
           const double (*slot)[3] = lc->cam[threadIdx.x];
-          for (int k = 0; k < ncache; ++k) accumulate(lc->pose[k] + 12, slot[k], H, bv, err, n_out);   // frame f - k
+          for (int k = 0; k < ncache; ++k) accumulate(lc->w2c[k], slot[k], H, bv, err, n_out);   // frame f - k
+        }
+        if (c.trail) {
+          // directly addressed measurements, four at a time: their (independent) loads are in flight together
+          for (int k0 = ncache; k0 < n_direct; k0 += 4) {
+            double mc[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int k = min(k0 + u, n_direct - 1);
+              const double* src = hcam_of(c, b, s, f - k) + 3 * (size_t)index_at(k);
+              mc[u][0] = src[0]; mc[u][1] = src[1]; mc[u][2] = src[2];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int k = k0 + u;
+              if (k < n_direct) {
+                if constexpr (LDS) {
+                  if (k < VS_LM_NP) accumulate(lc->w2c[k], mc[u], H, bv, err, n_out);
+                  else accumulate(hpose_of(c, b, s, f - k) + 12, mc[u], H, bv, err, n_out);
+                } else {
+                  accumulate(hpose_of(c, b, s, f - k) + 12, mc[u], H, bv, err, n_out);
+                }
+              }
+            }
+          }
         }
         if (!ended) {
           int ff = ffc, ii = iic;
-          for (int k = ncache; k < len; ++k) {
+          for (int k = c.trail ? n_direct : ncache; k < len; ++k) {
             accumulate(hpose_of(c, b, s, ff) + 12, hcam_of(c, b, s, ff) + 3 * (size_t)ii, H, bv, err, n_out);
             ii = hprev_of(c, b, s, ff)[ii];
             --ff;
@@ -449,7 +509,7 @@ __device__ __forceinline__ bool landmark_point_t(const DevCfg& c, const DevBuf& 
           }
         }
         double nb[3] = {-bv[0], -bv[1], -bv[2]}, dx[3];
-        full_piv_solve<3>(H, nb, dx);
+        full_piv_solve_regs<3>(H, nb, dx);
         for (int q = 0; q < 3; ++q) wv[q] += dx[q];
         if (fabs(err - err_prev) < 1e-5 || it == 999) {
           const int n_in = len - n_out;
@@ -484,13 +544,36 @@ __device__ __forceinline__ bool landmark_point(const DevCfg& c, const DevBuf& b,
   return landmark_point_t<false>(c, b, s, cv, f, i, nullptr);
 }
 
+// Besides the history ring (camera coordinates and `prev` link of every point of frame f), every point gets its trail: the
+// indices of its track's points in frames f-1 .. f-VS_TRAIL (its predecessor, then the predecessor's own trail shifted by one;
+// 0xFFFF where the track starts before that).  The landmark refinement then addresses its measurements directly instead of
+// walking the links, a chain of dependent HBM loads per measurement.
 __device__ __forceinline__ void wg_publish_history(const DevCfg& c, const DevBuf& b, int s, int n, int pb_cur, int f) {
   const PtView cv = pts_of(c, b, s, pb_cur);
+  const PtView pv = pts_of(c, b, s, pb_cur ^ 1);
   double* hc = hcam_of(c, b, s, f);
   int32_t* hp = hprev_of(c, b, s, f);
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     for (int k = 0; k < 3; ++k) hc[3 * (size_t)i + k] = cv.cam[3 * (size_t)i + k];
-    hp[i] = cv.meta[(size_t)i * META + M_PREV];
+    const int ip = cv.meta[(size_t)i * META + M_PREV];
+    hp[i] = ip;
+    if (c.trail) {
+      uint4* dst = reinterpret_cast<uint4*>(cv.trail + (size_t)i * VS_TRAIL);
+      if (ip < 0) {
+        dst[0] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);   // only entry 0 is ever reached: len = 1
+      } else {
+        const uint4* src = reinterpret_cast<const uint4*>(pv.trail + (size_t)ip * VS_TRAIL);
+        uint32_t w[VS_TRAIL / 2];
+#pragma unroll
+        for (int q = 0; q < VS_TRAIL / 8; ++q) { const uint4 v = src[q]; w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
+        uint32_t o[VS_TRAIL / 2];
+        o[0] = (uint32_t)ip | (w[0] << 16);
+#pragma unroll
+        for (int q = 1; q < VS_TRAIL / 2; ++q) o[q] = (w[q - 1] >> 16) | (w[q] << 16);
+#pragma unroll
+        for (int q = 0; q < VS_TRAIL / 8; ++q) dst[q] = make_uint4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+      }
+    }
   }
 }
 
@@ -867,6 +950,7 @@ __device__ __forceinline__ void wg_stereo(const DevCfg& c, const DevBuf& b, int 
   for (int j = n_tracked + tid; j < n_final; j += VS_WG) {
     for (int k = 0; k < 3; ++k) hc[3 * (size_t)j + k] = cv.cam[3 * (size_t)j + k];
     hp[j] = -1;
+    if (c.trail) *reinterpret_cast<uint4*>(cv.trail + (size_t)j * VS_TRAIL) = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);   // a track starts here
   }
   if (tid == 0) { sh.n_cand = added; sh.n_cur = n_final; }
   __syncthreads();
@@ -1123,7 +1207,7 @@ __global__ VS_FRAME_BOUNDS void k_frame(ConstDevCfg* cp, ConstDevBuf* bp, int ph
     int active = 0;
     static_assert(sizeof(LmCache) <= VS_ARENA, "landmark measurement cache must fit the LDS arena");
     LmCache* lc = reinterpret_cast<LmCache*>(arena);
-    for (int t = tid; t < VS_LM_CN * 24; t += VS_WG) { const int k = t / 24; if (f - k >= 0) lc->pose[k][t - 24 * k] = hpose_of(c, b, s, f - k)[t - 24 * k]; }
+    for (int t = tid; t < VS_LM_NP * 12; t += VS_WG) { const int k = t / 12; if (f - k >= 0 && k < c.HCAP) lc->w2c[k][t - 12 * k] = hpose_of(c, b, s, f - k)[12 + t - 12 * k]; }
     __syncthreads();
     for (int i = tid; i < sh.n_cur; i += VS_WG) active += landmark_point_t<true>(c, b, s, cvu, f, i, lc) ? 1 : 0;
     int total;

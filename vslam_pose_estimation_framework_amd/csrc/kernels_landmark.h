@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void k_landmark_update(int n, const int32_t* o
       }
     }
     double nb[3] = {-bv[0], -bv[1], -bv[2]}, dx[3];
-    full_piv_solve<3>(H, nb, dx);                                                   // :131
+    full_piv_solve_regs<3>(H, nb, dx);                                                   // :131
     for (int q = 0; q < 3; ++q) wv[q] += dx[q];
     if (fabs(err - err_prev) < 1e-5 || it == 999) {                                 // :134
       const int n_in = (e - a) - n_out;

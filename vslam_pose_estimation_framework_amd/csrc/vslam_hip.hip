@@ -220,6 +220,7 @@ static void derive_cfg(const vslam_config& in, int n_streams, DevCfg* d) {
   d->NMAX = in.max_keypoints;
   d->MAXP = in.max_points;
   d->HCAP = in.max_history_frames;
+  d->trail = in.max_points <= 65535 ? 1 : 0;
   d->n_streams = n_streams;
 }
 
@@ -379,7 +380,7 @@ static int create_internal(const vslam_config* cfg, int device, int n_streams, v
   A(rowcell, S2 * rows * (d.CW + 1)); A(used, S2 * N); A(kill, S2 * N);
   A(st, B); A(info, B); A(pose_log, B * VS_POSE_LOG * 12);
   A(p_kp, S2 * P * 4); A(p_desc, S2 * P * 64); A(p_meta, S2 * P * META); A(p_cam, S2 * P * 3); A(p_camlm, S2 * P * 3);
-  A(p_lm, S2 * P * 3); A(n_points, S2);
+  A(p_lm, S2 * P * 3); A(n_points, S2); A(p_trail, d.trail ? S2 * P * VS_TRAIL : (size_t)64);
   A(proj, B * P * 8); A(proj_q, B * P * 2); A(cand_key, B * P * VS_MAXCAND); A(cand_rkey, B * P * VS_MAXRCAND);
   A(res, B * P * 8); A(trk, B * P * 4); A(lost, B * P);
   A(al_moving, B * P * 3); A(al_fixed, B * P * 4); A(al_omega, B * P); A(al_weight, B * P); A(al_chi, B * P); A(al_inl, B * P);
