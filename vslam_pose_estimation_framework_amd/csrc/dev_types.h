@@ -19,7 +19,9 @@
 #include "../../include/vslam_hip.h"
 
 #define VS_TILE_W 64
-#define VS_TILE_H 32
+#ifndef VS_TILE_H
+#define VS_TILE_H 48          // rows of a k_fast_box tile (multiple of 8); 16 .. 64 measured: 48 is the fastest
+#endif
 #define VS_CELL 16
 #define VS_MAXCAND 16        // candidate list length per previous point (overflow -> exact rescan)
 #ifndef VS_WG

@@ -546,8 +546,12 @@ __device__ __forceinline__ void brief_wave(const uint16_t* box, int bstride, int
 // Tiled form: one workgroup owns the keypoints of a 128 x 32 pixel tile (found through the row/cell CSR), stages
 // the (128+48) x (32+48) u16 box region once in LDS with coalesced loads and evaluates the 256 tests from LDS,
 // one wavefront per keypoint.  Replaces 512 scattered 2-byte global gathers per keypoint.
+#ifndef VS_BT_W
 #define VS_BT_W 128
-#define VS_BT_H 64
+#endif
+#ifndef VS_BT_H
+#define VS_BT_H 64      // <= 64: the per-row keypoint counts of a tile are scanned by one wavefront
+#endif
 #define VS_BT_RW (VS_BT_W + 2 * VSLAM_BRIEF_PATCH_HALF)   // 176
 #define VS_BT_RH (VS_BT_H + 2 * VSLAM_BRIEF_PATCH_HALF)   // 80
 __global__ __launch_bounds__(256) void k_brief(const DevCfg c, const DevBuf b) {
