@@ -200,8 +200,8 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
   //  A) every pixel: the high-speed test (a 9-arc of 16 contains two ADJACENT compass points, i.e. one of {N,S} and one
   //     of {E,W}, on the dark or on the bright side) -> ~1 pixel in 8 survives, queued in LDS (one atomic per wave-row)
   //  B) queued pixels only, two per lane in packed i16: exact corner test + cornerScore
-  auto pretest = [&](int r, int cc) {
-    const int thr = uni_thr != -2 ? uni_thr : region_threshold(c, s_thr, x0 - 1 + cc, y0 - 1 + r);
+  auto pretest = [&](int r, int cc, bool valid = true) {
+    const int thr = !valid ? -1 : (uni_thr != -2 ? uni_thr : region_threshold(c, s_thr, x0 - 1 + cc, y0 - 1 + r));
     bool cand = false;
     if (thr >= 0) {
       const int ly = r + 3, lx = cc + 3;
@@ -230,12 +230,16 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
     // two other wavefronts test the halo columns 0 and 65.  The four candidate predicates are the sign bits of the packed
     // differences, balloted as they are (v_cmp_lt_i16 / _i32): one queue reservation per wave-pass.
     const s16x2 thr2 = {(short)uni_thr, (short)uni_thr};
+    // Tile heights that are a multiple of 16: the H tile rows (region rows 1 .. H) are whole passes of every wavefront, and the
+    // NMS halo ring (region rows 0 and H + 1, region columns 0 and 65) goes through the one-pixel test, spread over all lanes.
+    constexpr bool RING = (VS_TILE_H % 16) == 0;
+    constexpr int RBASE = RING ? 1 : 0, RCOUNT = RING ? VS_TILE_H : VS_TILE_H + 2;
 #pragma unroll 1
-    for (int pass = 0; pass < (VS_TILE_H + 2 + 15) / 16; ++pass) {
-      if (pass * 16 + w * 4 >= VS_TILE_H + 2) continue;          // wave-uniform: nothing of this wavefront in the pass
-      const int r = pass * 16 + (tid >> 4), q = (tid & 15) + 1;
+    for (int pass = 0; pass < (RCOUNT + 15) / 16; ++pass) {
+      if (pass * 16 + w * 4 >= RCOUNT) continue;          // wave-uniform: nothing of this wavefront in the pass
+      const int r = RBASE + pass * 16 + (tid >> 4), q = (tid & 15) + 1;
       uint32_t ng0 = 0, ng1 = 0;
-      if (r < VS_TILE_H + 2) {
+      if (r < RBASE + RCOUNT) {
         const uint32_t* rowp = reinterpret_cast<const uint32_t*>(&tile[r + 3][0]);
         const uint32_t C = rowp[q], C0 = rowp[q - 1], C2 = rowp[q + 1];
         const uint32_t N = reinterpret_cast<const uint32_t*>(&tile[r][0])[q], S = reinterpret_cast<const uint32_t*>(&tile[r + 6][0])[q];
@@ -270,8 +274,20 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
         queue[p3 ? base + n0 + n1 + n2 + below(m3) : trash] = (uint16_t)(ent + 3);
       }
     }
-    // region columns 0 and 65 (the NMS halo left and right of the tile): (H+2)*2 pixels on the wavefronts the last pass leaves idle
-    if (tid >= 64 && tid < 64 + (VS_TILE_H + 2) * 2) { const int i = tid - 64; pretest(i >> 1, (i & 1) ? 65 : 0); }
+    if (RING) {
+      constexpr int NRING = 2 * 66 + 2 * VS_TILE_H;
+      for (int i0 = 0; i0 < NRING; i0 += 256) {
+        const int i = i0 + tid;
+        int r = 0, cc = 0;
+        if (i < 66) { r = 0; cc = i; }
+        else if (i < 132) { r = VS_TILE_H + 1; cc = i - 66; }
+        else { const int k = i - 132; r = 1 + (k >> 1); cc = (k & 1) ? 65 : 0; }
+        pretest(r, cc, i < NRING);
+      }
+    } else {
+      // region columns 0 and 65 (the NMS halo left and right of the tile): (H+2)*2 pixels on the wavefronts the last pass leaves idle
+      if (tid >= 64 && tid < 64 + (VS_TILE_H + 2) * 2) { const int i = tid - 64; pretest(i >> 1, (i & 1) ? 65 : 0); }
+    }
   } else {
     for (int r = w; r < VS_TILE_H + 2; r += 4) pretest(r, lane);
     // the two halo columns 64, 65 of every row: (H+2)*2 pixels, waves 0-1
