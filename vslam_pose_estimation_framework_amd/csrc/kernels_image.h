@@ -226,8 +226,7 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
   if (uni_thr != -2) {
     // uniform threshold (the usual tile): four pixels per lane from aligned dwords, the compass differences in packed
     // i16 (v_perm_b32 unpacks, v_pk_sub/min/max_i16).  16 lanes per region row (dwords 1..16 = region columns 1..64), four rows
-    // per wavefront and pass: no division in the index arithmetic, the third pass (rows 32, 33) is one half wavefront while
-    // two other wavefronts test the halo columns 0 and 65.  The four candidate predicates are the sign bits of the packed
+    // per wavefront and pass: no division in the index arithmetic.  The four candidate predicates are the sign bits of the packed
     // differences, balloted as they are (v_cmp_lt_i16 / _i32): one queue reservation per wave-pass.
     const s16x2 thr2 = {(short)uni_thr, (short)uni_thr};
     // Tile heights that are a multiple of 16: the H tile rows (region rows 1 .. H) are whole passes of every wavefront, and the
