@@ -367,7 +367,9 @@ __global__ __launch_bounds__(256) void k_recover_brief(const DevCfg c, const Dev
 // VS_LM_CN measurements of the point's track once per point (the chain walk is a chase of dependent HBM loads, and the
 // Gauss-Newton rounds would repeat it); longer tracks continue in HBM from where the cache ends.  Same order of accumulation,
 // same bits.
+#ifndef VS_LM_CN
 #define VS_LM_CN 6
+#endif
 #define VS_LM_NP 48   // world_to_camera of the last VS_LM_NP frames staged in LDS (one copy for all points of the frame)
 struct LmCache { double w2c[VS_LM_NP][12]; double cam[VS_WG][VS_LM_CN][3]; };
 template <bool LDS>
