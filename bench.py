@@ -35,6 +35,7 @@ from vslam_pose_estimation_framework_amd import hip, sharding, synth  # noqa: E4
 
 KITTI_FRAMES = [4541, 1101, 4661, 801, 271, 2761, 1101, 1101, 4071, 1591, 1201]   # odometry sequences 00..10
 SEQ_FRAMES = KITTI_FRAMES[0]
+EUROC_MH01_FRAMES = 3682   # MH_01_easy stereo pairs
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PMC_SUMMARY = "r02_pmc_traffic.json"   # tools/pmc_traffic.sh of this build (rocprofv3 --pmc, separate passes)
 METRIC = "stereo frames/sec on KITTI-00 at 1/2/4/8 MI355X; ATE vs reference"
@@ -131,12 +132,15 @@ class Bench(object):
             else:
                 dist.init_process_group(self.backend)
         self.sy = synth.Synth()
-        self.scene = self.sy.scene_kitti(seed=7)
+        self.euroc = args.scene == "euroc"
+        self.scene = self.sy.scene_euroc(seed=7) if self.euroc else self.sy.scene_kitti(seed=7)
         if args.speed > 0:
             self.scene.speed_m = args.speed
         self.api = hip.load()
-        self.cfg = synth.config_for_scene(self.api, self.scene, "kitti")
-        self.cfg.bin_size_pixels = args.bin
+        self.cfg = synth.config_for_scene(self.api, self.scene, "euroc" if self.euroc else "kitti")
+        if not self.euroc or args.bin != 15:
+            self.cfg.bin_size_pixels = args.bin      # euroc: configuration_euroc.yaml's bin 20 unless --bin is given
+        self.seq_frames = EUROC_MH01_FRAMES if self.euroc else SEQ_FRAMES
         self.cfg.max_keypoints = 8192 if args.bin >= 15 else 16384
         self.cfg.max_points = 4096 if args.bin >= 15 else 8192
         self.stride = ((self.cfg.cols + 63) // 64) * 64
@@ -169,7 +173,7 @@ class Bench(object):
     def run_chunks(self):
         a, api, cfg = self.args, self.api, self.cfg
         B, overlap, world, rank = a.streams, a.overlap, self.world, self.rank
-        L = -(-SEQ_FRAMES // B)                      # unique frames per chunk
+        L = -(-self.seq_frames // B)                 # unique frames per chunk
         J = L + overlap                              # steps of one chunk job
         K = a.steps if a.steps > 0 else J
         W = max(0, a.warmup)
@@ -209,7 +213,7 @@ class Bench(object):
             for k in range(k0, k0 + n):
                 for s in range(B):
                     f = starts[s] + (k + phase[s]) % J
-                    if first_unique[s] <= f < min(first_unique[s] + L, SEQ_FRAMES * world):
+                    if first_unique[s] <= f < min(first_unique[s] + L, self.seq_frames * world):
                         cnt += 1
             return cnt
 
@@ -280,10 +284,13 @@ class Bench(object):
             "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "frames_processed": frames, "unique_frames_timed": int(unique), "raw_pairs_per_s": round(frames / elapsed, 1),
-            "config": {"workload": "KITTI-00-shaped synthetic stereo (1241x376, 4541 frames), configuration_kitti.yaml "
-                                   "values, bin %d (target %d kp/image), FAST+BRIEF-32, open loop; chunks as a steady-state "
-                                   "pipeline (streams staggered over the %d-step chunk job, restart when a chunk ends)"
-                                   % (a.bin, (cfg.cols // a.bin + 1) * (cfg.rows // a.bin + 1), J),
+            "config": {"workload": ("EuRoC-MH_01-shaped synthetic stereo (752x480, 3682 frames, 6-DoF), configuration_euroc.yaml "
+                                    "values (2x2 FAST detectors, bin %d: target %d kp/image, ORB extractor on the FAST keypoints), open loop; "
+                                    if self.euroc else
+                                    "KITTI-00-shaped synthetic stereo (1241x376, 4541 frames), configuration_kitti.yaml "
+                                    "values, bin %d (target %d kp/image), FAST+BRIEF-32, open loop; ")
+                                   % (cfg.bin_size_pixels, (cfg.cols // cfg.bin_size_pixels + 1) * (cfg.rows // cfg.bin_size_pixels + 1))
+                                   + "chunks as a steady-state pipeline (streams staggered over the %d-step chunk job, restart when a chunk ends)" % J,
                        "mode": "chunks", "streams_per_gpu": B, "chunk_frames": L, "chunk_overlap": overlap, "chunk_job_steps": J,
                        "preroll_steps": preroll, "frames_per_step": B * world,
                        "unique_frame_fraction": round(unique / frames, 4),
@@ -417,7 +424,7 @@ class Bench(object):
         dt = time.perf_counter() - t0
         api.destroy()
         pairs = n * B / dt
-        L = -(-SEQ_FRAMES // B)
+        L = -(-self.seq_frames // B)
         return {"pairs_per_s": round(pairs, 1), "unique_frames_per_s": round(pairs * L / J, 1), "steps": n,
                 "host_to_device_GBs": round(pairs * 2 * self.img_bytes / 1e9, 2),
                 "note": "pinned host images, one hipMemcpyAsync per side and step; PCIe-bound, never `value`"}
@@ -512,6 +519,7 @@ def main():
     ap.add_argument("--sequences", default="", help="--mode sequences: comma-separated KITTI sequence numbers")
     ap.add_argument("--bin", type=int, default=15, help="bin_size_pixels (15: ~2158 kp/image, 22: ~1026, 11: ~3955)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("VSLAM_BENCH_STREAMS", "144")))
+    ap.add_argument("--scene", choices=["kitti", "euroc"], default="kitti", help="euroc: MH_01-shaped 752x480 scene with configuration_euroc.yaml values (not the headline workload)")
     ap.add_argument("--speed", type=float, default=0.0, help="camera speed of the synthetic scene in m/frame (0 = the scene's default 0.9; slower = more of the points tracked)")
     ap.add_argument("--overlap", type=int, default=10, help="warm-up frames per chunk (SURVEY.md 8e default)")
     ap.add_argument("--cpu-frames", type=int, default=240)

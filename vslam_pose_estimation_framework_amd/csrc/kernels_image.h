@@ -191,17 +191,30 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
   }
   // one detector region covers the whole 66 x (H+2) score region of most tiles: its threshold is then tile-uniform
   __syncthreads();
-  int uni_thr = -2;
+  // Exactly one detector region's FAST-valid area (ROI minus 3 px) reaches into the score region: its threshold holds for every
+  // valid pixel of the tile, and validity is a rectangle [vx0, vx1) x [vy0, vy1) in region coordinates — the whole region for
+  // interior tiles (uni_full), clipped for tiles on the image border or on a ROI edge.  Two or more regions: per-pixel lookup.
+  int uni_thr = -2, vx0 = 0, vx1 = 0, vy0 = 0, vy1 = 0;
+  bool uni_full = false;
   {
-    const int ta = region_threshold(c, s_thr, x0 - 1, y0 - 1), tb = region_threshold(c, s_thr, x0 + 64, y0 + VS_TILE_H);
-    if (c.n_regions == 1 && ta >= 0 && tb >= 0) uni_thr = ta;
+    int hits = 0;
+    for (int r = 0; r < c.n_regions; ++r) {
+      const DevRegion& R = c.regions[r];
+      const int ax0 = max(R.x + 3, x0 - 1), ax1 = min(R.x + R.w - 3, x0 + 65), ay0 = max(R.y + 3, y0 - 1), ay1 = min(R.y + R.h - 3, y0 + VS_TILE_H + 1);
+      if (ax0 < ax1 && ay0 < ay1) {
+        if (hits == 0) { uni_thr = s_thr[r]; vx0 = ax0 - (x0 - 1); vx1 = ax1 - (x0 - 1); vy0 = ay0 - (y0 - 1); vy1 = ay1 - (y0 - 1); }
+        ++hits;
+      }
+    }
+    if (hits != 1) uni_thr = -2;
+    uni_full = uni_thr != -2 && vx0 == 0 && vx1 == 66 && vy0 == 0 && vy1 == VS_TILE_H + 2;
   }
   // ---- FAST on the 66 x (H+2) score region (tile + 1 px NMS halo), two passes:
   //  A) every pixel: the high-speed test (a 9-arc of 16 contains two ADJACENT compass points, i.e. one of {N,S} and one
   //     of {E,W}, on the dark or on the bright side) -> ~1 pixel in 8 survives, queued in LDS (one atomic per wave-row)
   //  B) queued pixels only, two per lane in packed i16: exact corner test + cornerScore
   auto pretest = [&](int r, int cc, bool valid = true) {
-    const int thr = !valid ? -1 : (uni_thr != -2 ? uni_thr : region_threshold(c, s_thr, x0 - 1 + cc, y0 - 1 + r));
+    const int thr = !valid ? -1 : (uni_full ? uni_thr : region_threshold(c, s_thr, x0 - 1 + cc, y0 - 1 + r));
     bool cand = false;
     if (thr >= 0) {
       const int ly = r + 3, lx = cc + 3;
@@ -257,7 +270,13 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
           if (half) ng1 = neg; else ng0 = neg;
         }
       }
-      const bool p0 = (short)(ng0 & 0xffffu) < 0, p1 = (int)ng0 < 0, p2 = (short)(ng1 & 0xffffu) < 0, p3 = (int)ng1 < 0;
+      bool p0 = (short)(ng0 & 0xffffu) < 0, p1 = (int)ng0 < 0, p2 = (short)(ng1 & 0xffffu) < 0, p3 = (int)ng1 < 0;
+      if (!uni_full) {   // clipped validity rectangle (wave-uniform branch): region columns 4q-3 .. 4q of region row r
+        const bool rok = r >= vy0 && r < vy1;
+        const int c0 = 4 * q - 3;
+        p0 = p0 && rok && c0 >= vx0 && c0 < vx1;         p1 = p1 && rok && c0 + 1 >= vx0 && c0 + 1 < vx1;
+        p2 = p2 && rok && c0 + 2 >= vx0 && c0 + 2 < vx1; p3 = p3 && rok && c0 + 3 >= vx0 && c0 + 3 < vx1;
+      }
       const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1), m2 = __ballot(p2), m3 = __ballot(p3);
       const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
       if (n0 + n1 + n2 + n3) {
