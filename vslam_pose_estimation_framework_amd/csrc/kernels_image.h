@@ -334,8 +334,10 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
       const int e0 = queue[2 * q], e1 = (2 * q + 1 < nq) ? queue[2 * q + 1] : e0;
       const int r0 = e0 >> 8, c0 = e0 & 255, r1 = e1 >> 8, c1 = e1 & 255;
       int sv0, sv1;
-      fast_pair_scores(tile, r0 + 3, c0 + 3, r1 + 3, c1 + 3, region_threshold(c, s_thr, x0 - 1 + c0, y0 - 1 + r0),
-                       region_threshold(c, s_thr, x0 - 1 + c1, y0 - 1 + r1), &sv0, &sv1);
+      // queued pixels are valid pixels: with one region in reach their threshold is that region's
+      const int t0 = uni_thr != -2 ? uni_thr : region_threshold(c, s_thr, x0 - 1 + c0, y0 - 1 + r0);
+      const int t1 = uni_thr != -2 ? uni_thr : region_threshold(c, s_thr, x0 - 1 + c1, y0 - 1 + r1);
+      fast_pair_scores(tile, r0 + 3, c0 + 3, r1 + 3, c1 + 3, t0, t1, &sv0, &sv1);
       sc[r0][c0] = (uint8_t)sv0;
       if (2 * q + 1 < nq) sc[r1][c1] = (uint8_t)sv1;
     }
