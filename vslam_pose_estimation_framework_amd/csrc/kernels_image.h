@@ -709,27 +709,64 @@ struct Gauss7 { int32_t k[4]; };   // k[0] = centre tap ... k[3] = outermost (sy
 __device__ __forceinline__ int reflect101(int p, int n) { return p < 0 ? -p : (p >= n ? 2 * n - 2 - p : p); }
 __device__ __forceinline__ uint8_t* blur_of(const DevCfg& c, const DevBuf& b, int s, int d) { return reinterpret_cast<uint8_t*>(box_of(c, b, s, d)); }
 
-// one 64 x 32 tile per workgroup: (64+6) x (32+6) source pixels staged in LDS (reflected at the image border), row sums as
-// u16 (255 * 257 < 2^16), column sums in registers
+// one 64 x H tile per workgroup: the (64+8) x (H+6) source pixels (columns x0-4 .. x0+67, reflected at the image border) staged in
+// LDS — aligned dwords for tiles inside the image, bytes for border tiles —, row sums four per thread from three dwords
+// (v_alignbyte + two v_dot4_u32_u8 per pixel; u16: 255 * 257 < 2^16), column sums four per thread (v_mad_u32_u24), one dword
+// store per four pixels where the output row allows it.  Same integers as the serial form.
 __device__ __forceinline__ void gauss7_tile(const uint8_t* img, int stride, int rows, int cols, int x0, int y0, const Gauss7& g, uint8_t* out, int ostride,
                                             uint8_t (*src)[72], uint16_t (*hs)[VS_TILE_W]) {
   const int tid = threadIdx.x;
-  for (int i = tid; i < (VS_TILE_H + 6) * 70; i += 256) {
-    const int r = i / 70, q = i - 70 * r;
-    src[r][q] = img[(size_t)reflect101(min(y0 - 3 + r, rows + 2), rows) * stride + reflect101(min(x0 - 3 + q, cols + 2), cols)];
+  const bool in_dwords = ((stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(img) & 3) == 0) && x0 >= 4 && x0 + 68 <= cols;
+  if (in_dwords) {
+    for (int i = tid; i < (VS_TILE_H + 6) * 18; i += 256) {
+      const int r = i / 18, q = i - 18 * r;
+      const int gy = reflect101(min(y0 - 3 + r, rows + 2), rows);
+      *reinterpret_cast<uint32_t*>(&src[r][4 * q]) = *reinterpret_cast<const uint32_t*>(img + (size_t)gy * stride + (x0 - 4 + 4 * q));
+    }
+  } else {
+    for (int i = tid; i < (VS_TILE_H + 6) * 70; i += 256) {
+      const int r = i / 70, q = i - 70 * r;
+      src[r][q + 1] = img[(size_t)reflect101(min(y0 - 3 + r, rows + 2), rows) * stride + reflect101(min(x0 - 3 + q, cols + 2), cols)];
+    }
   }
   __syncthreads();
-  for (int i = tid; i < (VS_TILE_H + 6) * VS_TILE_W; i += 256) {
-    const int r = i >> 6, x = i & 63;
-    const uint8_t* p = &src[r][x];
-    hs[r][x] = (uint16_t)(g.k[0] * p[3] + g.k[1] * (p[2] + p[4]) + g.k[2] * (p[1] + p[5]) + g.k[3] * (p[0] + p[6]));
+  // source column x0 - 3 + q lives at src[.][q + 1]: outputs 4t .. 4t+3 of a row need bytes 4t+1 .. 4t+10 = dwords t, t+1, t+2
+  const uint32_t klo = (uint32_t)g.k[3] | ((uint32_t)g.k[2] << 8) | ((uint32_t)g.k[1] << 16) | ((uint32_t)g.k[0] << 24);   // taps -3 .. 0
+  const uint32_t khi = (uint32_t)g.k[1] | ((uint32_t)g.k[2] << 8) | ((uint32_t)g.k[3] << 16);                              // taps +1 .. +3
+  for (int i = tid; i < (VS_TILE_H + 6) * 16; i += 256) {
+    const int r = i >> 4, t = i & 15;
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(&src[r][4 * t]);
+    const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t lo = j == 3 ? w1 : __builtin_amdgcn_alignbyte(w1, w0, 1 + j), hi = j == 3 ? w2 : __builtin_amdgcn_alignbyte(w2, w1, 1 + j);
+      o[j] = __builtin_amdgcn_udot4(lo, klo, __builtin_amdgcn_udot4(hi, khi, 0u, false), false);
+    }
+    *reinterpret_cast<uint2*>(&hs[r][4 * t]) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
   }
   __syncthreads();
-  for (int i = tid; i < VS_TILE_H * VS_TILE_W; i += 256) {
-    const int r = i >> 6, x = i & 63;
-    if (y0 + r >= rows || x0 + x >= cols) continue;
-    const int v = g.k[0] * hs[r + 3][x] + g.k[1] * (hs[r + 2][x] + hs[r + 4][x]) + g.k[2] * (hs[r + 1][x] + hs[r + 5][x]) + g.k[3] * (hs[r][x] + hs[r + 6][x]);
-    out[(size_t)(y0 + r) * ostride + x0 + x] = (uint8_t)min(max((v + (1 << 15)) >> 16, 0), 255);
+  const bool out_dwords = ((ostride & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 3) == 0);
+  for (int i = tid; i < VS_TILE_H * 16; i += 256) {
+    const int r = i >> 4, t = i & 15;
+    if (y0 + r >= rows || x0 + 4 * t >= cols) continue;
+    uint32_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int d = 0; d < 7; ++d) {
+      const uint2 v = *reinterpret_cast<const uint2*>(&hs[r + d][4 * t]);
+      const uint32_t kk = (uint32_t)g.k[d < 3 ? 3 - d : d - 3];
+      acc[0] += kk * (v.x & 0xFFFFu); acc[1] += kk * (v.x >> 16); acc[2] += kk * (v.y & 0xFFFFu); acc[3] += kk * (v.y >> 16);
+    }
+    uint32_t px[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) px[j] = min((acc[j] + (1u << 15)) >> 16, 255u);
+    uint8_t* dst = out + (size_t)(y0 + r) * ostride + x0 + 4 * t;
+    if (out_dwords && x0 + 4 * t + 4 <= (ostride > cols ? ostride : cols)) {
+      *reinterpret_cast<uint32_t*>(dst) = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (x0 + 4 * t + j < cols) dst[j] = (uint8_t)px[j];
+    }
   }
 }
 __global__ __launch_bounds__(256) void k_gauss7(const DevCfg c, const DevBuf b, const Gauss7 g) {
