@@ -443,7 +443,8 @@ int vslam_point_in_camera(vslam_ctx* ctx, int32_t n, const float* xy_previous, c
  * separable filter, kernel round(256 k) = {18, 34, 49, 55, 49, 34, 18}, result (sum + 2^15) >> 16 — and every keypoint gets
  * 256 steered tests I(c + R p1) < I(c + R p2), R = rotation by KeyPoint::angle (degrees; float arithmetic, cvRound), bit k
  * of byte i = test 8i + k.  The 256 pairs are REPO-DEFINED (include/vslam_orb_pattern.h; OpenCV's bit_pattern_31_ is not
- * in the reference tree).  vslam_gaussian_blur7_u8: host image in, host image out (dense, cols bytes per row).
+ * in the reference tree).  vslam_gaussian_blur7_u8: host image in, host image out (dense, cols bytes per row); rows, cols >= 4
+ * (one reflection per border).
  * vslam_orb_describe: n integer keypoints xy with one angle for all (FAST: -1), keep[i] = 0 for removed keypoints. */
 int vslam_gaussian_blur7_u8(vslam_ctx* ctx, const uint8_t* image, int32_t rows, int32_t cols, int32_t row_stride, uint8_t* blurred);
 int vslam_orb_describe(vslam_ctx* ctx, const uint8_t* image_host, int32_t rows, int32_t cols, int32_t stride, int32_t n,

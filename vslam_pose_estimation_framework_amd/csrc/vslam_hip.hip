@@ -315,7 +315,7 @@ static void scratch_put(vslam_ctx* parent, vslam_ctx* t) {
 static int create_internal(const vslam_config* cfg, int device, int n_streams, vslam_ctx** out) {
   if (!cfg || !out || n_streams < 1) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: null argument or n_streams < 1");
   if (n_streams > VS_MAX_STREAMS) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: more than 4096 streams in one context");
-  if (cfg->rows < 16 || cfg->cols < 16 || cfg->cols > 32767 || cfg->rows > 32767) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: invalid image dimensions");
+  if (cfg->rows < 1 || cfg->cols < 1 || cfg->cols > 32767 || cfg->rows > 32767) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: invalid image dimensions");
   if (cfg->det_rows < 1 || cfg->det_cols < 1 || cfg->det_rows * cfg->det_cols > VSLAM_MAX_REGIONS) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: invalid detector grid");
   if (!(-cfg->baseline_h[0] / cfg->K[0] > 0)) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: invalid baseline (m), verify intrinsic camera parameters");
   if (cfg->maximum_epipolar_search_offset_pixels < 0 || cfg->maximum_epipolar_search_offset_pixels > VSLAM_MAX_EPI) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: epipolar offset out of range");
@@ -457,6 +457,9 @@ static void depth_map_free(vslam_ctx* c) {
   m = vslam_ctx::DepthMap();
 }
 VS_API int vslam_create(const vslam_config* cfg, int device, int n_streams, vslam_ctx** out) {
+  // a tracker needs room for a keypoint (descriptor border 28 / 31 px); the scratch contexts of the stand-alone entries accept
+  // any image, a tiny one simply has no valid pixel
+  if (cfg && (cfg->rows < 16 || cfg->cols < 16)) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: invalid image dimensions");
   return create_internal(cfg, device, n_streams, out);
 }
 VS_API void vslam_destroy(vslam_ctx* c) {
@@ -1461,7 +1464,7 @@ static int orb_blur_device(vslam_ctx* c, const uint8_t* img, int32_t rows, int32
 VS_API int vslam_gaussian_blur7_u8(vslam_ctx* c, const uint8_t* img, int32_t rows, int32_t cols, int32_t stride, uint8_t* out) {
   if (!c) return VSLAM_ERR_INVALID;
   if (c->sticky != VSLAM_OK) return c->sticky;
-  if (!img || !out || rows < 8 || cols < 8 || stride < cols) return fail(c, VSLAM_ERR_INVALID, "gaussian_blur7: bad argument");
+  if (!img || !out || rows < 4 || cols < 4 || stride < cols) return fail(c, VSLAM_ERR_INVALID, "gaussian_blur7: bad argument");   // one reflection per border
   HIP_TRY(c, hipSetDevice(c->device));
   uint8_t *dimg = nullptr, *dblur = nullptr;
   int rc = orb_blur_device(c, img, rows, cols, stride, &dimg, &dblur);
@@ -1477,8 +1480,13 @@ VS_API int vslam_orb_describe(vslam_ctx* c, const uint8_t* img, int32_t rows, in
                               float angle_degrees, uint8_t* keep, uint8_t* desc) {
   if (!c) return VSLAM_ERR_INVALID;
   if (c->sticky != VSLAM_OK) return c->sticky;
-  if (!img || n < 0 || rows < 2 * VSLAM_ORB_BORDER + 1 || cols < 2 * VSLAM_ORB_BORDER + 1 || stride < cols || (n && (!xy || !keep || !desc))) return fail(c, VSLAM_ERR_INVALID, "orb_describe: bad argument");
+  if (!img || n < 0 || rows < 4 || cols < 4 || stride < cols || (n && (!xy || !keep || !desc))) return fail(c, VSLAM_ERR_INVALID, "orb_describe: bad argument");
   if (n == 0) return VSLAM_OK;
+  if (rows < 2 * VSLAM_ORB_BORDER + 1 || cols < 2 * VSLAM_ORB_BORDER + 1) {   // no pixel is 31 px away from every border: all keypoints removed
+    std::memset(keep, 0, (size_t)n);
+    std::memset(desc, 0, (size_t)n * 32);
+    return VSLAM_OK;
+  }
   HIP_TRY(c, hipSetDevice(c->device));
   uint8_t *dimg = nullptr, *dblur = nullptr, *dkeep = nullptr, *ddesc = nullptr; int16_t* dxy = nullptr;
   int rc = orb_blur_device(c, img, rows, cols, stride, &dimg, &dblur);
