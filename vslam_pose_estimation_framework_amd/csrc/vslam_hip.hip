@@ -587,7 +587,7 @@ static int launch_image_pipeline(vslam_ctx* c) {
       KernelTimer t(c, 2, st);
       Gauss7 gk; for (int i = 0; i < 4; ++i) gk.k[i] = d.gauss7[i];
       hipLaunchKernelGGL(k_gauss7, g1, dim3(256), 0, st, c->cfg, bs, gk);
-      hipLaunchKernelGGL(k_orb_describe, dim3(std::max(4, std::min(64, 4096 / std::max(g.n, 1))), g.n, 2), dim3(256), 0, st, c->cfg, bs, d.orb_cos, d.orb_sin);
+      hipLaunchKernelGGL(k_orb_describe, dim3((d.c.cols + VS_BT_W - 1) / VS_BT_W, (d.c.rows + VS_BT_H - 1) / VS_BT_H, 2 * g.n), dim3(256), 0, st, c->cfg, bs, d.orb_cos, d.orb_sin);
     } else {
       dim3 g3((d.c.cols + VS_BT_W - 1) / VS_BT_W, (d.c.rows + VS_BT_H - 1) / VS_BT_H, 2 * g.n);
       KernelTimer t(c, 2, st); hipLaunchKernelGGL(k_brief, g3, dim3(256), 0, st, c->cfg, bs);
