@@ -869,6 +869,9 @@ __device__ __forceinline__ void wg_one_round(const DevCfg& c, const DevBuf& b, i
     double dx[6];
     VS_PHASE_STAMP(9, tp0);
     if (!ldlt_solve6(sh.H, sh.bvec, dx)) {
+#ifdef VS_PROFILE_PHASES
+      if (lane == 0) b.st[s].dbg[7] += 100;   // counts the full-pivot fallbacks (reads as 1 "us" each in vslam_debug_ticks)
+#endif
       int lane_o = lane;
       asm volatile("" : "+v"(lane_o));   // opaque: the fallback's lane-index arithmetic stays here instead of being hoisted out of the round loop
       wave_solve6(a, lane_o, dx, &sh.key);
