@@ -90,8 +90,8 @@ def gather_poses(local_poses, group=None):
 
 
 def exchange_unique_id(unique_id, rank, group=None):
-    """Rank 0's 128-byte communicator id to every rank over the launcher's own channel (torch.distributed here; MPI or a
-    file work as well).  unique_id: numpy uint8[128], filled on rank 0."""
+    """Rank 0's communicator id (any byte string, 128 id bytes + status here) to every rank over the launcher's own channel
+    (torch.distributed here; MPI or a file work as well).  unique_id: numpy uint8 array, filled on rank 0."""
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -115,12 +115,20 @@ class PoseComm(object):
         self.api, self.rank, self.world = api, rank, world
         lib = api.lib
         lib.vslam_comm_last_error.restype = C.c_char_p
-        uid = np.zeros(128, np.uint8)
+        # 128 id bytes + 4 status bytes in one broadcast: when rank 0 cannot make an id every rank learns it (and raises) instead
+        # of waiting in a collective that rank 0 never joins
+        msg = np.zeros(132, np.uint8)
+        err = ""
         if rank == 0:
-            rc = lib.vslam_comm_unique_id(uid.ctypes.data_as(C.c_void_p))
+            rc = lib.vslam_comm_unique_id(msg.ctypes.data_as(C.c_void_p))
             if rc != 0:
-                raise RuntimeError("vslam_comm_unique_id: %d %s" % (rc, lib.vslam_comm_last_error().decode()))
-        uid = np.ascontiguousarray(exchange_unique_id(uid, rank, group), np.uint8)
+                err = lib.vslam_comm_last_error().decode()
+                msg[128:132] = np.frombuffer(np.int32(rc).tobytes(), np.uint8)
+        msg = np.ascontiguousarray(exchange_unique_id(msg, rank, group), np.uint8)
+        rc0 = int(np.frombuffer(msg[128:132].tobytes(), np.int32)[0])
+        if rc0 != 0:
+            raise RuntimeError("vslam_comm_unique_id on rank 0: %d %s" % (rc0, err))
+        uid = np.ascontiguousarray(msg[:128])
         self.comm = C.c_void_p()
         rc = lib.vslam_comm_init(C.c_int(rank), C.c_int(world), uid.ctypes.data_as(C.c_void_p), C.c_int(device), C.byref(self.comm))
         if rc != 0:
