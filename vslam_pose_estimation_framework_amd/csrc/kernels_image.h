@@ -71,7 +71,7 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* sh, int* total) 
 
 // ==============================================================================================
 // K1: FAST-9/16 score + strict 3x3 NMS -> 1 bit/pixel corner mask (+ sparse u8 scores), fused with
-// the 9x9 box-sum image BRIEF samples.  One 64x32 output tile per 256-thread workgroup; the u8
+// the 9x9 box-sum image BRIEF samples.  One 64 x VS_TILE_H (48) output tile per 256-thread workgroup; the u8
 // tile with a 4 px halo (FAST ring 3 + NMS 1 == box radius 4) is staged once in LDS.
 // HBM traffic per pixel: 1 B read, 2 B box write, 1/8 B mask write, sparse scores.
 // ==============================================================================================
@@ -579,8 +579,8 @@ __device__ __forceinline__ void brief_wave(const uint16_t* box, int bstride, int
   }
 }
 
-// Tiled form: one workgroup owns the keypoints of a 128 x 32 pixel tile (found through the row/cell CSR), stages
-// the (128+48) x (32+48) u16 box region once in LDS with coalesced loads and evaluates the 256 tests from LDS,
+// Tiled form: one workgroup owns the keypoints of a 128 x 64 pixel tile (found through the row/cell CSR), stages
+// the (128+48) x (64+48) u16 box region once in LDS with coalesced loads and evaluates the 256 tests from LDS,
 // one wavefront per keypoint.  Replaces 512 scattered 2-byte global gathers per keypoint.
 #ifndef VS_BT_W
 #define VS_BT_W 128
