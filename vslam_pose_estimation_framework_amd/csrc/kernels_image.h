@@ -718,10 +718,21 @@ __device__ __forceinline__ void gauss7_tile(const uint8_t* img, int stride, int 
   const int tid = threadIdx.x;
   const bool in_dwords = ((stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(img) & 3) == 0) && x0 >= 4 && x0 + 68 <= cols;
   if (in_dwords) {
-    for (int i = tid; i < (VS_TILE_H + 6) * 18; i += 256) {
+    constexpr int NST = ((VS_TILE_H + 6) * 18 + 255) / 256;   // all of a thread's loads in flight before the first LDS store
+    uint32_t v[NST];
+#pragma unroll
+    for (int u = 0; u < NST; ++u) {
+      const int i = tid + 256 * u;
       const int r = i / 18, q = i - 18 * r;
       const int gy = reflect101(min(y0 - 3 + r, rows + 2), rows);
-      *reinterpret_cast<uint32_t*>(&src[r][4 * q]) = *reinterpret_cast<const uint32_t*>(img + (size_t)gy * stride + (x0 - 4 + 4 * q));
+      v[u] = 0;
+      if (i < (VS_TILE_H + 6) * 18) v[u] = *reinterpret_cast<const uint32_t*>(img + (size_t)gy * stride + (x0 - 4 + 4 * q));
+    }
+#pragma unroll
+    for (int u = 0; u < NST; ++u) {
+      const int i = tid + 256 * u;
+      const int r = i / 18, q = i - 18 * r;
+      if (i < (VS_TILE_H + 6) * 18) *reinterpret_cast<uint32_t*>(&src[r][4 * q]) = v[u];
     }
   } else {
     for (int i = tid; i < (VS_TILE_H + 6) * 70; i += 256) {
