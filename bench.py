@@ -446,6 +446,7 @@ class Bench(object):
         chk.create(cfg, self.dev_index, 1)
         orc.create(cfg, 0, 1)
         cpu_t, knn_t, nfr, mism, max_rel = 0.0, 0.0, 0, 0, 0.0
+        frame_ms = []      # per-frame process() time like SLAMAssembly::printReport (slam_assembly.cpp:644-668): mean / median / min / max
         samples = []
         for sidx in range(n_chunks):
             orc.reset(); chk.reset()
@@ -454,7 +455,8 @@ class Bench(object):
             for k in range(J):
                 t = time.perf_counter()
                 orc.process_host(Lh[k], Rh[k])
-                cpu_t += time.perf_counter() - t
+                frame_ms.append((time.perf_counter() - t) * 1e3)
+                cpu_t += frame_ms[-1] * 1e-3
                 t = time.perf_counter()
                 orc.fn("dead_knn_match")(orc.ctx, C.c_int(0), C.c_int(1))      # use_matches: knnMatch(k=2), BRUTEFORCE (L2 on floats)
                 knn_t += time.perf_counter() - t
@@ -507,6 +509,8 @@ class Bench(object):
                 "all_cores": {"value": round(ncpu * per / all_dt, 2), "unit": "frames/s", "cores": ncpu, "nproc_visible": nproc,
                               "sample": "%d threads x %d frames, one independent chunk per thread" % (ncpu, per)},
                 "module_ms_per_frame": modules,
+                "frame_ms": {"mean": round(float(np.mean(frame_ms)), 3), "median": round(float(np.median(frame_ms)), 3),
+                             "min": round(float(np.min(frame_ms)), 3), "max": round(float(np.max(frame_ms)), 3)},
                 "parity_on_sample": {"frames": nfr, "int_field_mismatches": mism, "max_pose_rel_frobenius": max_rel}}
 
 
