@@ -177,6 +177,10 @@ public:
     if (!frame_) throw std::runtime_error("HipStereoFramePointGenerator::initialize|called with empty frame");
     if (!_hip->ctx) throw std::runtime_error("HipStereoFramePointGenerator::initialize|no device context: configure the aligner first");
     if (!extract_features_) { hipCheck(_hip->ctx, vslam_frame_restore(_hip->ctx), "HipStereoFramePointGenerator::initialize"); return; }
+    if (!_timers_enabled) {   // device-side chronometers (HIP events + in-kernel clocks) behind getTimeConsumptionSeconds_*()
+      hipCheck(_hip->ctx, vslam_enable_timers(_hip->ctx, 1), "HipStereoFramePointGenerator::initialize");
+      _timers_enabled = true;
+    }
     const cv::Mat& L = frame_->intensityImageLeft();
     const cv::Mat& R = frame_->intensityImageRight();
     if (!L.data || !R.data) throw std::runtime_error("HipStereoFramePointGenerator::initialize|called with empty frame");
@@ -222,6 +226,7 @@ public:
     hipCheck(_hip->ctx, vslam_update_points(_hip->ctx), "HipStereoFramePointGenerator::compute");
     hipCheck(_hip->ctx, vslam_stereo_new(_hip->ctx), "HipStereoFramePointGenerator::compute");
     materializeNewPoints(frame_);  // Frame::createFramepoint(feature_left, feature_right, distance, xyz)
+    updateChronometers();
   }
 
   HipContext* hip() { return _hip; }
@@ -229,6 +234,17 @@ public:
   vslam_frame_info frameInfo() const { vslam_frame_info info; hipCheck(_hip->ctx, vslam_get_frame_info(_hip->ctx, 0, &info), "frameInfo"); return info; }
 
 private:
+  //! SLAMAssembly::printReport reads getTimeConsumptionSeconds_keypoint_detection / _descriptor_extraction (base generator,
+  //! base_framepoint_generator.h:232-233) and _point_triangulation (stereo_framepoint_generator.h:81) from the generator
+  //! (slam_assembly.cpp:709-719); CREATE_CHRONOMETER makes the members protected (definitions.h:144-146), so they are set here
+  //! from the device's own clocks: accumulated seconds since the context was created, like CHRONOMETER_STOP accumulates
+  void updateChronometers() {
+    double seconds[8];
+    hipCheck(_hip->ctx, vslam_get_timers(_hip->ctx, seconds), "HipStereoFramePointGenerator|timers");
+    _time_consumption_seconds_keypoint_detection = seconds[0];
+    _time_consumption_seconds_descriptor_extraction = seconds[1];
+    _time_consumption_seconds_point_triangulation = seconds[2];
+  }
   void pushState(const TransformMatrix3D& prior_) const {
     double prior[12];
     hipToArray(prior_, prior);
@@ -368,6 +384,7 @@ private:
 
   HipContext* _hip;
   mutable bool _pruned = false;
+  bool _timers_enabled = false;
   std::vector<IntensityFeature> _features_left, _features_right;            // keypoints + descriptors of the current frame
   std::unordered_map<uint32_t, uint32_t> _pixel_left, _pixel_right;        // (row << 16 | col) -> feature (one feature per pixel)
 };

@@ -184,6 +184,7 @@ int main(int argc, char** argv) {
     std::vector<int16_t> kp((size_t)hip.config.max_points * 4); std::vector<int32_t> meta((size_t)hip.config.max_points * 6);
     std::vector<double> cam((size_t)hip.config.max_points * 3); std::vector<uint8_t> desc((size_t)hip.config.max_points * 64);
     int max_tracked = 0, total_recovered = 0;
+    double chrono_previous[3] = {0, 0, 0};
     for (k = 0; k < n_frames; ++k) {
       double Rm[9], t[3];
       synth_pose(&scene, k, Rm, t);
@@ -219,6 +220,13 @@ int main(int argc, char** argv) {
         REQUIRE(std::memcmp(q->descriptorLeft().ptr<uint8_t>(0), &desc[(size_t)64 * i], 32) == 0 && std::memcmp(q->descriptorRight().ptr<uint8_t>(0), &desc[(size_t)64 * i + 32], 32) == 0, "descriptors of point %d", i);
       }
       max_tracked = std::max(max_tracked, ff.n_tracked); total_recovered += ff.n_recovered;
+      // the chronometers SLAMAssembly::printReport reads from the generator (slam_assembly.cpp:709-719) accumulate frame by frame
+      const double chrono[3] = {generator.getTimeConsumptionSeconds_keypoint_detection(), generator.getTimeConsumptionSeconds_descriptor_extraction(),
+                                generator.getTimeConsumptionSeconds_point_triangulation()};
+      for (int q = 0; q < 3; ++q) {
+        REQUIRE(chrono[q] > chrono_previous[q] && chrono[q] < 10.0, "chronometer %d does not grow: %.9f after %.9f", q, chrono[q], chrono_previous[q]);
+        chrono_previous[q] = chrono[q];
+      }
     }
     REQUIRE((int)h.status == VSLAM_TRACKING && max_tracked > 50, "the tracker must lock on: status %d, tracked %d", (int)h.status, max_tracked);
     REQUIRE(!recovery || total_recovered > 0, "recovery never produced a point");

@@ -90,6 +90,35 @@ def check_aligner(api, g, rtol_pose=1e-9):
     assert r["chi"][-1] == -1 and r["chi"][-2] == -1 and r["inlier"][-1] == 0
 
 
+def check_aligner_iteration_limits(make_api, make_oracle, g):
+    """aligner_maximum_number_of_iterations 0, 1, 2 through vslam_align_points against the oracle (stereouv_aligner.cpp:216: the
+    loop bound covers the FIRST round too — 0 runs none: pose = initial guess, every error -1, not converged; 1 and 2 stop
+    unconverged after that many saturated rounds)."""
+    for max_it in (0, 1, 2):
+        apis = []
+        for make in (make_oracle, make_api):
+            a = make()
+            cfg = a.default_config("kitti")
+            cfg.aligner_maximum_number_of_iterations = max_it
+            a.create(cfg, 0, 1)
+            apis.append(a)
+        for name in ALIGNER_CASES:
+            T0 = np.eye(4)[:3].copy()
+            T0[0, 3] = 0.05
+            ro, rg = [a.align_points(g[name + "_moving"], g[name + "_fixed"], g[name + "_omega"], g[name + "_weight"], T0) for a in apis]
+            assert ro["iterations"] == max_it and rg["iterations"] == max_it, (name, max_it, ro["iterations"], rg["iterations"])
+            np.testing.assert_array_equal(rg["inlier"], ro["inlier"], err_msg="%s max_it %d" % (name, max_it))
+            assert rg["n_inliers"] == ro["n_inliers"], (name, max_it)
+            np.testing.assert_allclose(rg["chi"], ro["chi"], rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(rg["T"], ro["T"], rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(rg["total_error"], ro["total_error"], rtol=1e-9, atol=1e-12)
+            if max_it == 0:
+                np.testing.assert_array_equal(rg["T"], T0)
+                assert np.all(rg["chi"] == -1) and not rg["inlier"].any() and rg["n_inliers"] == 0
+        for a in apis:
+            a.destroy()
+
+
 def check_aligner_weights(api, g, cfg):
     """_weights_translation across a Tracking -> break -> Localizing script (fewer and more points than before): the stale
     inverse-depth weights of stereouv_aligner.cpp:22,57-61, bit for bit against the Python-list restatement."""

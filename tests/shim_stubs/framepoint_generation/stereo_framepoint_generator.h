@@ -29,6 +29,8 @@ protected:
   Count _target_number_of_keypoints = 0, _number_of_detected_keypoints = 0;
   int32_t _projection_tracking_distance_pixels = 0; real _maximum_descriptor_distance_tracking = 0;
   Count _number_of_tracked_landmarks = 0;
+  CREATE_CHRONOMETER(keypoint_detection)       // base_framepoint_generator.h:232-233
+  CREATE_CHRONOMETER(descriptor_extraction)
 private:
   BaseFramePointGeneratorParameters* _parameters;
 };
@@ -45,6 +47,7 @@ public:
   void setCameraRight(const Camera* camera_right_) { _camera_right = camera_right_; }
 protected:
   const Camera* _camera_right = nullptr;
+  CREATE_CHRONOMETER(point_triangulation)      // stereo_framepoint_generator.h:81
 private:
   StereoFramePointGeneratorParameters* _parameters;
 };

@@ -40,6 +40,11 @@ private:
 };
 }  // namespace cv
 
+// definitions.h:143-146 (timing): the members behind getTimeConsumptionSeconds_*() are protected
+#define CREATE_CHRONOMETER(NAME) \
+  protected: double _time_consumption_seconds_##NAME = 0; \
+  public: const double getTimeConsumptionSeconds_##NAME() const {return _time_consumption_seconds_##NAME;}
+
 namespace proslam {
 typedef double real;
 typedef uint32_t Identifier;

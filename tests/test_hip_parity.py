@@ -37,6 +37,11 @@ def test_aligner_golden(gpu, golden):
     pc.check_aligner(gpu, golden["aligner"], rtol_pose=1e-7)
 
 
+def test_aligner_iteration_limits_vs_oracle(golden):
+    from _oracle import Oracle
+    pc.check_aligner_iteration_limits(hip.load, Oracle, golden["aligner"])
+
+
 def test_aligner_stale_weights_golden(gpu, golden):
     pc.check_aligner_weights(gpu, golden["aligner_weights"], gpu.cfg)
 

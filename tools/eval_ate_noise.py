@@ -1,0 +1,130 @@
+"""Does the chunked (frame-sharded) trajectory lie inside the SEQUENTIAL pipeline's own ATE spread under input perturbation?
+
+The accuracy criterion of the north star ("ATE within 1 % of reference") compares two runs on the same images.  Open-loop
+visual odometry is a random walk in its measurement noise: the question a chunked run has to answer is whether it is
+distinguishable from the sequential run at all, i.e. whether its ATE lies inside the spread the sequential pipeline shows when
+nothing but the sensor noise changes.  This tool measures that spread and places the chunked runs in it:
+
+  * same world, same path (scene seed 7, the benchmark's), `noise_seed` = 0 .. n-1: another realisation of the +-2 grey levels of
+    per-pixel sensor noise (tools/synth/synth_scene.h), nothing else;
+  * sequential (exact mode, one stream, whole 4541-frame sequence) for every noise seed -> ATE distribution;
+  * chunked at every (B, overlap) asked for, same noise seeds -> ATE distribution, per-seed ratio to the sequential run.
+
+Both ATE definitions are reported: the closed-form SE3 alignment (`ate`) and the reference tool's own robust iterative alignment
+(executables/trajectory_analyzer.cpp:212-309 restated in evaluation.align_robust_icp: `ate_analyzer`).
+
+Usage: python tools/eval_ate_noise.py [--seeds 8] [--streams 36,72,144] [--overlaps 10,20,40] [--out file.json]"""
+import argparse, json, os, sys
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from vslam_pose_estimation_framework_amd import hip, synth, sharding, evaluation as ev
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seeds", type=int, default=8)
+ap.add_argument("--streams", default="36,72,144")
+ap.add_argument("--overlaps", default="10,20,40")
+ap.add_argument("--frames", type=int, default=4541)
+ap.add_argument("--out", default="")
+a = ap.parse_args()
+Bs = [int(v) for v in a.streams.split(",")]
+ovs = [int(v) for v in a.overlaps.split(",")]
+total = a.frames
+api = hip.load(); sy = synth.Synth()
+stride = 1280; dev = torch.device("cuda", 0)
+
+
+def analyzer_ate(est, gt):
+    """RMSE after the reference tool's alignment (trajectory_analyzer.cpp:212-284): start-point shift, 100 robust rounds."""
+    p = np.asarray(est).reshape(-1, 3, 4)[:, :, 3]
+    g = np.asarray(gt).reshape(-1, 3, 4)[:, :, 3]
+    p = p - p[0] + g[0]
+    T, _ = ev.align_robust_icp(p, g)
+    return ev.rmse(p @ T[:3, :3].T + T[:3, 3], g)
+
+
+def run_sequential(scene, cfg):
+    img = cfg.rows * stride
+    cfg.max_history_frames = 512
+    api.create(cfg, 0, 1)
+    CH = 256; flags = 0
+    for f0 in range(0, total, CH):
+        n = min(CH, total - f0)
+        L = torch.empty((n, cfg.rows, stride), dtype=torch.uint8, device=dev); R = torch.empty_like(L)
+        sy.render_device(scene, f0, n, L.data_ptr(), R.data_ptr(), stride, img, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        for k in range(n):
+            api.process_device(L[k].data_ptr(), R[k].data_ptr(), stride, img)
+        api.synchronize(); flags |= api.frame_info(0).error_flags
+    seq = api.poses(0, 0, total)
+    api.destroy()
+    return seq, flags
+
+
+def run_chunked(scene, cfg, B, ov):
+    img = cfg.rows * stride
+    plan, Lc = sharding.plan_chunks(total, B, ov)
+    steps = max(e - s for (s, f, e) in plan)
+    cfg.max_history_frames = steps + 2
+    api.create(cfg, 0, B)
+    Lb = torch.empty((steps, B, cfg.rows, stride), dtype=torch.uint8, device=dev); Rb = torch.empty_like(Lb)
+    for s_, (st, fi, en) in enumerate(plan):
+        n = min(steps, total - st)
+        sy.render_device(scene, st, n, Lb[0, s_].data_ptr(), Rb[0, s_].data_ptr(), stride, B * img, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for k in range(steps):
+        api.process_device(Lb[k].data_ptr(), Rb[k].data_ptr(), stride, img)
+    api.synchronize()
+    flags = 0
+    for s_ in range(B):
+        flags |= api.frame_info(s_).error_flags
+    chunks = [api.poses(s_, 0, en - st) for s_, (st, fi, en) in enumerate(plan)]
+    api.destroy(); del Lb, Rb
+    torch.cuda.empty_cache()
+    return sharding.assemble_trajectory(chunks, plan), flags
+
+
+rows = []
+for ns in range(a.seeds):
+    scene = sy.scene_kitti(7); scene.noise_seed = ns
+    cfg = synth.config_for_scene(api, scene)
+    cfg.max_keypoints = 8192; cfg.max_points = 4096
+    gt = np.array([sy.gt_pose(scene, k) for k in range(total)])
+    seq, flags = run_sequential(scene, cfg)
+    row = {"noise_seed": ns, "sequential": {"ate": ev.ate_rmse(seq, gt), "ate_analyzer": analyzer_ate(seq, gt)}, "chunked": {}, "error_flags": int(flags)}
+    for B in Bs:
+        for ov in ovs:
+            traj, fl = run_chunked(scene, cfg, B, ov)
+            row["chunked"]["B%d_ov%d" % (B, ov)] = {"ate": ev.ate_rmse(traj, gt), "ate_analyzer": analyzer_ate(traj, gt)}
+            row["error_flags"] |= int(fl)
+    rows.append(row)
+    print(json.dumps(row), flush=True)
+
+
+def dist(v):
+    v = np.asarray(v, float)
+    return {"mean": float(v.mean()), "std": float(v.std(ddof=1)) if len(v) > 1 else None, "min": float(v.min()), "max": float(v.max()),
+            "cv": float(v.std(ddof=1) / v.mean()) if len(v) > 1 else None}
+
+
+summary = {"frames": total, "noise_seeds": a.seeds, "scene_seed": 7,
+           "path_length_m": float(np.sum(np.linalg.norm(np.diff(gt[:, :, 3], axis=0), axis=1)))}
+for key in ("ate", "ate_analyzer"):
+    seqv = np.array([r["sequential"][key] for r in rows])
+    s = {"sequential": dist(seqv), "chunked": {}}
+    for name in rows[0]["chunked"]:
+        cv = np.array([r["chunked"][name][key] for r in rows])
+        ratio = cv / seqv
+        d = dist(cv)
+        # where the chunked runs sit in the sequential distribution: difference of the means in units of the sequential spread,
+        # Welch t, and how many chunked runs fall inside the sequential min .. max
+        se = np.sqrt(seqv.var(ddof=1) / len(seqv) + cv.var(ddof=1) / len(cv)) if len(seqv) > 1 else None
+        d.update({"ratio_of_means": float(cv.mean() / seqv.mean()), "per_seed_ratio_geomean": float(np.exp(np.log(ratio).mean())),
+                  "per_seed_ratio_min": float(ratio.min()), "per_seed_ratio_max": float(ratio.max()),
+                  "mean_shift_in_sequential_sigmas": float((cv.mean() - seqv.mean()) / seqv.std(ddof=1)) if len(seqv) > 1 else None,
+                  "welch_t": float((cv.mean() - seqv.mean()) / se) if se else None,
+                  "inside_sequential_range": int(((cv >= seqv.min()) & (cv <= seqv.max())).sum())})
+        s["chunked"][name] = d
+    summary[key] = s
+print(json.dumps(summary), flush=True)
+if a.out:
+    json.dump({"summary": summary, "runs": rows}, open(a.out, "w"), indent=1)

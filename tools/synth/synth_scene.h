@@ -33,6 +33,8 @@ typedef struct synth_scene {
   double roll_amp, pitch_amp;   /* radians; 0 = planar motion (the KITTI-shaped scene)           */
   double roll_rate, pitch_rate; /* radians per frame of the two oscillations                     */
   double contrast;       /* texture amplitude factor (1 = the KITTI-shaped scene)                  */
+  uint64_t noise_seed;   /* 0 = the scene's own sensor noise; other values: same world and path, another realisation of the
+                          * +-2 grey levels of sensor noise (ATE spread under input perturbation, tools/eval_ate_noise.py)  */
 } synth_scene;
 
 SYNTH_HD uint32_t synth_hash(uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
@@ -134,7 +136,7 @@ SYNTH_HD uint8_t synth_pixel(const synth_scene* s, const double R[9], const doub
     for (int i = 0; i < 2; ++i)
       acc += synth_sample(s, R, t, side, (double)x - 0.25 + 0.5 * i,
                           (double)y - 0.25 + 0.5 * j);
-  const int noise = (int)(synth_hash(s->seed ^ 0xABCDull, (uint64_t)frame * 2 + side, (uint64_t)x,
+  const int noise = (int)(synth_hash(s->seed ^ 0xABCDull ^ (s->noise_seed * 0x9E3779B97F4A7C15ull), (uint64_t)frame * 2 + side, (uint64_t)x,
                                      (uint64_t)y) % 5u) - 2;
   int val = (int)floor(acc * 0.25 + 0.5) + noise;
   if (val < 0) val = 0;
@@ -148,7 +150,7 @@ SYNTH_HD void synth_default_kitti(synth_scene* s) {
   s->baseline_m = 0.5371657; /* 386.1448 / 718.856 */
   s->cam_height_m = 1.65; s->wall_half_m = 7.0; s->max_depth_m = 90.0; s->cell_m = 0.18;
   s->speed_m = 0.9; s->sway_m = 1.2; s->sway_rate = 0.05; s->seed = 7;
-  s->bob_m = 0.03; s->roll_amp = 0.0; s->pitch_amp = 0.0; s->roll_rate = 0.0; s->pitch_rate = 0.0; s->contrast = 1.0;
+  s->bob_m = 0.03; s->roll_amp = 0.0; s->pitch_amp = 0.0; s->roll_rate = 0.0; s->pitch_rate = 0.0; s->contrast = 1.0; s->noise_seed = 0;
 }
 
 /* EuRoC-MH-shaped: 752x480, the cam0 intrinsics and 0.11 m baseline of configuration_euroc.yaml's data set, an indoor
@@ -160,6 +162,6 @@ SYNTH_HD void synth_default_euroc(synth_scene* s) {
   s->baseline_m = 0.11;
   s->cam_height_m = 1.2; s->wall_half_m = 3.0; s->max_depth_m = 25.0; s->cell_m = 0.045;
   s->speed_m = 0.04; s->sway_m = 0.2; s->sway_rate = 0.05; s->seed = 7;
-  s->bob_m = 0.02; s->roll_amp = 0.05; s->pitch_amp = 0.03; s->roll_rate = 0.11; s->pitch_rate = 0.07; s->contrast = 0.5;
+  s->bob_m = 0.02; s->roll_amp = 0.05; s->pitch_amp = 0.03; s->roll_rate = 0.11; s->pitch_rate = 0.07; s->contrast = 0.5; s->noise_seed = 0;
 }
 #endif

@@ -937,7 +937,7 @@ __device__ __forceinline__ void wg_align_converge(const DevCfg& c, const DevBuf&
   double e_prev = 0;
   int it = 0, it2 = 0;
   bool refine = false;
-  while (true) {
+  while (max_it > 0) {   // maximum_number_of_iterations 0: no round at all (:216), errors stay -1, T = T_init, not converged
     wg_one_round<UVD>(c, b, s, sh, n, refine, cache, chi_reg, inl_reg);
     const double E = sh.E;
     if (!refine) {

@@ -1328,8 +1328,10 @@ __global__ __launch_bounds__(VS_WG) void k_stage(const DevCfg c, const DevBuf b,
   if (stage == VS_STAGE_TRACK) {
     if (!st.has_prev) return;
     const double tau = st.tau_track;
+    const unsigned long long t0 = wall_clock64();
     wg_track_resolve(c, b, s, sh, pb_prev, arena, st.win, tau, st.tau_tri, arg);
     if (tid == 0) {
+      st.ticks[0] += wall_clock64() - t0;
       st.n_trk = sh.n_trk; st.n_lost = sh.n_lost; st.n_tracked_landmarks = sh.n_lm; st.aligner_valid = 0; st.tau_gen = tau;
       st.al_n = 0; st.track_calls += 1;
       info.n_tracked = sh.n_trk; info.n_lost = sh.n_lost; info.n_tracked_landmarks = sh.n_lm; info.track_attempts = st.track_calls;
@@ -1339,8 +1341,10 @@ __global__ __launch_bounds__(VS_WG) void k_stage(const DevCfg c, const DevBuf b,
     if (!st.has_prev) return;
     double T0[12];
     for (int k = 0; k < 12; ++k) T0[k] = st.prior[k];
+    const unsigned long long t0 = wall_clock64();
     wg_align(c, b, s, sh, pb_prev, arg != 0, T0);
     if (tid == 0) {
+      st.ticks[1] += wall_clock64() - t0;
       st.al_n = sh.n_trk; st.al_inliers = sh.inl; st.al_outliers = sh.outl; st.al_iterations = sh.its; st.al_converged = sh.conv;
       st.al_total_error = sh.E; st.aligner_valid = 1;
       for (int k = 0; k < 12; ++k) st.al_T[k] = sh.T[k];
@@ -1355,17 +1359,22 @@ __global__ __launch_bounds__(VS_WG) void k_stage(const DevCfg c, const DevBuf b,
     wg_prune(c, b, s, sh, pb_prev, pb_cur, st.aligner_valid != 0);
     const int n_after = sh.n_cur;
     int n_rec = 0;
+    const unsigned long long t0 = wall_clock64();
     if (arg) { wg_recover(c, b, s, sh, pb_prev, pb_cur, hpose_of(c, b, s, f) + 12, st.tau_gen, st.tau_tri, arena); n_rec = sh.flag; }
     if (tid == 0) {
+      if (arg) st.ticks[2] += wall_clock64() - t0;
       st.n_cur = sh.n_cur; st.n_after_prune = n_after; st.n_recovered = n_rec;
       info.n_after_prune = n_after; info.n_recovered = n_rec; info.n_points = sh.n_cur;
     }
   } else if (stage == VS_STAGE_UPDATE) {
+    const unsigned long long t0 = wall_clock64();
     wg_update_points(c, b, s, sh, pb_cur, f);
-    if (tid == 0) { st.n_active = sh.n_lm; info.n_active_landmarks = sh.n_lm; }
+    if (tid == 0) { st.n_active = sh.n_lm; info.n_active_landmarks = sh.n_lm; st.ticks[3] += wall_clock64() - t0; }
   } else if (stage == VS_STAGE_STEREO) {
+    const unsigned long long t0 = wall_clock64();
     wg_stereo(c, b, s, sh, pb_cur, st.tau_tri, f, arena, VS_ARENA);
     if (tid == 0) {
+      st.ticks[4] += wall_clock64() - t0;
       const double* c2w = hpose_of(c, b, s, f);
       *pts_of(c, b, s, pb_cur).n = sh.n_cur;
       st.n_cur = sh.n_cur; st.n_new = sh.n_cand;

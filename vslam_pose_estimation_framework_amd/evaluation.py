@@ -153,22 +153,23 @@ def align_robust_icp(meas, ref, iterations=100, kernel=1.0):
     """:212-276: T (4x4) that moves the measured positions onto the reference, by the tool's own iteration."""
     T = np.eye(4)
     log = []
+    meas = np.asarray(meas, float).reshape(-1, 3)
+    ref = np.asarray(ref, float).reshape(-1, 3)
     for _ in range(iterations):
-        H = np.zeros((6, 6)); b = np.zeros(6)
-        inliers, total = 0, 0.0
-        for p, g in zip(meas, ref):
-            s = T[:3, :3] @ p + T[:3, 3]
-            e = s - g
-            e2 = float(e @ e)
-            w = 1.0
-            if e2 > kernel:
-                w = kernel / e2
-            else:
-                inliers += 1
-            total += e2
-            J = np.hstack([np.eye(3), -2 * _skew(s)])
-            H += w * J.T @ J
-            b += w * J.T @ e
+        # all correspondences of a round at once (the tool's loop :222-262, one numpy expression per statement)
+        S = meas @ T[:3, :3].T + T[:3, 3]
+        E = S - ref
+        e2 = (E * E).sum(1)
+        w = np.where(e2 > kernel, kernel / np.where(e2 > 0, e2, 1.0), 1.0)
+        inliers = int((e2 <= kernel).sum())
+        total = float(e2.sum())
+        J = np.zeros((len(S), 3, 6))
+        J[:, 0, 0] = J[:, 1, 1] = J[:, 2, 2] = 1.0
+        J[:, 0, 4] = 2 * S[:, 2]; J[:, 0, 5] = -2 * S[:, 1]
+        J[:, 1, 3] = -2 * S[:, 2]; J[:, 1, 5] = 2 * S[:, 0]
+        J[:, 2, 3] = 2 * S[:, 1]; J[:, 2, 4] = -2 * S[:, 0]
+        H = np.einsum("n,nij,nik->jk", w, J, J)
+        b = np.einsum("n,nij,ni->j", w, J, E)
         # Eigen's H.ldlt().solve(-b); the least-squares solve covers the rank-deficient start (all points coincide)
         dx = np.linalg.lstsq(H, -b, rcond=None)[0]
         T = _v2t(dx) @ T

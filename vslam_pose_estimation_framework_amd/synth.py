@@ -19,7 +19,7 @@ class SynthScene(C.Structure):
                 ("cam_height_m", C.c_double), ("wall_half_m", C.c_double), ("max_depth_m", C.c_double),
                 ("cell_m", C.c_double), ("speed_m", C.c_double), ("sway_m", C.c_double),
                 ("sway_rate", C.c_double), ("seed", C.c_uint64), ("bob_m", C.c_double), ("roll_amp", C.c_double),
-                ("pitch_amp", C.c_double), ("roll_rate", C.c_double), ("pitch_rate", C.c_double), ("contrast", C.c_double)]
+                ("pitch_amp", C.c_double), ("roll_rate", C.c_double), ("pitch_rate", C.c_double), ("contrast", C.c_double), ("noise_seed", C.c_uint64)]
 
 
 class Synth(object):
