@@ -515,6 +515,10 @@ int vslam_copy_poses_device(vslam_ctx* ctx, int32_t first_frame, int32_t n_frame
  * on hip_stream (NULL: the default stream), asynchronous — synchronise the stream before reading. */
 typedef struct vslam_comm vslam_comm;
 #define VSLAM_COMM_ID_BYTES 128
+/* Local precondition of vslam_comm_init (librccl.so loadable with the expected symbols, the device selectable): every rank
+ * calls it and the ranks agree on the result over the launcher's channel BEFORE anyone enters the collective
+ * ncclCommInitRank — a rank that cannot take part must not leave its peers waiting in it. */
+int vslam_comm_available(int device);
 int vslam_comm_unique_id(uint8_t id[VSLAM_COMM_ID_BYTES]);
 int vslam_comm_init(int rank, int nranks, const uint8_t id[VSLAM_COMM_ID_BYTES], int device, vslam_comm** out);
 int vslam_allgather_poses(vslam_comm* comm, const double* send_device, double* recv_device, size_t count, void* hip_stream);

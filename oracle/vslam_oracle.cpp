@@ -1565,11 +1565,119 @@ ORC_API int orc_knn2(orc_ctx*, int norm, int32_t nq, const uint8_t* q, int32_t n
   }
   return VSLAM_OK;
 }
-/* The use_matches block (stereo_framepoint_generator.cpp:168-206) on the CURRENT frame of stream s: the knnMatch(k=2) of
- * the left against the right descriptors with the given norm, results discarded — exactly the dead work the reference pays
- * per frame when use_matches is true (configuration_kitti.yaml:95).  findHomography (:232-262) is not emulated.
- * Used by bench.py's cpu_baseline leg only; returns the number of query rows. */
-ORC_API int orc_dead_knn_match(orc_ctx* c, int s, int norm) {
+/* The reference's dead block of compute() (stereo_framepoint_generator.cpp:168-273), for the CPU baseline's cost only — every
+ * result is discarded there and here:
+ *   knnMatch(k = 2) of the left against the right descriptors converted to CV_32F (:199-206) with the given norm, and — with
+ *   `homography` != 0 — cv::findHomography(left points, right points of every first match, LMEDS, 1, mask, 1000, 0.99)
+ *   (:232-262 with configuration_kitti.yaml:99-103) restated from OpenCV's published algorithm [recalled: calib3d
+ *   fundam.cpp / ptsetreg.cpp]: niters = RANSACUpdateNumIters(0.99, 0.45, 4, 1000) minimal samples of 4 correspondences, a
+ *   direct linear 4-point homography each, the median of the squared reprojection errors over ALL correspondences as the
+ *   score; then the inlier mask (sigma = 2.5 * 1.4826 * (1 + 5 / (n - 4)) * sqrt(median)), a normalised DLT re-fit on the
+ *   inliers (9 x 9 normal matrix, smallest eigenvector by Jacobi sweeps) and 10 Levenberg-Marquardt rounds on the 8
+ *   free parameters.  Used by bench.py's cpu_baseline leg only; returns the number of query rows. */
+namespace {
+bool homography4(const double* x, const double* y, const double* u, const double* v, double H[9]) {   /* 8 x 8 linear system, h33 = 1 */
+  double A[8][9];
+  for (int i = 0; i < 4; ++i) {
+    const double r0[9] = {x[i], y[i], 1, 0, 0, 0, -u[i] * x[i], -u[i] * y[i], u[i]};
+    const double r1[9] = {0, 0, 0, x[i], y[i], 1, -v[i] * x[i], -v[i] * y[i], v[i]};
+    for (int k = 0; k < 9; ++k) { A[2 * i][k] = r0[k]; A[2 * i + 1][k] = r1[k]; }
+  }
+  for (int c = 0; c < 8; ++c) {
+    int p = c;
+    for (int r = c + 1; r < 8; ++r) if (std::fabs(A[r][c]) > std::fabs(A[p][c])) p = r;
+    if (std::fabs(A[p][c]) < 1e-12) return false;
+    if (p != c) for (int k = 0; k < 9; ++k) std::swap(A[p][k], A[c][k]);
+    for (int r = 0; r < 8; ++r) if (r != c) { const double f = A[r][c] / A[c][c]; for (int k = c; k < 9; ++k) A[r][k] -= f * A[c][k]; }
+  }
+  for (int k = 0; k < 8; ++k) H[k] = A[k][8] / A[k][k];
+  H[8] = 1;
+  return true;
+}
+inline double reproj2(const double H[9], double x, double y, double u, double v) {
+  const double w = 1.0 / (H[6] * x + H[7] * y + H[8]);
+  const double du = (H[0] * x + H[1] * y + H[2]) * w - u, dv = (H[3] * x + H[4] * y + H[5]) * w - v;
+  return du * du + dv * dv;
+}
+void smallest_eigenvector9(double M[9][9], double out[9]) {   /* cyclic Jacobi on a symmetric 9 x 9 */
+  double V[9][9];
+  for (int i = 0; i < 9; ++i) for (int j = 0; j < 9; ++j) V[i][j] = i == j;
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = 0;
+    for (int i = 0; i < 9; ++i) for (int j = i + 1; j < 9; ++j) off += M[i][j] * M[i][j];
+    if (off < 1e-30) break;
+    for (int p = 0; p < 8; ++p) for (int q = p + 1; q < 9; ++q) {
+      if (std::fabs(M[p][q]) < 1e-300) continue;
+      const double th = (M[q][q] - M[p][p]) / (2 * M[p][q]);
+      const double t = (th >= 0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1)), cs = 1 / std::sqrt(t * t + 1), sn = t * cs;
+      for (int k = 0; k < 9; ++k) { const double a = M[k][p], b = M[k][q]; M[k][p] = cs * a - sn * b; M[k][q] = sn * a + cs * b; }
+      for (int k = 0; k < 9; ++k) { const double a = M[p][k], b = M[q][k]; M[p][k] = cs * a - sn * b; M[q][k] = sn * a + cs * b; }
+      for (int k = 0; k < 9; ++k) { const double a = V[k][p], b = V[k][q]; V[k][p] = cs * a - sn * b; V[k][q] = sn * a + cs * b; }
+    }
+  }
+  int m = 0;
+  for (int i = 1; i < 9; ++i) if (M[i][i] < M[m][m]) m = i;
+  for (int k = 0; k < 9; ++k) out[k] = V[k][m];
+}
+int dead_find_homography_lmeds(const std::vector<double>& px, const std::vector<double>& py, const std::vector<double>& qx, const std::vector<double>& qy) {
+  const int n = (int)px.size();
+  if (n < 5) return 0;
+  const int niters = std::min(1000, (int)std::lround(std::log(1 - 0.99) / std::log(1 - std::pow(1 - 0.45, 4))));
+  uint64_t rng = 0x9E3779B97F4A7C15ull;
+  auto next = [&rng](int m) { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return (int)((rng >> 33) % (uint64_t)m); };
+  std::vector<float> err(n), tmp(n);
+  double best[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, best_med = 1e300;
+  for (int it = 0; it < niters; ++it) {
+    int id[4];
+    for (int k = 0; k < 4; ++k) { bool again; do { id[k] = next(n); again = false; for (int j = 0; j < k; ++j) again |= id[j] == id[k]; } while (again); }
+    double x[4], y[4], u[4], v[4], H[9];
+    for (int k = 0; k < 4; ++k) { x[k] = px[id[k]]; y[k] = py[id[k]]; u[k] = qx[id[k]]; v[k] = qy[id[k]]; }
+    if (!homography4(x, y, u, v, H)) continue;
+    for (int i = 0; i < n; ++i) err[i] = (float)reproj2(H, px[i], py[i], qx[i], qy[i]);
+    tmp = err;
+    std::nth_element(tmp.begin(), tmp.begin() + n / 2, tmp.end());
+    if (tmp[n / 2] < best_med) { best_med = tmp[n / 2]; std::memcpy(best, H, sizeof best); }
+  }
+  const double sigma = 2.5 * 1.4826 * (1 + 5.0 / (n - 4)) * std::sqrt(best_med), thr = std::max(sigma * sigma, 1e-6);
+  std::vector<int> inl;
+  for (int i = 0; i < n; ++i) if (reproj2(best, px[i], py[i], qx[i], qy[i]) <= thr) inl.push_back(i);
+  if (inl.size() < 4) return (int)inl.size();
+  double M[9][9] = {{0}};
+  for (int i : inl) {
+    const double r0[9] = {px[i], py[i], 1, 0, 0, 0, -qx[i] * px[i], -qx[i] * py[i], -qx[i]};
+    const double r1[9] = {0, 0, 0, px[i], py[i], 1, -qy[i] * px[i], -qy[i] * py[i], -qy[i]};
+    for (int a = 0; a < 9; ++a) for (int b2 = a; b2 < 9; ++b2) M[a][b2] += r0[a] * r0[b2] + r1[a] * r1[b2];
+  }
+  for (int a = 0; a < 9; ++a) for (int b2 = 0; b2 < a; ++b2) M[a][b2] = M[b2][a];
+  double H[9];
+  smallest_eigenvector9(M, H);
+  if (std::fabs(H[8]) > 1e-12) for (int k = 0; k < 9; ++k) H[k] /= H[8];
+  for (int round = 0; round < 10; ++round) {   /* Levenberg-Marquardt on h0..h7 (h8 = 1) */
+    double JtJ[8][9] = {{0}};
+    for (int i : inl) {
+      const double x = px[i], y = py[i], w = 1.0 / (H[6] * x + H[7] * y + 1), a = (H[0] * x + H[1] * y + H[2]) * w, b2 = (H[3] * x + H[4] * y + H[5]) * w;
+      const double ju[8] = {x * w, y * w, w, 0, 0, 0, -a * x * w, -a * y * w}, jv[8] = {0, 0, 0, x * w, y * w, w, -b2 * x * w, -b2 * y * w};
+      const double eu = a - qx[i], ev = b2 - qy[i];
+      for (int r = 0; r < 8; ++r) { for (int cc = 0; cc < 8; ++cc) JtJ[r][cc] += ju[r] * ju[cc] + jv[r] * jv[cc]; JtJ[r][8] -= ju[r] * eu + jv[r] * ev; }
+    }
+    for (int r = 0; r < 8; ++r) JtJ[r][r] *= 1.001;
+    bool ok = true;
+    for (int c = 0; c < 8 && ok; ++c) {
+      int p = c;
+      for (int r = c + 1; r < 8; ++r) if (std::fabs(JtJ[r][c]) > std::fabs(JtJ[p][c])) p = r;
+      if (std::fabs(JtJ[p][c]) < 1e-300) { ok = false; break; }
+      if (p != c) for (int k = 0; k < 9; ++k) std::swap(JtJ[p][k], JtJ[c][k]);
+      for (int r = 0; r < 8; ++r) if (r != c) { const double f = JtJ[r][c] / JtJ[c][c]; for (int k = c; k < 9; ++k) JtJ[r][k] -= f * JtJ[c][k]; }
+    }
+    if (!ok) break;
+    for (int k = 0; k < 8; ++k) H[k] += JtJ[k][8] / JtJ[k][k];
+  }
+  volatile double sink = H[0];
+  (void)sink;
+  return (int)inl.size();
+}
+}  // namespace
+ORC_API int orc_dead_knn_match(orc_ctx* c, int s, int norm, int homography) {
   if (!c || s < 0 || s >= (int)c->streams.size()) return VSLAM_ERR_INVALID;
   const Stream& st = c->streams[s];
   const int nq = (int)st.kpL.size(), nt = (int)st.kpR.size();
@@ -1579,7 +1687,17 @@ ORC_API int orc_dead_knn_match(orc_ctx* c, int s, int norm) {
   std::vector<int32_t> idx((size_t)std::max(nq, 1) * 2);
   std::vector<float> dist((size_t)std::max(nq, 1) * 2);
   const int rc = orc_knn2(c, norm, nq, dq.data(), nt, dt.data(), idx.data(), dist.data());
-  return rc == VSLAM_OK ? nq : rc;
+  if (rc != VSLAM_OK) return rc;
+  if (homography && nt > 0) {
+    std::vector<double> px, py, qx, qy;
+    for (int i = 0; i < nq; ++i) {
+      const int j = idx[2 * (size_t)i];
+      if (j < 0 || j >= nt) continue;
+      px.push_back(st.kpL[i].col); py.push_back(st.kpL[i].row); qx.push_back(st.kpR[j].col); qy.push_back(st.kpR[j].row);
+    }
+    (void)dead_find_homography_lmeds(px, py, qx, qy);
+  }
+  return nq;
 }
 ORC_API int orc_align_points(orc_ctx* c, int32_t n, const double* moving, const double* fixed, const double* omega,
                              const double* weight, const double T_init[12], double T_out[12], double* chi, uint8_t* inlier,

@@ -180,3 +180,88 @@ def test_config5_sequences_queued_on_fewer_streams_exact_mode():
     # the same sequence alone on a one-stream context gives the same trajectory (a queued stream carries nothing over)
     single, _ = _run_exact([lengths[1]], [[0]], 1, scale=0.4, ids=[1])
     np.testing.assert_array_equal(single[0], poses[1])
+
+
+# ---- long runs at full resolution (the long-run property checked inside the suite, not by a probe script) ----------
+LIGHT_FIELDS = ["frame_index", "status", "n_keypoints_left", "n_keypoints_right", "n_detected_left", "n_detected_right", "n_tracked",
+                "n_lost", "n_tracked_landmarks", "aligner_ran", "aligner_iterations", "n_inliers", "n_outliers", "track_attempts",
+                "n_after_prune", "n_recovered", "n_active_landmarks", "n_new_stereo", "n_points", "track_broken", "fallback",
+                "window_pixels", "error_flags"]
+
+
+def _long_run(lengths, seeds, speeds, full_every):
+    """Streams of the given lengths at 1241 x 376 (configuration_kitti.yaml values), every stream a whole sequence of its own
+    (exact mode).  The images are rendered on the GPU (the same bytes go to both sides).  EVERY frame of every live stream: all
+    integer counters, thresholds, tracker state and the pose against the oracle; every `full_every` frames and on each stream's
+    last frame the complete comparison (keypoints, descriptors, framepoint tuples, landmarks, aligner results, weights)."""
+    import torch
+    from _oracle import Oracle
+    from vslam_pose_estimation_framework_amd import synth
+    n_streams = len(lengths)
+    o = Oracle()
+    sy = synth.Synth()
+    scenes = []
+    for seed, speed in zip(seeds, speeds):
+        sc = sy.scene_kitti(seed=seed)
+        sc.speed_m = speed
+        scenes.append(sc)
+    cfg = synth.config_for_scene(o, scenes[0], "kitti")
+    cfg.max_keypoints, cfg.max_points, cfg.max_history_frames = 8192, 4096, 512
+    o.create(cfg, 0, n_streams)
+    g = hip.load()
+    g.create(cfg, 0, n_streams)
+    dev = torch.device("cuda", 0)
+    slab, worst, stats = 50, 0.0, {"tracked": 0, "recovered": 0, "tracking_frames": 0}
+    try:
+        for f0 in range(0, max(lengths), slab):
+            n = min(slab, max(lengths) - f0)
+            Ld = torch.zeros((n, n_streams, cfg.rows, cfg.cols), dtype=torch.uint8, device=dev)
+            Rd = torch.zeros_like(Ld)
+            for s, sc in enumerate(scenes):
+                m = min(n, lengths[s] - f0)
+                if m > 0:
+                    sy.render_device(sc, f0, m, Ld[0, s].data_ptr(), Rd[0, s].data_ptr(), cfg.cols, n_streams * cfg.rows * cfg.cols,
+                                     torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            Lh, Rh = Ld.cpu().numpy(), Rd.cpu().numpy()
+            for j in range(n):
+                k = f0 + j
+                for s in range(n_streams):
+                    if lengths[s] == k:                     # the stream's sequence has ended: switched off, its report stays
+                        o.set_stream_active(s, False); g.set_stream_active(s, False)
+                o.process_host(Lh[j], Rh[j])
+                g.process_host(Lh[j], Rh[j])
+                for s in range(n_streams):
+                    last = min(k, lengths[s] - 1)           # a finished stream keeps reporting its last frame
+                    fo, fg = o.frame_info(s), g.frame_info(s)
+                    assert fg.frame_index == last + 1
+                    for name in LIGHT_FIELDS:
+                        assert getattr(fo, name) == getattr(fg, name), "stream %d frame %d: %s oracle=%s hip=%s" % (s, k, name, getattr(fo, name), getattr(fg, name))
+                    assert list(fo.thresholds) == list(fg.thresholds) and fo.tau_track == fg.tau_track and fo.tau_triangulation == fg.tau_triangulation
+                    To, Tg = np.array(fo.camera_left_to_world), np.array(fg.camera_left_to_world)
+                    worst = max(worst, float(np.linalg.norm(Tg - To) / np.linalg.norm(To)))
+                    if k < lengths[s]:
+                        stats["tracked"] += fg.n_tracked; stats["recovered"] += fg.n_recovered; stats["tracking_frames"] += fg.status == 1
+                        if k % full_every == full_every - 1 or k == lengths[s] - 1:
+                            compare_frame(o, g, s, k, "long run")
+        assert worst <= 1e-4, worst                         # north_star: pose within 1e-4 relative Frobenius, over the whole run
+        for s in range(n_streams):
+            pg, po = g.poses(s, 0, lengths[s]), o.poses(s, 0, lengths[s])
+            assert np.abs(pg - po).max() <= 1e-6 * max(1.0, np.abs(po).max())
+        return worst, stats
+    finally:
+        g.destroy()
+        o.destroy()
+
+
+def test_config2_one_thousand_frames_full_resolution_one_stream():
+    """configs[1] (KITTI-00-shaped, bin 15, one sequence = one stream: the literal drop-in) over 1000 frames at 1241 x 376."""
+    worst, stats = _long_run([1000], [7], [0.9], full_every=125)
+    assert stats["tracking_frames"] > 950 and stats["tracked"] > 150 * 1000 and stats["recovered"] > 1000, stats
+
+
+def test_exact_mode_two_streams_of_different_lengths_full_resolution():
+    """Two whole sequences of 420 and 300 frames side by side at 1241 x 376: the shorter stream is switched off when it ends and
+    keeps its report and pose log while the longer one runs on."""
+    worst, stats = _long_run([420, 300], [21, 22], [0.8, 1.0], full_every=60)
+    assert stats["tracking_frames"] > 680, stats

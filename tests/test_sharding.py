@@ -156,6 +156,74 @@ def test_comm_id_exchange_and_pose_layout_two_ranks_gloo():
         np.testing.assert_array_equal(a[2:].ravel(), np.arange(72.0) + 1000.0)
 
 
+def test_chunk_job_accounting_single_rank():
+    """bench.py's chunk pipeline as numbers: over one whole chunk job every frame of the sequence is counted exactly once,
+    whatever window of J steps is taken; the strong plan is the single-GPU plan cut into rank shares."""
+    for total, B, ov in ((4541, 144, 10), (4541, 36, 40), (3682, 144, 10), (100, 7, 3)):
+        job = sharding.chunk_job(total, B, ov)
+        J = job["J"]
+        assert J == job["L"] + ov and job["n_streams"] == B and job["plan"] == sharding.plan_chunks(total, B, ov)[0]
+        for k0 in (0, 5, J, 3 * J + 1):
+            assert sharding.chunk_job_unique_frames(job, k0, J) == total
+        # every stream restarts exactly once per J steps, at the step its chunk frame index wraps to 0
+        hits = [0] * B
+        for k in range(1, J + 1):
+            for s in sharding.chunk_job_restarts(job, k):
+                hits[s] += 1
+                assert (k + job["phase"][s]) % J == 0
+        assert hits == [1] * B
+    for world in (2, 4, 8):
+        got = []
+        for r in range(world):
+            job = sharding.chunk_job(4541, 144, 10, r, world, "strong")
+            assert job["n_streams"] == 144 // world and job["plan"] == sharding.plan_chunks(4541, 144, 10)[0]
+            got += job["chunk_ids"]
+        assert got == list(range(144))
+
+
+def _bench_accounting_worker(rank, world, port, scaling, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    job = sharding.chunk_job(4541, 144, 10, rank, world, scaling)
+    K, k_first = job["J"], job["J"] + 2             # one whole chunk job timed after pre-roll + warm-up, as bench.py does
+    t = torch.tensor([float(sharding.chunk_job_unique_frames(job, k_first, K)), float(job["n_streams"] * K)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)          # bench.py: sum_over_ranks(unique), sum_over_ranks(frames)
+    ok = sharding.all_ranks_ok(rank == 0)            # one rank reporting a failure makes every rank see it
+    ok_all = sharding.all_ranks_ok(True)
+    # the [K][B][12] per-step pose blocks come back rank-major from the single all-gather
+    send = torch.full((K, job["n_streams"], 12), float(rank), dtype=torch.float64)
+    allp = sharding.gather_poses(send)
+    q.put((rank, t.tolist(), ok, ok_all, tuple(allp.shape), float(allp[K:].mean()) if world > 1 else 0.0))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_accounting_two_ranks_gloo(scaling):
+    """What `value` counts at N = 2 (bench.py --scaling weak | strong), on CPU: weak = two KITTI-00-shaped sequences (one per
+    rank) of 4541 unique frames each, strong = the ONE sequence's 144 chunks split 72 / 72 -> 4541 unique frames in total."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_accounting_worker, args=(r, 2, port, scaling, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=90) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, (unique, frames), ok, ok_all, shape, mean_other in res:
+        if scaling == "weak":
+            assert unique == 2 * 4541 and frames == 2 * 144 * 42 and shape == (2 * 42, 144, 12)
+        else:
+            assert unique == 4541 and frames == 144 * 42 and shape == (2 * 42, 72, 12)
+        assert ok is False and ok_all is True
+        assert mean_other == 1.0
+
+
 @pytest.mark.gpu
 def test_c_abi_pose_allgather_single_rank_rccl():
     """vslam_comm_unique_id / vslam_comm_init / vslam_allgather_poses on the GPU: librccl.so is loaded by the library itself, a

@@ -10,7 +10,7 @@ export VSLAM_IMG_STREAMS=0
 i=0
 for G in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_FLAT"; do
   i=$((i+1))
-  rocprofv3 --pmc $G --kernel-trace --output-format csv -d $OUT/g$i -- python3 bench.py --no-cpu --no-exact --no-pcie --steps 6 > $OUT/g$i.log 2>&1 || echo "group $i failed"
+  rocprofv3 --pmc $G --kernel-trace --output-format csv -d $OUT/g$i -- python3 bench.py --no-cpu --no-exact --no-pcie --no-ate --steps 6 > $OUT/g$i.log 2>&1 || echo "group $i failed"
 done
 python3 - "$OUT" << 'PY'
 import csv, glob, json, sys, collections

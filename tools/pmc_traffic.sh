@@ -7,10 +7,12 @@ OUT=$PWD/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -- python3 bench.py --no-cpu --no-exact --no-pcie --steps 8 > $OUT/$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -- python3 bench.py --no-cpu --no-exact --no-pcie --no-ate --steps 8 > $OUT/$C.log 2>&1
 done
 python3 - "$OUT" << 'PY'
-import csv, glob, json, sys, collections
+import csv, glob, json, os, sys, collections
+sys.path.insert(0, os.getcwd())
+from vslam_pose_estimation_framework_amd import buildinfo
 out = sys.argv[1]
 res = collections.defaultdict(dict)
 for cname in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -23,6 +25,6 @@ for cname in ("FETCH_SIZE", "WRITE_SIZE"):
             acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
     for k, (v, n) in acc.items():
         if k.startswith("k_") and not k.startswith("k_synth"): res[k][cname] = round(v / n, 1)
-json.dump({"streams": 144, "command": "python3 bench.py --no-cpu --no-exact --no-pcie --steps 8", "counters": "FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes, kernel-trace only; KB per launch as reported (see MI355X_MICROARCH.md for the fetch under-count of wide loads)", "per_launch_KB": res}, open(out + "/summary.json", "w"), indent=1)
+json.dump({"streams": 144, "source_sha16": buildinfo.source_sha16(), "library_sha16": buildinfo.library_sha16(), "command": "python3 bench.py --no-cpu --no-exact --no-pcie --no-ate --steps 8", "counters": "FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes, kernel-trace only; KB per launch as reported (see MI355X_MICROARCH.md for the fetch under-count of wide loads)", "per_launch_KB": res}, open(out + "/summary.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY

@@ -5,7 +5,7 @@ OUT=gpurun_out/$TAG; mkdir -p $OUT
 i=0
 for A in "$@"; do
   i=$((i+1))
-  timeout -k 10 200 python bench.py --no-cpu --no-exact --no-pcie $A > $OUT/a$i.json 2> $OUT/a$i.err
+  timeout -k 10 200 python bench.py --no-cpu --no-exact --no-pcie --no-ate $A > $OUT/a$i.json 2> $OUT/a$i.err
   python - $OUT/a$i.json "$A" <<'PY'
 import json,sys
 try:

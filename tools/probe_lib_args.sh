@@ -5,7 +5,7 @@ OUT=gpurun_out/$TAG; mkdir -p $OUT
 i=0
 for A in "$@"; do
   i=$((i+1))
-  VSLAM_HIP_LIB=$PWD/vslam_pose_estimation_framework_amd/csrc/$LIB timeout -k 10 200 python bench.py --no-cpu --no-exact --no-pcie $A > $OUT/$LIB.$i.json 2> $OUT/$LIB.$i.err
+  VSLAM_HIP_LIB=$PWD/vslam_pose_estimation_framework_amd/csrc/$LIB timeout -k 10 200 python bench.py --no-cpu --no-exact --no-pcie --no-ate $A > $OUT/$LIB.$i.json 2> $OUT/$LIB.$i.err
   python - $OUT/$LIB.$i.json "$LIB $A" <<'PY'
 import json,sys
 try:

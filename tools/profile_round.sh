@@ -4,16 +4,17 @@
 #   2. HBM traffic per kernel launch (FETCH_SIZE / WRITE_SIZE, separate --pmc passes): tools/pmc_traffic.sh
 #   3. instruction mix / LDS / wait counters, kernels back to back on one stream: tools/pmc_sq.sh
 #   4. the N x M 2-NN kernel at N = M = 2158 for the four norms (rocprofv3 --stats)
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --no-cpu --no-exact --no-pcie --steps 39 > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --no-cpu --no-exact --no-pcie --no-ate --steps 39 > $OUT/stats.log 2>&1
 echo "stats rc=$?"
 bash tools/pmc_traffic.sh $TAG > $OUT/pmc_traffic.log 2>&1; echo "traffic rc=$?"
 bash tools/pmc_sq.sh $TAG > $OUT/pmc_sq.log 2>&1; echo "sq rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/knn -- python3 tools/probe/bench_knn.py > $OUT/knn.log 2>&1
 echo "knn rc=$?"
+python3 vslam_pose_estimation_framework_amd/buildinfo.py > $OUT/build.json
 python3 - $OUT <<'PY'
 import csv, glob, sys
 out = sys.argv[1]

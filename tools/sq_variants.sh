@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export VSLAM_IMG_STREAMS=0
 for L in "$@"; do
   n=$(basename $L .so)
-  VSLAM_HIP_LIB=$GRAFT_REPO_ROOT/vslam_pose_estimation_framework_amd/csrc/$L rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d $OUT/$n -- python3 bench.py --no-cpu --no-exact --no-pcie --steps 4 > $OUT/$n.log 2>&1 || echo "$n failed"
+  VSLAM_HIP_LIB=$GRAFT_REPO_ROOT/vslam_pose_estimation_framework_amd/csrc/$L rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d $OUT/$n -- python3 bench.py --no-cpu --no-exact --no-pcie --no-ate --steps 4 > $OUT/$n.log 2>&1 || echo "$n failed"
 done
 python3 - $OUT "$@" <<'PY'
 import csv, glob, sys, collections

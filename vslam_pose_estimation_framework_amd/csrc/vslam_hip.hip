@@ -1946,6 +1946,13 @@ int rccl_load() {
 }  // namespace
 struct vslam_comm { void* comm = nullptr; int rank = 0, nranks = 1, device = 0; };
 VS_API const char* vslam_comm_last_error(void) { return g_comm_error.c_str(); }
+VS_API int vslam_comm_available(int device) {
+  int rc = rccl_load();
+  if (rc != VSLAM_OK) return rc;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return comm_fail(VSLAM_ERR_NO_DEVICE, "vslam_comm_available: no such HIP device");
+  return VSLAM_OK;
+}
 VS_API int vslam_comm_unique_id(uint8_t id[VSLAM_COMM_ID_BYTES]) {
   if (!id) return comm_fail(VSLAM_ERR_INVALID, "null id");
   int rc = rccl_load();

@@ -24,6 +24,55 @@ def plan_chunks(total_frames, n_chunks, overlap):
     return plan, L
 
 
+def chunk_job(seq_frames, streams, overlap, rank=0, world=1, scaling="weak"):
+    """The steady-state chunk pipeline one rank of bench.py runs, as plain numbers.
+
+    weak   every rank owns one whole `seq_frames`-frame sequence of its own (N GPUs = N KITTI-00-shaped drives), cut into
+           `streams` chunks: per-GPU work is fixed.
+    strong ONE `seq_frames`-frame sequence: the plan of `streams` chunks is the single-GPU plan and rank r runs chunks
+           r*streams/world .. (r+1)*streams/world - 1 of it (the assembled trajectory does not depend on the GPU count).
+    Stream s is `phase[s]` frames into its chunk when the pipeline starts and restarts whenever its chunk job of J = L + overlap
+    steps ends.  Returns a dict: L, J, n_streams (of this rank), chunk_ids (global chunk of every local stream), plan (the
+    global (start, first_unique, end) list), starts / first_unique / end_unique / phase per local stream."""
+    if scaling not in ("weak", "strong"):
+        raise ValueError("scaling must be weak or strong")
+    n_chunks = int(streams)
+    plan, L = plan_chunks(seq_frames, n_chunks, overlap)
+    if scaling == "weak":
+        ids = list(range(n_chunks))
+    else:
+        per = -(-n_chunks // world)
+        ids = list(range(rank * per, min((rank + 1) * per, n_chunks)))
+    J = L + overlap
+    B = len(ids)
+    job = {"L": L, "J": J, "n_streams": B, "chunk_ids": ids, "plan": plan, "scaling": scaling, "seq_frames": seq_frames,
+           "starts": [], "first_unique": [], "end_unique": [], "phase": []}
+    for s, c in enumerate(ids):
+        job["starts"].append(max(0, c * L - overlap))         # every chunk job is J steps long: the same pipeline period for all
+        job["first_unique"].append(c * L)
+        job["end_unique"].append(min((c + 1) * L, seq_frames))
+        job["phase"].append((s * J) // max(B, 1))
+    return job
+
+
+def chunk_job_unique_frames(job, k0, n):
+    """Frames inside their chunk's own range among pipeline steps k0 .. k0+n-1 of this rank (what `value` counts)."""
+    J = job["J"]
+    cnt = 0
+    for k in range(k0, k0 + n):
+        for s in range(job["n_streams"]):
+            f = job["starts"][s] + (k + job["phase"][s]) % J
+            if job["first_unique"][s] <= f < job["end_unique"][s]:
+                cnt += 1
+    return cnt
+
+
+def chunk_job_restarts(job, k):
+    """Local streams whose chunk starts over at pipeline step k (k > 0)."""
+    J = job["J"]
+    return [s for s in range(job["n_streams"]) if (k + job["phase"][s]) % J == 0]
+
+
 def plan_sequences(lengths, world):
     """Whole sequences onto `world` ranks, longest-processing-time first (the exact mode — every
     sequence runs start to end on one stream of one GPU, results identical to the sequential reference).
@@ -105,6 +154,19 @@ def exchange_unique_id(unique_id, rank, group=None):
     return t.cpu().numpy()
 
 
+def all_ranks_ok(ok, group=None):
+    """Logical AND of a per-rank status over the launcher's channel (torch.distributed; True without a process group)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return bool(ok)
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    if dist.get_backend(group) == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()))
+
+
 class PoseComm(object):
     """The pose all-gather behind the C ABI (vslam_comm_init / vslam_allgather_poses: RCCL called by libvslam_hip.so itself),
     what a C++ caller of the library uses; `gather_poses` above is the Python convenience over torch.distributed."""
@@ -115,6 +177,12 @@ class PoseComm(object):
         self.api, self.rank, self.world = api, rank, world
         lib = api.lib
         lib.vslam_comm_last_error.restype = C.c_char_p
+        # every rank checks its local preconditions (librccl.so, the device) and the ranks agree on the result BEFORE anyone
+        # enters the collective ncclCommInitRank: a rank that cannot take part would leave its peers waiting there for ever
+        ok = lib.vslam_comm_available(C.c_int(device)) == 0
+        why = "" if ok else lib.vslam_comm_last_error().decode()
+        if not all_ranks_ok(ok, group):
+            raise RuntimeError("vslam_comm_available failed on %s%s" % ("this rank: " if not ok else "another rank", why))
         # 128 id bytes + 4 status bytes in one broadcast: when rank 0 cannot make an id every rank learns it (and raises) instead
         # of waiting in a collective that rank 0 never joins
         msg = np.zeros(132, np.uint8)
@@ -131,8 +199,12 @@ class PoseComm(object):
         uid = np.ascontiguousarray(msg[:128])
         self.comm = C.c_void_p()
         rc = lib.vslam_comm_init(C.c_int(rank), C.c_int(world), uid.ctypes.data_as(C.c_void_p), C.c_int(device), C.byref(self.comm))
-        if rc != 0:
-            raise RuntimeError("vslam_comm_init: %d %s" % (rc, lib.vslam_comm_last_error().decode()))
+        why = "" if rc == 0 else lib.vslam_comm_last_error().decode()
+        if not all_ranks_ok(rc == 0, group):     # ncclCommInitRank returned everywhere: one more agreement, so that all ranks raise together
+            if rc == 0:
+                lib.vslam_comm_destroy(self.comm)
+                self.comm = None
+            raise RuntimeError("vslam_comm_init failed on %s%s" % ("this rank: %d " % rc if rc != 0 else "another rank", why))
 
     def allgather(self, send):
         """send: contiguous float64 CUDA tensor; returns [world * send.shape[0], ...] ordered by rank (synchronised)."""
