@@ -4,7 +4,7 @@ A second, independent statement of what PoseTracker3D does with a DepthFramePoin
 (slam_assembly.cpp `_createDepthTracker`; pose_tracker_3d.cpp:32-566; depth_framepoint_generator.cpp:24-407;
 uvd_aligner.cpp:11-69), written over an object with the CApi interface: run over the CPU oracle it is the checker for the
 product's C++ loop (csrc/rgbd_tracker.h behind vslam_rgbd_*), run over libvslam_hip.so it chains the device kernels exactly
-as that loop does.  Detector grid 1 x 1 (all RGB-D configurations of the reference).
+as that loop does.  Detector grids of any shape (configuration_icl.yaml runs 2 x 2, tum and xtion 1 x 1).
 
 Reference behaviour restated here (file:line relative to the reference root):
   * initialize() ignores `extract_features`: every re-registration detects again with the thresholds the controller has
@@ -100,8 +100,25 @@ class RgbdTracker(object):
         self.prior = np.hstack([np.eye(3), np.zeros((3, 1))])
         self.win = cfg.maximum_projection_tracking_distance_pixels
         self.tau_track = cfg.minimum_descriptor_distance_tracking
-        self.thr = cfg.detector_threshold_minimum
         self.target = (cfg.cols // cfg.bin_size_pixels + 1) * (cfg.rows // cfg.bin_size_pixels + 1)
+        # BaseFramePointGenerator::configure (base_framepoint_generator.cpp:229-312): the detector regions (A.1 of SURVEY.md)
+        nv, nh = cfg.det_rows, cfg.det_cols
+        ph, pw = cfg.rows / nv, cfg.cols / nh
+        self.regions = []
+        for r in range(nv):
+            for cc in range(nh):
+                off_w, off_h, off_r, off_c = (2 if nh > 1 else 0), (2 if nv > 1 else 0), 0, 0
+                if r > 0:
+                    off_r = -off_h
+                    if r < nv - 1:
+                        off_h *= 2
+                if cc > 0:
+                    off_c = -off_w
+                    if cc < nh - 1:
+                        off_w *= 2
+                self.regions.append((int(math.floor(cc * pw + 0.5)) + off_c, int(math.floor(r * ph + 0.5)) + off_r, int(pw + off_w), int(ph + off_h)))
+        self.thr = [cfg.detector_threshold_minimum] * len(self.regions)
+        self.per_detector = int(float(self.target) / len(self.regions))
         self.world = np.hstack([np.eye(3), np.zeros((3, 1))])
         self.frames, self.landmarks, self.lost = [], [], []
         self.n_lm_prev = 0
@@ -113,15 +130,20 @@ class RgbdTracker(object):
     def initialize(self, left, depth):
         api, c = self.api, self.cfg
         self.space, _, _ = api.depth_space_map(self.p, depth)
-        xy, _ = api.fast_detect(left, (0, 0, c.cols, c.rows), self.thr)
-        n = len(xy)
-        t = float(self.thr)                                 # detectKeypoints' controller, one region (base_framepoint_generator.cpp:382-415)
-        delta = (float(n) - self.target) / self.target
-        if delta < -c.target_number_of_keypoints_tolerance:
-            t = t + min(max(delta, -c.detector_threshold_maximum_change) * t, -1.0); t = max(t, float(c.detector_threshold_minimum))
-        elif delta > c.target_number_of_keypoints_tolerance:
-            t = t + max(min(delta, c.detector_threshold_maximum_change) * t, 1.0); t = min(t, float(c.detector_threshold_maximum))
-        self.thr = int(np.rint(t / 1))                      # adjustDetectorThresholds over ONE detection (:440-459)
+        parts = []
+        for r, (rx, ry, rw, rh) in enumerate(self.regions):     # detectKeypoints: region-major, per-region threshold and controller
+            pxy, _ = api.fast_detect(left, (rx, ry, rw, rh), self.thr[r])
+            n = len(pxy)
+            if n:
+                parts.append(pxy.astype(np.int32) + np.array([rx, ry], np.int32))
+            t = float(self.thr[r])                              # base_framepoint_generator.cpp:382-415
+            delta = (float(n) - self.per_detector) / self.per_detector
+            if delta < -c.target_number_of_keypoints_tolerance:
+                t = t + min(max(delta, -c.detector_threshold_maximum_change) * t, -1.0); t = max(t, float(c.detector_threshold_minimum))
+            elif delta > c.target_number_of_keypoints_tolerance:
+                t = t + max(min(delta, c.detector_threshold_maximum_change) * t, 1.0); t = min(t, float(c.detector_threshold_maximum))
+            self.thr[r] = int(np.rint(t / 1))                   # adjustDetectorThresholds over ONE detection (:440-459)
+        xy = (np.concatenate(parts) if parts else np.zeros((0, 2), np.int32)).astype(np.int16)
         keep, desc = (api.orb_describe(left, xy, -1.0) if self.p.descriptor_type == 1 else api.brief_describe(left, xy))
         sel = keep.astype(bool)
         self.feat_xy = xy[sel].astype(np.int32); self.feat_desc = desc[sel]
@@ -371,6 +393,6 @@ class RgbdTracker(object):
         n_new, n_temp_new = self.compute(cur)
         self.n_lm_prev = self.n_active
         info.update(status=self.status, n_keypoints=self.n_detected, n_active_landmarks=self.n_active, n_new=n_new, n_points=len(cur.points),
-                    n_temporary=len(cur.temps), threshold=self.thr, window_pixels=self.win, tau_track=self.tau_track, pose=cur.c2w.copy(),
+                    n_temporary=len(cur.temps), threshold=self.thr[0], thresholds=list(self.thr), window_pixels=self.win, tau_track=self.tau_track, pose=cur.c2w.copy(),
                     prior=self.prior.copy())
         return info

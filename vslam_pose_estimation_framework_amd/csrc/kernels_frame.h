@@ -242,16 +242,29 @@ __device__ __forceinline__ void candidates_wave(const DevCfg& c, const DevBuf& b
   __builtin_amdgcn_wave_barrier();
 }
 
+// XCD-aware labels for (blocks-per-stream, streams) grids: workgroups are dealt round-robin over the 8 XCDs, so with the plain
+// grid the blocks of ONE stream land on all eight and every L2 fetches that stream's descriptors, keypoints and row / cell CSR.
+// Re-labelled, the gridDim.x blocks of stream s all run on XCD s mod 8 — the XCD its frame workgroup (block s of k_frame) and
+// its two k_emit workgroups run on, whose L2 then already holds / will want the same lines.  Speed only, never correctness.
+__device__ __forceinline__ void xcd_stream_block(int* bx, int* sy) {
+  const int gx = gridDim.x, ns = gridDim.y;
+  const int lin = blockIdx.y * gx + blockIdx.x, per = (ns >> 3) * gx;      // blocks per XCD among the first 8 * (ns / 8) streams
+  *bx = blockIdx.x; *sy = blockIdx.y;
+  if (lin < (per << 3)) { const int x = lin & 7, j = lin >> 3, q = j / gx; *sy = x + 8 * q; *bx = j - q * gx; }
+}
+
 __global__ __launch_bounds__(256, 8) void k_track_candidates(const DevCfg c, const DevBuf b, int mode) {
   // mode < 0: fused path (appearance iff the tracker is Localizing, window forced to max in that case);
   // mode 0/1: stage path, window and distance exactly as set through vslam_set_tracker_state
   __shared__ CandWave cw[256 / VS_CGL];
-  const int s = b.s0 + blockIdx.y;
+  int bx, sy;
+  xcd_stream_block(&bx, &sy);
+  const int s = b.s0 + sy;
   if (!vs_active(b, s)) return;
   const StreamState& st = b.st[s];
   if (!st.has_prev) return;
   const int lane = threadIdx.x % VS_CGL, w = threadIdx.x / VS_CGL;
-  const int wave = blockIdx.x * (256 / VS_CGL) + w, nwaves = gridDim.x * (256 / VS_CGL);
+  const int wave = bx * (256 / VS_CGL) + w, nwaves = gridDim.x * (256 / VS_CGL);
   const int pb_prev = st.cur;  // the previous frame's points: buffer that was current last frame
   const int P = b.n_points[s * 2 + pb_prev];
   const int by_app = mode < 0 ? (st.status == VSLAM_LOCALIZING) : mode;

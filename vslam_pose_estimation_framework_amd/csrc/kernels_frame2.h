@@ -337,11 +337,13 @@ __device__ __forceinline__ void wg_recover(const DevCfg& c, const DevBuf& b, int
 
 // fused path: BRIEF of the projected lost points of ALL streams, one wavefront each
 __global__ __launch_bounds__(256) void k_recover_brief(const DevCfg c, const DevBuf b) {
-  const int s = b.s0 + blockIdx.y;
+  int bx, sy;
+  xcd_stream_block(&bx, &sy);
+  const int s = b.s0 + sy;
   if (!vs_active(b, s)) return;
   const StreamState& st = b.st[s];
   const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  const int wave = bx * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
   const int nl = st.fc.n_lost;
   if (c.c.descriptor_type == VSLAM_DESCRIPTOR_ORB) {
     const OrbTaps taps = orb_taps(lane, c.orb_cos, c.orb_sin, c.bstride);
@@ -961,9 +963,11 @@ __device__ __forceinline__ void wg_stereo(const DevCfg& c, const DevBuf& b, int 
 // L-R Hamming distances of the first epipolar pass for every left feature of every stream (image pipeline): the window
 // wg_stereo's step A reads.  One thread per left feature.
 __global__ __launch_bounds__(256) void k_stereo_dist(const DevCfg c, const DevBuf b) {
-  const int s = b.s0 + blockIdx.y;
+  int bx, sy;
+  xcd_stream_block(&bx, &sy);
+  const int s = b.s0 + sy;
   if (!vs_active(b, s)) return;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = bx * blockDim.x + threadIdx.x;
   const int nL = b.n_kp[s * 2];
   if (i >= nL) return;
   const int16_t* kxyL = kpxy_of(c, b, s, 0);

@@ -75,15 +75,19 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* sh, int* total) 
 // tile with a 4 px halo (FAST ring 3 + NMS 1 == box radius 4) is staged once in LDS.
 // HBM traffic per pixel: 1 B read, 2 B box write, 1/8 B mask write, sparse scores.
 // ==============================================================================================
-// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (block b and b+8 share an L2), so the
-// linear block id is re-labelled such that CONSECUTIVE tiles (x fastest, then y, then image) run on the same XCD
-// and the halo lines neighbouring tiles share are fetched into one L2 only.  Speed only, never correctness.
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (block b and b+8 share an L2), so the linear block id
+// is re-labelled such that (1) CONSECUTIVE tiles (x fastest, then y, then side) run on the same XCD — the halo lines neighbouring
+// tiles share are fetched into one L2 only — and (2) ALL tiles of stream s run on XCD s mod 8, the XCD of the stream's k_emit
+// workgroups, of its candidate / distance blocks (xcd_stream_block) and of its frame workgroup: what one kernel of the step
+// leaves in that L2 (corner masks, keypoints, row / cell CSR, descriptors) is what the next one reads.  gridDim.z = 2 * streams
+// (z = 2 * stream + side).  Speed only, never correctness.
 __device__ __forceinline__ void xcd_tile(int* tx, int* ty, int* tz) {
   const int gx = gridDim.x, gy = gridDim.y;
-  const int total = gx * gy * gridDim.z;
+  const int tps = gx * gy * 2;                          // tiles of one stream (both images)
+  const int ns = gridDim.z >> 1;
   int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-  const int per = total >> 3;
-  if (lin < (per << 3)) lin = (lin & 7) * per + (lin >> 3);
+  const int per = (ns >> 3) * tps;                      // tiles per XCD among the first 8 * (ns / 8) streams
+  if (lin < (per << 3)) { const int x = lin & 7, j = lin >> 3, q = j / tps; lin = (x + 8 * q) * tps + (j - q * tps); }
   *tx = lin % gx;
   const int r = lin / gx;
   *ty = r % gy;

@@ -4,7 +4,8 @@
 // run here in C++, every data-parallel step is one of the library's own device entry points (vslam_depth_space_map /
 // _compute / _track / _recover, vslam_fast_detect, vslam_brief_describe | vslam_orb_describe, vslam_align_points_uvd,
 // vslam_landmark_update, vslam_point_in_camera).  A fused device version is the follow-up; this one exists so that the
-// icl / tum / xtion configurations run end to end and can be checked frame by frame.  Detector grid 1 x 1 (all three).
+// icl / tum / xtion configurations run end to end and can be checked frame by frame.  Detector grids of any shape (configuration_icl.yaml:57-58 runs 2 x 2; tum and
+// xtion 1 x 1): one FAST detection, one threshold and one controller per region, keypoints in region-major order.
 //
 // Reference behaviour kept (DESIGN.md "RGB-D mode" lists the citations): initialize() detects and runs the controller on
 // EVERY call (also on re-registration); temporary points are not cleared between re-registrations; hasUnreliableDepth is
@@ -65,7 +66,7 @@ public:
 
   int create(const vslam_config& c, const vslam_depth_params& dp, int device) {
     cfg = c; p = dp;
-    if (cfg.det_rows != 1 || cfg.det_cols != 1) { err = "RGB-D mode: detector grid 1 x 1 only"; return VSLAM_ERR_INVALID; }
+    if (cfg.det_rows < 1 || cfg.det_cols < 1 || cfg.det_rows * cfg.det_cols > VSLAM_MAX_REGIONS) { err = "RGB-D mode: bad detector grid"; return VSLAM_ERR_INVALID; }
     if (p.rows != cfg.rows || p.cols != cfg.cols) { err = "RGB-D mode: depth parameters and configuration disagree on the image size"; return VSLAM_ERR_INVALID; }
     int rc = vslam_create(&cfg, device, 1, &ctx);
     if (rc != VSLAM_OK) { err = vslam_last_error(nullptr); return rc; }
@@ -75,8 +76,22 @@ public:
   ~Tracker() { if (ctx) vslam_destroy(ctx); }
   void reset() {
     status = VSLAM_LOCALIZING; tf_id(prior); tf_id(world); win = cfg.maximum_projection_tracking_distance_pixels;
-    tau_track = cfg.minimum_descriptor_distance_tracking; thr = cfg.detector_threshold_minimum;
+    tau_track = cfg.minimum_descriptor_distance_tracking;
     target = (cfg.cols / cfg.bin_size_pixels + 1) * (cfg.rows / cfg.bin_size_pixels + 1);
+    // BaseFramePointGenerator::configure (base_framepoint_generator.cpp:229-312): detector regions with their overlaps, one
+    // threshold per region starting at the minimum, the per-region keypoint target
+    regions.clear();
+    const int nv = cfg.det_rows, nh = cfg.det_cols;
+    const double ph = (double)cfg.rows / nv, pw = (double)cfg.cols / nh;
+    for (int r = 0; r < nv; ++r)
+      for (int c = 0; c < nh; ++c) {
+        int off_w = nh > 1 ? 2 : 0, off_h = nv > 1 ? 2 : 0, off_r = 0, off_c = 0;
+        if (r > 0) { off_r = -off_h; if (r < nv - 1) off_h *= 2; }
+        if (c > 0) { off_c = -off_w; if (c < nh - 1) off_w *= 2; }
+        regions.push_back({(int)(std::round(c * pw) + off_c), (int)(std::round(r * ph) + off_r), (int)(pw + off_w), (int)(ph + off_h)});
+      }
+    thr.assign(regions.size(), cfg.detector_threshold_minimum);
+    target_per_detector = (int)((double)target / (double)regions.size());
     pool.clear(); lms.clear(); frames.clear(); lost.clear(); weights.clear(); n_lm_prev = 0;
     std::memset(&info, 0, sizeof info);
   }
@@ -125,10 +140,11 @@ public:
     if (rc) return rc;
     n_lm_prev = n_active;
     info.frame_index = fi + 1; info.status = status; info.n_keypoints_left = n_detected; info.n_detected_left = n_raw;
-    info.thresholds[0] = thr; info.track_attempts = attempts; info.n_active_landmarks = n_active; info.n_points = (int)frames[fi].points.size();
+    for (size_t r = 0; r < thr.size(); ++r) info.thresholds[r] = thr[r];
+    info.track_attempts = attempts; info.n_active_landmarks = n_active; info.n_points = (int)frames[fi].points.size();
     info.window_pixels = win; info.tau_track = tau_track;
     std::memcpy(info.camera_left_to_world, frames[fi].c2w, 96); std::memcpy(info.previous_to_current, prior, 96);
-    n_temporary = (int)frames[fi].temps.size(); threshold = thr;
+    n_temporary = (int)frames[fi].temps.size(); threshold = thr[0];
     return VSLAM_OK;
   }
 
@@ -145,7 +161,10 @@ public:
   }
 
 private:
-  int status = VSLAM_LOCALIZING, win = 0, thr = 0, target = 0, n_lm_prev = 0, n_tracked = 0, n_tracked_lm = 0, n_active = 0, n_detected = 0, n_raw = 0, attempts = 0;
+  struct Region { int x, y, w, h; };
+  std::vector<Region> regions; std::vector<int> thr;   // _detector_regions, the FastDetector thresholds in effect
+  int target_per_detector = 0;
+  int status = VSLAM_LOCALIZING, win = 0, target = 0, n_lm_prev = 0, n_tracked = 0, n_tracked_lm = 0, n_active = 0, n_detected = 0, n_raw = 0, attempts = 0;
   double tau_track = 0, prior[12], world[12];
   std::vector<Pt> pool; std::vector<Lm> lms; std::vector<Fr> frames; std::vector<int> lost;
   std::vector<double> weights;          // UVDAligner::_weights_translation: a member, resize(n, 1) keeps what it holds (uvd_aligner.cpp:22)
@@ -185,17 +204,26 @@ private:
     const int cap = 65535;
     std::vector<int16_t> xy((size_t)cap * 2); std::vector<int32_t> score(cap);
     int32_t n = 0;
-    rc = vslam_fast_detect(ctx, img, cfg.rows, cfg.cols, img_stride, 0, 0, cfg.cols, cfg.rows, thr, cap, &n, xy.data(), score.data());
-    if (rc) return fail(rc, "fast_detect");
-    n_raw = n;
-    double t = (double)thr;   // detectKeypoints' controller (base_framepoint_generator.cpp:382-415), adjust over one detection (:440-459)
-    const double delta = ((double)n - target) / target;
-    if (delta < -cfg.target_number_of_keypoints_tolerance) {
-      t += std::min(std::max(delta, -cfg.detector_threshold_maximum_change) * t, -1.0); t = std::max(t, (double)cfg.detector_threshold_minimum);
-    } else if (delta > cfg.target_number_of_keypoints_tolerance) {
-      t += std::max(std::min(delta, cfg.detector_threshold_maximum_change) * t, 1.0); t = std::min(t, (double)cfg.detector_threshold_maximum);
+    // detectKeypoints (base_framepoint_generator.cpp:355-429): region by region (row-major over the grid) with the region's own
+    // threshold, its controller against the per-region target, coordinates shifted by the region's corner, lists concatenated;
+    // adjustDetectorThresholds (:440-459) over ONE detection per frame: the new threshold is rint of the controller's value
+    for (size_t r = 0; r < regions.size(); ++r) {
+      const Region& R = regions[r];
+      int32_t nr = 0;
+      rc = vslam_fast_detect(ctx, img, cfg.rows, cfg.cols, img_stride, R.x, R.y, R.w, R.h, thr[r], cap - n, &nr, xy.data() + 2 * (size_t)n, score.data() + n);
+      if (rc) return fail(rc, "fast_detect");
+      for (int i = n; i < n + nr; ++i) { xy[2 * i] = (int16_t)(xy[2 * i] + R.x); xy[2 * i + 1] = (int16_t)(xy[2 * i + 1] + R.y); }
+      double t = (double)thr[r];
+      const double delta = ((double)nr - target_per_detector) / target_per_detector;
+      if (delta < -cfg.target_number_of_keypoints_tolerance) {
+        t += std::min(std::max(delta, -cfg.detector_threshold_maximum_change) * t, -1.0); t = std::max(t, (double)cfg.detector_threshold_minimum);
+      } else if (delta > cfg.target_number_of_keypoints_tolerance) {
+        t += std::max(std::min(delta, cfg.detector_threshold_maximum_change) * t, 1.0); t = std::min(t, (double)cfg.detector_threshold_maximum);
+      }
+      thr[r] = (int)std::rint(t / 1);
+      n += nr;
     }
-    thr = (int)std::rint(t / 1);
+    n_raw = n;
     std::vector<uint8_t> keep(std::max(n, 1)), desc((size_t)std::max(n, 1) * 32);
     rc = p.descriptor_type == VSLAM_DESCRIPTOR_ORB ? vslam_orb_describe(ctx, img, cfg.rows, cfg.cols, img_stride, n, xy.data(), -1.f, keep.data(), desc.data())
                                                    : vslam_brief_describe(ctx, img, cfg.rows, cfg.cols, img_stride, n, xy.data(), keep.data(), desc.data());

@@ -63,6 +63,10 @@ struct vslam_ctx {
   // five times per frame
   struct Scratch { vslam_ctx* t; vslam_config cfg; bool busy; size_t base_allocs; };
   std::vector<Scratch> scratch;
+  // per-call device scratch of the stand-alone entry points: blocks kept between calls and handed out by bumping an offset
+  // (tmp_get / tmp_reset below) — hipMalloc and hipFree cost tens of microseconds each, hipFree synchronises the device, and the
+  // host-driven RGB-D loop would pay ~60 of them per frame
+  struct Tmp { std::vector<std::pair<char*, size_t>> blocks; size_t used = 0; } tmp;
   int split = 0;   // 0: one frame launch; 1: three phase launches with wide recovery / landmark kernels in between (measured slower);
                    // 2: two phase launches around the wide recovery kernel (faster for few streams: VS_SPLIT2_MAX_STREAMS)
   int sticky = VSLAM_OK;
@@ -85,6 +89,43 @@ static hipError_t dalloc(vslam_ctx* c, T** p, size_t count) {
   hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
   if (e == hipSuccess) { c->allocs.push_back(q); *p = (T*)q; }
   return e;
+}
+
+// ---- per-call device scratch ------------------------------------------------------------------------------
+static hipError_t tmp_get(vslam_ctx* c, void** p, size_t bytes) {
+  bytes = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+  auto& T = c->tmp;
+  if (T.blocks.empty() || T.used + bytes > T.blocks.back().second) {
+    const size_t want = std::max<size_t>(bytes, T.blocks.empty() ? ((size_t)1 << 20) : 2 * T.blocks.back().second);
+    void* q = nullptr;
+    const hipError_t e = hipMalloc(&q, want);
+    if (e != hipSuccess) return e;
+    T.blocks.push_back({(char*)q, want});
+    T.used = 0;
+  }
+  *p = T.blocks.back().first + T.used;
+  T.used += bytes;
+  return hipSuccess;
+}
+template <typename T>
+static hipError_t tmp_alloc(vslam_ctx* c, T** p, size_t count) { return tmp_get(c, (void**)p, count * sizeof(T)); }
+// start of an entry point: everything handed out before is dead (every entry synchronises before it returns its results); blocks that
+// had to be chained during a call are merged into one, so that a steady caller allocates nothing
+static void tmp_reset(vslam_ctx* c) {
+  if (!c) return;
+  auto& T = c->tmp;
+  if (T.blocks.size() > 1) {
+    size_t total = 0;
+    for (auto& b : T.blocks) { total += b.second; (void)hipFree(b.first); }
+    T.blocks.clear();
+    void* q = nullptr;
+    if (hipMalloc(&q, total) == hipSuccess) T.blocks.push_back({(char*)q, total});
+  }
+  T.used = 0;
+}
+static void tmp_free(vslam_ctx* c) {
+  for (auto& b : c->tmp.blocks) (void)hipFree(b.first);
+  c->tmp.blocks.clear(); c->tmp.used = 0;
 }
 
 // ---- optional per-kernel timing (HIP events on the context stream) -----------------------------------
@@ -469,6 +510,7 @@ VS_API void vslam_destroy(vslam_ctx* c) {
   for (auto& e : c->scratch) vslam_destroy(e.t);
   c->scratch.clear();
   for (void* p : c->allocs) (void)hipFree(p);
+  tmp_free(c);
   depth_map_free(c);
   for (int i = 0; i < 6; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   harvest_events(c);
@@ -837,6 +879,7 @@ VS_API int vslam_get_aligner_weights(vslam_ctx* c, int s, int32_t cap, int32_t* 
   return VSLAM_OK;
 }
 VS_API int vslam_aligner_weights(vslam_ctx* c, int32_t n_calls, const int32_t* n, const int32_t* inverse_depth, const double* depth, double* out) {
+  tmp_reset(c);
   if (!c) return VSLAM_ERR_INVALID;
   if (c->sticky != VSLAM_OK) return c->sticky;
   if (n_calls < 0 || (n_calls && (!n || !inverse_depth))) return fail(c, VSLAM_ERR_INVALID, "aligner_weights: bad argument");
@@ -846,11 +889,11 @@ VS_API int vslam_aligner_weights(vslam_ctx* c, int32_t n_calls, const int32_t* n
   if (!n_calls || !total) return VSLAM_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   int32_t *dn = nullptr, *di = nullptr; double *dd = nullptr, *dw = nullptr, *dout = nullptr;
-  hipError_t e = hipMalloc((void**)&dn, (size_t)n_calls * 4);
-  if (e == hipSuccess) e = hipMalloc((void**)&di, (size_t)n_calls * 4);
-  if (e == hipSuccess) e = hipMalloc((void**)&dd, total * 8);
-  if (e == hipSuccess) e = hipMalloc((void**)&dw, (size_t)nmax * 8);
-  if (e == hipSuccess) e = hipMalloc((void**)&dout, total * 8);
+  hipError_t e = tmp_get(c, (void**)&dn, (size_t)n_calls * 4);
+  if (e == hipSuccess) e = tmp_get(c, (void**)&di, (size_t)n_calls * 4);
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dd, total * 8);
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dw, (size_t)nmax * 8);
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dout, total * 8);
   if (e == hipSuccess) e = hipMemcpyAsync(dn, n, (size_t)n_calls * 4, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(di, inverse_depth, (size_t)n_calls * 4, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(dd, depth, total * 8, hipMemcpyHostToDevice, c->stream);
@@ -859,7 +902,6 @@ VS_API int vslam_aligner_weights(vslam_ctx* c, int32_t n_calls, const int32_t* n
     e = hipMemcpyAsync(out, dout, total * 8, hipMemcpyDeviceToHost, c->stream);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  (void)hipFree(dn); (void)hipFree(di); (void)hipFree(dd); (void)hipFree(dw); (void)hipFree(dout);
   if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   return VSLAM_OK;
 }
@@ -915,6 +957,7 @@ VS_API int vslam_depth_space_map(vslam_ctx* c, const vslam_depth_params* p, cons
 VS_API int vslam_depth_compute(vslam_ctx* c, const vslam_depth_params* p, const float* space, int32_t nF, const int32_t* rcF, int32_t nT,
                                const int32_t* rcT, int32_t cap, int32_t* n_new, int32_t* new_feat, double* new_xyz, int32_t* n_temp,
                                int32_t* temp_feat, double* temp_xyz) {
+  tmp_reset(c);
   int rc = depth_params_ok(c, p);
   if (rc != VSLAM_OK) return rc;
   if (nF < 0 || nT < 0 || cap < 0 || !n_new || !n_temp || (nF && !rcF) || (nT && !rcT) || (cap && (!new_feat || !new_xyz || !temp_feat || !temp_xyz)))
@@ -931,16 +974,16 @@ VS_API int vslam_depth_compute(vslam_ctx* c, const vslam_depth_params* p, const 
   double *dnx = nullptr, *dtx = nullptr; unsigned long long* dbins = nullptr; uint8_t* dcls = nullptr;
   const size_t capa = std::max(cap, 1);
   hipError_t e = hipSuccess;
-  if (space) { e = hipMalloc((void**)&dspace, n * 3 * sizeof(float)); if (e == hipSuccess) e = hipMemcpyAsync(dspace, space, n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream); }
-  if (e == hipSuccess) e = hipMalloc((void**)&dF, std::max(nF, 1) * 2 * sizeof(int32_t));
-  if (e == hipSuccess) e = hipMalloc((void**)&dT, std::max(nT, 1) * 2 * sizeof(int32_t));
-  if (e == hipSuccess) e = hipMalloc((void**)&dcnt, 2 * sizeof(int32_t));
-  if (e == hipSuccess) e = hipMalloc((void**)&dnf, capa * sizeof(int32_t));
-  if (e == hipSuccess) e = hipMalloc((void**)&dtf, capa * sizeof(int32_t));
-  if (e == hipSuccess) e = hipMalloc((void**)&dnx, capa * 3 * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc((void**)&dtx, capa * 3 * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc((void**)&dbins, (size_t)n_bins * sizeof(unsigned long long));
-  if (e == hipSuccess) e = hipMalloc((void**)&dcls, std::max(nF, 1));
+  if (space) { e = tmp_get(c, (void**)&dspace, n * 3 * sizeof(float)); if (e == hipSuccess) e = hipMemcpyAsync(dspace, space, n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream); }
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dF, std::max(nF, 1) * 2 * sizeof(int32_t));
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dT, std::max(nT, 1) * 2 * sizeof(int32_t));
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dcnt, 2 * sizeof(int32_t));
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dnf, capa * sizeof(int32_t));
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dtf, capa * sizeof(int32_t));
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dnx, capa * 3 * sizeof(double));
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dtx, capa * 3 * sizeof(double));
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dbins, (size_t)n_bins * sizeof(unsigned long long));
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dcls, std::max(nF, 1));
   if (e == hipSuccess && nF) e = hipMemcpyAsync(dF, rcF, (size_t)nF * 2 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess && nT) e = hipMemcpyAsync(dT, rcT, (size_t)nT * 2 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
   int32_t cnt[2] = {0, 0};
@@ -957,8 +1000,7 @@ VS_API int vslam_depth_compute(vslam_ctx* c, const vslam_depth_params* p, const 
     if (a) { e = hipMemcpy(new_feat, dnf, (size_t)a * sizeof(int32_t), hipMemcpyDeviceToHost); if (e == hipSuccess) e = hipMemcpy(new_xyz, dnx, (size_t)a * 3 * sizeof(double), hipMemcpyDeviceToHost); }
     if (e == hipSuccess && b) { e = hipMemcpy(temp_feat, dtf, (size_t)b * sizeof(int32_t), hipMemcpyDeviceToHost); if (e == hipSuccess) e = hipMemcpy(temp_xyz, dtx, (size_t)b * 3 * sizeof(double), hipMemcpyDeviceToHost); }
   }
-  (void)hipFree(dspace); (void)hipFree(dF); (void)hipFree(dT); (void)hipFree(dcnt); (void)hipFree(dnf); (void)hipFree(dtf);
-  (void)hipFree(dnx); (void)hipFree(dtx); (void)hipFree(dbins); (void)hipFree(dcls);
+
   if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   if (cnt[0] > cap || cnt[1] > cap) return fail(c, VSLAM_ERR_CAPACITY, "depth_compute: output capacity too small");
   return VSLAM_OK;
@@ -967,6 +1009,7 @@ VS_API int vslam_depth_track(vslam_ctx* c, const vslam_depth_params* p, const fl
                              int32_t by_appearance, int32_t nP, const double* cam, const uint8_t* pdesc, const uint8_t* pflags, int32_t nL,
                              const int32_t* rcL, const uint8_t* dL, int32_t* n_tracked, int32_t* out2, double* xyz, int32_t* n_temp,
                              int32_t* temp2, int32_t* n_lost, int32_t* lost, int32_t* n_tracked_landmarks) {
+  tmp_reset(c);
   int rc = depth_params_ok(c, p);
   if (rc != VSLAM_OK) return rc;
   if (!T || d < 0 || nP < 0 || nL < 0 || !n_tracked || !n_temp || !n_lost || !n_tracked_landmarks || (nP && (!cam || !pdesc || !pflags || !out2 || !xyz || !temp2 || !lost)) ||
@@ -1002,21 +1045,21 @@ VS_API int vslam_depth_track(vslam_ctx* c, const vslam_depth_params* p, const fl
   int32_t *drc = nullptr, *dhold = nullptr, *dpick = nullptr, *dcnt = nullptr, *dout2 = nullptr, *dtmp2 = nullptr, *dlost = nullptr;
   unsigned long long* dcand = nullptr;
   hipError_t e = hipSuccess;
-  if (space) { e = hipMalloc((void**)&dspace, n * 3 * sizeof(float)); if (e == hipSuccess) e = hipMemcpyAsync(dspace, space, n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream); }
-  if (e == hipSuccess) e = hipMalloc((void**)&dcand, P1 * (VS_DT_K + 1) * sizeof(unsigned long long));
-  if (e == hipSuccess) e = hipMalloc((void**)&dcam, P1 * 3 * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc((void**)&dxyz, P1 * 3 * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc((void**)&dpd, P1 * 32);
-  if (e == hipSuccess) e = hipMalloc((void**)&dpf, P1);
-  if (e == hipSuccess) e = hipMalloc((void**)&dds, L1 * 32);
-  if (e == hipSuccess) e = hipMalloc((void**)&dxy, L1 * 2 * sizeof(int16_t));
-  if (e == hipSuccess) e = hipMalloc((void**)&drc, rowcell.size() * sizeof(int32_t));
-  if (e == hipSuccess) e = hipMalloc((void**)&dhold, L1 * 2 * sizeof(int32_t));
-  if (e == hipSuccess) e = hipMalloc((void**)&dpick, P1 * sizeof(int32_t));
-  if (e == hipSuccess) e = hipMalloc((void**)&dcnt, 4 * sizeof(int32_t));
-  if (e == hipSuccess) e = hipMalloc((void**)&dout2, P1 * 2 * sizeof(int32_t));
-  if (e == hipSuccess) e = hipMalloc((void**)&dtmp2, P1 * 2 * sizeof(int32_t));
-  if (e == hipSuccess) e = hipMalloc((void**)&dlost, P1 * sizeof(int32_t));
+  if (space) { e = tmp_get(c, (void**)&dspace, n * 3 * sizeof(float)); if (e == hipSuccess) e = hipMemcpyAsync(dspace, space, n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream); }
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dcand, P1 * (VS_DT_K + 1) * sizeof(unsigned long long));
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dcam, P1 * 3 * sizeof(double));
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dxyz, P1 * 3 * sizeof(double));
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dpd, P1 * 32);
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dpf, P1);
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dds, L1 * 32);
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dxy, L1 * 2 * sizeof(int16_t));
+  if (e == hipSuccess) e = tmp_get(c, (void**)&drc, rowcell.size() * sizeof(int32_t));
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dhold, L1 * 2 * sizeof(int32_t));
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dpick, P1 * sizeof(int32_t));
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dcnt, 4 * sizeof(int32_t));
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dout2, P1 * 2 * sizeof(int32_t));
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dtmp2, P1 * 2 * sizeof(int32_t));
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dlost, P1 * sizeof(int32_t));
   if (e == hipSuccess && nP) e = hipMemcpyAsync(dcam, cam, (size_t)nP * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess && nP) e = hipMemcpyAsync(dpd, pdesc, (size_t)nP * 32, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess && nP) e = hipMemcpyAsync(dpf, pflags, (size_t)nP, hipMemcpyHostToDevice, c->stream);
@@ -1041,14 +1084,14 @@ VS_API int vslam_depth_track(vslam_ctx* c, const vslam_depth_params* p, const fl
     for (int u = 0; u < cnt[0]; ++u) out2[2 * u + 1] = ord[out2[2 * u + 1]];     // back to the caller's feature numbering
     for (int u = 0; u < cnt[1]; ++u) temp2[2 * u + 1] = ord[temp2[2 * u + 1]];
   }
-  (void)hipFree(dspace); (void)hipFree(dcam); (void)hipFree(dxyz); (void)hipFree(dpd); (void)hipFree(dpf); (void)hipFree(dds); (void)hipFree(dxy);
-  (void)hipFree(dcand); (void)hipFree(drc); (void)hipFree(dhold); (void)hipFree(dpick); (void)hipFree(dcnt); (void)hipFree(dout2); (void)hipFree(dtmp2); (void)hipFree(dlost);
+
   if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   return VSLAM_OK;
 }
 VS_API int vslam_depth_recover(vslam_ctx* c, const vslam_depth_params* p, const float* space, const uint8_t* img, int32_t row_stride,
                                const double w2c[12], int32_t n, const uint8_t* has_lm, const double* lm, const uint8_t* pdesc, float kp_size,
                                double tau, int32_t* n_rec, int32_t* rec_index, float* rec_xy, uint8_t* rec_desc, double* rec_xyz) {
+  tmp_reset(c);
   int rc = depth_params_ok(c, p);
   if (rc != VSLAM_OK) return rc;
   if (!img || !w2c || n < 0 || !n_rec || (n && (!has_lm || !lm || !pdesc || !rec_index || !rec_xy || !rec_desc || !rec_xyz)))
@@ -1068,20 +1111,20 @@ VS_API int vslam_depth_recover(vslam_ctx* c, const vslam_depth_params* p, const 
   float *dspace = nullptr, *dkxy = nullptr, *drxy = nullptr; double *dlm = nullptr, *drxyz = nullptr; uint8_t *dhl = nullptr, *dpd = nullptr, *dkeep = nullptr, *ddesc = nullptr, *drdesc = nullptr;
   int16_t* dbxy = nullptr; int32_t *dcell = nullptr, *dcnt = nullptr, *dridx = nullptr;
   hipError_t e = hipSuccess;
-  if (space) { e = dalloc(t, &dspace, npx * 3); if (e == hipSuccess) e = hipMemcpyAsync(dspace, space, npx * 3 * sizeof(float), hipMemcpyHostToDevice, t->stream_img); }
-  if (e == hipSuccess) e = dalloc(t, &dkxy, (size_t)n * 2);
-  if (e == hipSuccess) e = dalloc(t, &drxy, (size_t)n * 2);
-  if (e == hipSuccess) e = dalloc(t, &dlm, (size_t)n * 3);
-  if (e == hipSuccess) e = dalloc(t, &drxyz, (size_t)n * 3);
-  if (e == hipSuccess) e = dalloc(t, &dhl, (size_t)n);
-  if (e == hipSuccess) e = dalloc(t, &dpd, (size_t)n * 32);
-  if (e == hipSuccess) e = dalloc(t, &dkeep, (size_t)n);
-  if (e == hipSuccess) e = dalloc(t, &ddesc, (size_t)n * 32);
-  if (e == hipSuccess) e = dalloc(t, &drdesc, (size_t)n * 32);
-  if (e == hipSuccess) e = dalloc(t, &dbxy, (size_t)n * 2);
-  if (e == hipSuccess) e = dalloc(t, &dcell, (size_t)n);
-  if (e == hipSuccess) e = dalloc(t, &dcnt, 1);
-  if (e == hipSuccess) e = dalloc(t, &dridx, (size_t)n);
+  if (space) { e = tmp_alloc(c, &dspace, npx * 3); if (e == hipSuccess) e = hipMemcpyAsync(dspace, space, npx * 3 * sizeof(float), hipMemcpyHostToDevice, t->stream_img); }
+  if (e == hipSuccess) e = tmp_alloc(c, &dkxy, (size_t)n * 2);
+  if (e == hipSuccess) e = tmp_alloc(c, &drxy, (size_t)n * 2);
+  if (e == hipSuccess) e = tmp_alloc(c, &dlm, (size_t)n * 3);
+  if (e == hipSuccess) e = tmp_alloc(c, &drxyz, (size_t)n * 3);
+  if (e == hipSuccess) e = tmp_alloc(c, &dhl, (size_t)n);
+  if (e == hipSuccess) e = tmp_alloc(c, &dpd, (size_t)n * 32);
+  if (e == hipSuccess) e = tmp_alloc(c, &dkeep, (size_t)n);
+  if (e == hipSuccess) e = tmp_alloc(c, &ddesc, (size_t)n * 32);
+  if (e == hipSuccess) e = tmp_alloc(c, &drdesc, (size_t)n * 32);
+  if (e == hipSuccess) e = tmp_alloc(c, &dbxy, (size_t)n * 2);
+  if (e == hipSuccess) e = tmp_alloc(c, &dcell, (size_t)n);
+  if (e == hipSuccess) e = tmp_alloc(c, &dcnt, 1);
+  if (e == hipSuccess) e = tmp_alloc(c, &dridx, (size_t)n);
   if (e == hipSuccess) e = hipMemcpyAsync(dhl, has_lm, (size_t)n, hipMemcpyHostToDevice, t->stream_img);
   if (e == hipSuccess) e = hipMemcpyAsync(dlm, lm, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, t->stream_img);
   if (e == hipSuccess) e = hipMemcpyAsync(dpd, pdesc, (size_t)n * 32, hipMemcpyHostToDevice, t->stream_img);
@@ -1121,17 +1164,18 @@ VS_API int vslam_depth_recover(vslam_ctx* c, const vslam_depth_params* p, const 
   return rc;
 }
 VS_API int vslam_point_in_camera(vslam_ctx* c, int32_t n, const float* xp, const float* xc, const double T[12], const double K[9], double* out) {
+  tmp_reset(c);
   if (!c) return VSLAM_ERR_INVALID;
   if (c->sticky != VSLAM_OK) return c->sticky;
   if (n < 0 || !T || !K || (n && (!xp || !xc || !out))) return fail(c, VSLAM_ERR_INVALID, "point_in_camera: bad argument");
   if (n == 0) return VSLAM_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   float *dp = nullptr, *dc = nullptr; double *dT = nullptr, *dK = nullptr, *dout = nullptr;
-  hipError_t e = hipMalloc((void**)&dp, (size_t)n * 2 * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc((void**)&dc, (size_t)n * 2 * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc((void**)&dT, 12 * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc((void**)&dK, 9 * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc((void**)&dout, (size_t)n * 3 * sizeof(double));
+  hipError_t e = tmp_get(c, (void**)&dp, (size_t)n * 2 * sizeof(float));
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dc, (size_t)n * 2 * sizeof(float));
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dT, 12 * sizeof(double));
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dK, 9 * sizeof(double));
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dout, (size_t)n * 3 * sizeof(double));
   if (e == hipSuccess) e = hipMemcpyAsync(dp, xp, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(dc, xc, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(dT, T, 12 * sizeof(double), hipMemcpyHostToDevice, c->stream);
@@ -1141,13 +1185,13 @@ VS_API int vslam_point_in_camera(vslam_ctx* c, int32_t n, const float* xp, const
     e = hipMemcpyAsync(out, dout, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  (void)hipFree(dp); (void)hipFree(dc); (void)hipFree(dT); (void)hipFree(dK); (void)hipFree(dout);
   if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   return VSLAM_OK;
 }
 
 VS_API int vslam_landmark_update(vslam_ctx* c, int32_t n, const int32_t* offsets, const int32_t* frame_of, int32_t n_frames, const double* w2c,
                                  const double* c2w, const double* cam, double* world, int32_t* updates) {
+  tmp_reset(c);
   if (!c) return VSLAM_ERR_INVALID;
   if (c->sticky != VSLAM_OK) return c->sticky;
   if (n < 0 || n_frames < 0 || (n && (!offsets || !world || !updates))) return fail(c, VSLAM_ERR_INVALID, "landmark_update: bad argument");
@@ -1158,13 +1202,13 @@ VS_API int vslam_landmark_update(vslam_ctx* c, int32_t n, const int32_t* offsets
   for (int m = 0; m < M; ++m) if (frame_of[m] < 0 || frame_of[m] >= n_frames) return fail(c, VSLAM_ERR_INVALID, "landmark_update: frame index out of range");
   HIP_TRY(c, hipSetDevice(c->device));
   int32_t *doff = nullptr, *dfo = nullptr, *dup = nullptr; double *dw2c = nullptr, *dc2w = nullptr, *dcam = nullptr, *dworld = nullptr;
-  hipError_t e = hipMalloc((void**)&doff, (size_t)(n + 1) * 4);
-  if (e == hipSuccess) e = hipMalloc((void**)&dfo, std::max<size_t>(M, 1) * 4);
-  if (e == hipSuccess) e = hipMalloc((void**)&dup, (size_t)n * 4);
-  if (e == hipSuccess) e = hipMalloc((void**)&dw2c, std::max<size_t>(n_frames, 1) * 96);
-  if (e == hipSuccess) e = hipMalloc((void**)&dc2w, std::max<size_t>(n_frames, 1) * 96);
-  if (e == hipSuccess) e = hipMalloc((void**)&dcam, std::max<size_t>(M, 1) * 24);
-  if (e == hipSuccess) e = hipMalloc((void**)&dworld, (size_t)n * 24);
+  hipError_t e = tmp_get(c, (void**)&doff, (size_t)(n + 1) * 4);
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dfo, std::max<size_t>(M, 1) * 4);
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dup, (size_t)n * 4);
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dw2c, std::max<size_t>(n_frames, 1) * 96);
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dc2w, std::max<size_t>(n_frames, 1) * 96);
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dcam, std::max<size_t>(M, 1) * 24);
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dworld, (size_t)n * 24);
   if (e == hipSuccess) e = hipMemcpyAsync(doff, offsets, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess && M) e = hipMemcpyAsync(dfo, frame_of, (size_t)M * 4, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(dup, updates, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
@@ -1179,7 +1223,6 @@ VS_API int vslam_landmark_update(vslam_ctx* c, int32_t n, const int32_t* offsets
   }
   if (e == hipSuccess) e = hipMemcpyAsync(updates, dup, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  (void)hipFree(doff); (void)hipFree(dfo); (void)hipFree(dup); (void)hipFree(dw2c); (void)hipFree(dc2w); (void)hipFree(dcam); (void)hipFree(dworld);
   if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   return VSLAM_OK;
 }
@@ -1187,20 +1230,20 @@ VS_API int vslam_landmark_update(vslam_ctx* c, int32_t n, const int32_t* offsets
 // ---- OrbDetector components ---------------------------------------------------------------------------------------
 VS_API int vslam_resize_linear_u8(vslam_ctx* c, const uint8_t* src, int32_t rows, int32_t cols, int32_t row_stride, uint8_t* dst, int32_t drows,
                                   int32_t dcols) {
+  tmp_reset(c);
   if (!c) return VSLAM_ERR_INVALID;
   if (c->sticky != VSLAM_OK) return c->sticky;
   if (!src || !dst || rows < 2 || cols < 2 || drows < 1 || dcols < 1 || row_stride < cols) return fail(c, VSLAM_ERR_INVALID, "resize: bad argument");
   HIP_TRY(c, hipSetDevice(c->device));
   uint8_t *ds = nullptr, *dd = nullptr;
-  hipError_t e = hipMalloc((void**)&ds, (size_t)rows * row_stride);
-  if (e == hipSuccess) e = hipMalloc((void**)&dd, (size_t)drows * dcols);
+  hipError_t e = tmp_get(c, (void**)&ds, (size_t)rows * row_stride);
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dd, (size_t)drows * dcols);
   if (e == hipSuccess) e = hipMemcpyAsync(ds, src, (size_t)(rows - 1) * row_stride + cols, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_resize_linear_u8, dim3((dcols + 255) / 256, drows), dim3(256), 0, c->stream, ds, rows, cols, row_stride, dd, drows, dcols, dcols);
     e = hipMemcpyAsync(dst, dd, (size_t)drows * dcols, hipMemcpyDeviceToHost, c->stream);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  (void)hipFree(ds); (void)hipFree(dd);
   if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   return VSLAM_OK;
 }
@@ -1214,6 +1257,7 @@ static OrbUmax orb_umax_table(int half) {   // orb.cpp computeKeyPoints: row hal
 }
 VS_API int vslam_harris_angle(vslam_ctx* c, const uint8_t* img, int32_t rows, int32_t cols, int32_t row_stride, int32_t n, const int16_t* xy,
                               float* response, float* angle) {
+  tmp_reset(c);
   if (!c) return VSLAM_ERR_INVALID;
   if (c->sticky != VSLAM_OK) return c->sticky;
   if (!img || n < 0 || rows < 33 || cols < 33 || row_stride < cols || (n && (!xy || !response || !angle))) return fail(c, VSLAM_ERR_INVALID, "harris_angle: bad argument");
@@ -1222,11 +1266,11 @@ VS_API int vslam_harris_angle(vslam_ctx* c, const uint8_t* img, int32_t rows, in
   if (n == 0) return VSLAM_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   uint8_t* di = nullptr; int16_t* dxy = nullptr; float *dr = nullptr, *da = nullptr; int32_t* dn = nullptr;
-  hipError_t e = hipMalloc((void**)&di, (size_t)rows * row_stride);
-  if (e == hipSuccess) e = hipMalloc((void**)&dxy, (size_t)n * 4);
-  if (e == hipSuccess) e = hipMalloc((void**)&dr, (size_t)n * 4);
-  if (e == hipSuccess) e = hipMalloc((void**)&da, (size_t)n * 4);
-  if (e == hipSuccess) e = hipMalloc((void**)&dn, 4);
+  hipError_t e = tmp_get(c, (void**)&di, (size_t)rows * row_stride);
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dxy, (size_t)n * 4);
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dr, (size_t)n * 4);
+  if (e == hipSuccess) e = tmp_get(c, (void**)&da, (size_t)n * 4);
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dn, 4);
   if (e == hipSuccess) e = hipMemcpyAsync(di, img, (size_t)(rows - 1) * row_stride + cols, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(dxy, xy, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(dn, &n, 4, hipMemcpyHostToDevice, c->stream);
@@ -1239,7 +1283,6 @@ VS_API int vslam_harris_angle(vslam_ctx* c, const uint8_t* img, int32_t rows, in
   }
   if (e == hipSuccess) e = hipMemcpyAsync(angle, da, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  (void)hipFree(di); (void)hipFree(dxy); (void)hipFree(dr); (void)hipFree(da); (void)hipFree(dn);
   if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   return VSLAM_OK;
 }
@@ -1428,14 +1471,15 @@ VS_API int vslam_fast_detect(vslam_ctx* c, const uint8_t* img, int32_t rows, int
 }
 VS_API int vslam_brief_describe(vslam_ctx* c, const uint8_t* img, int32_t rows, int32_t cols, int32_t stride, int32_t n,
                                 const int16_t* xy, uint8_t* keep, uint8_t* desc) {
+  tmp_reset(c);
   if (!c || !img || !xy || !keep || !desc || n < 0) return VSLAM_ERR_INVALID;
   vslam_ctx* t = nullptr;
   int rc = make_scratch_ctx(c, rows, cols, 64, 64, &t);
   if (rc != VSLAM_OK) return rc;
   int16_t* dxy = nullptr; uint8_t* dkeep = nullptr; uint8_t* ddesc = nullptr;
-  hipError_t e = dalloc(t, &dxy, (size_t)n * 2);
-  if (e == hipSuccess) e = dalloc(t, &dkeep, (size_t)n);
-  if (e == hipSuccess) e = dalloc(t, &ddesc, (size_t)n * 32);
+  hipError_t e = tmp_alloc(c, &dxy, (size_t)n * 2);
+  if (e == hipSuccess) e = tmp_alloc(c, &dkeep, (size_t)n);
+  if (e == hipSuccess) e = tmp_alloc(c, &ddesc, (size_t)n * 32);
   if (e == hipSuccess && n) e = hipMemcpyAsync(dxy, xy, (size_t)n * 2 * sizeof(int16_t), hipMemcpyHostToDevice, t->stream_img);
   rc = e == hipSuccess ? upload_images(t, img, img, stride, 0) : fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   if (rc == VSLAM_OK && n) {
@@ -1453,8 +1497,8 @@ VS_API int vslam_brief_describe(vslam_ctx* c, const uint8_t* img, int32_t rows, 
 }
 // cv::ORB::create()->compute() pieces, stand-alone (known-answer tests)
 static int orb_blur_device(vslam_ctx* c, const uint8_t* img, int32_t rows, int32_t cols, int32_t stride, uint8_t** dimg, uint8_t** dblur) {
-  hipError_t e = hipMalloc((void**)dimg, (size_t)rows * stride);
-  if (e == hipSuccess) e = hipMalloc((void**)dblur, (size_t)rows * cols);
+  hipError_t e = tmp_get(c, (void**)dimg, (size_t)rows * stride);     // per-call scratch: the caller has reset the arena
+  if (e == hipSuccess) e = tmp_get(c, (void**)dblur, (size_t)rows * cols);
   if (e == hipSuccess) e = hipMemcpyAsync(*dimg, img, (size_t)(rows - 1) * stride + cols, hipMemcpyHostToDevice, c->stream);
   if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   Gauss7 gk; for (int i = 0; i < 4; ++i) gk.k[i] = c->cfg.gauss7[i];
@@ -1466,18 +1510,19 @@ VS_API int vslam_gaussian_blur7_u8(vslam_ctx* c, const uint8_t* img, int32_t row
   if (c->sticky != VSLAM_OK) return c->sticky;
   if (!img || !out || rows < 4 || cols < 4 || stride < cols) return fail(c, VSLAM_ERR_INVALID, "gaussian_blur7: bad argument");   // one reflection per border
   HIP_TRY(c, hipSetDevice(c->device));
+  tmp_reset(c);
   uint8_t *dimg = nullptr, *dblur = nullptr;
   int rc = orb_blur_device(c, img, rows, cols, stride, &dimg, &dblur);
   hipError_t e = hipSuccess;
   if (rc == VSLAM_OK) e = hipMemcpyAsync(out, dblur, (size_t)rows * cols, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  (void)hipFree(dimg); (void)hipFree(dblur);
   if (rc != VSLAM_OK) return rc;
   if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   return VSLAM_OK;
 }
 VS_API int vslam_orb_describe(vslam_ctx* c, const uint8_t* img, int32_t rows, int32_t cols, int32_t stride, int32_t n, const int16_t* xy,
                               float angle_degrees, uint8_t* keep, uint8_t* desc) {
+  tmp_reset(c);
   if (!c) return VSLAM_ERR_INVALID;
   if (c->sticky != VSLAM_OK) return c->sticky;
   if (!img || n < 0 || rows < 4 || cols < 4 || stride < cols || (n && (!xy || !keep || !desc))) return fail(c, VSLAM_ERR_INVALID, "orb_describe: bad argument");
@@ -1492,9 +1537,9 @@ VS_API int vslam_orb_describe(vslam_ctx* c, const uint8_t* img, int32_t rows, in
   int rc = orb_blur_device(c, img, rows, cols, stride, &dimg, &dblur);
   hipError_t e = hipSuccess;
   if (rc == VSLAM_OK) {
-    e = hipMalloc((void**)&dxy, (size_t)n * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&dkeep, (size_t)n);
-    if (e == hipSuccess) e = hipMalloc((void**)&ddesc, (size_t)n * 32);
+    e = tmp_get(c, (void**)&dxy, (size_t)n * 4);
+    if (e == hipSuccess) e = tmp_get(c, (void**)&dkeep, (size_t)n);
+    if (e == hipSuccess) e = tmp_get(c, (void**)&ddesc, (size_t)n * 32);
     if (e == hipSuccess) e = hipMemcpyAsync(dxy, xy, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
       float a, b;
@@ -1505,20 +1550,20 @@ VS_API int vslam_orb_describe(vslam_ctx* c, const uint8_t* img, int32_t rows, in
     if (e == hipSuccess) e = hipMemcpyAsync(desc, ddesc, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   }
-  (void)hipFree(dimg); (void)hipFree(dblur); (void)hipFree(dxy); (void)hipFree(dkeep); (void)hipFree(ddesc);
   if (rc != VSLAM_OK) return rc;
   if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   return VSLAM_OK;
 }
 VS_API int vslam_knn2(vslam_ctx* c, int norm, int32_t nq, const uint8_t* q, int32_t nt, const uint8_t* t, int32_t* idx, float* dist) {
+  tmp_reset(c);
   if (!c || !q || !t || !idx || !dist || nq < 0 || nt < 0 || norm < 0 || norm > 3) return VSLAM_ERR_INVALID;
   if (nq == 0) return VSLAM_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   uint8_t *dq = nullptr, *dt = nullptr; int32_t* di = nullptr; float* dd = nullptr;
-  hipError_t e = hipMalloc((void**)&dq, (size_t)nq * 32);
-  if (e == hipSuccess) e = hipMalloc((void**)&dt, std::max<size_t>((size_t)nt * 32, 32));
-  if (e == hipSuccess) e = hipMalloc((void**)&di, (size_t)nq * 2 * sizeof(int32_t));
-  if (e == hipSuccess) e = hipMalloc((void**)&dd, (size_t)nq * 2 * sizeof(float));
+  hipError_t e = tmp_get(c, (void**)&dq, (size_t)nq * 32);
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dt, std::max<size_t>((size_t)nt * 32, 32));
+  if (e == hipSuccess) e = tmp_get(c, (void**)&di, (size_t)nq * 2 * sizeof(int32_t));
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dd, (size_t)nq * 2 * sizeof(float));
   if (e == hipSuccess) e = hipMemcpyAsync(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess && nt) e = hipMemcpyAsync(dt, t, (size_t)nt * 32, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) {
@@ -1527,20 +1572,20 @@ VS_API int vslam_knn2(vslam_ctx* c, int norm, int32_t nq, const uint8_t* q, int3
   }
   if (e == hipSuccess) e = hipMemcpyAsync(dist, dd, (size_t)nq * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  (void)hipFree(dq); (void)hipFree(dt); (void)hipFree(di); (void)hipFree(dd);
   if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   return VSLAM_OK;
 }
 static int align_points_impl(vslam_ctx* c, bool uvd, int32_t n, const double* moving, const double* fixed4, const double* omega,
                              const double* weight, const double T_init[12], double T_out[12], double* chi, uint8_t* inlier,
                              int32_t* n_inliers, double* total_error, int32_t* iterations, double H_out[36]) {
+  tmp_reset(c);
   vslam_ctx* t = nullptr;
   vslam_config cfg = c->cfg.c;
   cfg.max_points = (std::max(64, n) + 1023) / 1024 * 1024; cfg.max_keypoints = 64; cfg.max_history_frames = 2;   // rounded: one pooled scratch context serves every call
   int rc = scratch_get(c, cfg, &t);
   if (rc != VSLAM_OK) return rc;
   double* dT = nullptr;
-  hipError_t e = dalloc(t, &dT, 12);
+  hipError_t e = tmp_alloc(c, &dT, 12);
   if (e == hipSuccess) e = hipMemcpyAsync(dT, T_init, 12 * sizeof(double), hipMemcpyHostToDevice, t->stream);
   if (e == hipSuccess && n) e = hipMemcpyAsync(t->buf.al_moving, moving, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, t->stream);
   if (e == hipSuccess && n) e = hipMemcpyAsync(t->buf.al_fixed, fixed4, (size_t)n * 4 * sizeof(double), hipMemcpyHostToDevice, t->stream);
