@@ -447,6 +447,23 @@ int vslam_point_in_camera(vslam_ctx* ctx, int32_t n, const float* xy_previous, c
  * (one reflection per border).
  * vslam_orb_describe: n integer keypoints xy with one angle for all (FAST: -1), keep[i] = 0 for removed keypoints. */
 int vslam_gaussian_blur7_u8(vslam_ctx* ctx, const uint8_t* image, int32_t rows, int32_t cols, int32_t row_stride, uint8_t* blurred);
+
+/* ---- the descriptor test pairs are DATA ------------------------------------------------------------------------------------
+ * BRIEF-32 and ORB each compare 256 fixed pixel pairs.  OpenCV's tables (xfeatures2d generated_32.i; features2d orb.cpp
+ * bit_pattern_31_) are not in the reference tree, so this library ships tables of its own (include/vslam_brief_pattern.h,
+ * vslam_orb_pattern.h): same construction, different numbers — descriptors are NOT bit-compatible with an OpenCV build until
+ * the caller passes OpenCV's tables in.  An integration that has them (shim/proslam_hip_plugin.h: HipContext::brief_pattern /
+ * orb_pattern) calls these once before the first frame; maps, relocalization data and Hamming thresholds tuned on OpenCV
+ * descriptors then keep their meaning.
+ *   BRIEF pair i = {y1, x1, y2, x2}: bit i (byte i / 8, MSB first) = box9x9(p + (x1, y1)) < box9x9(p + (x2, y2)); |.| <= 24.
+ *   ORB   pair i = {x1, y1, x2, y2}: bit i (byte i / 8, LSB first) = I(c + R (x1, y1)) < I(c + R (x2, y2)); |.| <= 15 and
+ *   x^2 + y^2 <= 15^2 (the rotated point must stay inside the 16 px margin the tiles stage).
+ * The tables live in the device's constant memory: the setting holds for every context on `device` in this process.  Call
+ * them while no frame is in flight.  vslam_get_*_pattern returns the table in effect (256 * 4 bytes). */
+int vslam_set_brief_pattern(int device, const int8_t* pairs_y1x1y2x2 /* 256 * 4 */);
+int vslam_set_orb_pattern(int device, const int8_t* pairs_x1y1x2y2 /* 256 * 4 */);
+int vslam_get_brief_pattern(int device, int8_t* pairs_out /* 256 * 4 */);
+int vslam_get_orb_pattern(int device, int8_t* pairs_out /* 256 * 4 */);
 int vslam_orb_describe(vslam_ctx* ctx, const uint8_t* image_host, int32_t rows, int32_t cols, int32_t stride, int32_t n,
                        const int16_t* xy, float angle_degrees, uint8_t* keep, uint8_t* desc);
 

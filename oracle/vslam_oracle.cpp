@@ -223,7 +223,7 @@ void fast_detect_roi(const uint8_t* img, int stride, int rx, int ry, int rw, int
  * integral image (CV_32S), KeyPointsFilter::runByImageBorder(28), pixelTests32 on 9x9 box sums.
  * Reference call site: base_framepoint_generator.cpp:431-438.
  * ---------------------------------------------------------------------------------------- */
-const int8_t kBriefPattern[256][4] = VSLAM_BRIEF_PATTERN_INIT;
+int8_t kBriefPattern[256][4] = VSLAM_BRIEF_PATTERN_INIT;   /* run-time data: orc_set_brief_pattern (the C ABI's vslam_set_brief_pattern) */
 
 void integral_image(const uint8_t* img, int rows, int cols, int stride, std::vector<int32_t>& sum) {
   sum.assign((size_t)(rows + 1) * (cols + 1), 0);
@@ -258,7 +258,7 @@ void brief_at(const std::vector<int32_t>& sum, int cols, int x, int y, uint8_t d
  * features2d/src/orb.cpp detectAndCompute(useProvidedKeypoints) + computeOrbDescriptors, imgproc smooth.cpp].
  * Reference call sites: base_framepoint_generator.cpp:190-196,219-224 (extractor), :431-438 (compute).
  * ---------------------------------------------------------------------------------------- */
-const int8_t kOrbPattern[256][4] = VSLAM_ORB_PATTERN_INIT;
+int8_t kOrbPattern[256][4] = VSLAM_ORB_PATTERN_INIT;       /* run-time data: orc_set_orb_pattern */
 
 /* getGaussianKernel(7, 2, CV_32F) -> fixed point for 8-bit images: cvRound(k * 256) (createSeparableLinearFilter, bits = 8) */
 inline void gauss7_kernel_fixed(int32_t k[7]) {
@@ -1677,6 +1677,21 @@ int dead_find_homography_lmeds(const std::vector<double>& px, const std::vector<
   return (int)inl.size();
 }
 }  // namespace
+/* the descriptor test pairs as run-time data (vslam_set_brief_pattern / vslam_set_orb_pattern of the C ABI; `device` unused) */
+ORC_API int orc_set_brief_pattern(int, const int8_t* pairs) {
+  if (!pairs) return VSLAM_ERR_INVALID;
+  for (int i = 0; i < 1024; ++i) if (pairs[i] < -24 || pairs[i] > 24) return VSLAM_ERR_INVALID;
+  std::memcpy(kBriefPattern, pairs, 1024);
+  return VSLAM_OK;
+}
+ORC_API int orc_set_orb_pattern(int, const int8_t* pairs) {
+  if (!pairs) return VSLAM_ERR_INVALID;
+  for (int i = 0; i < 512; ++i) if (pairs[2 * i] * pairs[2 * i] + pairs[2 * i + 1] * pairs[2 * i + 1] > 225) return VSLAM_ERR_INVALID;
+  std::memcpy(kOrbPattern, pairs, 1024);
+  return VSLAM_OK;
+}
+ORC_API int orc_get_brief_pattern(int, int8_t* out) { if (!out) return VSLAM_ERR_INVALID; std::memcpy(out, kBriefPattern, 1024); return VSLAM_OK; }
+ORC_API int orc_get_orb_pattern(int, int8_t* out) { if (!out) return VSLAM_ERR_INVALID; std::memcpy(out, kOrbPattern, 1024); return VSLAM_OK; }
 ORC_API int orc_dead_knn_match(orc_ctx* c, int s, int norm, int homography) {
   if (!c || s < 0 || s >= (int)c->streams.size()) return VSLAM_ERR_INVALID;
   const Stream& st = c->streams[s];

@@ -45,6 +45,11 @@ struct HipContext {
   const PoseTracker3DParameters* tracker_parameters = nullptr;   // tracking: (parameters.h:262-300)
   const LandmarkParameters* landmark_parameters = nullptr;       // world_map: landmark (parameters.h:97-112)
   HipStereoUVAligner* aligner = nullptr;
+  //! the 256 test pairs of the descriptor extractors (null: the library's own tables).  An OpenCV build has them in
+  //! xfeatures2d/src/generated_32.i (BRIEF, as {y1, x1, y2, x2}) and features2d/src/orb.cpp bit_pattern_31_ (ORB, {x1, y1, x2, y2});
+  //! passing them makes Frame::descriptorsLeft/Right bit-compatible with the reference's own extractors (include/vslam_hip.h)
+  const int8_t* brief_pattern = nullptr;
+  const int8_t* orb_pattern = nullptr;
   //! tracker-owned state last pushed to the device (Frame::status, window, descriptor distance)
   int status = VSLAM_LOCALIZING;
   int32_t window_pixels = 0;
@@ -87,7 +92,11 @@ public:
       c.landmark_maximum_error_squared_meters = l->maximum_error_squared_meters;
       c.landmark_maximum_number_of_iterations = (int32_t)l->maximum_number_of_iterations;
     }
-    if (!_hip->ctx) hipCheck(nullptr, vslam_create(&c, _hip->device, 1, &_hip->ctx), "HipStereoUVAligner::configure");
+    if (!_hip->ctx) {
+      if (_hip->brief_pattern) hipCheck(nullptr, vslam_set_brief_pattern(_hip->device, _hip->brief_pattern), "HipStereoUVAligner::configure|brief pattern");
+      if (_hip->orb_pattern) hipCheck(nullptr, vslam_set_orb_pattern(_hip->device, _hip->orb_pattern), "HipStereoUVAligner::configure|orb pattern");
+      hipCheck(nullptr, vslam_create(&c, _hip->device, 1, &_hip->ctx), "HipStereoUVAligner::configure");
+    }
   }
 
   //! StereoUVAligner::initialize (stereouv_aligner.cpp:10-69): the correspondences are already on the device (the list

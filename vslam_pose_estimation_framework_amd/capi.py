@@ -294,6 +294,21 @@ class CApi(object):
                                              _p(desc, C.c_uint8)))
         return keep, desc
 
+    # -- descriptor test pairs (run-time data, one table per device) --------------------------------
+    def get_pattern(self, which, device=0):
+        """which: "brief" ({y1, x1, y2, x2}) or "orb" ({x1, y1, x2, y2}); returns int8 [256, 4]."""
+        out = np.zeros((256, 4), np.int8)
+        rc = getattr(self.lib, self.prefix + "get_%s_pattern" % which)(C.c_int(device), _p(out, C.c_int8))
+        if rc != 0:
+            raise VslamError(rc, "get_%s_pattern" % which)
+        return out
+
+    def set_pattern(self, which, pairs, device=0):
+        pairs = np.ascontiguousarray(pairs, np.int8).reshape(256, 4)
+        rc = getattr(self.lib, self.prefix + "set_%s_pattern" % which)(C.c_int(device), _p(pairs, C.c_int8))
+        if rc != 0:
+            raise VslamError(rc, "set_%s_pattern: table rejected" % which)
+
     def knn2(self, query, train, norm=0):
         query = np.ascontiguousarray(query, np.uint8)
         train = np.ascontiguousarray(train, np.uint8)

@@ -92,13 +92,25 @@ public:
       }
     thr.assign(regions.size(), cfg.detector_threshold_minimum);
     target_per_detector = (int)((double)target / (double)regions.size());
-    pool.clear(); lms.clear(); frames.clear(); lost.clear(); weights.clear(); n_lm_prev = 0;
+    pool.clear(); lms.clear(); frames.clear(); lost.clear(); weights.clear(); n_lm_prev = 0; failed = false; failed_why.clear();
     std::memset(&info, 0, sizeof info);
   }
 
-  // PoseTracker3D::compute
+  // PoseTracker3D::compute.  A stage that fails (capacity, HIP error) leaves the frame half registered — points linked, landmarks
+  // partly updated — and there is no cheap way back: the tracker refuses further frames until reset() instead of tracking against
+  // a broken history (the reference throws out of compute() and the run ends, app.cpp:128).
   int process(const uint8_t* left, int32_t lstride, const uint16_t* depth, int32_t dstride) {
     if (!left || !depth) { err = "called with empty frame"; return VSLAM_ERR_INVALID; }
+    if (failed) { err = "RGB-D tracker: an earlier frame failed (" + failed_why + "); reset() before the next frame"; return VSLAM_ERR_STATE; }
+    const int rc = process_frame(left, lstride, depth, dstride);
+    if (rc != VSLAM_OK) { failed = true; failed_why = err; }
+    return rc;
+  }
+
+private:
+  bool failed = false;
+  std::string failed_why;
+  int process_frame(const uint8_t* left, int32_t lstride, const uint16_t* depth, int32_t dstride) {
     img = left; img_stride = lstride; dep = depth; dep_stride = dstride;
     std::memset(&info, 0, sizeof info);
     info.status_at_start = status;
@@ -148,6 +160,7 @@ public:
     return VSLAM_OK;
   }
 
+public:
   const Fr& current() const { return frames.back(); }
   const Pt& point(int id) const { return pool[id]; }
   const std::vector<Lm>& landmarks() const { return lms; }

@@ -1554,6 +1554,33 @@ VS_API int vslam_orb_describe(vslam_ctx* c, const uint8_t* img, int32_t rows, in
   if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   return VSLAM_OK;
 }
+// ---- descriptor test pairs as run-time data (the tables are __constant__ arrays of this module: one copy per device) ------
+static int pattern_io(int device, int which, const int8_t* in, int8_t* out) {
+  if ((!in && !out) || device < 0) { g_create_error = "pattern: bad argument"; return VSLAM_ERR_INVALID; }
+  if (in) {
+    for (int i = 0; i < 256; ++i) {
+      const int8_t* q = in + 4 * i;
+      if (which == 0) {
+        for (int k = 0; k < 4; ++k) if (q[k] < -VSLAM_BRIEF_PATCH_HALF || q[k] > VSLAM_BRIEF_PATCH_HALF) { g_create_error = "brief pattern: offset beyond the 48 px patch"; return VSLAM_ERR_INVALID; }
+      } else {
+        for (int h = 0; h < 2; ++h)
+          if (q[2 * h] * q[2 * h] + q[2 * h + 1] * q[2 * h + 1] > 15 * 15) { g_create_error = "orb pattern: point beyond radius 15"; return VSLAM_ERR_INVALID; }
+      }
+    }
+  }
+  if (hipSetDevice(device) != hipSuccess) { g_create_error = "pattern: no such HIP device"; return VSLAM_ERR_NO_DEVICE; }
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess && in) e = which == 0 ? hipMemcpyToSymbol(HIP_SYMBOL(c_brief), in, 1024) : hipMemcpyToSymbol(HIP_SYMBOL(c_orb), in, 1024);
+  if (e == hipSuccess && out) e = which == 0 ? hipMemcpyFromSymbol(out, HIP_SYMBOL(c_brief), 1024) : hipMemcpyFromSymbol(out, HIP_SYMBOL(c_orb), 1024);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) { g_create_error = std::string("pattern: ") + hipGetErrorString(e); return VSLAM_ERR_HIP; }
+  return VSLAM_OK;
+}
+VS_API int vslam_set_brief_pattern(int device, const int8_t* pairs) { return pattern_io(device, 0, pairs, nullptr); }
+VS_API int vslam_set_orb_pattern(int device, const int8_t* pairs) { return pattern_io(device, 1, pairs, nullptr); }
+VS_API int vslam_get_brief_pattern(int device, int8_t* out) { return pattern_io(device, 0, nullptr, out); }
+VS_API int vslam_get_orb_pattern(int device, int8_t* out) { return pattern_io(device, 1, nullptr, out); }
+
 VS_API int vslam_knn2(vslam_ctx* c, int norm, int32_t nq, const uint8_t* q, int32_t nt, const uint8_t* t, int32_t* idx, float* dist) {
   tmp_reset(c);
   if (!c || !q || !t || !idx || !dist || nq < 0 || nt < 0 || norm < 0 || norm > 3) return VSLAM_ERR_INVALID;
