@@ -25,6 +25,10 @@ for cname in ("FETCH_SIZE", "WRITE_SIZE"):
             acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
     for k, (v, n) in acc.items():
         if k.startswith("k_") and not k.startswith("k_synth"): res[k][cname] = round(v / n, 1)
-json.dump({"streams": 144, "source_sha16": buildinfo.source_sha16(), "library_sha16": buildinfo.library_sha16(), "command": "python3 bench.py --no-cpu --no-exact --no-pcie --no-ate --steps 8", "counters": "FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes, kernel-trace only; KB per launch as reported (see MI355X_MICROARCH.md for the fetch under-count of wide loads)", "per_launch_KB": res}, open(out + "/summary.json", "w"), indent=1)
+streams = None
+for line in open(out + "/FETCH_SIZE.log"):          # the bench line of the profiled run says how many streams it ran
+    if line.startswith("{") and "streams_per_gpu" in line:
+        streams = json.loads(line)["config"]["streams_per_gpu"]
+json.dump({"streams": streams, "source_sha16": buildinfo.source_sha16(), "library_sha16": buildinfo.library_sha16(), "command": "python3 bench.py --no-cpu --no-exact --no-pcie --no-ate --steps 8", "counters": "FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes, kernel-trace only; KB per launch as reported (see MI355X_MICROARCH.md for the fetch under-count of wide loads)", "per_launch_KB": res}, open(out + "/summary.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY

@@ -40,6 +40,48 @@ __global__ __launch_bounds__(THREADS) void mid(unsigned long long ticks, unsigne
   if (lds[threadIdx.x ^ 1] == 7) *sink = 1;
 }
 
+// A latency-bound chain like the frame kernel's (dependent fp64 FMAs, one wave per SIMD, an LDS round trip and a barrier every 64
+// steps): how much longer does it take when its SIMDs are shared with the flood's VALU-busy waves, and does s_setprio help?
+template <int PRIO>
+__global__ __launch_bounds__(256) void chain(int steps, double* out, unsigned long long* dur) {
+  __shared__ double x[256];
+  if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
+  asm volatile("v_mov_b32 v124, 0" ::: "v124");          // a 128-VGPR allocation
+  const unsigned long long t0 = wall_clock64();
+  double a = threadIdx.x * 1e-3, b = 1.0000001;
+  for (int i = 0; i < steps; ++i) {
+#pragma unroll
+    for (int k = 0; k < 64; ++k) a = fma(a, b, 1e-9);
+    x[threadIdx.x] = a;
+    __syncthreads();
+    a += x[(threadIdx.x + 1) & 255] * 1e-30;
+  }
+  if (threadIdx.x == 0) dur[blockIdx.x] = wall_clock64() - t0;
+  if (a == 123.0) out[0] = a;
+}
+template <int FLDS, int PRIO>
+void run_chain(const char* name, int flood_blocks, unsigned long long flood_ticks) {
+  hipStream_t sa, sb;
+  CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+  int* sink; unsigned long long *first, *dur; double* out;
+  CK(hipMalloc(&sink, 4)); CK(hipMalloc(&first, 8)); CK(hipMalloc(&dur, 8 * 144)); CK(hipMalloc(&out, 8));
+  double med[2];
+  for (int with = 0; with < 2; ++with) {
+    CK(hipMemset(dur, 0, 8 * 144));
+    CK(hipDeviceSynchronize());
+    if (with) hipLaunchKernelGGL(flood<FLDS>, dim3(flood_blocks), dim3(256), 0, sa, flood_ticks, first, sink);
+    hipLaunchKernelGGL(chain<PRIO>, dim3(144), dim3(256), 0, sb, 150, out, dur);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> d(144);
+    CK(hipMemcpy(d.data(), dur, 8 * 144, hipMemcpyDeviceToHost));
+    std::sort(d.begin(), d.end());
+    med[with] = d[72] * 0.01;
+  }
+  std::printf("%-10s chain of 150 x 64 dependent fp64 FMAs + LDS + barrier, s_setprio %d: %.1f us alone, %.1f us beside the flood (x %.2f)\n", name, PRIO, med[0], med[1], med[1] / med[0]);
+  CK(hipFree(sink)); CK(hipFree(first)); CK(hipFree(dur)); CK(hipFree(out));
+  CK(hipStreamDestroy(sa)); CK(hipStreamDestroy(sb));
+}
+
 struct Result { float f_alone, f_with; double s_min, s_med, s_max; };
 
 template <int FLDS, int THREADS, int VGPRS, int LDS_BYTES>
@@ -92,6 +134,8 @@ int main() {
     ROW(23142, 256, 256, 8 * 1024, "fast_box")
     ROW(23142, 512, 256, 8 * 1024, "fast_box")
     ROW(23142, 512, 256, 140 * 1024, "fast_box")
+    run_chain<23142, 0>("fast_box", fb, ft);
+    run_chain<23142, 3>("fast_box", fb, ft);
   }
   {
     const int fb = 256 * 4 * 8; const unsigned long long ft = 4000;      // brief-like: 40 us, 4 per CU, ~320 us in all

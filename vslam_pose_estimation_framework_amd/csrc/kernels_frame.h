@@ -286,6 +286,7 @@ struct FrameShared {
   double tau_track;
   double prior[12];      // _previous_to_current_camera of the frame in flight
   double T[12];          // aligner estimate
+  double Tprev[12];      // estimate the LAST round linearized at (VS_ALIGN_LDS builds recompute errors / inlier flags from it)
   double H[36];
   double bvec[6];
   double E, Eprev;
@@ -825,41 +826,10 @@ __device__ __forceinline__ void load_align_point(const DevCfg& c, const DevBuf& 
   P.wt = (b.al_weight + (size_t)s * c.MAXP)[u];
 }
 
-template <bool UVD>
-__device__ __forceinline__ void wg_one_round(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int n, bool ignore_outliers,
-                             const AlignPoint* cache, double* chi_reg, uint8_t* inl_reg) {
+// second half of a round: totals of the 29 sums, damping, 6 x 6 solve, pose update, re-orthonormalisation (oneRound, :190-207)
+__device__ __forceinline__ void wg_round_solve(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int n, const double* T) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  double* chi_o = b.al_chi + (size_t)s * c.MAXP;
-  uint8_t* inl_o = b.al_inl + (size_t)s * c.MAXP;
   VS_PHASE_BEGIN(tp0);
-  double T[12];
-  for (int k = 0; k < 12; ++k) T[k] = sh.T[k];
-  // one measurement per thread and chunk: its rows, then the 29 products reduced four at a time — nothing but the rows
-  // stays live (29 fp64 accumulators per thread were what pushed the kernel to 256 VGPRs and into scratch)
-  for (int base = 0; base < n; base += VS_WG) {
-    const int u = base + tid;
-    const bool have = u < n;
-    AlignRows R;
-    if (base == 0) {
-      align_rows<UVD>(c, T, cache[0], have, ignore_outliers, R, &chi_reg[0], &inl_reg[0]);   // stored after the last round
-    } else {
-      AlignPoint P;
-      P.m[0] = P.m[1] = P.m[2] = 0; P.f[0] = P.f[1] = P.f[2] = P.f[3] = 0; P.om = 0; P.wt = 0;
-      if (have) load_align_point(c, b, s, u, P);
-      double chi_w; uint8_t inl_w;
-      align_rows<UVD>(c, T, P, have, ignore_outliers, R, &chi_w, &inl_w);
-      if (have) { chi_o[u] = chi_w; inl_o[u] = inl_w; }
-    }
-    if (base + w * 64 < n) {   // waves without a measurement in this chunk would add exact zeros
-      double (*red)[32] = sh.red4[w];
-      const bool fc = base == 0;
-      align_reduce4<UVD, 0>(R, red, lane, fc);  align_reduce4<UVD, 4>(R, red, lane, fc);  align_reduce4<UVD, 8>(R, red, lane, fc);
-      align_reduce4<UVD, 12>(R, red, lane, fc); align_reduce4<UVD, 16>(R, red, lane, fc); align_reduce4<UVD, 20>(R, red, lane, fc);
-      align_reduce4<UVD, 24>(R, red, lane, fc); align_reduce4<UVD, 28>(R, red, lane, fc);
-    }
-  }
-  __syncthreads();
-  VS_PHASE_STAMP(5, tp0);
   if (w == 0) {
     // lane k < 29 owns total k; the 6x6 system then lives one element per lane (column-major: lane = 6*col+row,
     // right-hand side in lanes 36..41) and is solved by wave_solve6 without leaving registers.
@@ -912,7 +882,7 @@ __device__ __forceinline__ void wg_one_round(const DevCfg& c, const DevBuf& b, i
         for (int jj = 0; jj < 3; ++jj)
           Tn[4 * ii + jj] = R[3 * ii + jj] - 0.5 * ((R[3 * ii] * RtR[jj] + R[3 * ii + 1] * RtR[3 + jj]) + R[3 * ii + 2] * RtR[6 + jj]);
 #pragma unroll
-      for (int k = 0; k < 12; ++k) sh.T[k] = Tn[k];
+      for (int k = 0; k < 12; ++k) { sh.Tprev[k] = T[k]; sh.T[k] = Tn[k]; }
       ++sh.its;
     }
   }
@@ -920,9 +890,141 @@ __device__ __forceinline__ void wg_one_round(const DevCfg& c, const DevBuf& b, i
   VS_PHASE_STAMP(11, tp0);
 }
 
+template <bool UVD>
+__device__ __forceinline__ void wg_one_round(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int n, bool ignore_outliers,
+                             const AlignPoint* cache, double* chi_reg, uint8_t* inl_reg) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  double* chi_o = b.al_chi + (size_t)s * c.MAXP;
+  uint8_t* inl_o = b.al_inl + (size_t)s * c.MAXP;
+  VS_PHASE_BEGIN(tp0);
+  double T[12];
+  for (int k = 0; k < 12; ++k) T[k] = sh.T[k];
+  // one measurement per thread and chunk: its rows, then the 29 products reduced four at a time — nothing but the rows
+  // stays live (29 fp64 accumulators per thread were what pushed the kernel to 256 VGPRs and into scratch)
+  for (int base = 0; base < n; base += VS_WG) {
+    const int u = base + tid;
+    const bool have = u < n;
+    AlignRows R;
+    if (base == 0) {
+      align_rows<UVD>(c, T, cache[0], have, ignore_outliers, R, &chi_reg[0], &inl_reg[0]);   // stored after the last round
+    } else {
+      AlignPoint P;
+      P.m[0] = P.m[1] = P.m[2] = 0; P.f[0] = P.f[1] = P.f[2] = P.f[3] = 0; P.om = 0; P.wt = 0;
+      if (have) load_align_point(c, b, s, u, P);
+      double chi_w; uint8_t inl_w;
+      align_rows<UVD>(c, T, P, have, ignore_outliers, R, &chi_w, &inl_w);
+      if (have) { chi_o[u] = chi_w; inl_o[u] = inl_w; }
+    }
+    if (base + w * 64 < n) {   // waves without a measurement in this chunk would add exact zeros
+      double (*red)[32] = sh.red4[w];
+      const bool fc = base == 0;
+      align_reduce4<UVD, 0>(R, red, lane, fc);  align_reduce4<UVD, 4>(R, red, lane, fc);  align_reduce4<UVD, 8>(R, red, lane, fc);
+      align_reduce4<UVD, 12>(R, red, lane, fc); align_reduce4<UVD, 16>(R, red, lane, fc); align_reduce4<UVD, 20>(R, red, lane, fc);
+      align_reduce4<UVD, 24>(R, red, lane, fc); align_reduce4<UVD, 28>(R, red, lane, fc);
+    }
+  }
+  __syncthreads();
+  VS_PHASE_STAMP(5, tp0);
+  wg_round_solve(c, b, s, sh, n, T);
+}
+
+// Small-register form of the round (VS_ALIGN_LDS builds: the co-scheduled frame kernel must live in 128 VGPRs).  The measurements
+// are staged in LDS once per converge() instead of being held in registers across the rounds (those beyond the LDS capacity are
+// re-read from HBM, L2 hits), no error / inlier value is carried from round to round — after the last round they are recomputed
+// from sh.Tprev, the estimate that round linearized at — and there is ONE code path per chunk.  Same arithmetic per measurement,
+// same reduction, same bits as wg_one_round.
+template <bool UVD>
+__device__ __forceinline__ void wg_one_round_lds(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int n, bool ignore_outliers,
+                                                 const AlignPoint* lp, int cap) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  VS_PHASE_BEGIN(tp0);
+  for (int base = 0; base < n; base += VS_WG) {
+    const int u = base + tid;
+    const bool have = u < n;
+    AlignPoint P;
+    P.m[0] = P.m[1] = P.m[2] = 0; P.f[0] = P.f[1] = P.f[2] = P.f[3] = 0; P.om = 0; P.wt = 0;
+    if (have) { if (u < cap) P = lp[u]; else load_align_point(c, b, s, u, P); }
+    AlignRows R;
+    double chi_w; uint8_t inl_w;
+    align_rows<UVD>(c, sh.T, P, have, ignore_outliers, R, &chi_w, &inl_w);
+    if (base + w * 64 < n) {
+      double (*red)[32] = sh.red4[w];
+      const bool fc = base == 0;
+      align_reduce4<UVD, 0>(R, red, lane, fc);  align_reduce4<UVD, 4>(R, red, lane, fc);  align_reduce4<UVD, 8>(R, red, lane, fc);
+      align_reduce4<UVD, 12>(R, red, lane, fc); align_reduce4<UVD, 16>(R, red, lane, fc); align_reduce4<UVD, 20>(R, red, lane, fc);
+      align_reduce4<UVD, 24>(R, red, lane, fc); align_reduce4<UVD, 28>(R, red, lane, fc);
+    }
+  }
+  __syncthreads();
+  VS_PHASE_STAMP(5, tp0);
+  wg_round_solve(c, b, s, sh, n, sh.T);
+}
+
+template <bool UVD>
+__device__ __forceinline__ void wg_align_converge_lds(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int n, const double* T_init,
+                                                      unsigned char* lds, int lds_bytes) {
+  const int tid = threadIdx.x;
+  AlignPoint* lp = reinterpret_cast<AlignPoint*>(lds);
+  const int cap = lds_bytes / (int)sizeof(AlignPoint);
+  __syncthreads();
+  if (tid == 0) {
+    for (int k = 0; k < 12; ++k) { sh.T[k] = T_init[k]; sh.Tprev[k] = T_init[k]; }
+    sh.its = 0; sh.conv = 0; sh.Eprev = 0; sh.E = 0; sh.inl = 0; sh.outl = n;
+    for (int k = 0; k < 36; ++k) sh.H[k] = 0;
+  }
+  for (int u = tid; u < n && u < cap; u += VS_WG) { AlignPoint P; load_align_point(c, b, s, u, P); lp[u] = P; }
+  __syncthreads();
+  const int max_it = c.c.aligner_maximum_number_of_iterations;
+  const double delta = c.c.aligner_error_delta_for_convergence;
+  double e_prev = 0;
+  int it = 0, it2 = 0;
+  bool refine = false;
+  while (max_it > 0) {
+    wg_one_round_lds<UVD>(c, b, s, sh, n, refine, lp, cap);
+    const double E = sh.E;
+    if (!refine) {
+      ++it;
+      if (delta > fabs(e_prev - E)) {
+        e_prev = E;
+        const int min_inl = UVD ? 100 : c.c.aligner_minimum_number_of_inliers;
+        if (sh.inl > min_inl && sh.inl > sh.outl && max_it > 0) { refine = true; continue; }
+        if (tid == 0) sh.conv = 1;
+        break;
+      }
+      e_prev = E;
+      if (it >= max_it) break;
+    } else {
+      ++it2;
+      const bool done = fabs(e_prev - E) < delta;
+      e_prev = E;
+      if (done || it2 >= max_it) { if (tid == 0) sh.conv = 1; break; }
+    }
+  }
+  // errors / inlier flags of the last linearization: one more evaluation of the rows at the estimate it used
+  double* chi_o = b.al_chi + (size_t)s * c.MAXP;
+  uint8_t* inl_o = b.al_inl + (size_t)s * c.MAXP;
+  const bool ran = sh.its > 0;
+  for (int u = tid; u < n; u += VS_WG) {
+    double chi_w = -1; uint8_t inl_w = 0;
+    if (ran) {
+      AlignPoint P;
+      if (u < cap) P = lp[u]; else load_align_point(c, b, s, u, P);
+      AlignRows R;
+      align_rows<UVD>(c, sh.Tprev, P, true, false, R, &chi_w, &inl_w);
+    }
+    chi_o[u] = chi_w; inl_o[u] = inl_w;
+  }
+  __syncthreads();
+}
+
 // converge (:210-264) on the aligner SoA of stream s (n measurements), starting from T_init
 template <bool UVD = false>
-__device__ __forceinline__ void wg_align_converge(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int n, const double* T_init) {
+__device__ __forceinline__ void wg_align_converge(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int n, const double* T_init,
+                                                  unsigned char* lds = nullptr, int lds_bytes = 0) {
+#ifdef VS_ALIGN_LDS
+  if (lds) { wg_align_converge_lds<UVD>(c, b, s, sh, n, T_init, lds, lds_bytes); return; }
+#endif
+  (void)lds; (void)lds_bytes;
   const int tid = threadIdx.x;
   __syncthreads();
   if (tid == 0) {
@@ -995,7 +1097,7 @@ __device__ __forceinline__ double al_weight_rule(bool inverse_depth, int u, int 
 
 // initialize (:10-69) on the tracked list, then converge
 __device__ __forceinline__ void wg_align(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_prev, bool inverse_depth,
-                         const double* T_init) {
+                         const double* T_init, unsigned char* lds = nullptr, int lds_bytes = 0) {
   const int tid = threadIdx.x;
   const int n = sh.n_trk;
   const PtView pv = pts_of(c, b, s, pb_prev);
@@ -1026,7 +1128,7 @@ __device__ __forceinline__ void wg_align(const DevCfg& c, const DevBuf& b, int s
     triangulate(c, xL, yL, xR, yR, cam);
     weight[u] = al_weight_rule(inverse_depth, u, wprev, (!inverse_depth && u < wprev) ? weight[u] : 1.0, cam[2], c.c.maximum_reliable_depth_meters);
   }
-  wg_align_converge(c, b, s, sh, n, T_init);
+  wg_align_converge(c, b, s, sh, n, T_init, lds, lds_bytes);
 }
 
 // stand-alone aligner on caller-provided correspondences (vslam_align_points, vslam_align_points_uvd)
@@ -1060,7 +1162,12 @@ __global__ VS_ALIGN_BOUNDS void k_align_points(const DevCfg c, const DevBuf b, i
   __shared__ FrameShared sh;
   double T0[12];
   for (int k = 0; k < 12; ++k) T0[k] = T_init[k];
+#ifdef VS_ALIGN_LDS
+  __shared__ __align__(16) unsigned char al_lds[VS_ARENA];
+  wg_align_converge<UVD>(c, b, 0, sh, n, T0, al_lds, VS_ARENA);
+#else
   wg_align_converge<UVD>(c, b, 0, sh, n, T0);
+#endif
   if (threadIdx.x == 0) {
     StreamState& st = b.st[0];
     st.al_n = n; st.al_inliers = sh.inl; st.al_outliers = sh.outl; st.al_iterations = sh.its; st.al_converged = sh.conv;

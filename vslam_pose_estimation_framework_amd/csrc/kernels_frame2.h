@@ -252,11 +252,27 @@ __device__ __forceinline__ void recover_brief_patch(const DevCfg& c, const DevBu
 
 // in-workgroup BRIEF step: the LDS work list first, then (list overflow only) the remaining points through rec[]
 #define VS_RLIST_OFF ((VS_WG / 64) * VS_RPATCH)
-#define VS_RLIST_CAP ((VS_ARENA - VS_RLIST_OFF) / 24)
+// builds whose LDS arena is too small for the patches (co-scheduling experiments: a frame workgroup that fits into the hole one
+// image-kernel workgroup leaves) gather the 2 x 512 taps of a point straight from the box images instead, like k_recover_brief
+#define VS_RPATCH_IN_LDS (VS_RLIST_OFF + 24 * 64 <= VS_ARENA)
+#define VS_RLIST_CAP (VS_RPATCH_IN_LDS ? (VS_ARENA - VS_RLIST_OFF) / 24 : 0)
 __device__ __forceinline__ void wg_recover_brief(const DevCfg& c, const DevBuf& b, int s, int pb_prev, int n_lost, int n_list,
                                                  double tau_track, double tau_tri, unsigned char* arena) {
-  static_assert(VS_RLIST_OFF + 24 * 64 <= VS_ARENA, "recovery patches + work list must fit the LDS arena");
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if constexpr (!VS_RPATCH_IN_LDS) {
+    if (c.c.descriptor_type == VSLAM_DESCRIPTOR_ORB) {
+      const OrbTaps taps = orb_taps(lane, c.orb_cos, c.orb_sin, c.bstride);
+      const int32_t* rec = b.rec + (size_t)s * c.MAXP * 6;
+      const int32_t* lost = b.lost + (size_t)s * c.MAXP;
+      for (int q = w; q < n_lost; q += VS_WG / 64) {
+        if (rec[6 * q] != 2) continue;   // wave-uniform
+        recover_orb_wave(c, b, s, pb_prev, q, lost[q], rec[6 * q + 1], rec[6 * q + 2], rec[6 * q + 3], rec[6 * q + 4], lane, tau_track, tau_tri, taps);
+      }
+    } else {
+      for (int q = w; q < n_lost; q += VS_WG / 64) recover_brief_wave(c, b, s, pb_prev, q, lane, tau_track, tau_tri);
+    }
+    return;
+  }
   uint16_t* patch = reinterpret_cast<uint16_t*>(arena + (size_t)w * VS_RPATCH);
   const int32_t* list = reinterpret_cast<const int32_t*>(arena + VS_RLIST_OFF);
   if (c.c.descriptor_type == VSLAM_DESCRIPTOR_ORB) {
@@ -284,7 +300,8 @@ __device__ __forceinline__ void wg_recover_brief(const DevCfg& c, const DevBuf& 
   }
 }
 
-__device__ __forceinline__ void wg_recover_append(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_prev, int pb_cur) {
+template <int NT, class SH>
+__device__ __forceinline__ void wg_recover_append_t(const DevCfg& c, const DevBuf& b, int s, SH& sh, int pb_prev, int pb_cur) {
   const int tid = threadIdx.x;
   const PtView pv = pts_of(c, b, s, pb_prev);
   const PtView cv = pts_of(c, b, s, pb_cur);
@@ -292,7 +309,7 @@ __device__ __forceinline__ void wg_recover_append(const DevCfg& c, const DevBuf&
   const int32_t* rec = b.rec + (size_t)s * c.MAXP * 6;
   const uint8_t* rdesc = b.rec_desc + (size_t)s * c.MAXP * 64;
   const int nl = sh.n_lost;
-  const int per = (nl + VS_WG - 1) / VS_WG;
+  const int per = (nl + NT - 1) / NT;
   const int q0 = tid * per, q1 = min(q0 + per, nl);
   int cnt = 0;
   for (int q = q0; q < q1; ++q) cnt += rec[6 * q] == 1 ? 1 : 0;
@@ -321,6 +338,10 @@ __device__ __forceinline__ void wg_recover_append(const DevCfg& c, const DevBuf&
   __syncthreads();
   if (tid == 0) { sh.flag = total; sh.n_cur = min(sh.n_cur + total, c.MAXP); }
   __syncthreads();
+}
+
+__device__ __forceinline__ void wg_recover_append(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_prev, int pb_cur) {
+  wg_recover_append_t<VS_WG, FrameShared>(c, b, s, sh, pb_prev, pb_cur);
 }
 
 // whole recovery inside one workgroup (stage path)
@@ -373,9 +394,12 @@ __global__ __launch_bounds__(256) void k_recover_brief(const DevCfg c, const Dev
 #define VS_LM_CN 6
 #endif
 #define VS_LM_NP 48   // world_to_camera of the last VS_LM_NP frames staged in LDS (one copy for all points of the frame)
-struct LmCache { double w2c[VS_LM_NP][12]; double cam[VS_WG][VS_LM_CN][3]; };
-template <bool LDS>
-__device__ __forceinline__ bool landmark_point_t(const DevCfg& c, const DevBuf& b, int s, const PtView& cv, int f, int i, LmCache* lc) {
+template <int NT, int CN>
+struct LmCacheT { static constexpr int kCN = CN; static constexpr int kBatch = NT >= 512 ? 4 : 2; double w2c[VS_LM_NP][12]; double cam[NT][CN][3]; };
+typedef LmCacheT<VS_WG, VS_LM_CN> LmCache;
+template <bool LDS, class LC = LmCache>
+__device__ __forceinline__ bool landmark_point_t(const DevCfg& c, const DevBuf& b, int s, const PtView& cv, int f, int i, LC* lc) {
+  constexpr int VS_LM_CN_ = LC::kCN;
   const double* w2c_cur = hpose_of(c, b, s, f) + 12;
   {
     int32_t* m = cv.meta + (size_t)i * META;
@@ -441,22 +465,22 @@ __device__ __forceinline__ bool landmark_point_t(const DevCfg& c, const DevBuf& 
         }
       }
       auto index_at = [&](int k) -> int { return k == 0 ? i : (int)tr[k - 1]; };   // k < n_direct
-      // the first VS_LM_CN measurements into the thread's LDS slots, once
+      // the first VS_LM_CN_ measurements into the thread's LDS slots, once
       int ncache = 0, ffc = f, iic = i;
       if constexpr (LDS) {
         double (*slot)[3] = lc->cam[threadIdx.x];
         if (c.trail) {
-          const int nc = min(min(len, VS_LM_CN), n_direct);
-          double mv[VS_LM_CN][3];
+          const int nc = min(min(len, VS_LM_CN_), n_direct);
+          double mv[VS_LM_CN_][3];
 #pragma unroll
-          for (int k = 0; k < VS_LM_CN; ++k)
+          for (int k = 0; k < VS_LM_CN_; ++k)
             if (k < nc) { const double* mc = hcam_of(c, b, s, f - k) + 3 * (size_t)index_at(k); mv[k][0] = mc[0]; mv[k][1] = mc[1]; mv[k][2] = mc[2]; }
 #pragma unroll
-          for (int k = 0; k < VS_LM_CN; ++k)
+          for (int k = 0; k < VS_LM_CN_; ++k)
             if (k < nc) { slot[k][0] = mv[k][0]; slot[k][1] = mv[k][1]; slot[k][2] = mv[k][2]; }
           ncache = nc;
         } else {
-          for (int k = 0; k < len && k < VS_LM_CN; ++k) {
+          for (int k = 0; k < len && k < VS_LM_CN_; ++k) {
             const double* mc = hcam_of(c, b, s, ffc) + 3 * (size_t)iic;
             slot[k][0] = mc[0]; slot[k][1] = mc[1]; slot[k][2] = mc[2];
             ++ncache;
@@ -481,16 +505,17 @@ __device__ __forceinline__ bool landmark_point_t(const DevCfg& c, const DevBuf& 
         }
         if (c.trail) {
           // directly addressed measurements, four at a time: their (independent) loads are in flight together
-          for (int k0 = ncache; k0 < n_direct; k0 += 4) {
-            double mc[4][3];
+          constexpr int NB = LC::kBatch;     // loads in flight together (fewer in the small-register tail kernel)
+          for (int k0 = ncache; k0 < n_direct; k0 += NB) {
+            double mc[NB][3];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NB; ++u) {
               const int k = min(k0 + u, n_direct - 1);
               const double* src = hcam_of(c, b, s, f - k) + 3 * (size_t)index_at(k);
               mc[u][0] = src[0]; mc[u][1] = src[1]; mc[u][2] = src[2];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NB; ++u) {
               const int k = k0 + u;
               if (k < n_direct) {
                 if constexpr (LDS) {
@@ -545,7 +570,7 @@ __device__ __forceinline__ bool landmark_point_t(const DevCfg& c, const DevBuf& 
 }
 
 __device__ __forceinline__ bool landmark_point(const DevCfg& c, const DevBuf& b, int s, const PtView& cv, int f, int i) {
-  return landmark_point_t<false>(c, b, s, cv, f, i, nullptr);
+  return landmark_point_t<false, LmCache>(c, b, s, cv, f, i, (LmCache*)nullptr);
 }
 
 // Besides the history ring (camera coordinates and `prev` link of every point of frame f), every point gets its trail: the
@@ -647,8 +672,10 @@ __device__ __forceinline__ void stereo_dist_row(const uint8_t* descL, const uint
 // compute() (stereo_framepoint_generator.cpp:135-462): stereo sweep with one thread per image row (rows are
 // independent: the right cursor only moves inside a row), then the order-dependent bin competition with
 // one thread per bin, then emission in bin-grid row-major order.
-__device__ __forceinline__ void wg_stereo(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_cur, double tau_tri, int f,
-                          unsigned char* arena, int arena_bytes) {
+// FULL: the arena can hold the whole staging / the 32-bit bin tables (the 512-thread frame kernel); false compiles those paths out
+template <int NT, class SH, bool FULL = true>
+__device__ __forceinline__ void wg_stereo_t(const DevCfg& c, const DevBuf& b, int s, SH& sh, int pb_cur, double tau_tri, int f,
+                            unsigned char* arena, int arena_bytes) {
   const int tid = threadIdx.x;
   const PtView cv = pts_of(c, b, s, pb_cur);
   const int rows = c.c.rows, CW1 = c.CW + 1;
@@ -676,7 +703,7 @@ __device__ __forceinline__ void wg_stereo(const DevCfg& c, const DevBuf& b, int 
   //      window (more than 16 unconsumed right features behind the left feature) needs the reference's explicit scan.
   const int nLp = (nL + 7) & ~7, nRp = (nR + 7) & ~7, rowsp = (rows + 8) & ~7;
   const size_t stage_bytes = (size_t)4 * 2 * rowsp + (size_t)(8 + 4 + 4 + 2 + 1 + 1) * nLp + (size_t)(2 + 1) * nRp;
-  const bool staged = stage_bytes <= (size_t)arena_bytes;
+  const bool staged = FULL && stage_bytes <= (size_t)arena_bytes;
   // the distance rows of the first pass (from k_stereo_dist of the image pipeline) ride along when they fit
   const bool sd_lds = staged && ((stage_bytes + 15) & ~(size_t)15) + (size_t)16 * nL <= (size_t)arena_bytes;
   unsigned long long* ssuf = reinterpret_cast<unsigned long long*>(arena);   // step A: suffix-argmin nibbles
@@ -698,22 +725,22 @@ __device__ __forceinline__ void wg_stereo(const DevCfg& c, const DevBuf& b, int 
     const int o = c.offsets[oi];
     uint8_t* sdist = b.sdist + (size_t)s * c.NMAX * 16;
     if (staged) {
-      for (int r = tid; r <= rows; r += VS_WG) {
+      for (int r = tid; r <= rows; r += NT) {
         srL[r] = r < rows ? rcL[(size_t)r * CW1] : rcL[(size_t)(rows - 1) * CW1 + c.CW];
         srR[r] = r < rows ? rcR[(size_t)r * CW1] : rcR[(size_t)(rows - 1) * CW1 + c.CW];
       }
 #pragma unroll 4
-      for (int i = tid; i < nL; i += VS_WG) { sxyL[i] = reinterpret_cast<const uint32_t*>(kxyL)[i]; suL[i] = usedL[i]; }
+      for (int i = tid; i < nL; i += NT) { sxyL[i] = reinterpret_cast<const uint32_t*>(kxyL)[i]; suL[i] = usedL[i]; }
 #pragma unroll 4
-      for (int g = tid; g < nR; g += VS_WG) { sxR[g] = kxyR[2 * g]; suR[g] = usedR[g]; }
+      for (int g = tid; g < nR; g += NT) { sxR[g] = kxyR[2 * g]; suR[g] = usedR[g]; }
       if (oi == 0 && sd_lds) {
 #pragma unroll 4
-        for (int i = tid; i < nL; i += VS_WG) sd4[i] = reinterpret_cast<const uint4*>(sdist)[i];
+        for (int i = tid; i < nL; i += NT) sd4[i] = reinterpret_cast<const uint4*>(sdist)[i];
       }
       __syncthreads();
       // distances of the first pass came from k_stereo_dist (image pipeline); later offsets recompute them here
       if (oi > 0) {
-        for (int i = tid; i < nL; i += VS_WG) {
+        for (int i = tid; i < nL; i += NT) {
           if (suL[i]) continue;
           const int rr = (int)(sxyL[i] >> 16) - o;
           if (rr < 0 || rr >= rows) continue;
@@ -726,7 +753,7 @@ __device__ __forceinline__ void wg_stereo(const DevCfg& c, const DevBuf& b, int 
       auto steps_ab = [&](auto sd_tag) {
         constexpr bool SD = decltype(sd_tag)::value;
         // ---- step A ---------------------------------------------------------------------------------------------------
-        for (int i = tid; i < nL; i += VS_WG) {
+        for (int i = tid; i < nL; i += NT) {
           unsigned long long suf = 0;
           unsigned val = 0;
           int m = 0;
@@ -757,7 +784,7 @@ __device__ __forceinline__ void wg_stereo(const DevCfg& c, const DevBuf& b, int 
         }
         __syncthreads();
         // ---- step B ---------------------------------------------------------------------------------------------------
-        for (int r = tid; r < rows; r += VS_WG) {
+        for (int r = tid; r < rows; r += NT) {
           const int rr = r - o;  // right row: L.row == R.row + o
           const bool rv = rr >= 0 && rr < rows;
           const int l0 = srL[r], l1 = srL[r + 1];
@@ -799,11 +826,191 @@ __device__ __forceinline__ void wg_stereo(const DevCfg& c, const DevBuf& b, int 
         }
       };
       if (oi == 0 && sd_lds) steps_ab(std::true_type{}); else steps_ab(std::false_type{});
+    } else if (arena_bytes >= 8192) {
+      // The staging does not fit the arena as a whole (small-LDS builds of the frame's tail kernel, very large feature counts): the
+      // same two steps band by band.  Rows are independent, a band of rows [r0, r1) owns the contiguous left features
+      // [l0, l1) and the right features [g0, g1) of the rows r - o, so a band stages only its own slices (local indices = global
+      // index minus l0 / g0) and appends its matches before the next band starts: same results, same order.
+      const int32_t nLend = rcL[(size_t)(rows - 1) * CW1 + c.CW], nRend = rcR[(size_t)(rows - 1) * CW1 + c.CW];
+      auto rsL = [&](int r) { return r < rows ? rcL[(size_t)r * CW1] : nLend; };
+      auto rsR = [&](int r) { return r <= 0 ? 0 : (r < rows ? rcR[(size_t)r * CW1] : nRend); };
+      int rb = max(1, (int)((size_t)rows * (size_t)arena_bytes * 3 / (4 * stage_bytes)));   // first guess: average density, 25 % slack
+      int r0 = 0;
+      while (r0 < rows) {
+        int r1, l0, l1, g0, g1;
+        size_t need;
+        for (;;) {   // shrink the band until its slices fit (one row always does: <= 255 usable right features, a few hundred left ones)
+          r1 = min(r0 + rb, rows);
+          l0 = rsL(r0); l1 = rsL(r1);
+          g0 = rsR(min(max(r0 - o, 0), rows)); g1 = rsR(min(max(r1 - o, 0), rows));
+          const int nLb = ((l1 - l0) + 7) & ~7, nRb = ((g1 - g0) + 7) & ~7, rbp = (r1 - r0 + 8) & ~7;
+          need = (size_t)4 * 2 * rbp + (size_t)20 * nLb + (size_t)3 * nRb;
+          if (need <= (size_t)arena_bytes || rb == 1) break;
+          rb = max(1, rb / 2);
+        }
+        const int nLb = ((l1 - l0) + 7) & ~7, nRb = ((g1 - g0) + 7) & ~7, rbn = r1 - r0, rbp = (rbn + 8) & ~7;
+        if (need > (size_t)arena_bytes) {   // a single row beyond the arena (cannot happen below ~600 features in one row): reference loop on HBM
+          for (int i = l0 + tid; i < l1; i += NT) match[2 * i] = -1;
+          __syncthreads();
+          if (tid == 0) {
+            const int rr = r0 - o;
+            if (rr >= 0 && rr < rows) {
+              int cur = g0;
+              for (int i = l0; i < l1 && cur < g1; ++i) {
+                if (usedL[i]) continue;
+                const int xl = kxyL[2 * i];
+                uint32_t ld[8];
+                for (int q = 0; q < 8; ++q) ld[q] = reinterpret_cast<const uint32_t*>(descL + (size_t)32 * i)[q];
+                int best = itau, bg = -1;
+                for (int g = cur; g < g1; ++g) {
+                  if (usedR[g]) continue;
+                  if (xl - kxyR[2 * g] < 0) break;
+                  const int h = hamming32(ld, reinterpret_cast<const uint32_t*>(descR + (size_t)32 * g));
+                  if (h < best) { best = h; bg = g; }
+                }
+                if (bg >= 0 && !((double)(xl - kxyR[2 * bg]) < c.c.minimum_disparity_pixels)) { match[2 * i] = bg; match[2 * i + 1] = best; cur = bg + 1; }
+              }
+            }
+          }
+          __syncthreads();
+          const int perb = (l1 - l0 + NT - 1) / NT;
+          const int i0 = l0 + tid * perb, i1 = min(i0 + perb, l1);
+          int cnt = 0;
+          for (int i = i0; i < i1; ++i) cnt += match[2 * i] >= 0 ? 1 : 0;
+          int total;
+          int off = n_cand + block_exclusive_scan(cnt, sh.scan, &total);
+          for (int i = i0; i < i1; ++i) {
+            const int g = match[2 * i];
+            if (g < 0) continue;
+            sc[4 * off] = i; sc[4 * off + 1] = g; sc[4 * off + 2] = match[2 * i + 1]; sc[4 * off + 3] = o;
+            usedL[i] = 1; usedR[g] = 1;
+            ++off;
+          }
+          n_cand += total;
+          r0 = r1;
+          continue;
+        }
+        unsigned long long* bsuf = reinterpret_cast<unsigned long long*>(arena);
+        int32_t* brL = reinterpret_cast<int32_t*>(bsuf + nLb);       // left row starts of rows r0 .. r1 (global indices)
+        int32_t* brR = brL + rbp;                                     // right row starts of rows r0 - o .. r1 - o
+        uint32_t* bxyL = reinterpret_cast<uint32_t*>(brR + rbp);
+        int32_t* bmatch = reinterpret_cast<int32_t*>(bxyL + nLb);
+        uint16_t* bval = reinterpret_cast<uint16_t*>(bmatch + nLb);
+        int16_t* bxR = reinterpret_cast<int16_t*>(bval + nLb);
+        uint8_t* buL = reinterpret_cast<uint8_t*>(bxR + nRb);
+        uint8_t* buR = buL + nLb;
+        uint8_t* bmL = buR + nRb;
+        __syncthreads();   // the previous band's arrays are dead
+        for (int q = tid; q <= rbn; q += NT) { brL[q] = rsL(r0 + q); brR[q] = rsR(min(max(r0 + q - o, 0), rows)); }
+        for (int i = l0 + tid; i < l1; i += NT) { bxyL[i - l0] = reinterpret_cast<const uint32_t*>(kxyL)[i]; buL[i - l0] = usedL[i]; }
+        for (int g = g0 + tid; g < g1; g += NT) { bxR[g - g0] = kxyR[2 * g]; buR[g - g0] = usedR[g]; }
+        __syncthreads();
+        if (oi > 0) {   // later offsets recompute their distance rows (the first pass came from k_stereo_dist)
+          for (int i = l0 + tid; i < l1; i += NT) {
+            if (buL[i - l0]) continue;
+            const int q = (int)(bxyL[i - l0] >> 16) - r0, rr = r0 + q - o;
+            if (rr < 0 || rr >= rows) continue;
+            stereo_dist_row(descL, descR, i, brR[q], brR[q + 1], (int)(bxyL[i - l0] & 0xFFFFu), [&](int g) { return (int)bxR[g - g0]; }, sdist);
+          }
+          __syncthreads();
+        }
+        // ---- step A (band) ----
+        for (int i = l0 + tid; i < l1; i += NT) {
+          unsigned long long suf = 0;
+          unsigned val = 0;
+          int m = 0;
+          const uint32_t xy = bxyL[i - l0];
+          const int q = (int)(xy >> 16) - r0, rr = r0 + q - o;
+          if (!buL[i - l0] && rr >= 0 && rr < rows) {
+            const int h0 = brR[q], h1 = brR[q + 1];
+            const int xl = (int)(xy & 0xFFFFu);
+            { int lo = h0, hi = h1; while (lo < hi) { const int mid = (lo + hi) >> 1; if (xl - bxR[mid - g0] >= 0) lo = mid + 1; else hi = mid; } m = min(lo - h0, 255); }
+            if (m > 0 && m < 255) {
+              const int w0 = max(m - 16, 0), mw = m - w0;
+              const uint4 dq = *reinterpret_cast<const uint4*>(sdist + (size_t)i * 16);
+              const unsigned long long d01 = ((unsigned long long)dq.y << 32) | dq.x, d23 = ((unsigned long long)dq.w << 32) | dq.z;
+              int bh = 0, bj = -1;
+              for (int k = mw - 1; k >= 0; --k) {
+                const int h = (int)(((k < 8 ? d01 : d23) >> (8 * (k & 7))) & 255ull);
+                if (!buR[h0 + w0 + k - g0] && h < itau && (bj < 0 || h <= bh)) { bh = h; bj = k; }
+                if (bj >= 0) { suf |= (unsigned long long)bj << (4 * k); val |= 1u << k; }
+              }
+            }
+          }
+          bsuf[i - l0] = suf; bval[i - l0] = (uint16_t)val; bmL[i - l0] = (uint8_t)m;
+        }
+        __syncthreads();
+        // ---- step B (band): one thread per row ----
+        for (int q = tid; q < rbn; q += NT) {
+          const int rr = r0 + q - o;
+          const bool rv = rr >= 0 && rr < rows;
+          const int a0 = brL[q], a1 = brL[q + 1];
+          const int h0 = rv ? brR[q] : 0, h1 = rv ? brR[q + 1] : 0;
+          int cur = h0;
+          for (int i = a0; i < a1; ++i) {
+            const int m = bmL[i - l0];
+            int bg = -1, best = 0;
+            if (m > 0 && cur < h0 + m) {
+              const int w0 = max(m - 16, 0), cpos = cur - h0 - w0;
+              if (m < 255 && cpos >= 0) {
+                const unsigned val = bval[i - l0];
+                if ((val >> cpos) & 1u) {
+                  const int k = (int)((bsuf[i - l0] >> (4 * cpos)) & 15ull);
+                  bg = h0 + w0 + k;
+                  best = 0x100 | k;     // bit 8: "distance = sdist[i][k]", fetched by the parallel append below (no HBM round trip in this loop)
+                }
+              } else {
+                const int xl = (int)(bxyL[i - l0] & 0xFFFFu);
+                uint32_t ld[8];
+                for (int u = 0; u < 8; ++u) ld[u] = reinterpret_cast<const uint32_t*>(descL + (size_t)32 * i)[u];
+                best = itau;
+                for (int g = cur; g < h1; ++g) {
+                  if (buR[g - g0]) continue;
+                  if (xl - bxR[g - g0] < 0) break;
+                  const int h = hamming32(ld, reinterpret_cast<const uint32_t*>(descR + (size_t)32 * g));
+                  if (h < best) { best = h; bg = g; }
+                }
+              }
+            }
+            int res = -1;
+            if (bg >= 0 && !((double)((int)(bxyL[i - l0] & 0xFFFFu) - bxR[bg - g0]) < c.c.minimum_disparity_pixels)) {
+              res = (best << 16) | bg;
+              cur = bg + 1;
+            }
+            bmatch[i - l0] = res;
+          }
+        }
+        __syncthreads();
+        // append the band's matches in sorted-left order
+        {
+          const int perb = (l1 - l0 + NT - 1) / NT;
+          const int i0 = l0 + tid * perb, i1 = min(i0 + perb, l1);
+          int cnt = 0;
+          for (int i = i0; i < i1; ++i) cnt += bmatch[i - l0] >= 0 ? 1 : 0;
+          int total;
+          int off = n_cand + block_exclusive_scan(cnt, sh.scan, &total);
+          for (int i = i0; i < i1; ++i) {
+            const int sm = bmatch[i - l0];
+            if (sm < 0) continue;
+            const int g = sm & 0xFFFF;
+            int dist = sm >> 16;
+            if (dist & 0x100) dist = sdist[(size_t)i * 16 + (dist & 15)];
+            sc[4 * off] = i; sc[4 * off + 1] = g; sc[4 * off + 2] = dist; sc[4 * off + 3] = o;
+            usedL[i] = 1; usedR[g] = 1;
+            ++off;
+          }
+          n_cand += total;
+        }
+        r0 = r1;
+      }
+      DBG_STAMP(0);
+      DBG_STAMP(1);
+      continue;   // this offset's matches are appended
     } else {
-      // capacities beyond the LDS arena: the reference's loop on HBM, one thread per row
-      for (int i = tid; i < nL; i += VS_WG) match[2 * i] = -1;
+      // no usable arena: the reference's loop on HBM, one thread per row
+      for (int i = tid; i < nL; i += NT) match[2 * i] = -1;
       __syncthreads();
-      for (int r = tid; r < rows; r += VS_WG) {
+      for (int r = tid; r < rows; r += NT) {
         const int rr = r - o;  // right row: L.row == R.row + o
         if (rr < 0 || rr >= rows) continue;
         const int l0 = rcL[(size_t)r * CW1], l1 = rcL[(size_t)r * CW1 + c.CW];
@@ -832,7 +1039,7 @@ __device__ __forceinline__ void wg_stereo(const DevCfg& c, const DevBuf& b, int 
     }
     DBG_STAMP(0);
     // append the matches of this offset in sorted-left order; mark both features used (prune)
-    const int per = (nL + VS_WG - 1) / VS_WG;
+    const int per = (nL + NT - 1) / NT;
     const int i0 = tid * per, i1 = min(i0 + per, nL);
     int cnt = 0;
     for (int i = i0; i < i1; ++i) cnt += (staged ? smatch[i] : match[2 * i]) >= 0 ? 1 : 0;
@@ -856,7 +1063,86 @@ __device__ __forceinline__ void wg_stereo(const DevCfg& c, const DevBuf& b, int 
   int added = 0;
   if (c.c.enable_keypoint_binning) {
     // working arrays of the bin competition: in LDS (the sweep's staging is dead by now) when they fit, else in HBM
-    const bool bl = ((size_t)3 * (nb + 1) + (size_t)4 * n_cand) * 4 <= (size_t)arena_bytes;
+    const bool bl = FULL && ((size_t)3 * (nb + 1) + (size_t)4 * n_cand) * 4 <= (size_t)arena_bytes;
+    // small arenas: the same competition on 16-bit tables (bin cursors two to a word, candidate lists as u16) — 4 (nb + 2) + 8 n_cand
+    // + a few bytes, e.g. 15 KB for 2158 bins and 800 candidates
+    const size_t cw_words = ((size_t)nb + 2) / 2, occ_words = ((size_t)nb + 2) / 2;
+    const bool bc = !bl && n_cand < 32767 && (cw_words + occ_words + (size_t)n_cand) * 4 + (size_t)n_cand * 4 + 16 <= (size_t)arena_bytes;
+    if (bc) {
+      uint32_t* cw = reinterpret_cast<uint32_t*>(arena);                     // per bin: count -> start -> fill cursor (u16 halves)
+      int16_t* occ16 = reinterpret_cast<int16_t*>(cw + cw_words);            // -1 empty, -2 tracked occupant, >= 0 winning candidate
+      uint32_t* cpk = reinterpret_cast<uint32_t*>(occ16) + occ_words;        // [n_cand] disparity << 16 | distance
+      uint16_t* items = reinterpret_cast<uint16_t*>(cpk + n_cand);           // [n_cand] per-bin lists, then the winners in bin order
+      uint16_t* cbin16 = items + n_cand;                                     // [n_cand] bin of candidate q
+      auto half = [&](int k) -> int { return (int)((__hip_atomic_load(cw + (k >> 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> (16 * (k & 1))) & 0xFFFFu); };
+      __syncthreads();
+      for (int k = tid; k < (int)cw_words; k += NT) cw[k] = 0u;
+      for (int k = tid; k < (int)occ_words; k += NT) reinterpret_cast<uint32_t*>(occ16)[k] = 0xFFFFFFFFu;
+      __syncthreads();
+      for (int j = tid; j < n_tracked; j += NT) {      // tracked points seed the grid: a tracked occupant is never replaced
+        const int rb = min((int)rint((double)cv.kp[4 * (size_t)j + 1] / bin), c.rows_bin - 1);
+        const int cb = min((int)rint((double)cv.kp[4 * (size_t)j] / bin), c.cols_bin - 1);
+        occ16[rb * c.cols_bin + cb] = (int16_t)-2;
+      }
+      for (int q = tid; q < n_cand; q += NT) {
+        const int4 e = *reinterpret_cast<const int4*>(sc + 4 * q);
+        const int lxy = *reinterpret_cast<const int32_t*>(kxyL + 2 * e.x);
+        const int xl = (int16_t)(lxy & 0xFFFF), yl = lxy >> 16;
+        const int rb = min((int)rint((double)yl / bin), c.rows_bin - 1);
+        const int cb = min((int)rint((double)xl / bin), c.cols_bin - 1);
+        const int k = rb * c.cols_bin + cb;
+        cbin16[q] = (uint16_t)k;
+        cpk[q] = ((uint32_t)(xl - kxyR[2 * e.y]) << 16) | (uint32_t)(e.z & 0xFFFF);
+        atomicAdd(cw + (k >> 1), 1u << (16 * (k & 1)));
+      }
+      __syncthreads();
+      {   // counts -> exclusive starts, in place
+        const int perb = (nb + NT - 1) / NT;
+        const int k0 = tid * perb, k1 = min(k0 + perb, nb);
+        int cnt = 0;
+        for (int k = k0; k < k1; ++k) cnt += half(k);
+        int total;
+        int off = block_exclusive_scan(cnt, sh.scan, &total);
+        uint16_t* ch = reinterpret_cast<uint16_t*>(cw);
+        for (int k = k0; k < k1; ++k) { const int m = ch[k]; ch[k] = (uint16_t)off; off += m; }
+      }
+      __syncthreads();
+      for (int q = tid; q < n_cand; q += NT) {          // fill: the cursor of bin k moves from its start to its end
+        const int k = cbin16[q];
+        const uint32_t old = atomicAdd(cw + (k >> 1), 1u << (16 * (k & 1)));
+        items[(old >> (16 * (k & 1))) & 0xFFFFu] = (uint16_t)q;
+      }
+      __syncthreads();
+      for (int k = tid; k < nb; k += NT) {              // one thread per bin replays its candidates in sweep order
+        if (occ16[k] != -1) continue;                   // tracked occupant
+        const int i0 = k ? half(k - 1) : 0, m = half(k) - i0;
+        int win = -1, wdisp = 0, wdist = 0, last = -1;
+        for (int t = 0; t < m; ++t) {
+          int q = 0x7FFFFFFF;
+          for (int u = 0; u < m; ++u) { const int v = items[i0 + u]; if (v > last && v < q) q = v; }
+          last = q;
+          const uint32_t pk = cpk[q];
+          const int disp = (int)pk >> 16, dist = (int)(pk & 0xFFFFu);
+          if (win < 0 || (disp > wdisp && dist <= wdist)) { win = q; wdisp = disp; wdist = dist; }
+        }
+        occ16[k] = (int16_t)win;
+      }
+      __syncthreads();
+      const int per = (nb + NT - 1) / NT;
+      const int k0 = tid * per, k1 = min(k0 + per, nb);
+      int cnt = 0;
+      for (int k = k0; k < k1; ++k) cnt += occ16[k] >= 0 ? 1 : 0;
+      int total;
+      int off = block_exclusive_scan(cnt, sh.scan, &total);      // (its barriers also retire every reader of `items`)
+      for (int k = k0; k < k1; ++k) { const int q = occ16[k]; if (q >= 0) items[off++] = (uint16_t)q; }
+      __syncthreads();
+      if (n_tracked + total > c.MAXP && tid == 0) atomicOr(&b.st[s].error_flags, 2);
+      for (int t = tid; t < total && n_tracked + t < c.MAXP; t += NT) {
+        const int4 e = *reinterpret_cast<const int4*>(sc + 4 * items[t]);
+        materialize_point(c, b, s, cv, n_tracked + t, e.x, e.y, e.z, e.w, -1, 0);
+      }
+      added = total;
+    } else {
     int32_t* occ = bl ? reinterpret_cast<int32_t*>(arena) : bin_occ;
     int32_t* bcnt = bl ? occ + (nb + 1) : b.bin_aux + (size_t)s * (2 * ((size_t)nb + 1) + c.NMAX);
     int32_t* bstart = bcnt + (nb + 1);
@@ -864,16 +1150,16 @@ __device__ __forceinline__ void wg_stereo(const DevCfg& c, const DevBuf& b, int 
     int32_t* cbin = bl ? bitems + n_cand : match;              // [n_cand][2]: bin id, (disparity << 16 | distance)
     int32_t* emit_q = bl ? cbin + 2 * n_cand : match + 2 * (size_t)c.NMAX;   // [<= n_cand] winners in bin order
     __syncthreads();
-    for (int k = tid; k < nb; k += VS_WG) { occ[k] = -1; bcnt[k] = 0; }
+    for (int k = tid; k < nb; k += NT) { occ[k] = -1; bcnt[k] = 0; }
     __syncthreads();
     // tracked points seed the grid; later points overwrite earlier ones -> keep the largest index
-    for (int j = tid; j < n_tracked; j += VS_WG) {
+    for (int j = tid; j < n_tracked; j += NT) {
       const int rb = min((int)rint((double)cv.kp[4 * (size_t)j + 1] / bin), c.rows_bin - 1);
       const int cb = min((int)rint((double)cv.kp[4 * (size_t)j] / bin), c.cols_bin - 1);
       atomicMax(occ + rb * c.cols_bin + cb, j);
     }
     // bin id / disparity / distance of every candidate, once; per-bin counts
-    for (int q = tid; q < n_cand; q += VS_WG) {
+    for (int q = tid; q < n_cand; q += NT) {
       const int4 e = *reinterpret_cast<const int4*>(sc + 4 * q);
       const int lxy = *reinterpret_cast<const int32_t*>(kxyL + 2 * e.x);
       const int xl = (int16_t)(lxy & 0xFFFF), yl = lxy >> 16;
@@ -888,7 +1174,7 @@ __device__ __forceinline__ void wg_stereo(const DevCfg& c, const DevBuf& b, int 
     DBG_STAMP(2);
     // per-bin candidate lists by counting sort (arrival order inside a bin is arbitrary, restored by a tiny sort)
     {
-      const int perb = (nb + VS_WG - 1) / VS_WG;
+      const int perb = (nb + NT - 1) / NT;
       const int k0 = tid * perb, k1 = min(k0 + perb, nb);
       int cnt = 0;
       for (int k = k0; k < k1; ++k) cnt += ld_relaxed(bcnt + k);   // written by atomics: read past the vector L1
@@ -898,13 +1184,13 @@ __device__ __forceinline__ void wg_stereo(const DevCfg& c, const DevBuf& b, int 
       if (tid == 0) bstart[nb] = total;
     }
     __syncthreads();
-    for (int q = tid; q < n_cand; q += VS_WG) {
+    for (int q = tid; q < n_cand; q += NT) {
       const int k = cbin[2 * q];
       bitems[bstart[k] + atomicAdd(bcnt + k, 1)] = q;
     }
     __syncthreads();
     // one thread per bin replays its candidates in sweep order (the rule is not an argmax)
-    for (int k = tid; k < nb; k += VS_WG) {
+    for (int k = tid; k < nb; k += NT) {
       const int o0 = ld_relaxed(occ + k);
       if (o0 >= 0) { occ[k] = -2 - o0; continue; }  // tracked occupant: never replaced
       const int i0 = bstart[k], m = bstart[k + 1] - i0;
@@ -923,7 +1209,7 @@ __device__ __forceinline__ void wg_stereo(const DevCfg& c, const DevBuf& b, int 
     __syncthreads();
     DBG_STAMP(3);
     // winners in bin-grid row-major order, then one thread per new point
-    const int per = (nb + VS_WG - 1) / VS_WG;
+    const int per = (nb + NT - 1) / NT;
     const int k0 = tid * per, k1 = min(k0 + per, nb);
     int cnt = 0;
     for (int k = k0; k < k1; ++k) cnt += occ[k] >= 0 ? 1 : 0;
@@ -932,13 +1218,14 @@ __device__ __forceinline__ void wg_stereo(const DevCfg& c, const DevBuf& b, int 
     for (int k = k0; k < k1; ++k) { const int q = occ[k]; if (q >= 0) emit_q[off++] = q; }
     __syncthreads();
     if (n_tracked + total > c.MAXP && tid == 0) atomicOr(&b.st[s].error_flags, 2);
-    for (int t = tid; t < total && n_tracked + t < c.MAXP; t += VS_WG) {
+    for (int t = tid; t < total && n_tracked + t < c.MAXP; t += NT) {
       const int4 e = *reinterpret_cast<const int4*>(sc + 4 * emit_q[t]);
       materialize_point(c, b, s, cv, n_tracked + t, e.x, e.y, e.z, e.w, -1, 0);
     }
     added = total;
+    }   // !bc
   } else {
-    for (int q = tid; q < n_cand; q += VS_WG) {
+    for (int q = tid; q < n_cand; q += NT) {
       const int j = n_tracked + q;
       if (j < c.MAXP) materialize_point(c, b, s, cv, j, sc[4 * q], sc[4 * q + 1], sc[4 * q + 2], sc[4 * q + 3], -1, 0);
       else atomicOr(&b.st[s].error_flags, 2);
@@ -951,13 +1238,18 @@ __device__ __forceinline__ void wg_stereo(const DevCfg& c, const DevBuf& b, int 
   // history of the appended points
   double* hc = hcam_of(c, b, s, f);
   int32_t* hp = hprev_of(c, b, s, f);
-  for (int j = n_tracked + tid; j < n_final; j += VS_WG) {
+  for (int j = n_tracked + tid; j < n_final; j += NT) {
     for (int k = 0; k < 3; ++k) hc[3 * (size_t)j + k] = cv.cam[3 * (size_t)j + k];
     hp[j] = -1;
     if (c.trail) *reinterpret_cast<uint4*>(cv.trail + (size_t)j * VS_TRAIL) = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);   // a track starts here
   }
   if (tid == 0) { sh.n_cand = added; sh.n_cur = n_final; }
   __syncthreads();
+}
+
+__device__ __forceinline__ void wg_stereo(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_cur, double tau_tri, int f,
+                          unsigned char* arena, int arena_bytes) {
+  wg_stereo_t<VS_WG, FrameShared>(c, b, s, sh, pb_cur, tau_tri, f, arena, arena_bytes);
 }
 
 // L-R Hamming distances of the first epipolar pass for every left feature of every stream (image pipeline): the window
@@ -1011,6 +1303,9 @@ __global__ VS_FRAME_BOUNDS void k_frame(ConstDevCfg* cp, ConstDevBuf* bp, int ph
   const DevBuf& b = *(const DevBuf*)bp;
   __shared__ FrameShared sh;
   __shared__ __align__(16) unsigned char arena[VS_ARENA];
+#ifdef VS_FRAME_PRIO
+  __builtin_amdgcn_s_setprio(VS_FRAME_PRIO);   // co-scheduled builds: the latency-bound frame wavefronts issue ahead of the image kernels' wavefronts on their SIMD
+#endif
   const int s = b.s0 + blockIdx.x, tid = threadIdx.x;
   if (!vs_active(b, s)) return;
   StreamState& st = b.st[s];
@@ -1097,7 +1392,7 @@ __global__ VS_FRAME_BOUNDS void k_frame(ConstDevCfg* cp, ConstDevBuf* bp, int ph
           fall = true;
         } else {
           const unsigned long long ta = wall_clock64();
-          wg_align(c, b, s, sh, pb_prev, false, prior);
+          wg_align(c, b, s, sh, pb_prev, false, prior, arena, VS_ARENA);
           if (tid == 0) st.ticks[1] += wall_clock64() - ta;
           aligner_valid = true;
           if (sh.inl < c.c.minimum_number_of_landmarks_to_track) fall = true; else accept = true;
@@ -1114,7 +1409,7 @@ __global__ VS_FRAME_BOUNDS void k_frame(ConstDevCfg* cp, ConstDevBuf* bp, int ph
           }
         } else {
           const unsigned long long ta = wall_clock64();
-          wg_align(c, b, s, sh, pb_prev, true, prior);
+          wg_align(c, b, s, sh, pb_prev, true, prior, arena, VS_ARENA);
           if (tid == 0) st.ticks[1] += wall_clock64() - ta;
           aligner_valid = true;
           if (sh.inl > c.c.minimum_number_of_landmarks_to_track) {
@@ -1272,6 +1567,109 @@ __global__ VS_FRAME_BOUNDS void k_frame(ConstDevCfg* cp, ConstDevBuf* bp, int ph
   }
 }
 
+// ==============================================================================================
+// The frame's TAIL as a kernel of its own (launch sequence 3: k_track_candidates, k_frame phase 0, k_recover_brief, k_tail):
+// recovery append, history, landmark creation / refinement, status switch, stereo sweep + binning + emission, report — everything
+// after registration and pruning.  None of it needs the aligner's 245 registers, so this kernel is shaped to fit the HOLE ONE
+// image-kernel workgroup leaves on a busy CU (tools/probe/cosched.hip: 256 threads, <= 128 VGPRs, <= ~22 KB LDS start within
+// microseconds beside k_fast_box's flood; anything with 512 threads, more registers or more LDS waits until the flood's grid is
+// exhausted): it runs BESIDE the image pipeline of the next frame instead of on CUs of its own.  Its wavefronts raise their
+// priority: a latency-bound chain loses nothing beside VALU-busy neighbours (same probe) and should not queue behind them.
+// Same device functions as k_frame's phases 1-2, instantiated for 256 threads, the landmark cache one measurement deep, the
+// stereo sweep band by band and the bin competition on 16-bit tables (wg_stereo_t).
+// ==============================================================================================
+#define VS_TAIL_WG 256
+#ifndef VS_TAIL_ARENA
+#define VS_TAIL_ARENA 17408
+#endif
+struct TailShared { int scan[17]; int flag; int n_lost, n_cur, n_cand; };
+__global__ __launch_bounds__(VS_TAIL_WG, 4) void k_tail(ConstDevCfg* cp, ConstDevBuf* bp) {
+  const DevCfg& c = *(const DevCfg*)cp;
+  const DevBuf& b = *(const DevBuf*)bp;
+  __shared__ TailShared sh;
+  __shared__ __align__(16) unsigned char arena[VS_TAIL_ARENA];
+  __builtin_amdgcn_s_setprio(2);
+  const int s = b.s0 + blockIdx.x, tid = threadIdx.x;
+  if (!vs_active(b, s)) return;
+  StreamState& st = b.st[s];
+  vslam_frame_info& info = b.info[s];
+  const int f = st.frame_count;
+  const int has_prev = st.has_prev;
+  const int pb_prev = st.cur, pb_cur = st.cur ^ 1;
+  FrameCarry& fc = st.fc;
+  if (tid == 0) { sh.n_cur = fc.n_cur; sh.n_lost = fc.n_lost; sh.flag = 0; sh.n_cand = 0; }
+  __syncthreads();
+  if (has_prev && c.c.enable_landmark_recovery) {
+    const unsigned long long tr = wall_clock64();
+    wg_recover_append_t<VS_TAIL_WG, TailShared>(c, b, s, sh, pb_prev, pb_cur);
+    if (tid == 0) { st.ticks[2] += wall_clock64() - tr; fc.n_recovered = sh.flag; }
+  }
+  wg_publish_history(c, b, s, sh.n_cur, pb_cur, f);
+  __syncthreads();
+  // ---- _updatePoints: landmarks --------------------------------------------------------------------------------------
+  int n_active = 0;
+  {
+    const unsigned long long tu = wall_clock64();
+    const PtView cvu = pts_of(c, b, s, pb_cur);
+    typedef LmCacheT<VS_TAIL_WG, 1> LC;
+    static_assert(sizeof(LC) + 2048 <= VS_TAIL_ARENA, "landmark cache + work list must fit the tail's arena");
+    LC* lc = reinterpret_cast<LC*>(arena);
+    for (int t = tid; t < VS_LM_NP * 12; t += VS_TAIL_WG) { const int k = t / 12; if (f - k >= 0 && k < c.HCAP) lc->w2c[k][t - 12 * k] = hpose_of(c, b, s, f - k)[12 + t - 12 * k]; }
+    constexpr int LIST_CAP = (VS_TAIL_ARENA - (int)sizeof(LC)) / 2;
+    uint16_t* work = reinterpret_cast<uint16_t*>(arena + sizeof(LC));
+    int active = 0;
+    // the points that carry a landmark, compacted into a work list (LIST_CAP points of the frame at a time): one per thread
+    for (int c0 = 0; c0 < sh.n_cur; c0 += LIST_CAP) {
+      const int c1 = min(c0 + LIST_CAP, sh.n_cur);
+      __syncthreads();
+      if (tid == 0) sh.flag = 0;
+      __syncthreads();
+      for (int i0 = c0; i0 < c1; i0 += VS_TAIL_WG) {
+        const int i = i0 + tid;
+        const bool need = i < c1 && cvu.meta[(size_t)i * META + M_TLEN] >= c.c.minimum_track_length_for_landmark_creation;
+        const unsigned long long m = __ballot(need);
+        int base = 0;
+        if ((tid & 63) == 0 && m) base = atomicAdd(&sh.flag, __popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (need) work[base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)(i - c0);
+      }
+      __syncthreads();
+      const int n_work = sh.flag;
+      for (int q = tid; q < n_work; q += VS_TAIL_WG) active += landmark_point_t<true, LC>(c, b, s, cvu, f, c0 + work[q], lc) ? 1 : 0;
+    }
+    block_exclusive_scan(active, sh.scan, &n_active);
+    if (tid == 0) { fc.n_active = n_active; sh.flag = 0; st.ticks[3] += wall_clock64() - tu; }
+    __syncthreads();
+  }
+  int status = fc.status;
+  if (n_active > c.c.minimum_number_of_landmarks_to_track) status = VSLAM_TRACKING;
+  const double tau_tri2 = fc.tau_tri;
+  const unsigned long long ts = wall_clock64();
+  wg_stereo_t<VS_TAIL_WG, TailShared, false>(c, b, s, sh, pb_cur, tau_tri2, f, arena, VS_TAIL_ARENA);
+  if (tid == 0) {
+    st.ticks[4] += wall_clock64() - ts;
+    const double* c2w = hpose_of(c, b, s, f);
+    *pts_of(c, b, s, pb_cur).n = sh.n_cur;
+    st.status = status; st.win = fc.win; st.tau_track = fc.tau_track; st.tau_tri = tau_tri2;
+    for (int k = 0; k < 12; ++k) { st.prior[k] = fc.prior[k]; st.pose[k] = c2w[k]; }
+    st.n_tracked_landmarks_prev = n_active;
+    st.frame_count = f + 1; st.has_prev = 1; st.cur = pb_cur; st.aligner_valid = fc.aligner_valid;
+    info.frame_index = f + 1; info.status = status; info.status_at_start = fc.status0;
+    info.n_keypoints_left = b.n_kp[s * 2]; info.n_keypoints_right = b.n_kp[s * 2 + 1];
+    int rl = 0, rr = 0;
+    for (int r = 0; r < c.n_regions; ++r) { rl += b.iinfo[s].raw_count[0][r]; rr += b.iinfo[s].raw_count[1][r]; info.thresholds[r] = b.iinfo[s].thr_after[r]; }
+    for (int r = c.n_regions; r < VSLAM_MAX_REGIONS; ++r) info.thresholds[r] = 0;
+    info.n_detected_left = rl; info.n_detected_right = rr;
+    info.track_attempts = fc.attempts; info.n_after_prune = fc.n_after_prune; info.n_recovered = fc.n_recovered;
+    info.n_active_landmarks = n_active; info.n_new_stereo = sh.n_cand; info.n_points = sh.n_cur;
+    info.track_broken = fc.broken; info.fallback = fc.fallback; info.window_pixels = fc.win;
+    info.error_flags = st.error_flags; info.tau_track = fc.tau_track; info.tau_triangulation = tau_tri2;
+    for (int k = 0; k < 12; ++k) { info.camera_left_to_world[k] = c2w[k]; info.previous_to_current[k] = fc.prior[k]; }
+    if (f < VS_POSE_LOG) { double* pl = b.pose_log + ((size_t)s * VS_POSE_LOG + f) * 12; for (int k = 0; k < 12; ++k) pl[k] = c2w[k]; }
+    st.dbg[8] += wall_clock64() - fc.t0;
+  }
+}
+
 // recoverPoints on caller-provided lost points (vslam_stereo_recover): previous buffer 0 holds the lost points' descriptors,
 // landmarks and landmark flags, the lost list is 0..n-1, survivors are appended to buffer 1 from its start.
 struct RecoverAlone { double w2c[12]; double tau_track, tau_tri; int n; };
@@ -1346,7 +1744,7 @@ __global__ __launch_bounds__(VS_WG) void k_stage(const DevCfg c, const DevBuf b,
     double T0[12];
     for (int k = 0; k < 12; ++k) T0[k] = st.prior[k];
     const unsigned long long t0 = wall_clock64();
-    wg_align(c, b, s, sh, pb_prev, arg != 0, T0);
+    wg_align(c, b, s, sh, pb_prev, arg != 0, T0, arena, VS_ARENA);
     if (tid == 0) {
       st.ticks[1] += wall_clock64() - t0;
       st.al_n = sh.n_trk; st.al_inliers = sh.inl; st.al_outliers = sh.outl; st.al_iterations = sh.its; st.al_converged = sh.conv;

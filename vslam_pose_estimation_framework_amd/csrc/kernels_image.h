@@ -137,7 +137,14 @@ __device__ __forceinline__ void fast_pair_scores(const uint8_t (*t)[80], int ly0
   *s1 = (thr1 >= 0 && (a1 > thr1 || b1 > thr1)) ? max(thr1, max(a1, b1)) - 1 : 0;
 }
 
-__global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b) {
+// The candidate queue is DYNAMIC shared memory (VS_FB_DYN_LDS bytes at every launch): with all 22.6 KB declared statically the
+// compiler sees an LDS-bound occupancy of 7 wavefronts per SIMD and allows itself 72 VGPRs (it used 65); with the queue out of
+// sight it has to honour 8 wavefronts = 64 VGPRs.  The kernel still runs 7 workgroups per CU (LDS), but each SIMD now keeps
+// 64 VGPRs free, so that ONE workgroup leaving makes room for a 128-VGPR wavefront of another kernel (tools/probe/cosched.hip).
+#define VS_FB_QCAP ((VS_TILE_H + 2) * 66)
+#define VS_FB_DYN_LDS ((VS_FB_QCAP + 256) * 2)
+__global__ __launch_bounds__(256, 8) void k_fast_box(const DevCfg c, const DevBuf b) {
+  extern __shared__ __align__(16) unsigned char fb_dyn[];
   __shared__ __align__(16) uint8_t tile[VS_TILE_H + 8][80];
   __shared__ __align__(4) uint8_t sc[VS_TILE_H + 2][68];
   __shared__ __align__(8) uint16_t hs[VS_TILE_H + 8][VS_TILE_W];
@@ -145,8 +152,8 @@ __global__ __launch_bounds__(256) void k_fast_box(const DevCfg c, const DevBuf b
   // candidate queue of the tile (packed: the scoring pass fills whole wavefronts — per-wavefront queues were measured slower,
   // they leave every wavefront a partly filled scoring pass); the 256 slots behind it take the stores of lanes without a
   // candidate, so that the four queue writes of a pretest pass need no exec-mask branches
-  constexpr int QCAP = (VS_TILE_H + 2) * 66;
-  __shared__ uint16_t queue[QCAP + 256];
+  constexpr int QCAP = VS_FB_QCAP;
+  uint16_t* queue = reinterpret_cast<uint16_t*>(fb_dyn);
   __shared__ unsigned long long lmask[VS_TILE_H];
   __shared__ int qn;
   int tx, ty, tz;

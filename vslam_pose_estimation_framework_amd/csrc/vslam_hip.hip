@@ -407,7 +407,7 @@ static int create_internal(const vslam_config* cfg, int device, int n_streams, v
     c->stream_img = c->groups[0].st_img;
     c->own_stream = true;
     c->split = n_streams <= VS_SPLIT2_MAX_STREAMS ? 2 : 0;
-    if (const char* e = getenv("VSLAM_SPLIT")) c->split = std::max(0, std::min(2, atoi(e)));
+    if (const char* e = getenv("VSLAM_SPLIT")) c->split = std::max(0, std::min(3, atoi(e)));
   }
   const DevCfg& d = c->cfg;
   DevBuf& b = c->buf;
@@ -621,7 +621,7 @@ static int launch_image_pipeline(vslam_ctx* c) {
     if (g.frm_pending[set] && st != g.st_frm) HIP_TRY(c, hipStreamWaitEvent(st, g.ev_frm[set], 0));
     if (g.emit_pending[set ^ 1] && g.st_img != g.st_img2) HIP_TRY(c, hipStreamWaitEvent(st, g.ev_emit[set ^ 1], 0));
     dim3 g1(d.TX, (d.c.rows + VS_TILE_H - 1) / VS_TILE_H, 2 * g.n);
-    { KernelTimer t(c, 0, st); hipLaunchKernelGGL(k_fast_box, g1, dim3(256), 0, st, c->cfg, bs); }
+    { KernelTimer t(c, 0, st); hipLaunchKernelGGL(k_fast_box, g1, dim3(256), VS_FB_DYN_LDS, st, c->cfg, bs); }
     const bool orb = d.c.descriptor_type == VSLAM_DESCRIPTOR_ORB;
     { KernelTimer t(c, 1, st); hipLaunchKernelGGL(k_emit, dim3(g.n, 2), dim3(512), 0, st, c->cfg, bs, orb ? (int)VSLAM_ORB_BORDER : (int)VSLAM_BRIEF_BORDER, 1); }
     if (g.st_img != g.st_img2) { HIP_TRY(c, hipEventRecord(g.ev_emit[set], st)); g.emit_pending[set] = true; }
@@ -670,6 +670,12 @@ static int launch_frame(vslam_ctx* c) {
     if (!c->split || (c->split == 2 && !c->cfg.c.enable_landmark_recovery)) {
       KernelTimer t(c, 4, g.st_frm);
       hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, kc, kb, -1);
+    } else if (c->split == 3) {
+      // registration + prune on CUs of its own (the aligner needs the whole register file), then the tail co-scheduled with the
+      // image pipeline of the next frame (k_tail)
+      { KernelTimer t(c, 4, g.st_frm); hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, kc, kb, 0); }
+      if (c->cfg.c.enable_landmark_recovery) { KernelTimer t(c, 5, g.st_frm); hipLaunchKernelGGL(k_recover_brief, dim3(std::max(4, std::min(64, 1024 / std::max(g.n, 1))), g.n), dim3(256), 0, g.st_frm, c->cfg, bs); }
+      { KernelTimer t(c, 6, g.st_frm); hipLaunchKernelGGL(k_tail, dim3(g.n), dim3(VS_TAIL_WG), 0, g.st_frm, kc, kb); }
     } else if (c->split == 2) {
       { KernelTimer t(c, 4, g.st_frm, false); hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, kc, kb, 0); }
       { KernelTimer t(c, 5, g.st_frm); hipLaunchKernelGGL(k_recover_brief, dim3(std::max(4, std::min(64, 1024 / std::max(g.n, 1))), g.n), dim3(256), 0, g.st_frm, c->cfg, bs); }
@@ -1143,7 +1149,7 @@ VS_API int vslam_depth_recover(vslam_ctx* c, const vslam_depth_params* p, const 
       hipLaunchKernelGGL(k_orb_at, dim3(std::min(64, (n + 3) / 4)), dim3(256), 0, t->stream_img, dblur, t->cfg.bstride, p->rows, p->cols, n, dbxy, t->cfg.orb_cos, t->cfg.orb_sin, dkeep, ddesc);
     } else {
       dim3 g1(t->cfg.TX, (p->rows + VS_TILE_H - 1) / VS_TILE_H, 2);
-      hipLaunchKernelGGL(k_fast_box, g1, dim3(256), 0, t->stream_img, t->cfg, t->buf);
+      hipLaunchKernelGGL(k_fast_box, g1, dim3(256), VS_FB_DYN_LDS, t->stream_img, t->cfg, t->buf);
       hipLaunchKernelGGL(k_brief_at, dim3(std::min(64, (n + 3) / 4)), dim3(256), 0, t->stream_img, t->buf.box, t->cfg.bstride, p->rows, p->cols, n, dbxy, dkeep, ddesc);
     }
     hipLaunchKernelGGL(k_depth_recover_finish, dim3(1), dim3(1024), 0, t->stream_img, a);
@@ -1352,7 +1358,7 @@ VS_API int vslam_orb_detect(vslam_ctx* c, const uint8_t* img, int32_t rows, int3
     int32_t* n1 = (int32_t*)dmal(4); int32_t* n2 = (int32_t*)dmal(4);
     if (!xy1 || !xy2 || !r1 || !r2 || !rh || !n1 || !n2) { e = hipErrorOutOfMemory; break; }
     dim3 g1(t->cfg.TX, (lrows + VS_TILE_H - 1) / VS_TILE_H, 1);
-    hipLaunchKernelGGL(k_fast_box, g1, dim3(256), 0, st, t->cfg, t->buf);
+    hipLaunchKernelGGL(k_fast_box, g1, dim3(256), VS_FB_DYN_LDS, st, t->cfg, t->buf);
     hipLaunchKernelGGL(k_emit, dim3(1, 1), dim3(512), 0, st, t->cfg, t->buf, edge, 0);                                  // runByImageBorder(edgeThreshold)
     hipLaunchKernelGGL(k_orb_select<uint8_t>, dim3(1), dim3(1024), 0, st, t->buf.n_kp, t->buf.kp_xy, t->buf.kp_score, 2 * per[l], n1, xy1, r1, N);   // retainBest(2 n) on the FAST score
     hipLaunchKernelGGL(k_orb_harris, dim3(256), dim3(256), 0, st, lev, lstride, n1, xy1, rh);
@@ -1450,7 +1456,7 @@ VS_API int vslam_fast_detect(vslam_ctx* c, const uint8_t* img, int32_t rows, int
   rc = e == hipSuccess ? upload_images(t, img, img, stride, 0) : fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   if (rc == VSLAM_OK) {
     dim3 g1(t->cfg.TX, (rows + VS_TILE_H - 1) / VS_TILE_H, 2);
-    hipLaunchKernelGGL(k_fast_box, g1, dim3(256), 0, t->stream_img, t->cfg, t->buf);
+    hipLaunchKernelGGL(k_fast_box, g1, dim3(256), VS_FB_DYN_LDS, t->stream_img, t->cfg, t->buf);
     hipLaunchKernelGGL(k_emit, dim3(1, 2), dim3(512), 0, t->stream_img, t->cfg, t->buf, 0, 0);
     int32_t cnt = 0;
     rc = vslam_get_keypoints(t, 0, 0, cap, &cnt, xy, score, nullptr);
@@ -1484,7 +1490,7 @@ VS_API int vslam_brief_describe(vslam_ctx* c, const uint8_t* img, int32_t rows, 
   rc = e == hipSuccess ? upload_images(t, img, img, stride, 0) : fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   if (rc == VSLAM_OK && n) {
     dim3 g1(t->cfg.TX, (rows + VS_TILE_H - 1) / VS_TILE_H, 2);
-    hipLaunchKernelGGL(k_fast_box, g1, dim3(256), 0, t->stream_img, t->cfg, t->buf);
+    hipLaunchKernelGGL(k_fast_box, g1, dim3(256), VS_FB_DYN_LDS, t->stream_img, t->cfg, t->buf);
     hipLaunchKernelGGL(k_brief_at, dim3(std::min(64, (n + 3) / 4)), dim3(256), 0, t->stream_img, t->buf.box, t->cfg.bstride, rows, cols,
                        n, dxy, dkeep, ddesc);
     e = hipMemcpyAsync(keep, dkeep, (size_t)n, hipMemcpyDeviceToHost, t->stream_img);
@@ -1838,7 +1844,7 @@ VS_API int vslam_stereo_recover(vslam_ctx* c, const uint8_t* imgL, const uint8_t
       Gauss7 gk; for (int i = 0; i < 4; ++i) gk.k[i] = t->cfg.gauss7[i];
       hipLaunchKernelGGL(k_gauss7, dim3(t->cfg.TX, (rows + VS_TILE_H - 1) / VS_TILE_H, 2), dim3(256), 0, q, t->cfg, t->buf, gk);
     } else {
-      hipLaunchKernelGGL(k_fast_box, dim3(t->cfg.TX, (rows + VS_TILE_H - 1) / VS_TILE_H, 2), dim3(256), 0, q, t->cfg, t->buf);
+      hipLaunchKernelGGL(k_fast_box, dim3(t->cfg.TX, (rows + VS_TILE_H - 1) / VS_TILE_H, 2), dim3(256), VS_FB_DYN_LDS, q, t->cfg, t->buf);
     }
     RecoverAlone a;
     std::memcpy(a.w2c, w2c, sizeof a.w2c); a.tau_track = tau_track; a.tau_tri = tau_tri; a.n = n;
