@@ -110,8 +110,11 @@ def test_python_loop_over_the_oracle_runs_every_configuration(which):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("which,descriptor,max_depth,seed", [("tum", 1, None, 23), ("tum", 0, 25.0, 31), ("icl", 1, None, 29), ("xtion", 1, None, 37)])
-def test_rgbd_tracker_matches_the_checker_loop(which, descriptor, max_depth, seed):
+def test_rgbd_tracker_matches_the_checker_loop(which, descriptor, max_depth, seed, monkeypatch):
     from _oracle import Oracle
+    # the product loop compacts its point pool every 4 frames here (32 by default): three compactions inside the 12 frames, the
+    # checker loop keeps everything — dropping the unreachable points and landmarks must not change a single result
+    monkeypatch.setenv("VSLAM_RGBD_COMPACT", "4")
     o = Oracle()
     scene, cfg, p = setup(o, which, descriptor=descriptor, max_depth=max_depth, seed=seed)
     o.create(cfg, 0, 1)

@@ -15,6 +15,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -70,6 +71,7 @@ public:
     if (p.rows != cfg.rows || p.cols != cfg.cols) { err = "RGB-D mode: depth parameters and configuration disagree on the image size"; return VSLAM_ERR_INVALID; }
     int rc = vslam_create(&cfg, device, 1, &ctx);
     if (rc != VSLAM_OK) { err = vslam_last_error(nullptr); return rc; }
+    if (const char* e = std::getenv("VSLAM_RGBD_COMPACT")) compact_period = std::atoi(e);   // frames between two compactions of the point pool (tests: a small number; 0 = never)
     reset();
     return VSLAM_OK;
   }
@@ -110,6 +112,7 @@ public:
 private:
   bool failed = false;
   std::string failed_why;
+  int compact_period = 32;
   int process_frame(const uint8_t* left, int32_t lstride, const uint16_t* depth, int32_t dstride) {
     img = left; img_stride = lstride; dep = depth; dep_stride = dstride;
     std::memset(&info, 0, sizeof info);
@@ -157,6 +160,7 @@ private:
     info.window_pixels = win; info.tau_track = tau_track;
     std::memcpy(info.camera_left_to_world, frames[fi].c2w, 96); std::memcpy(info.previous_to_current, prior, 96);
     n_temporary = (int)frames[fi].temps.size(); threshold = thr[0];
+    if (compact_period > 0 && (fi + 1) % compact_period == 0) compact(fi);
     return VSLAM_OK;
   }
 
@@ -207,6 +211,50 @@ private:
     Pt& q = pool[id];
     if (q.prev >= 0) { pool[q.prev].next = -1; q.prev = -1; }
     q.landmark = -1; q.next = -1; q.track_len = 0; q.origin = id;
+  }
+
+  // Bounded memory on long sequences: every 32 frames the point pool keeps only the points of the newest frames — the previous
+  // frame's lists feed the next track() and the lost list, a landmark is created from a chain of minimum_track_length + 1 points
+  // (pose_tracker_3d.cpp:485-511) — and the landmarks those points still refer to.  Older points are unreachable from then on:
+  // links into them become "none" (the track length stays a number), an origin that is dropped moves to the oldest kept ancestor
+  // (same landmark: a track's landmark is written to every point of its chain).  Frame POSES are kept for the whole run (the
+  // landmark measurements name them); their point lists are not.  Results are unchanged (tests/test_rgbd_mode.py runs across a
+  // compaction).
+  void compact(int fi) {
+    const int keep = std::max(3, cfg.minimum_track_length_for_landmark_creation + 2);
+    const int first = fi - keep + 1;
+    if (first <= 0) return;
+    std::vector<int> new_id(pool.size(), -1);
+    std::vector<Pt> np;
+    for (int f = first; f <= fi; ++f)
+      for (std::vector<int>* list : {&frames[f].points, &frames[f].temps})
+        for (int& id : *list) { new_id[id] = (int)np.size(); np.push_back(pool[id]); id = new_id[id]; }
+    for (int& id : lost) id = id >= 0 ? new_id[id] : -1;
+    lost.erase(std::remove(lost.begin(), lost.end(), -1), lost.end());
+    std::vector<int> lm_id(lms.size(), -1);
+    std::vector<Lm> nl;
+    // (links are remapped in a second pass: np[] still holds OLD indices in prev / next / origin)
+    for (size_t k = 0; k < np.size(); ++k) {
+      Pt& q = np[k];
+      q.prev = q.prev >= 0 ? new_id[q.prev] : -1;
+      q.next = q.next >= 0 ? new_id[q.next] : -1;
+    }
+    for (size_t k = 0; k < np.size(); ++k) {   // origins: the dropped ones walk forward to the first kept point of the chain
+      Pt& q = np[k];
+      const int mapped = q.origin >= 0 ? new_id[q.origin] : -1;
+      if (mapped >= 0) { q.origin = mapped; continue; }
+      int a = (int)k;
+      while (np[a].prev >= 0) a = np[a].prev;
+      q.origin = a;
+    }
+    for (Pt& q : np)
+      if (q.landmark >= 0) {
+        if (lm_id[q.landmark] < 0) { lm_id[q.landmark] = (int)nl.size(); nl.push_back(std::move(lms[q.landmark])); }
+        q.landmark = lm_id[q.landmark];
+      }
+    for (int f = 0; f < first; ++f) { std::vector<int>().swap(frames[f].points); std::vector<int>().swap(frames[f].temps); }
+    pool.swap(np);
+    lms.swap(nl);
   }
 
   // DepthFramePointGenerator::initialize (depth_framepoint_generator.cpp:24-44): depth map, FAST + controller over ONE image,
@@ -436,15 +484,14 @@ private:
       for (auto& lq : todo) for (const Meas& m : lms[lq.first].meas) used.push_back(m.frame);
       used.push_back(fi);
       std::sort(used.begin(), used.end()); used.erase(std::unique(used.begin(), used.end()), used.end());
-      std::vector<int> remap(frames.size(), -1);
-      for (size_t i = 0; i < used.size(); ++i) remap[used[i]] = (int)i;
+      auto remap = [&used](int frame) { return (int)(std::lower_bound(used.begin(), used.end(), frame) - used.begin()); };   // `used` is sorted, every frame asked for is in it
       std::vector<double> w2c(used.size() * 12), c2w(used.size() * 12);
       for (size_t i = 0; i < used.size(); ++i) { std::memcpy(&w2c[12 * i], frames[used[i]].w2c, 96); std::memcpy(&c2w[12 * i], frames[used[i]].c2w, 96); }
       std::vector<int32_t> off(1, 0), frame_of, upd; std::vector<double> cams, wld;
       for (auto& lq : todo) {
         const Lm& L = lms[lq.first];
-        for (const Meas& m : L.meas) { frame_of.push_back(remap[m.frame]); cams.insert(cams.end(), m.cam, m.cam + 3); }
-        frame_of.push_back(remap[fi]); cams.insert(cams.end(), pool[lq.second].cam, pool[lq.second].cam + 3);
+        for (const Meas& m : L.meas) { frame_of.push_back(remap(m.frame)); cams.insert(cams.end(), m.cam, m.cam + 3); }
+        frame_of.push_back(remap(fi)); cams.insert(cams.end(), pool[lq.second].cam, pool[lq.second].cam + 3);
         off.push_back((int32_t)frame_of.size());
         wld.insert(wld.end(), L.world, L.world + 3); upd.push_back(L.updates);
       }
