@@ -85,13 +85,16 @@ def run_sequence(oracle_cls, scene_kw, n_frames, n_streams=1, which="kitti", cfg
     # kernel up to 4 streams, one fused launch above) and the other one forced through VSLAM_SPLIT
     g = create_hip(cfg, n_streams)
     g2 = create_hip(cfg, n_streams, split=0 if n_streams <= 4 else 2)
+    # third launch sequence: registration, wide recovery kernel, then the frame's tail as the small co-schedulable kernel (k_tail:
+    # 256 threads, stereo sweep band by band, bin competition on 16-bit tables, landmark cache one measurement deep)
+    g3 = create_hip(cfg, n_streams, split=3)
     try:
         for k in range(n_frames):
             imgs = [o.render(sc, k) for sc in scenes]
             L = np.stack([im[0] for im in imgs])
             R = np.stack([im[1] for im in imgs])
             o.process_host(L, R)
-            for h in (g, g2):
+            for h in (g, g2, g3):
                 h.process_host(L, R)
                 for s in range(n_streams):
                     compare_frame(o, h, s, k)
@@ -100,6 +103,7 @@ def run_sequence(oracle_cls, scene_kw, n_frames, n_streams=1, which="kitti", cfg
     finally:
         g.destroy()
         g2.destroy()
+        g3.destroy()
         o.destroy()
 
 

@@ -1,0 +1,21 @@
+import ctypes as C, os, sys
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+mode = sys.argv[1]
+from vslam_pose_estimation_framework_amd import hip
+g = hip.load()
+if mode in ("full", "full_alive"):
+    g.create(g.default_config("kitti"), 0, 1)
+elif mode == "half":
+    from _oracle import Oracle
+    o = Oracle(); sc = o.scene_kitti(scale=0.5); g.create(o.config_for_scene(sc), 0, 1)
+if mode != "full_alive" and mode != "none":
+    g.destroy()
+print("maps:", sorted({l.split()[-1] for l in open("/proc/self/maps") if "amdhip" in l or "hsa-runtime" in l}))
+import torch
+print("torch hip:", torch.version.hip)
+try:
+    print("device_count", torch.cuda.device_count())
+    x = torch.zeros(4, device="cuda"); print(mode, "torch ok")
+except Exception as e:
+    print(mode, "torch FAILED:", str(e)[:120])
+print("maps after:", sorted({l.split()[-1] for l in open("/proc/self/maps") if "amdhip" in l or "hsa-runtime" in l}))

@@ -14,6 +14,30 @@ def lib_path():
     return LIB
 
 
+_torch_checked = False
+
+
+def _initialise_torch_first():
+    """A process that uses both PyTorch-ROCm and this library holds TWO ROCm runtimes: torch's wheel bundles its own libamdhip64 /
+    libhsa-runtime64, libvslam_hip.so links the system's (/opt/rocm).  Measured on this image (tools/probe/torch_after_hip.py):
+    when the system runtime creates a context first, torch's later fails with "No HIP GPUs are available"; the other way round
+    both work.  So when torch is installed its GPU context is initialised before the library's first HIP call."""
+    global _torch_checked
+    if _torch_checked:
+        return
+    _torch_checked = True
+    try:
+        import torch
+    except ImportError:
+        return
+    try:
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:      # no usable GPU for torch: the library reports its own error at vslam_create
+        pass
+
+
 def load():
     """Bind libvslam_hip.so (prefix vslam_).  Creating a context additionally needs an MI355X."""
+    _initialise_torch_first()
     return CApi(lib_path(), "vslam_")
