@@ -38,7 +38,7 @@ SEQ_FRAMES = KITTI_FRAMES[0]
 EUROC_MH01_FRAMES = 3682   # MH_01_easy stereo pairs
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PMC_SUMMARY = "r03_pmc_traffic.json"   # tools/pmc_traffic.sh (rocprofv3 --pmc, separate passes); carries the source hash of its build
-ATE_NOISE_STUDY = "r03_ate_noise_seeds.json"   # tools/eval_ate_noise.py: sequential ATE spread under sensor noise vs chunked
+ATE_NOISE_STUDY = ["r03_ate_noise_seeds16.json", "r03_ate_noise_seeds.json"]   # tools/eval_ate_noise.py: sequential ATE spread under sensor noise vs chunked (16 seeds for the default configuration, 8 seeds for the B x overlap grid)
 METRIC = "stereo frames/sec on KITTI-00 at 1/2/4/8 MI355X; ATE vs reference"
 KERNELS = ["k_fast_box", "k_emit", "k_brief", "k_track_candidates", "k_frame", "k_recover_brief", "k_update_landmarks", "k_stereo_dist"]
 
@@ -385,18 +385,23 @@ class Bench(object):
                              "the reference tool's own alignment (trajectory_analyzer.cpp:212-309 as restated in evaluation.py)",
                "chunked_is": "the timed configuration itself: %d chunks of %d frames + %d warm-up frames, chained at the seams" % (B, job["L"], self.args.overlap),
                "sequential_is": "the same images as ONE stream (exact mode: identical to the CPU port to rounding), %.2f s for the whole sequence" % seq_s}
-        try:       # where single runs sit in the pipeline's own spread under sensor noise (tools/eval_ate_noise.py)
-            st = json.load(open(os.path.join(ROOT, "profiles", ATE_NOISE_STUDY)))["summary"]["ate"]
-            key = "B%d_ov%d" % (self.args.streams, self.args.overlap)
-            out["noise_study"] = {"file": "profiles/" + ATE_NOISE_STUDY, "sequential_mean": round(st["sequential"]["mean"], 3),
+        key = "B%d_ov%d" % (self.args.streams, self.args.overlap)
+        for name in ATE_NOISE_STUDY:      # where single runs sit in the pipeline's own spread under sensor noise (tools/eval_ate_noise.py)
+            try:
+                full = json.load(open(os.path.join(ROOT, "profiles", name)))["summary"]
+                st = full["ate"]
+            except (OSError, KeyError, ValueError):
+                continue
+            if key not in st["chunked"] and name != ATE_NOISE_STUDY[-1]:
+                continue
+            out["noise_study"] = {"file": "profiles/" + name, "noise_seeds": full.get("noise_seeds"), "sequential_mean": round(st["sequential"]["mean"], 3),
                                   "sequential_std": round(st["sequential"]["std"], 3)}
             if key in st["chunked"]:
                 c = st["chunked"][key]
                 out["noise_study"].update({"chunked_mean": round(c["mean"], 3), "chunked_std": round(c["std"], 3),
                                            "mean_shift_in_sequential_sigmas": round(c["mean_shift_in_sequential_sigmas"], 3),
-                                           "welch_t": round(c["welch_t"], 3)})
-        except (OSError, KeyError, ValueError):
-            pass
+                                           "welch_t": round(c["welch_t"], 3), "chunked_runs_inside_sequential_range": c["inside_sequential_range"]})
+            break
         return out
 
     # ------------------------------------------------------------------------------------------------------------------
