@@ -20,7 +20,8 @@
 
 #define VS_TILE_W 64
 #ifndef VS_TILE_H
-#define VS_TILE_H 48          // rows of a k_fast_box tile (multiple of 8); 16 .. 64 measured: 48 is the fastest
+#define VS_TILE_H 64          // rows of a k_fast_box tile (multiple of 8); 32 .. 96 measured with the 20 KB LDS footprint:
+                              // 64 is the fastest (48 was, while the horizontal sums had their own 7 KB)
 #endif
 #define VS_CELL 16
 #define VS_MAXCAND 16        // candidate list length per previous point (overflow -> exact rescan)

@@ -71,7 +71,7 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* sh, int* total) 
 
 // ==============================================================================================
 // K1: FAST-9/16 score + strict 3x3 NMS -> 1 bit/pixel corner mask (+ sparse u8 scores), fused with
-// the 9x9 box-sum image BRIEF samples.  One 64 x VS_TILE_H (48) output tile per 256-thread workgroup; the u8
+// the 9x9 box-sum image BRIEF samples.  One 64 x VS_TILE_H (64) output tile per 256-thread workgroup; the u8
 // tile with a 4 px halo (FAST ring 3 + NMS 1 == box radius 4) is staged once in LDS.
 // HBM traffic per pixel: 1 B read, 2 B box write, 1/8 B mask write, sparse scores.
 // ==============================================================================================
@@ -139,21 +139,25 @@ __device__ __forceinline__ void fast_pair_scores(const uint8_t (*t)[80], int ly0
 
 // The candidate queue is DYNAMIC shared memory (VS_FB_DYN_LDS bytes at every launch): with all 22.6 KB declared statically the
 // compiler sees an LDS-bound occupancy of 7 wavefronts per SIMD and allows itself 72 VGPRs (it used 65); with the queue out of
-// sight it has to honour 8 wavefronts = 64 VGPRs.  The kernel still runs 7 workgroups per CU (LDS), but each SIMD now keeps
-// 64 VGPRs free, so that ONE workgroup leaving makes room for a 128-VGPR wavefront of another kernel (tools/probe/cosched.hip).
+// sight it has to honour 8 wavefronts = 64 VGPRs (tools/probe/cosched.hip: a 64-VGPR neighbour is what lets a 128-VGPR wavefront
+// of another kernel in when one workgroup leaves).
 #define VS_FB_QCAP ((VS_TILE_H + 2) * 66)
-#define VS_FB_DYN_LDS ((VS_FB_QCAP + 256) * 2)
+#define VS_FB_HS_BYTES ((VS_TILE_H + 8) * VS_TILE_W * 2)
+#define VS_FB_DYN_LDS (((VS_FB_QCAP + 256) * 2) > VS_FB_HS_BYTES ? ((VS_FB_QCAP + 256) * 2) : VS_FB_HS_BYTES)
 __global__ __launch_bounds__(256, 8) void k_fast_box(const DevCfg c, const DevBuf b) {
   extern __shared__ __align__(16) unsigned char fb_dyn[];
   __shared__ __align__(16) uint8_t tile[VS_TILE_H + 8][80];
   __shared__ __align__(4) uint8_t sc[VS_TILE_H + 2][68];
-  __shared__ __align__(8) uint16_t hs[VS_TILE_H + 8][VS_TILE_W];
   __shared__ int32_t s_thr[VSLAM_MAX_REGIONS];
   // candidate queue of the tile (packed: the scoring pass fills whole wavefronts — per-wavefront queues were measured slower,
   // they leave every wavefront a partly filled scoring pass); the 256 slots behind it take the stores of lanes without a
   // candidate, so that the four queue writes of a pretest pass need no exec-mask branches
   constexpr int QCAP = VS_FB_QCAP;
   uint16_t* queue = reinterpret_cast<uint16_t*>(fb_dyn);
+  // the horizontal 9-sums of the box pass live in the SAME memory: the queue is dead once the NMS has read it, the sums are built after
+  // that (one more barrier, 7-9 KB less LDS).  With that a 64-row tile costs 20 052 B, 8 workgroups = 32 wavefronts still share a CU, and the
+  // taller tile stages 72 rows for 64 instead of 56 for 48 (measured: 0.309 -> 0.275 ms back to back at 160 streams; 32/48/80/96 rows slower)
+  uint16_t (*hs)[VS_TILE_W] = reinterpret_cast<uint16_t (*)[VS_TILE_W]>(fb_dyn);
   __shared__ unsigned long long lmask[VS_TILE_H];
   __shared__ int qn;
   int tx, ty, tz;
@@ -319,24 +323,9 @@ __global__ __launch_bounds__(256, 8) void k_fast_box(const DevCfg c, const DevBu
     }
   } else {
     for (int r = w; r < VS_TILE_H + 2; r += 4) pretest(r, lane);
-    // the two halo columns 64, 65 of every row: (H+2)*2 pixels, waves 0-1
-    if (tid < 128) {
-      const int i = tid;
-      if (i < (VS_TILE_H + 2) * 2) pretest(i >> 1, 64 + (i & 1));
-    }
-  }
-  // ---- horizontal 9-sums, four outputs per thread from three aligned dwords -----------------------------------------
-  const bool want_box = !(VS_PROBE & 4) && c.c.descriptor_type == VSLAM_DESCRIPTOR_BRIEF;   // ORB samples the Gaussian image instead
-  if (want_box)
-  for (int i = tid; i < (VS_TILE_H + 8) * 16; i += 256) {
-    const int r = i >> 4, q = i & 15;
-    const uint32_t* p = reinterpret_cast<const uint32_t*>(&tile[r][4 * q]);
-    const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
-    const uint32_t s0 = __builtin_amdgcn_sad_u8(w0, 0u, __builtin_amdgcn_sad_u8(w1, 0u, w2 & 255u));
-    const uint32_t s1 = s0 - (w0 & 255u) + ((w2 >> 8) & 255u);
-    const uint32_t s2 = s1 - ((w0 >> 8) & 255u) + ((w2 >> 16) & 255u);
-    const uint32_t s3 = s2 - ((w0 >> 16) & 255u) + (w2 >> 24);
-    *reinterpret_cast<uint2*>(&hs[r][4 * q]) = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
+    // the two halo columns 64, 65 of every row: (H+2)*2 pixels
+    if (tid < (VS_TILE_H + 2) * 2) pretest(tid >> 1, 64 + (tid & 1));
+    static_assert((VS_TILE_H + 2) * 2 <= 256, "one pass over the halo columns");
   }
   __syncthreads();
   if (!(VS_PROBE & 2)) {
@@ -376,6 +365,21 @@ __global__ __launch_bounds__(256, 8) void k_fast_box(const DevCfg c, const DevBu
       }
     }
   }
+  __syncthreads();   // every reader of the candidate queue is done: its memory becomes the horizontal sums
+  // ---- horizontal 9-sums, four outputs per thread from three aligned dwords -----------------------------------------
+  const bool want_box = !(VS_PROBE & 4) && c.c.descriptor_type == VSLAM_DESCRIPTOR_BRIEF;   // ORB samples the Gaussian image instead
+  if (want_box)
+  for (int i = tid; i < (VS_TILE_H + 8) * 16; i += 256) {
+    const int r = i >> 4, q = i & 15;
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(&tile[r][4 * q]);
+    const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+    const uint32_t s0 = __builtin_amdgcn_sad_u8(w0, 0u, __builtin_amdgcn_sad_u8(w1, 0u, w2 & 255u));
+    const uint32_t s1 = s0 - (w0 & 255u) + ((w2 >> 8) & 255u);
+    const uint32_t s2 = s1 - ((w0 >> 8) & 255u) + ((w2 >> 16) & 255u);
+    const uint32_t s3 = s2 - ((w0 >> 16) & 255u) + (w2 >> 24);
+    *reinterpret_cast<uint2*>(&hs[r][4 * q]) = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
+  }
+  __syncthreads();
   // ---- vertical 9-sums (sliding), two pixels per lane in packed u16 -> u16 box image: lanes 0-31 own the upper half of
   // the wave's rows, lanes 32-63 the lower half --------------------------------------------------------------------------
   if (want_box) {
