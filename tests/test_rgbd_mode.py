@@ -1,7 +1,9 @@
 """RGB-D mode end to end: PoseTracker3D with a DepthFramePointGenerator and a UVDAligner.
 
 Two independent statements of the same tracker are compared on rendered image + depth sequences:
-  * the product: the C++ host loop inside libvslam_hip.so (csrc/rgbd_tracker.h, vslam_rgbd_*) over the device entry points;
+  * the product (vslam_rgbd_*): the device-resident loop inside libvslam_hip.so (csrc/rgbd_device.h + kernels_rgbd.h: the tracker's state
+    stays in HBM, a frame is one launch sequence and one small read-back), and its second implementation, the C++ host loop over the
+    library's stand-alone device entry points (csrc/rgbd_tracker.h, VSLAM_RGBD_HOST=1) — both run here;
   * the checker: tests/rgbd_loop.py, a plain Python loop, run over the CPU oracle's stand-alone functions.
 Counters and point lists must agree exactly, poses within 1e-4 relative Frobenius (north_star).  The Python loop is also run
 over the HIP entry points (same control flow, device kernels), which separates a kernel difference from a loop difference."""
@@ -109,9 +111,11 @@ def test_python_loop_over_the_oracle_runs_every_configuration(which):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("impl", ["device", "host"])
 @pytest.mark.parametrize("which,descriptor,max_depth,seed", [("tum", 1, None, 23), ("tum", 0, 25.0, 31), ("icl", 1, None, 29), ("xtion", 1, None, 37)])
-def test_rgbd_tracker_matches_the_checker_loop(which, descriptor, max_depth, seed, monkeypatch):
+def test_rgbd_tracker_matches_the_checker_loop(which, descriptor, max_depth, seed, impl, monkeypatch):
     from _oracle import Oracle
+    monkeypatch.setenv("VSLAM_RGBD_HOST", "1" if impl == "host" else "0")
     # the product loop compacts its point pool every 4 frames here (32 by default): three compactions inside the 12 frames, the
     # checker loop keeps everything — dropping the unreachable points and landmarks must not change a single result
     monkeypatch.setenv("VSLAM_RGBD_COMPACT", "4")
@@ -177,10 +181,12 @@ def test_rgbd_tracker_argument_errors():
 
 
 @pytest.mark.gpu
-def test_rgbd_degenerate_inputs():
+@pytest.mark.parametrize("impl", ["device", "host"])
+def test_rgbd_degenerate_inputs(impl, monkeypatch):
     """Featureless frames, a depth image without a single measurement (every feature becomes a temporary point), a depth image
     that comes back, a scene cut: product loop and checker loop stay identical and nothing raises."""
     from _oracle import Oracle
+    monkeypatch.setenv("VSLAM_RGBD_HOST", "1" if impl == "host" else "0")
     o = Oracle()
     scene, cfg, p = setup(o, "tum", descriptor=0, max_depth=30.0, seed=41)
     scene2 = o.scene_kitti(scale=0.5, seed=977)

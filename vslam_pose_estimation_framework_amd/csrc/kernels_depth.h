@@ -105,11 +105,12 @@ __device__ __forceinline__ int depth_bin(const vslam_depth_params& p, int row, i
   return rb * cols_bin1 + cb;
 }
 
-__global__ __launch_bounds__(1024) void k_depth_compute(const vslam_depth_params p, const float* space, int nF, const int32_t* rcF, int nT,
-                                                        const int32_t* rcT, unsigned long long* bins, int n_bins, int rows_bin, int cols_bin,
-                                                        int cap, int32_t* counts, int32_t* new_feat, double* new_xyz, int32_t* temp_feat,
-                                                        double* temp_xyz, uint8_t* cls) {
-  __shared__ int sh[17];
+// body (1024 threads, sh = 17 ints of LDS): also called by the device-resident RGB-D loop (kernels_rgbd.h) with counts it reads
+// from device memory
+__device__ __forceinline__ void depth_compute_body(const vslam_depth_params& p, const float* space, int nF, const int32_t* rcF, int nT,
+                                                   const int32_t* rcT, unsigned long long* bins, int n_bins, int rows_bin, int cols_bin,
+                                                   int cap, int32_t* counts, int32_t* new_feat, double* new_xyz, int32_t* temp_feat,
+                                                   double* temp_xyz, uint8_t* cls, int* sh) {
   const int tid = threadIdx.x;
   const int cols_bin1 = cols_bin + 1;   // rint() can reach the grid size (latent overflow upstream): spare row / column
   for (int i = tid; i < n_bins; i += 1024) bins[i] = ~0ull;
@@ -174,18 +175,20 @@ __global__ __launch_bounds__(1024) void k_depth_compute(const vslam_depth_params
   }
   if (tid == 0) { counts[0] = n_new; counts[1] = n_temp; }
 }
+__global__ __launch_bounds__(1024) void k_depth_compute(const vslam_depth_params p, const float* space, int nF, const int32_t* rcF, int nT,
+                                                        const int32_t* rcT, unsigned long long* bins, int n_bins, int rows_bin, int cols_bin,
+                                                        int cap, int32_t* counts, int32_t* new_feat, double* new_xyz, int32_t* temp_feat,
+                                                        double* temp_xyz, uint8_t* cls) {
+  __shared__ int sh[17];
+  depth_compute_body(p, space, nF, rcF, nT, rcT, bins, n_bins, rows_bin, cols_bin, cap, counts, new_feat, new_xyz, temp_feat, temp_xyz, cls, sh);
+}
 
 // ---- midpoint triangulation -------------------------------------------------------------------------------------
 // The 3x2 least-squares system [-R x0 | x1] z = t (:480-486): QR of the two columns, triangular solve; minimum-norm
 // solution when the rays are parallel to rounding (JacobiSVD's rank rule: sigma_min <= 2 eps sigma_max).
-__global__ __launch_bounds__(256) void k_point_in_camera(int n, const float* xp, const float* xc, const double* Tg, const double* Kg, double* out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  double T[12], K[9];
-  for (int k = 0; k < 12; ++k) T[k] = Tg[k];
-  for (int k = 0; k < 9; ++k) K[k] = Kg[k];
-  const double a0 = ((double)xp[2 * i] - K[2]) / K[0], b0 = ((double)xp[2 * i + 1] - K[5]) / K[4];   // :470-473
-  const double a1 = ((double)xc[2 * i] - K[2]) / K[0], b1 = ((double)xc[2 * i + 1] - K[5]) / K[4];
+__device__ __forceinline__ void point_in_camera_one(const float* xp2, const float* xc2, const double* T, const double* K, double* out3) {
+  const double a0 = ((double)xp2[0] - K[2]) / K[0], b0 = ((double)xp2[1] - K[5]) / K[4];   // :470-473
+  const double a1 = ((double)xc2[0] - K[2]) / K[0], b1 = ((double)xc2[1] - K[5]) / K[4];
   const double x0[3] = {a0, b0, 1}, x1[3] = {a1, b1, 1};
   double c0[3], t[3];
   for (int k = 0; k < 3; ++k) { c0[k] = -((T[4 * k] * x0[0] + T[4 * k + 1] * x0[1]) + T[4 * k + 2] * x0[2]); t[k] = T[4 * k + 3]; }
@@ -209,8 +212,16 @@ __global__ __launch_bounds__(256) void k_point_in_camera(int n, const float* xp,
   const double pp[3] = {x0[0] * z0, x0[1] * z0, x0[2] * z0};                                        // :489
   for (int k = 0; k < 3; ++k) {
     const double moved = ((T[4 * k] * pp[0] + T[4 * k + 1] * pp[1]) + T[4 * k + 2] * pp[2]) + T[4 * k + 3];
-    out[3 * (size_t)i + k] = (x1[k] * z1 + moved) / 2.0;                                            // :490-493
+    out3[k] = (x1[k] * z1 + moved) / 2.0;                                                           // :490-493
   }
+}
+__global__ __launch_bounds__(256) void k_point_in_camera(int n, const float* xp, const float* xc, const double* Tg, const double* Kg, double* out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double T[12], K[9];
+  for (int k = 0; k < 12; ++k) T[k] = Tg[k];
+  for (int k = 0; k < 9; ++k) K[k] = Kg[k];
+  point_in_camera_one(xp + 2 * (size_t)i, xc + 2 * (size_t)i, T, K, out + 3 * (size_t)i);
 }
 
 // ---- track ------------------------------------------------------------------------------------------------------
@@ -288,9 +299,7 @@ __device__ __forceinline__ bool depth_track_project(const DepthTrack& a, int i, 
 // sweeps of k_depth_track.  More than VS_DT_CAP candidates: the list is declared incomplete (count = huge, no keys), the
 // resolution kernel then rescans that window itself.
 #define VS_DT_CAP 32
-__global__ __launch_bounds__(256) void k_depth_track_candidates(const DepthTrack a) {
-  __shared__ unsigned long long keys[16][VS_DT_CAP];
-  __shared__ int cnt[16];
+__device__ __forceinline__ void depth_track_candidates_body(const DepthTrack& a, unsigned long long (*keys)[VS_DT_CAP], int* cnt) {
   const int lane = threadIdx.x & 15, g = threadIdx.x >> 4;
   for (int i = blockIdx.x * 16 + g; i < a.nP; i += gridDim.x * 16) {
     unsigned long long* list = a.cand + (size_t)i * (VS_DT_K + 1);
@@ -343,10 +352,15 @@ __global__ __launch_bounds__(256) void k_depth_track_candidates(const DepthTrack
     __builtin_amdgcn_wave_barrier();
   }
 }
+__global__ __launch_bounds__(256) void k_depth_track_candidates(const DepthTrack a) {
+  __shared__ unsigned long long keys[16][VS_DT_CAP];
+  __shared__ int cnt[16];
+  depth_track_candidates_body(a, keys, cnt);
+}
 
-__global__ __launch_bounds__(1024) void k_depth_track(const DepthTrack a) {
-  __shared__ int sh[17];
-  __shared__ int changed;
+// body (1024 threads; sh = 17 ints, changed_p = one int of LDS)
+__device__ __forceinline__ void depth_track_body(const DepthTrack& a, int* sh, int* changed_p) {
+  int& changed = *changed_p;
   const int tid = threadIdx.x;
   int32_t* hold = a.hold;
   int32_t* next = a.hold + a.nL;
@@ -428,6 +442,11 @@ __global__ __launch_bounds__(1024) void k_depth_track(const DepthTrack a) {
   }
   if (tid == 0) { a.counts[0] = n_trk; a.counts[1] = n_tmp; a.counts[2] = n_lost; a.counts[3] = n_lm; }
 }
+__global__ __launch_bounds__(1024) void k_depth_track(const DepthTrack a) {
+  __shared__ int sh[17];
+  __shared__ int changed;
+  depth_track_body(a, sh, &changed);
+}
 
 // ---- recoverPoints ----------------------------------------------------------------------------------------------
 // One thread per lost point: projection of its landmark, field-of-view, depth and border gates (:317-359), the pixel
@@ -449,9 +468,7 @@ struct DepthRecover {
   int32_t* count; int32_t* rec_index; float* rec_xy; uint8_t* rec_desc; double* rec_xyz;
 };
 
-__global__ __launch_bounds__(256) void k_depth_recover_project(const DepthRecover a) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.n) return;
+__device__ __forceinline__ void depth_recover_project_one(const DepthRecover& a, int i) {
   int cell = -1, bx = 0, by = 0;
   float kx = 0.f, ky = 0.f;
   if (a.has_lm[i]) {                                                              // :305-307
@@ -483,9 +500,13 @@ __global__ __launch_bounds__(256) void k_depth_recover_project(const DepthRecove
   a.bxy[2 * i] = (int16_t)(cell >= 0 ? bx : 0); a.bxy[2 * i + 1] = (int16_t)(cell >= 0 ? by : 0);
   a.kxy[2 * i] = kx; a.kxy[2 * i + 1] = ky;
 }
+__global__ __launch_bounds__(256) void k_depth_recover_project(const DepthRecover a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  depth_recover_project_one(a, i);
+}
 
-__global__ __launch_bounds__(1024) void k_depth_recover_finish(const DepthRecover a) {
-  __shared__ int sh[17];
+__device__ __forceinline__ void depth_recover_finish_body(const DepthRecover& a, int* sh) {
   const int tid = threadIdx.x;
   int n_rec = 0;
   for (int base = 0; base < a.n; base += 1024) {
@@ -510,4 +531,8 @@ __global__ __launch_bounds__(1024) void k_depth_recover_finish(const DepthRecove
     }
   }
   if (tid == 0) a.count[0] = n_rec;
+}
+__global__ __launch_bounds__(1024) void k_depth_recover_finish(const DepthRecover a) {
+  __shared__ int sh[17];
+  depth_recover_finish_body(a, sh);
 }

@@ -407,6 +407,8 @@ __global__ __launch_bounds__(256, 8) void k_fast_box(const DevCfg c, const DevBu
 // row-major, builds the row/cell CSR, counts raw detections per detector region, then runs the
 // threshold controller + adjustDetectorThresholds and the triangulation-distance rule
 // (stereo_framepoint_generator.cpp:109-125).  `border` = 28 in the pipeline, 0 for stand-alone FAST.
+// run_controller: 0 none, 1 over the stream's two images (stereo: grid (streams, 2)), 2 over ONE image (RGB-D mode, grid
+// (streams, 1): adjustDetectorThresholds averages a single detection, depth_framepoint_generator.cpp:24-44).
 // ==============================================================================================
 __device__ __forceinline__ unsigned long long col_mask(int lo, int hi, int wx0) {
   // bits of a 64-px word starting at column wx0 whose column lies in [lo, hi)
@@ -540,9 +542,10 @@ __global__ __launch_bounds__(512, 4) void k_emit(const DevCfg c, const DevBuf b,
   if (tid == 0) {
     for (int r = 0; r < c.n_regions; ++r) b.iinfo[s].raw_count[side][r] = sh_cnt[r];
     __threadfence();
+    const int last_ticket = (int)gridDim.y - 1;
     const int ticket = atomicAdd(&b.iinfo[s].ticket, 1);
-    sh_last = ticket == 1;
-    if (ticket == 1) { __threadfence(); b.iinfo[s].ticket = 0; }
+    sh_last = ticket == last_ticket;
+    if (ticket == last_ticket) { __threadfence(); b.iinfo[s].ticket = 0; }
   }
   __syncthreads();
   if (tid == 0 && sh_last) {
@@ -553,9 +556,10 @@ __global__ __launch_bounds__(512, 4) void k_emit(const DevCfg c, const DevBuf b,
       const double tol = c.c.target_number_of_keypoints_tolerance, maxchg = c.c.detector_threshold_maximum_change;
       const double tmin = c.c.detector_threshold_minimum, tmax = c.c.detector_threshold_maximum;
       const double target = (double)c.target_per_detector;
+      const int n_sides = run_controller == 2 ? 1 : 2;
       for (int r = 0; r < c.n_regions; ++r) {
         double acc = 0;
-        for (int sd = 0; sd < 2; ++sd) {
+        for (int sd = 0; sd < n_sides; ++sd) {
           double t = (double)st.thr[r];
           const double delta = ((double)__hip_atomic_load(&cnt[sd][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) / target;
           if (delta < -tol) {
@@ -569,7 +573,7 @@ __global__ __launch_bounds__(512, 4) void k_emit(const DevCfg c, const DevBuf b,
           }
           acc += t;
         }
-        st.thr[r] = (int)rint(acc / 2);
+        st.thr[r] = (int)rint(acc / n_sides);
       }
     }
     for (int r = 0; r < c.n_regions; ++r) b.iinfo[s].thr_after[r] = st.thr[r];

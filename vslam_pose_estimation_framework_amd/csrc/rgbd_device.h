@@ -1,0 +1,215 @@
+// rgbd_device.h — host side of the device-resident RGB-D loop (kernels_rgbd.h): buffers, the per-frame launch sequence on one HIP stream,
+// one small read-back per frame.  Included by vslam_hip.hip after the context code (it uses create_internal / buf_set / fail of that file).
+//
+// A frame is: two host-to-device copies (image, depth), ~19 kernel launches, one 1.2 KB device-to-host copy, one stream synchronisation.  When
+// the registration asks for another attempt (RgbdState::done still 0 after the tail skipped itself: pose_tracker_3d.cpp:333-418, a lost
+// track), the block image pipeline .. aligner .. tail is enqueued again, at most twice.
+#pragma once
+#include "kernels_rgbd.h"
+
+namespace vs_rgbd {
+
+class DeviceTracker {
+public:
+  vslam_ctx* ic = nullptr;       // inner context: image pipeline buffers, aligner SoA, detector thresholds (stream 0)
+  vslam_config cfg;
+  vslam_depth_params p;
+  std::string err;
+  RgbdState host;                // last state block read back
+  bool failed = false;
+  std::string failed_why;
+
+  ~DeviceTracker() { release(); }
+
+  int create(const vslam_config& c, const vslam_depth_params& dp, int device) {
+    cfg = c; p = dp;
+    if (cfg.det_rows < 1 || cfg.det_cols < 1 || cfg.det_rows * cfg.det_cols > VSLAM_MAX_REGIONS) { err = "RGB-D mode: bad detector grid"; return VSLAM_ERR_INVALID; }
+    if (p.rows != cfg.rows || p.cols != cfg.cols) { err = "RGB-D mode: depth parameters and configuration disagree on the image size"; return VSLAM_ERR_INVALID; }
+    if (cfg.max_points > 65535) { err = "RGB-D mode: max_points above 65535 (16-bit trail indices)"; return VSLAM_ERR_INVALID; }
+    vslam_config in = cfg;
+    in.descriptor_type = p.descriptor_type;      // the extractor initialize() uses (depth_framepoint_generator.cpp:24-44 -> computeDescriptors)
+    in.max_history_frames = 2;                    // the stereo tracker's history ring is not used in this mode
+    int rc = create_internal(&in, device, 1, &ic);
+    if (rc != VSLAM_OK) { err = vslam_last_error(nullptr); return rc; }
+    q = ic->stream_img;
+    const size_t MAXP = ic->cfg.MAXP, NMAX = ic->cfg.NMAX, npx = (size_t)p.rows * p.cols;
+    H = std::max(4, std::min(cfg.max_history_frames, 512));
+    TR = H - 2;
+    std::memset(&rb, 0, sizeof rb);
+    rb.p = p; rb.TR = TR; rb.H = H;
+    hipError_t e = hipSuccess;
+    auto A = [&](auto** ptr, size_t count) { if (e == hipSuccess) e = dalloc(ic, ptr, count); };
+    A(&rb.st, 1);
+    for (RgbdList* l : {&rb.fl[0], &rb.fl[1], &rb.tmp}) {
+      A(&l->xy, MAXP * 2); A(&l->desc, MAXP * 32); A(&l->cam, MAXP * 3); A(&l->prev, MAXP); A(&l->tlen, MAXP); A(&l->flags, MAXP);
+      A(&l->lmw, MAXP * 3); A(&l->lmu, MAXP); A(&l->lmm, MAXP);
+      if (l != &rb.tmp) A(&l->trail, MAXP * (size_t)TR);
+    }
+    A(&rb.order, NMAX); A(&rb.matched, NMAX);
+    A(&d_depth, npx); A(&rb.dkey, npx); A(&rb.dlast, npx); A(&rb.space, npx * 3); A(&rb.row_map, npx); A(&rb.col_map, npx);
+    A(&rb.hold, NMAX * 2); A(&rb.pick, MAXP); A(&rb.cand, MAXP * (VS_DT_K + 1)); A(&rb.out2, MAXP * 2); A(&rb.xyz, MAXP * 3); A(&rb.temp2, MAXP * 2); A(&rb.lost_raw, MAXP);
+    A(&rb.lost, MAXP); A(&rb.lost_has, MAXP); A(&rb.lost_lm, MAXP * 3); A(&rb.lost_desc, MAXP * 32);
+    A(&rb.rbxy, MAXP * 2); A(&rb.rkxy, MAXP * 2); A(&rb.rcell, MAXP); A(&rb.rkeep, MAXP); A(&rb.rdesc, MAXP * 32); A(&rb.ridx, MAXP); A(&rb.rxy, MAXP * 2);
+    A(&rb.rrdesc, MAXP * 32); A(&rb.rxyz, MAXP * 3);
+    const int rows_bin = p.enable_keypoint_binning ? p.rows / std::max(p.bin_size_pixels, 1) + 1 : 0, cols_bin = p.enable_keypoint_binning ? p.cols / std::max(p.bin_size_pixels, 1) + 1 : 0;
+    A(&rb.rcF, NMAX * 2); A(&rb.remf, NMAX); A(&rb.rcT, MAXP * 2); A(&rb.bins, (size_t)(rows_bin + 1) * (cols_bin + 1)); A(&rb.cls, NMAX);
+    A(&rb.new_feat, NMAX); A(&rb.new_xyz, NMAX * 3); A(&rb.temp_feat, NMAX); A(&rb.temp_xyz, NMAX * 3);
+    A(&rb.weights, MAXP);
+    A(&rb.h_cam, (size_t)H * MAXP * 3); A(&rb.h_pose, (size_t)H * 24); A(&rb.pose_log, (size_t)VS_POSE_LOG * 12);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&pinned, sizeof(RgbdState), hipHostMallocDefault);
+    if (e != hipSuccess) { err = std::string("RGB-D mode: ") + hipGetErrorString(e); release(); return VSLAM_ERR_HIP; }
+    rb.depth = d_depth;
+    return reset();
+  }
+
+  int reset() {
+    if (!ic) return VSLAM_ERR_STATE;
+    (void)hipSetDevice(ic->device);
+    (void)hipStreamSynchronize(q);
+    int rc = init_state(ic);                                                 // detector thresholds back to the minimum (FastDetector of a fresh generator)
+    if (rc != VSLAM_OK) { err = ic->err; return rc; }
+    RgbdState s;
+    std::memset(&s, 0, sizeof s);
+    s.status = VSLAM_LOCALIZING;
+    s.win = cfg.maximum_projection_tracking_distance_pixels;
+    s.tau_track = cfg.minimum_descriptor_distance_tracking;
+    tf_identity(s.prior); tf_identity(s.world);
+    host = s;
+    hipError_t e = hipMemcpy(rb.st, &s, sizeof s, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { err = hipGetErrorString(e); return VSLAM_ERR_HIP; }
+    failed = false; failed_why.clear();
+    return VSLAM_OK;
+  }
+
+  int process(const uint8_t* left, int32_t lstride, const uint16_t* depth, int32_t dstride) {
+    if (!left || !depth) { err = "called with empty frame"; return VSLAM_ERR_INVALID; }
+    if (failed) { err = "RGB-D tracker: an earlier frame failed (" + failed_why + "); reset() before the next frame"; return VSLAM_ERR_STATE; }
+    const int rc = process_frame(left, lstride, depth, dstride);
+    if (rc != VSLAM_OK) { failed = true; failed_why = err; }
+    return rc;
+  }
+
+  int get_points(int32_t cap, int32_t* n, float* xy, double* cam, int32_t* meta4, uint8_t* desc) {
+    if (host.frame_count == 0) { *n = 0; return VSLAM_OK; }
+    const int np = host.last_points;
+    *n = np;
+    if (np > cap) { err = "point output capacity too small"; return VSLAM_ERR_CAPACITY; }
+    if (np == 0) return VSLAM_OK;
+    const RgbdList& l = rb.fl[(host.frame_count - 1) & 1];
+    hipError_t e = hipSuccess;
+    if (xy) e = hipMemcpy(xy, l.xy, (size_t)np * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && cam) e = hipMemcpy(cam, l.cam, (size_t)np * 24, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && desc) e = hipMemcpy(desc, l.desc, (size_t)np * 32, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && meta4) {
+      std::vector<int32_t> prev(np), tlen(np), lmu(np); std::vector<uint8_t> fl(np);
+      e = hipMemcpy(prev.data(), l.prev, (size_t)np * 4, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(tlen.data(), l.tlen, (size_t)np * 4, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(lmu.data(), l.lmu, (size_t)np * 4, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(fl.data(), l.flags, (size_t)np, hipMemcpyDeviceToHost);
+      for (int i = 0; i < np && e == hipSuccess; ++i) {
+        meta4[4 * i] = prev[i]; meta4[4 * i + 1] = tlen[i]; meta4[4 * i + 2] = (fl[i] & RGBD_F_LM) ? lmu[i] : 0; meta4[4 * i + 3] = (fl[i] & RGBD_F_UNREL) ? 1 : 0;
+      }
+    }
+    if (e != hipSuccess) { err = hipGetErrorString(e); return VSLAM_ERR_HIP; }
+    return VSLAM_OK;
+  }
+
+private:
+  RgbdBuf rb;
+  hipStream_t q = nullptr;
+  int H = 0, TR = 0;
+  uint16_t* d_depth = nullptr;
+  uint8_t* d_img = nullptr; size_t img_bytes = 0;
+  RgbdState* pinned = nullptr;
+
+  void release() {
+    if (pinned) { (void)hipHostFree(pinned); pinned = nullptr; }
+    if (d_img) { (void)hipFree(d_img); d_img = nullptr; }
+    if (ic) { vslam_destroy(ic); ic = nullptr; }      // frees everything dalloc() registered
+  }
+  int hip_fail(hipError_t e, const char* where) { err = std::string(where) + ": " + hipGetErrorString(e); return VSLAM_ERR_HIP; }
+
+  // initialize() .. registration of one attempt: image pipeline on ONE image, features, track, aligner
+  void enqueue_attempt(const DevBuf& bs) {
+    const DevCfg& d = ic->cfg;
+    const dim3 g1(d.TX, (d.c.rows + VS_TILE_H - 1) / VS_TILE_H, 1);
+    hipLaunchKernelGGL(k_fast_box, g1, dim3(256), VS_FB_DYN_LDS, q, d, bs);
+    const bool orb = d.c.descriptor_type == VSLAM_DESCRIPTOR_ORB;
+    hipLaunchKernelGGL(k_emit, dim3(1, 1), dim3(512), 0, q, d, bs, orb ? (int)VSLAM_ORB_BORDER : (int)VSLAM_BRIEF_BORDER, 2);
+    const dim3 g3((d.c.cols + VS_BT_W - 1) / VS_BT_W, (d.c.rows + VS_BT_H - 1) / VS_BT_H, 1);
+    if (orb) {
+      Gauss7 gk; for (int i = 0; i < 4; ++i) gk.k[i] = d.gauss7[i];
+      hipLaunchKernelGGL(k_gauss7, g1, dim3(256), 0, q, d, bs, gk);
+      hipLaunchKernelGGL(k_orb_describe, g3, dim3(256), 0, q, d, bs, d.orb_cos, d.orb_sin);
+    } else {
+      hipLaunchKernelGGL(k_brief, g3, dim3(256), 0, q, d, bs);
+    }
+    hipLaunchKernelGGL(k_rgbd_features, dim3(1), dim3(1024), 0, q, d, bs, rb);
+    hipLaunchKernelGGL(k_rgbd_track_candidates, dim3(256), dim3(256), 0, q, d, bs, rb);
+    hipLaunchKernelGGL(k_rgbd_track, dim3(1), dim3(1024), 0, q, d, bs, rb);
+    hipLaunchKernelGGL(k_rgbd_align, dim3(1), dim3(VS_WG), 0, q, d, bs, rb);
+  }
+  void enqueue_tail(const DevBuf& bs) {
+    const DevCfg& d = ic->cfg;
+    hipLaunchKernelGGL(k_rgbd_prune, dim3(1), dim3(1024), 0, q, d, bs, rb);
+    hipLaunchKernelGGL(k_rgbd_recover_project, dim3(16), dim3(256), 0, q, d, rb);
+    hipLaunchKernelGGL(k_rgbd_describe_at, dim3(64), dim3(256), 0, q, d, bs, rb);
+    hipLaunchKernelGGL(k_rgbd_recover_finish, dim3(1), dim3(1024), 0, q, d, rb);
+    hipLaunchKernelGGL(k_rgbd_landmarks, dim3((d.MAXP + 255) / 256), dim3(256), 0, q, d, rb);
+    hipLaunchKernelGGL(k_rgbd_finish, dim3(1), dim3(1024), 0, q, d, bs, rb);
+  }
+
+  int process_frame(const uint8_t* left, int32_t lstride, const uint16_t* depth, int32_t dstride) {
+    (void)hipSetDevice(ic->device);
+    const int rows = p.rows, cols = p.cols;
+    // inputs: one contiguous copy each, the caller's strides kept on the device
+    const size_t ib = (size_t)(rows - 1) * lstride + cols;
+    if (ib > img_bytes) {
+      (void)hipStreamSynchronize(q);
+      if (d_img) (void)hipFree(d_img);
+      d_img = nullptr; img_bytes = 0;
+      const hipError_t e = hipMalloc((void**)&d_img, ib + 64);
+      if (e != hipSuccess) return hip_fail(e, "image buffer");
+      img_bytes = ib;
+    }
+    hipError_t e = hipMemcpyAsync(d_img, left, ib, hipMemcpyHostToDevice, q);
+    if (e != hipSuccess) return hip_fail(e, "image upload");
+    if (dstride == cols) e = hipMemcpyAsync(d_depth, depth, (size_t)rows * cols * 2, hipMemcpyHostToDevice, q);
+    else e = hipMemcpy2DAsync(d_depth, (size_t)cols * 2, depth, (size_t)dstride * 2, (size_t)cols * 2, rows, hipMemcpyHostToDevice, q);
+    if (e != hipSuccess) return hip_fail(e, "depth upload");
+    DevBuf bs = buf_set(ic, 0, 0);
+    bs.img[0] = d_img; bs.img[1] = d_img; bs.img_row_stride = lstride; bs.img_stream_stride = 0;
+    hipLaunchKernelGGL(k_rgbd_begin, dim3(1), dim3(64), 0, q, rb);
+    // _computeDepthMap (once per frame: every initialize() of the frame sees the same depth image)
+    const size_t npx = (size_t)rows * cols;
+    const float f0 = (float)p.maximum_depth_meters;
+    uint32_t f0_bits;
+    std::memcpy(&f0_bits, &f0, 4);
+    const dim3 grid((cols + 255) / 256, rows);
+    hipLaunchKernelGGL(k_depth_init, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, q, (int)npx, f0_bits, rb.dkey, rb.dlast);
+    hipLaunchKernelGGL(k_depth_min, grid, dim3(256), 0, q, p, d_depth, cols, rb.dkey);
+    hipLaunchKernelGGL(k_depth_pick, grid, dim3(256), 0, q, p, d_depth, cols, f0_bits, rb.dkey, rb.dlast);
+    hipLaunchKernelGGL(k_depth_write, grid, dim3(256), 0, q, p, d_depth, cols, f0_bits, rb.dkey, rb.dlast, rb.space, rb.row_map, rb.col_map);
+    for (int attempt = 0; attempt < 3; ++attempt) {
+      enqueue_attempt(bs);
+      enqueue_tail(bs);
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipMemcpyAsync(pinned, rb.st, sizeof(RgbdState), hipMemcpyDeviceToHost, q);
+      if (e == hipSuccess) e = hipStreamSynchronize(q);
+      if (e != hipSuccess) { ic->sticky = VSLAM_ERR_HIP; return hip_fail(e, "RGB-D frame"); }
+      host = *pinned;
+      if (host.tail_done) break;
+    }
+    if (!host.tail_done) { err = "RGB-D frame: registration did not finish in three attempts"; return VSLAM_ERR_STATE; }
+    // bit 0: more corners than max_keypoints (k_emit), bit 1: more points than max_points — results would be truncated: the frame fails.
+    // bit 2 (a track longer than the history ring: its oldest measurements are left out of the landmark refinement) is reported in
+    // vslam_frame_info::error_flags only, like the stereo tracker does.
+    if (host.error_flags & 3) {
+      err = std::string("RGB-D frame: capacity exceeded (") + ((host.error_flags & 1) ? "max_keypoints " : "") + ((host.error_flags & 2) ? "max_points" : "") + ")";
+      return VSLAM_ERR_CAPACITY;
+    }
+    return VSLAM_OK;
+  }
+};
+
+}  // namespace vs_rgbd

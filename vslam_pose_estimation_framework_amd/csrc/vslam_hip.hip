@@ -1445,7 +1445,7 @@ VS_API int vslam_fast_detect(vslam_ctx* c, const uint8_t* img, int32_t rows, int
   if (rx < 0 || ry < 0 || rw < 1 || rh < 1 || rx + rw > cols || ry + rh > rows || cap < 0 || (cap && (!xy))) return fail(c, VSLAM_ERR_INVALID, "ROI outside the image");
   HIP_TRY(c, hipSetDevice(c->device));
   vslam_ctx* t = nullptr;
-  int rc = make_scratch_ctx(c, rows, cols, std::min(std::min(cap, rows * cols), 65535), 64, &t);   // 16-bit feature indices
+  int rc = make_scratch_ctx(c, rows, cols, std::min(rows * cols, 65535), 64, &t);   // 16-bit feature indices; independent of `cap`: one pooled scratch context serves every call
   if (rc != VSLAM_OK) return rc;
   t->cfg.n_regions = 1;
   t->cfg.regions[0].x = rx; t->cfg.regions[0].y = ry; t->cfg.regions[0].w = rw; t->cfg.regions[0].h = rh;
@@ -1946,35 +1946,51 @@ VS_API int vslam_set_pose(vslam_ctx* c, int s, const double pose[12]) {
   return VSLAM_OK;
 }
 
-// ---- RGB-D mode: host-driven tracker over the device entry points (csrc/rgbd_tracker.h) -----------------------------------------
+// ---- RGB-D mode -----------------------------------------------------------------------------------------------------------------
+// Two implementations behind the same entry points: the device-resident loop (csrc/rgbd_device.h + kernels_rgbd.h; the default) and the
+// host-driven loop over the library's own stand-alone entry points (csrc/rgbd_tracker.h; VSLAM_RGBD_HOST=1), kept as the cross-check.
 #include "rgbd_tracker.h"
-struct vslam_rgbd { vs_rgbd::Tracker t; };
+#include "rgbd_device.h"
+struct vslam_rgbd {
+  bool on_host = false;
+  vs_rgbd::Tracker t;
+  vs_rgbd::DeviceTracker d;
+  std::string& err() { return on_host ? t.err : d.err; }
+};
 static thread_local std::string g_rgbd_error;
-VS_API const char* vslam_rgbd_last_error(const vslam_rgbd* r) { return r ? r->t.err.c_str() : g_rgbd_error.c_str(); }
+VS_API const char* vslam_rgbd_last_error(const vslam_rgbd* r) { return r ? (r->on_host ? r->t.err.c_str() : r->d.err.c_str()) : g_rgbd_error.c_str(); }
 VS_API int vslam_rgbd_create(const vslam_config* cfg, const vslam_depth_params* p, int device, vslam_rgbd** out) {
   if (!cfg || !p || !out) { g_rgbd_error = "vslam_rgbd_create: null argument"; return VSLAM_ERR_INVALID; }
   vslam_rgbd* r = new vslam_rgbd;
-  const int rc = r->t.create(*cfg, *p, device);
-  if (rc != VSLAM_OK) { g_rgbd_error = r->t.err; delete r; return rc; }
+  if (const char* e = std::getenv("VSLAM_RGBD_HOST")) r->on_host = std::atoi(e) != 0;
+  const int rc = r->on_host ? r->t.create(*cfg, *p, device) : r->d.create(*cfg, *p, device);
+  if (rc != VSLAM_OK) { g_rgbd_error = r->err(); delete r; return rc; }
   *out = r;
   return VSLAM_OK;
 }
 VS_API void vslam_rgbd_destroy(vslam_rgbd* r) { delete r; }
-VS_API int vslam_rgbd_reset(vslam_rgbd* r) { if (!r) return VSLAM_ERR_INVALID; r->t.reset(); return VSLAM_OK; }
+VS_API int vslam_rgbd_reset(vslam_rgbd* r) {
+  if (!r) return VSLAM_ERR_INVALID;
+  if (r->on_host) { r->t.reset(); return VSLAM_OK; }
+  return r->d.reset();
+}
 VS_API int vslam_rgbd_process_host(vslam_rgbd* r, const uint8_t* left, int32_t lstride, const uint16_t* depth, int32_t dstride) {
   if (!r) return VSLAM_ERR_INVALID;
-  if (!left || !depth) { r->t.err = "called with empty frame"; return VSLAM_ERR_INVALID; }   // depth_framepoint_generator.cpp:48-50
-  if (lstride < r->t.cfg.cols || dstride < r->t.cfg.cols) { r->t.err = "row stride smaller than image width"; return VSLAM_ERR_INVALID; }
-  return r->t.process(left, lstride, depth, dstride);
+  if (!left || !depth) { r->err() = "called with empty frame"; return VSLAM_ERR_INVALID; }   // depth_framepoint_generator.cpp:48-50
+  const int cols = r->on_host ? r->t.cfg.cols : r->d.cfg.cols;
+  if (lstride < cols || dstride < cols) { r->err() = "row stride smaller than image width"; return VSLAM_ERR_INVALID; }
+  return r->on_host ? r->t.process(left, lstride, depth, dstride) : r->d.process(left, lstride, depth, dstride);
 }
 VS_API int vslam_rgbd_get_frame_info(vslam_rgbd* r, vslam_frame_info* out, int32_t* n_temporary) {
   if (!r || !out) return VSLAM_ERR_INVALID;
-  *out = r->t.info;
-  if (n_temporary) *n_temporary = r->t.n_temporary;
+  if (r->on_host) { *out = r->t.info; if (n_temporary) *n_temporary = r->t.n_temporary; return VSLAM_OK; }
+  *out = r->d.host.info;
+  if (n_temporary) *n_temporary = r->d.host.n_temporary;
   return VSLAM_OK;
 }
 VS_API int vslam_rgbd_get_points(vslam_rgbd* r, int32_t cap, int32_t* n, float* xy, double* cam, int32_t* meta4, uint8_t* desc) {
   if (!r || !n) return VSLAM_ERR_INVALID;
+  if (!r->on_host) return r->d.get_points(cap, n, xy, cam, meta4, desc);
   if (r->t.info.frame_index == 0) { *n = 0; return VSLAM_OK; }
   const vs_rgbd::Fr& f = r->t.current();
   *n = (int32_t)f.points.size();
