@@ -2,7 +2,7 @@
 """RGB-D mode, milliseconds per frame of the two product loops behind vslam_rgbd_* on the same rendered sequence: the device-resident loop
 (csrc/rgbd_device.h + kernels_rgbd.h) and the host-driven loop over the stand-alone entry points (csrc/rgbd_tracker.h, VSLAM_RGBD_HOST=1).
 Both must report identical frame counters; the wall clock is around vslam_rgbd_process_host (host images, copies included).
-usage: rgbd_bench.py [icl|tum|xtion] [frames] [scale]"""
+usage: rgbd_bench.py [icl|tum|xtion] [frames] [scale] [both|device|host]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -21,7 +21,8 @@ g = hip.load()
 frames = [(o.render(scene, k)[0], o.render_depth(scene, k, 2e-3)) for k in range(n)]
 out = {"config": which, "rows": int(cfg.rows), "cols": int(cfg.cols), "frames": n}
 infos = {}
-for impl in ("device", "host"):
+impls = ("device", "host") if len(sys.argv) <= 4 or sys.argv[4] == "both" else (sys.argv[4],)
+for impl in impls:
     os.environ["VSLAM_RGBD_HOST"] = "1" if impl == "host" else "0"
     t = RgbdTracker(g, cfg, p)
     rec, times = [], []
@@ -36,6 +37,8 @@ for impl in ("device", "host"):
     warm = times[8:]
     out[impl] = {"ms_per_frame_mean": 1e3 * float(np.mean(warm)), "ms_per_frame_median": 1e3 * float(np.median(warm)), "ms_per_frame_min": 1e3 * float(np.min(warm))}
     out[impl]["last"] = dict(n_keypoints=rec[-1][1], n_tracked=rec[-1][2], n_active_landmarks=rec[-1][6], n_points=rec[-1][8])
+if len(impls) < 2:
+    print(json.dumps(out)); sys.exit(0)
 same = all(a[:11] == b[:11] and np.allclose(a[11], b[11], rtol=0, atol=1e-6) for a, b in zip(infos["device"], infos["host"]))
 out["identical_counters"] = bool(same)
 out["speedup_median"] = out["host"]["ms_per_frame_median"] / out["device"]["ms_per_frame_median"]

@@ -10,15 +10,15 @@
 //   k_rgbd_begin            frame scalars
 //   k_depth_init/min/pick/write    space map                                                      (kernels_depth.h)
 //   k_fast_box, k_emit, k_brief | k_gauss7 + k_orb_describe   the image pipeline on ONE image     (kernels_image.h; k_emit run_controller = 2)
-//   k_rgbd_features         feature order of the reference (detector regions row-major, row-major inside a region), counters
 //   k_rgbd_track_candidates wide: window candidates of every previous point
-//   k_rgbd_track            order-exact resolution (depth_track_body), then _track's bookkeeping: framepoints, temporary points, links, lost list,
+//   k_rgbd_track            feature order of the reference (detector regions row-major, row-major inside a region); order-exact resolution
+//                           (depth_track_body), then _track's bookkeeping: framepoints, temporary points, links, lost list,
 //                           window / descriptor-distance adaptation, and what the registration does next
 //   k_rgbd_align            UVDAligner::initialize + converge (wg_align_converge<UVD>), then accept / fall back / ask for another attempt
 //        ... a frame whose registration asks for another attempt (pose_tracker_3d.cpp:333-418, rare) gets the block from the image pipeline to
 //        k_rgbd_align enqueued again by the host (it reads RgbdState::done); the tail below is enqueued optimistically and skips itself until then
-//   k_rgbd_prune            _prunePoints
-//   k_rgbd_recover_project, k_rgbd_describe_at, k_rgbd_recover_finish      recoverPoints
+//   k_rgbd_prune            _prunePoints; projection of the lost points' landmarks
+//   k_rgbd_describe_at, k_rgbd_recover_finish      recoverPoints: descriptors at the projections, gates, new framepoints
 //   k_rgbd_landmarks        wide: Landmark::Landmark / Landmark::update of every framepoint's track, measurements in the reference's order
 //   k_rgbd_finish           temporary points triangulated, compute() on the unmatched features, lists joined, history, trails, frame info
 #pragma once
@@ -81,7 +81,7 @@ struct RgbdBuf {
   // aligner weights (UVDAligner::_weights_translation: a member vector that is never cleared)
   double* weights;
   // history ring
-  double* h_cam;              // [H][MAXP][3]
+  double* h_cam;              // [H][MAXP][4] camera coordinates and 1 / z (Measurement::inverse_depth_meters, divided once)
   double* h_pose;             // [H][24] camera_to_world, world_to_camera
   double* pose_log;           // [VS_POSE_LOG][12]
 };
@@ -114,11 +114,9 @@ __global__ void k_rgbd_begin(const RgbdBuf r) {
 // ---- features of one initialize() ------------------------------------------------------------------------------------------------------------
 // detectKeypoints concatenates the regions' keypoints in region order (base_framepoint_generator.cpp:355-429); k_emit leaves them row-major.
 // A corner lies in exactly one region's FAST-valid area (the regions overlap by 2-4 px, FAST's border is 3), so the reference's order is a
-// stable partition of the row-major list by region.  One 1024-thread workgroup.
-__global__ __launch_bounds__(1024) void k_rgbd_features(const DevCfg c, const DevBuf b, const RgbdBuf r) {
-  __shared__ int sh[17];
+// stable partition of the row-major list by region.  First part of k_rgbd_track (1024 threads).
+__device__ __forceinline__ void rgbd_features(const DevCfg& c, const DevBuf& b, const RgbdBuf& r, int* sh) {
   RgbdState& st = *r.st;
-  if (st.done && st.frame_count > 0) return;
   const int tid = threadIdx.x;
   const int n = b.n_kp[0];
   const int16_t* kxy = kpxy_of(c, b, 0, 0);
@@ -146,6 +144,7 @@ __global__ __launch_bounds__(1024) void k_rgbd_features(const DevCfg c, const De
     for (int q = 0; q < c.n_regions; ++q) raw += b.iinfo[0].raw_count[0][q];
     st.n_raw = raw;
   }
+  __syncthreads();
 }
 
 // ---- _track (pose_tracker_3d.cpp:225-298) around DepthFramePointGenerator::track (:166-287) --------------------------------------------------
@@ -157,7 +156,7 @@ __device__ __forceinline__ void rgbd_track_args(const DevCfg& c, const DevBuf& b
   a.by_app = st.next_by_app;
   a.d = a.by_app ? c.c.maximum_projection_tracking_distance_pixels : st.win;   // :229-231
   a.tau = c.c.minimum_descriptor_distance_tracking;
-  a.nP = st.last_all; a.nL = st.n_detected; a.CW = c.CW;
+  a.nP = st.last_all; a.nL = b.n_kp[0]; a.CW = c.CW;
   a.cam = pv.cam; a.pdesc = pv.desc; a.pflags = pv.flags;
   a.kxy = kpxy_of(c, b, 0, 0); a.desc = desc_of(c, b, 0, 0); a.rowcell = rowcell_of(c, b, 0, 0);
   a.space = r.space;
@@ -205,6 +204,7 @@ __global__ __launch_bounds__(1024) void k_rgbd_track(const DevCfg c, const DevBu
   __shared__ int sh[17];
   __shared__ int changed;
   RgbdState& st = *r.st;
+  rgbd_features(c, b, r, sh);          // also on the first frame: compute() walks the features in this order
   if (st.done) return;
   const int tid = threadIdx.x;
   DepthTrack a;
@@ -356,6 +356,19 @@ __device__ __forceinline__ void rgbd_store(const RgbdList& l, int i, const RgbdP
   l.prev[i] = q.prev; l.tlen[i] = q.tlen; l.lmu[i] = q.lmu; l.lmm[i] = q.lmm; l.flags[i] = q.flags;
 }
 
+// DepthFramePointGenerator::recoverPoints (:289-407)
+__device__ __forceinline__ void rgbd_recover_args(const DevCfg& c, const RgbdBuf& r, DepthRecover& a) {
+  const RgbdState& st = *r.st;
+  a.p = r.p;
+  for (int k = 0; k < 12; ++k) a.w2c[k] = st.w2c[k];
+  a.kp_size = 7.f; a.tau = c.c.minimum_descriptor_distance_tracking; a.n = st.n_lost;
+  a.has_lm = r.lost_has; a.lm = r.lost_lm; a.pdesc = r.lost_desc; a.space = r.space;
+  a.bxy = r.rbxy; a.kxy = r.rkxy; a.cell = r.rcell; a.keep = r.rkeep; a.desc = r.rdesc;
+  a.count = &r.st->rcount; a.rec_index = r.ridx; a.rec_xy = r.rxy; a.rec_desc = r.rrdesc; a.rec_xyz = r.rxyz;
+}
+__device__ __forceinline__ bool rgbd_recover_on(const DevCfg& c, const RgbdState& st) {
+  return rgbd_tail_on(st) && st.frame_count > 0 && c.c.enable_landmark_recovery && st.n_lost > 0;
+}
 // _prunePoints (:437-472): without a fresh aligner result every tracked point is dropped.  Order-preserving compaction in place, 1024
 // points per pass (a pass reads its points before it writes, and writes never reach the next pass's points).
 __global__ __launch_bounds__(1024) void k_rgbd_prune(const DevCfg c, const DevBuf b, const RgbdBuf r) {
@@ -366,6 +379,12 @@ __global__ __launch_bounds__(1024) void k_rgbd_prune(const DevCfg c, const DevBu
   const int n = st.n_points;
   if (tid == 0) st.n_registered = n;
   if (st.frame_count == 0) return;
+  // recoverPoints, first step: projection of the lost points' landmarks with the frame's pose (independent of the pruning)
+  if (c.c.enable_landmark_recovery && st.n_lost > 0) {
+    DepthRecover a;
+    rgbd_recover_args(c, r, a);
+    for (int i = tid; i < a.n; i += 1024) depth_recover_project_one(a, i);
+  }
   const RgbdList cur = rgbd_cur(r);
   const bool valid = st.aligner_valid != 0;
   const double kern = c.c.aligner_maximum_error_kernel;
@@ -388,26 +407,6 @@ __global__ __launch_bounds__(1024) void k_rgbd_prune(const DevCfg c, const DevBu
   if (tid == 0) { st.n_points = out; st.n_after_prune = out; }
 }
 
-// DepthFramePointGenerator::recoverPoints (:289-407)
-__device__ __forceinline__ void rgbd_recover_args(const DevCfg& c, const RgbdBuf& r, DepthRecover& a) {
-  const RgbdState& st = *r.st;
-  a.p = r.p;
-  for (int k = 0; k < 12; ++k) a.w2c[k] = st.w2c[k];
-  a.kp_size = 7.f; a.tau = c.c.minimum_descriptor_distance_tracking; a.n = st.n_lost;
-  a.has_lm = r.lost_has; a.lm = r.lost_lm; a.pdesc = r.lost_desc; a.space = r.space;
-  a.bxy = r.rbxy; a.kxy = r.rkxy; a.cell = r.rcell; a.keep = r.rkeep; a.desc = r.rdesc;
-  a.count = &r.st->rcount; a.rec_index = r.ridx; a.rec_xy = r.rxy; a.rec_desc = r.rrdesc; a.rec_xyz = r.rxyz;
-}
-__device__ __forceinline__ bool rgbd_recover_on(const DevCfg& c, const RgbdState& st) {
-  return rgbd_tail_on(st) && st.frame_count > 0 && c.c.enable_landmark_recovery && st.n_lost > 0;
-}
-__global__ __launch_bounds__(256) void k_rgbd_recover_project(const DevCfg c, const RgbdBuf r) {
-  const RgbdState& st = *r.st;
-  if (!rgbd_recover_on(c, st)) return;
-  DepthRecover a;
-  rgbd_recover_args(c, r, a);
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += gridDim.x * 256) depth_recover_project_one(a, i);
-}
 // descriptors at the projected pixels: BRIEF on the box image / steered ORB tests on the Gaussian image the image pipeline left
 __global__ __launch_bounds__(256) void k_rgbd_describe_at(const DevCfg c, const DevBuf b, const RgbdBuf r) {
   const RgbdState& st = *r.st;
@@ -471,27 +470,45 @@ __global__ __launch_bounds__(1024) void k_rgbd_recover_finish(const DevCfg c, co
 // predecessor (k = 1), then the predecessor's trail — direct addresses, no link walk.  Landmark::Landmark (landmark.cpp:8-33) sums the world
 // coordinates from the newest point back to the origin; Landmark::update (:66-167) runs Gauss-Newton over _measurements in THEIR order: the
 // creation's (newest first: the point the landmark was created at, back to the origin), then one per later frame, the current point last.
+#define RGBD_LM_NP 64     // world_to_camera (and R^T R) of the newest RGBD_LM_NP frames staged in LDS, one copy for the workgroup
+#define RGBD_LM_NB 4      // measurements whose (independent) loads are in flight together
+struct RgbdPoseLds { double w2c[12]; double rtr[9]; };
 __global__ __launch_bounds__(256) void k_rgbd_landmarks(const DevCfg c, const RgbdBuf r) {
+  __shared__ RgbdPoseLds s_pose[RGBD_LM_NP];
   RgbdState& st = *r.st;
   if (!rgbd_tail_on(st)) return;
-  const int i = blockIdx.x * 256 + threadIdx.x;
   const int n = st.n_points;
+  if ((int)(blockIdx.x * 256) >= n) return;
+  const int f = st.frame_count, H = r.H;
+  for (int t = threadIdx.x; t < RGBD_LM_NP * 12; t += 256) {
+    const int k = t / 12, e = t - 12 * k;
+    if (k <= f && k < H) s_pose[k].w2c[e] = k == 0 ? st.w2c[e] : r.h_pose[(size_t)((f - k) % H) * 24 + 12 + e];
+  }
+  __syncthreads();
+  // J^T J of a measurement (J = the rotation of world_to_camera) depends on the frame only: once per frame instead of once per measurement and round
+  for (int t = threadIdx.x; t < RGBD_LM_NP * 9; t += 256) {
+    const int k = t / 9, e = t - 9 * k, rr = e / 3, cc = e - 3 * rr;
+    if (k <= f && k < H) { const double* W = s_pose[k].w2c; s_pose[k].rtr[e] = (W[rr] * W[cc] + W[4 + rr] * W[4 + cc]) + W[8 + rr] * W[8 + cc]; }
+  }
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
   bool active = false;
   if (i < n) {
     const RgbdList cur = rgbd_cur(r), pv = rgbd_prev(r);
     const int T = cur.tlen[i], fl = cur.flags[i];
     if (!(T < c.c.minimum_track_length_for_landmark_creation || (fl & RGBD_F_UNREL))) {
       active = true;
-      const int f = st.frame_count, H = r.H, TR = r.TR, MAXP = c.MAXP;
+      const int TR = r.TR, MAXP = c.MAXP;
       const int p1 = cur.prev[i];
-      auto cam_of = [&](int k, double* o) {
-        if (k == 0) { for (int q = 0; q < 3; ++q) o[q] = cur.cam[3 * (size_t)i + q]; return; }
+      const double own[4] = {cur.cam[3 * (size_t)i], cur.cam[3 * (size_t)i + 1], cur.cam[3 * (size_t)i + 2], 1 / cur.cam[3 * (size_t)i + 2]};
+      auto cam_of = [&](int k, double* o) {     // x, y, z, 1 / z of measurement k
+        if (k == 0) { o[0] = own[0]; o[1] = own[1]; o[2] = own[2]; o[3] = own[3]; return; }
         const int idx = k == 1 ? p1 : (int)pv.trail[(size_t)p1 * TR + (k - 2)];
-        const double* src = r.h_cam + ((size_t)((f - k) % H) * MAXP + idx) * 3;
-        o[0] = src[0]; o[1] = src[1]; o[2] = src[2];
+        const double2* src = reinterpret_cast<const double2*>(r.h_cam + ((size_t)((f - k) % H) * MAXP + idx) * 4);
+        const double2 a = src[0], bq = src[1];
+        o[0] = a.x; o[1] = a.y; o[2] = bq.x; o[3] = bq.y;
       };
       auto pose_of = [&](int k) -> const double* { return k == 0 ? st.c2w : r.h_pose + (size_t)((f - k) % H) * 24; };          // camera_to_world
-      auto w2c_of = [&](int k) -> const double* { return k == 0 ? st.w2c : r.h_pose + (size_t)((f - k) % H) * 24 + 12; };
       int len = T + 1;                               // measurements of the track, this frame's included
       const int reach = min(min(H - 1, TR + 1), f);  // oldest k that can still be addressed
       if (len - 1 > reach) { len = reach + 1; atomicOr(&st.error_flags, 4); }
@@ -499,7 +516,7 @@ __global__ __launch_bounds__(256) void k_rgbd_landmarks(const DevCfg c, const Rg
       if (!(fl & RGBD_F_CHAIN)) {
         double acc[3] = {0, 0, 0};
         for (int k = 0; k < len; ++k) {
-          double m[3], w[3];
+          double m[4], w[3];
           cam_of(k, m);
           tf_apply(pose_of(k), m, w);
           for (int q = 0; q < 3; ++q) acc[q] = acc[q] + w[q];
@@ -519,21 +536,36 @@ __global__ __launch_bounds__(256) void k_rgbd_landmarks(const DevCfg c, const Rg
           double Hm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bv[3] = {0, 0, 0};
           double err = 0;
           int n_out = 0;
-          for (int j = 0; j < len; ++j) {
-            const int k = k_at(j);
-            const double* W = w2c_of(k);
-            double mc[3], sp[3];
-            cam_of(k, mc);
-            tf_apply(W, wv, sp);
-            if (sp[2] <= 0) { ++n_out; continue; }
-            const double er[3] = {sp[0] - mc[0], sp[1] - mc[1], sp[2] - mc[2]};
-            double om = 1 / mc[2];
-            const double e2 = om * ((er[0] * er[0] + er[1] * er[1]) + er[2] * er[2]);
-            err += e2;
-            if (e2 > kern) { om *= kern / e2; ++n_out; }
-            for (int rr = 0; rr < 3; ++rr) {
-              for (int cc = 0; cc < 3; ++cc) Hm[3 * rr + cc] += om * ((W[rr] * W[cc] + W[4 + rr] * W[4 + cc]) + W[8 + rr] * W[8 + cc]);
-              bv[rr] += om * ((W[rr] * er[0] + W[4 + rr] * er[1]) + W[8 + rr] * er[2]);
+          for (int j0 = 0; j0 < len; j0 += RGBD_LM_NB) {
+            double mc[RGBD_LM_NB][4];
+            int kk[RGBD_LM_NB];
+#pragma unroll
+            for (int u = 0; u < RGBD_LM_NB; ++u) { kk[u] = k_at(min(j0 + u, len - 1)); cam_of(kk[u], mc[u]); }
+#pragma unroll
+            for (int u = 0; u < RGBD_LM_NB; ++u) {
+              if (j0 + u >= len) continue;
+              const double* W = s_pose[0].w2c;
+              const double* RtR = s_pose[0].rtr;
+              double rtr_far[9];
+              if (kk[u] < RGBD_LM_NP) { W = s_pose[kk[u]].w2c; RtR = s_pose[kk[u]].rtr; }
+              else {     // a track older than the staged poses: the same expressions from HBM
+                W = r.h_pose + (size_t)((f - kk[u]) % H) * 24 + 12;
+                for (int e = 0; e < 9; ++e) { const int rr = e / 3, cc = e - 3 * rr; rtr_far[e] = (W[rr] * W[cc] + W[4 + rr] * W[4 + cc]) + W[8 + rr] * W[8 + cc]; }
+                RtR = rtr_far;
+              }
+              double sp[3];
+              tf_apply(W, wv, sp);
+              if (sp[2] <= 0) { ++n_out; continue; }
+              const double er[3] = {sp[0] - mc[u][0], sp[1] - mc[u][1], sp[2] - mc[u][2]};
+              double om = mc[u][3];
+              const double e2 = om * ((er[0] * er[0] + er[1] * er[1]) + er[2] * er[2]);
+              err += e2;
+              if (e2 > kern) { om *= kern / e2; ++n_out; }
+              // R^T R is symmetric to the bit (its entries are sums of commuting products): six products instead of nine
+              { const double h01 = om * RtR[1], h02 = om * RtR[2], h12 = om * RtR[5];
+                Hm[0] += om * RtR[0]; Hm[4] += om * RtR[4]; Hm[8] += om * RtR[8];
+                Hm[1] += h01; Hm[3] += h01; Hm[2] += h02; Hm[6] += h02; Hm[5] += h12; Hm[7] += h12; }
+              for (int rr = 0; rr < 3; ++rr) bv[rr] += om * ((W[rr] * er[0] + W[4 + rr] * er[1]) + W[8 + rr] * er[2]);
             }
           }
           double nb[3] = {-bv[0], -bv[1], -bv[2]}, dx[3];
@@ -548,7 +580,7 @@ __global__ __launch_bounds__(256) void k_rgbd_landmarks(const DevCfg c, const Rg
               double acc[3] = {0, 0, 0};
               for (int j = 0; j < len; ++j) {
                 const int k = k_at(j);
-                double mc[3], wp[3];
+                double mc[4], wp[3];
                 cam_of(k, mc);
                 tf_apply(pose_of(k), mc, wp);
                 for (int q = 0; q < 3; ++q) acc[q] += wp[q];
@@ -658,8 +690,12 @@ __global__ __launch_bounds__(1024) void k_rgbd_finish(const DevCfg c, const DevB
   __syncthreads();
   // ---- history ring and trails
   {
-    double* hc = r.h_cam + (size_t)(f % r.H) * c.MAXP * 3;
-    for (int i = tid; i < n_all; i += 1024) for (int q = 0; q < 3; ++q) hc[3 * (size_t)i + q] = cur.cam[3 * (size_t)i + q];
+    double* hc = r.h_cam + (size_t)(f % r.H) * c.MAXP * 4;
+    for (int i = tid; i < n_all; i += 1024) {
+      const double x = cur.cam[3 * (size_t)i], y = cur.cam[3 * (size_t)i + 1], z = cur.cam[3 * (size_t)i + 2];
+      reinterpret_cast<double2*>(hc + 4 * (size_t)i)[0] = make_double2(x, y);
+      reinterpret_cast<double2*>(hc + 4 * (size_t)i)[1] = make_double2(z, 1 / z);
+    }
     if (tid < 12) { r.h_pose[(size_t)(f % r.H) * 24 + tid] = st.c2w[tid]; r.h_pose[(size_t)(f % r.H) * 24 + 12 + tid] = st.w2c[tid]; }
     if (tid < 12 && f < VS_POSE_LOG) r.pose_log[(size_t)f * 12 + tid] = st.c2w[tid];
     // 16 lanes per point: entry 0 = the predecessor, entries 1.. = the predecessor's trail

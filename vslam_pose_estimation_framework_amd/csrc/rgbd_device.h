@@ -1,7 +1,7 @@
 // rgbd_device.h — host side of the device-resident RGB-D loop (kernels_rgbd.h): buffers, the per-frame launch sequence on one HIP stream,
 // one small read-back per frame.  Included by vslam_hip.hip after the context code (it uses create_internal / buf_set / fail of that file).
 //
-// A frame is: two host-to-device copies (image, depth), ~19 kernel launches, one 1.2 KB device-to-host copy, one stream synchronisation.  When
+// A frame is: two host-to-device copies (image, depth), ~17 kernel launches on two streams (the space map runs beside the image pipeline), one 1.2 KB device-to-host copy, one stream synchronisation.  When
 // the registration asks for another attempt (RgbdState::done still 0 after the tail skipped itself: pose_tracker_3d.cpp:333-418, a lost
 // track), the block image pipeline .. aligner .. tail is enqueued again, at most twice.
 #pragma once
@@ -33,7 +33,7 @@ public:
     if (rc != VSLAM_OK) { err = vslam_last_error(nullptr); return rc; }
     q = ic->stream_img;
     const size_t MAXP = ic->cfg.MAXP, NMAX = ic->cfg.NMAX, npx = (size_t)p.rows * p.cols;
-    H = std::max(4, std::min(cfg.max_history_frames, 512));
+    H = std::max(4, std::min(cfg.max_history_frames, 512));   // measurements of a track the landmark refinement can address
     TR = H - 2;
     std::memset(&rb, 0, sizeof rb);
     rb.p = p; rb.TR = TR; rb.H = H;
@@ -55,8 +55,11 @@ public:
     A(&rb.rcF, NMAX * 2); A(&rb.remf, NMAX); A(&rb.rcT, MAXP * 2); A(&rb.bins, (size_t)(rows_bin + 1) * (cols_bin + 1)); A(&rb.cls, NMAX);
     A(&rb.new_feat, NMAX); A(&rb.new_xyz, NMAX * 3); A(&rb.temp_feat, NMAX); A(&rb.temp_xyz, NMAX * 3);
     A(&rb.weights, MAXP);
-    A(&rb.h_cam, (size_t)H * MAXP * 3); A(&rb.h_pose, (size_t)H * 24); A(&rb.pose_log, (size_t)VS_POSE_LOG * 12);
+    A(&rb.h_cam, (size_t)H * MAXP * 4); A(&rb.h_pose, (size_t)H * 24); A(&rb.pose_log, (size_t)VS_POSE_LOG * 12);
     if (e == hipSuccess) e = hipHostMalloc((void**)&pinned, sizeof(RgbdState), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&q2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_depth, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_begin, hipEventDisableTiming);
     if (e != hipSuccess) { err = std::string("RGB-D mode: ") + hipGetErrorString(e); release(); return VSLAM_ERR_HIP; }
     rb.depth = d_depth;
     return reset();
@@ -116,14 +119,19 @@ public:
 
 private:
   RgbdBuf rb;
-  hipStream_t q = nullptr;
+  hipStream_t q = nullptr, q2 = nullptr;      // q: everything of a frame; q2: the depth image's copy and the space map, beside the image pipeline
+  hipEvent_t ev_depth = nullptr, ev_begin = nullptr;
   int H = 0, TR = 0;
   uint16_t* d_depth = nullptr;
   uint8_t* d_img = nullptr; size_t img_bytes = 0;
   RgbdState* pinned = nullptr;
+  bool depth_pending = false;
 
   void release() {
     if (pinned) { (void)hipHostFree(pinned); pinned = nullptr; }
+    if (q2) { (void)hipStreamDestroy(q2); q2 = nullptr; }
+    if (ev_depth) { (void)hipEventDestroy(ev_depth); ev_depth = nullptr; }
+    if (ev_begin) { (void)hipEventDestroy(ev_begin); ev_begin = nullptr; }
     if (d_img) { (void)hipFree(d_img); d_img = nullptr; }
     if (ic) { vslam_destroy(ic); ic = nullptr; }      // frees everything dalloc() registered
   }
@@ -144,7 +152,7 @@ private:
     } else {
       hipLaunchKernelGGL(k_brief, g3, dim3(256), 0, q, d, bs);
     }
-    hipLaunchKernelGGL(k_rgbd_features, dim3(1), dim3(1024), 0, q, d, bs, rb);
+    if (depth_pending) { (void)hipStreamWaitEvent(q, ev_depth, 0); depth_pending = false; }     // the space map is first read here
     hipLaunchKernelGGL(k_rgbd_track_candidates, dim3(256), dim3(256), 0, q, d, bs, rb);
     hipLaunchKernelGGL(k_rgbd_track, dim3(1), dim3(1024), 0, q, d, bs, rb);
     hipLaunchKernelGGL(k_rgbd_align, dim3(1), dim3(VS_WG), 0, q, d, bs, rb);
@@ -152,7 +160,6 @@ private:
   void enqueue_tail(const DevBuf& bs) {
     const DevCfg& d = ic->cfg;
     hipLaunchKernelGGL(k_rgbd_prune, dim3(1), dim3(1024), 0, q, d, bs, rb);
-    hipLaunchKernelGGL(k_rgbd_recover_project, dim3(16), dim3(256), 0, q, d, rb);
     hipLaunchKernelGGL(k_rgbd_describe_at, dim3(64), dim3(256), 0, q, d, bs, rb);
     hipLaunchKernelGGL(k_rgbd_recover_finish, dim3(1), dim3(1024), 0, q, d, rb);
     hipLaunchKernelGGL(k_rgbd_landmarks, dim3((d.MAXP + 255) / 256), dim3(256), 0, q, d, rb);
@@ -174,22 +181,26 @@ private:
     }
     hipError_t e = hipMemcpyAsync(d_img, left, ib, hipMemcpyHostToDevice, q);
     if (e != hipSuccess) return hip_fail(e, "image upload");
-    if (dstride == cols) e = hipMemcpyAsync(d_depth, depth, (size_t)rows * cols * 2, hipMemcpyHostToDevice, q);
-    else e = hipMemcpy2DAsync(d_depth, (size_t)cols * 2, depth, (size_t)dstride * 2, (size_t)cols * 2, rows, hipMemcpyHostToDevice, q);
+    if (dstride == cols) e = hipMemcpyAsync(d_depth, depth, (size_t)rows * cols * 2, hipMemcpyHostToDevice, q2);
+    else e = hipMemcpy2DAsync(d_depth, (size_t)cols * 2, depth, (size_t)dstride * 2, (size_t)cols * 2, rows, hipMemcpyHostToDevice, q2);
     if (e != hipSuccess) return hip_fail(e, "depth upload");
     DevBuf bs = buf_set(ic, 0, 0);
     bs.img[0] = d_img; bs.img[1] = d_img; bs.img_row_stride = lstride; bs.img_stream_stride = 0;
     hipLaunchKernelGGL(k_rgbd_begin, dim3(1), dim3(64), 0, q, rb);
-    // _computeDepthMap (once per frame: every initialize() of the frame sees the same depth image)
+    // _computeDepthMap (once per frame: every initialize() of the frame sees the same depth image), on the second stream beside the image
+    // pipeline; the previous frame has been synchronised, nothing reads the old map any more
     const size_t npx = (size_t)rows * cols;
     const float f0 = (float)p.maximum_depth_meters;
     uint32_t f0_bits;
     std::memcpy(&f0_bits, &f0, 4);
     const dim3 grid((cols + 255) / 256, rows);
-    hipLaunchKernelGGL(k_depth_init, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, q, (int)npx, f0_bits, rb.dkey, rb.dlast);
-    hipLaunchKernelGGL(k_depth_min, grid, dim3(256), 0, q, p, d_depth, cols, rb.dkey);
-    hipLaunchKernelGGL(k_depth_pick, grid, dim3(256), 0, q, p, d_depth, cols, f0_bits, rb.dkey, rb.dlast);
-    hipLaunchKernelGGL(k_depth_write, grid, dim3(256), 0, q, p, d_depth, cols, f0_bits, rb.dkey, rb.dlast, rb.space, rb.row_map, rb.col_map);
+    hipLaunchKernelGGL(k_depth_init, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, q2, (int)npx, f0_bits, rb.dkey, rb.dlast);
+    hipLaunchKernelGGL(k_depth_min, grid, dim3(256), 0, q2, p, d_depth, cols, rb.dkey);
+    hipLaunchKernelGGL(k_depth_pick, grid, dim3(256), 0, q2, p, d_depth, cols, f0_bits, rb.dkey, rb.dlast);
+    hipLaunchKernelGGL(k_depth_write, grid, dim3(256), 0, q2, p, d_depth, cols, f0_bits, rb.dkey, rb.dlast, rb.space, rb.row_map, rb.col_map);
+    e = hipEventRecord(ev_depth, q2);
+    if (e != hipSuccess) return hip_fail(e, "event");
+    depth_pending = true;
     for (int attempt = 0; attempt < 3; ++attempt) {
       enqueue_attempt(bs);
       enqueue_tail(bs);
