@@ -19,7 +19,7 @@
 //        k_rgbd_align enqueued again by the host (it reads RgbdState::done); the tail below is enqueued optimistically and skips itself until then
 //   k_rgbd_prune            _prunePoints; projection of the lost points' landmarks
 //   k_rgbd_describe_at, k_rgbd_recover_finish      recoverPoints: descriptors at the projections, gates, new framepoints
-//   k_rgbd_landmarks        wide: Landmark::Landmark / Landmark::update of every framepoint's track, measurements in the reference's order
+//   k_rgbd_landmarks        wide, eight lanes per framepoint: Landmark::Landmark / Landmark::update of its track, measurements in the reference's order
 //   k_rgbd_finish           temporary points triangulated, compute() on the unmatched features, lists joined, history, trails, frame info
 #pragma once
 #include <hip/hip_runtime.h>
@@ -466,19 +466,28 @@ __global__ __launch_bounds__(1024) void k_rgbd_recover_finish(const DevCfg c, co
   if (tid == 0) { st.n_points = n0 + nr; st.n_recovered = nr; }
 }
 
-// _updatePoints (:475-520), one thread per framepoint.  Measurement k of a track is its point in frame f - k: the point itself (k = 0), its
-// predecessor (k = 1), then the predecessor's trail — direct addresses, no link walk.  Landmark::Landmark (landmark.cpp:8-33) sums the world
-// coordinates from the newest point back to the origin; Landmark::update (:66-167) runs Gauss-Newton over _measurements in THEIR order: the
-// creation's (newest first: the point the landmark was created at, back to the origin), then one per later frame, the current point last.
+// _updatePoints (:475-520).  Measurement k of a track is its point in frame f - k: the point itself (k = 0), its predecessor (k = 1), then the
+// predecessor's trail — direct addresses, no link walk.  Landmark::Landmark (landmark.cpp:8-33) sums the world coordinates from the newest point
+// back to the origin; Landmark::update (:66-167) runs Gauss-Newton over _measurements in THEIR order: the creation's (newest first: the point the
+// landmark was created at, back to the origin), then one per later frame, the current point last.
+//
+// Eight lanes per framepoint.  A Gauss-Newton round over a long track is a chain of ~65 dependent fp64 operations per measurement on one lane
+// (measured: 72 us per frame for 60-frame tracks with one lane per point) — but only the thirteen ADDITIONS into H, b and the error have to
+// happen in the list's order.  So the eight lanes evaluate eight consecutive measurements at once (projection, residual, kernel, the products
+// om * R^T R and om * R^T e), park the results in LDS, and every lane then adds the eight contributions in list order: same operations on the
+// same operands in the same order as the serial loop, an eighth of its multiplications on the critical path.
 #define RGBD_LM_NP 64     // world_to_camera (and R^T R) of the newest RGBD_LM_NP frames staged in LDS, one copy for the workgroup
-#define RGBD_LM_NB 4      // measurements whose (independent) loads are in flight together
+#define RGBD_LM_G 8       // lanes per framepoint
+#define RGBD_LM_PTS (256 / RGBD_LM_G)
 struct RgbdPoseLds { double w2c[12]; double rtr[9]; };
+struct RgbdLmTerm { double e2, h[6], b[3]; int kind, pad; };   // kind 0: behind the camera (an outlier, nothing added), 1: inlier, 2: outlier with a saturated kernel
 __global__ __launch_bounds__(256) void k_rgbd_landmarks(const DevCfg c, const RgbdBuf r) {
   __shared__ RgbdPoseLds s_pose[RGBD_LM_NP];
+  __shared__ RgbdLmTerm s_term[RGBD_LM_PTS][RGBD_LM_G];
   RgbdState& st = *r.st;
   if (!rgbd_tail_on(st)) return;
   const int n = st.n_points;
-  if ((int)(blockIdx.x * 256) >= n) return;
+  if ((int)(blockIdx.x * RGBD_LM_PTS) >= n) return;
   const int f = st.frame_count, H = r.H;
   for (int t = threadIdx.x; t < RGBD_LM_NP * 12; t += 256) {
     const int k = t / 12, e = t - 12 * k;
@@ -491,13 +500,14 @@ __global__ __launch_bounds__(256) void k_rgbd_landmarks(const DevCfg c, const Rg
     if (k <= f && k < H) { const double* W = s_pose[k].w2c; s_pose[k].rtr[e] = (W[rr] * W[cc] + W[4 + rr] * W[4 + cc]) + W[8 + rr] * W[8 + cc]; }
   }
   __syncthreads();
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int g = threadIdx.x / RGBD_LM_G, gl = threadIdx.x % RGBD_LM_G;
+  const int i = blockIdx.x * RGBD_LM_PTS + g;
   bool active = false;
   if (i < n) {
     const RgbdList cur = rgbd_cur(r), pv = rgbd_prev(r);
     const int T = cur.tlen[i], fl = cur.flags[i];
     if (!(T < c.c.minimum_track_length_for_landmark_creation || (fl & RGBD_F_UNREL))) {
-      active = true;
+      active = gl == 0;
       const int TR = r.TR, MAXP = c.MAXP;
       const int p1 = cur.prev[i];
       const double own[4] = {cur.cam[3 * (size_t)i], cur.cam[3 * (size_t)i + 1], cur.cam[3 * (size_t)i + 2], 1 / cur.cam[3 * (size_t)i + 2]};
@@ -511,9 +521,11 @@ __global__ __launch_bounds__(256) void k_rgbd_landmarks(const DevCfg c, const Rg
       auto pose_of = [&](int k) -> const double* { return k == 0 ? st.c2w : r.h_pose + (size_t)((f - k) % H) * 24; };          // camera_to_world
       int len = T + 1;                               // measurements of the track, this frame's included
       const int reach = min(min(H - 1, TR + 1), f);  // oldest k that can still be addressed
-      if (len - 1 > reach) { len = reach + 1; atomicOr(&st.error_flags, 4); }
+      if (len - 1 > reach) { len = reach + 1; if (gl == 0) atomicOr(&st.error_flags, 4); }
       double world[3];
+      int updates = cur.lmu[i], lmm = cur.lmm[i];
       if (!(fl & RGBD_F_CHAIN)) {
+        // (every lane of the group computes the same short sum)
         double acc[3] = {0, 0, 0};
         for (int k = 0; k < len; ++k) {
           double m[4], w[3];
@@ -522,50 +534,66 @@ __global__ __launch_bounds__(256) void k_rgbd_landmarks(const DevCfg c, const Rg
           for (int q = 0; q < 3; ++q) acc[q] = acc[q] + w[q];
         }
         for (int q = 0; q < 3; ++q) world[q] = acc[q] / (double)len;
-        cur.lmu[i] = len; cur.lmm[i] = T;
+        updates = len; lmm = T;
       } else {
         // _measurements in their order: k = T - m .. T (the creation), then k = T - m - 1 .. 0
-        const int m0 = min(max(T - cur.lmm[i], 0), len - 1);
+        const int m0 = min(max(T - lmm, 0), len - 1);
         auto k_at = [&](int j) { return j <= len - 1 - m0 ? m0 + j : len - 1 - j; };   // j-th measurement -> k
         double wv[3] = {cur.lmw[3 * (size_t)i], cur.lmw[3 * (size_t)i + 1], cur.lmw[3 * (size_t)i + 2]};
         for (int q = 0; q < 3; ++q) world[q] = wv[q];
-        int updates = cur.lmu[i];
         const double kern = c.c.landmark_maximum_error_squared_meters;
         double err_prev = 0;
+        RgbdLmTerm* terms = s_term[g];
         for (int it = 0; it < c.c.landmark_maximum_number_of_iterations; ++it) {
           double Hm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bv[3] = {0, 0, 0};
           double err = 0;
           int n_out = 0;
-          for (int j0 = 0; j0 < len; j0 += RGBD_LM_NB) {
-            double mc[RGBD_LM_NB][4];
-            int kk[RGBD_LM_NB];
-#pragma unroll
-            for (int u = 0; u < RGBD_LM_NB; ++u) { kk[u] = k_at(min(j0 + u, len - 1)); cam_of(kk[u], mc[u]); }
-#pragma unroll
-            for (int u = 0; u < RGBD_LM_NB; ++u) {
-              if (j0 + u >= len) continue;
+          for (int j0 = 0; j0 < len; j0 += RGBD_LM_G) {
+            // this lane's measurement of the batch
+            const int j = j0 + gl;
+            RgbdLmTerm t;
+            t.kind = -1;
+            if (j < len) {
+              const int k = k_at(j);
+              double mc[4];
+              cam_of(k, mc);
               const double* W = s_pose[0].w2c;
               const double* RtR = s_pose[0].rtr;
               double rtr_far[9];
-              if (kk[u] < RGBD_LM_NP) { W = s_pose[kk[u]].w2c; RtR = s_pose[kk[u]].rtr; }
+              if (k < RGBD_LM_NP) { W = s_pose[k].w2c; RtR = s_pose[k].rtr; }
               else {     // a track older than the staged poses: the same expressions from HBM
-                W = r.h_pose + (size_t)((f - kk[u]) % H) * 24 + 12;
+                W = r.h_pose + (size_t)((f - k) % H) * 24 + 12;
                 for (int e = 0; e < 9; ++e) { const int rr = e / 3, cc = e - 3 * rr; rtr_far[e] = (W[rr] * W[cc] + W[4 + rr] * W[4 + cc]) + W[8 + rr] * W[8 + cc]; }
                 RtR = rtr_far;
               }
               double sp[3];
               tf_apply(W, wv, sp);
-              if (sp[2] <= 0) { ++n_out; continue; }
-              const double er[3] = {sp[0] - mc[u][0], sp[1] - mc[u][1], sp[2] - mc[u][2]};
-              double om = mc[u][3];
-              const double e2 = om * ((er[0] * er[0] + er[1] * er[1]) + er[2] * er[2]);
-              err += e2;
-              if (e2 > kern) { om *= kern / e2; ++n_out; }
-              // R^T R is symmetric to the bit (its entries are sums of commuting products): six products instead of nine
-              { const double h01 = om * RtR[1], h02 = om * RtR[2], h12 = om * RtR[5];
-                Hm[0] += om * RtR[0]; Hm[4] += om * RtR[4]; Hm[8] += om * RtR[8];
-                Hm[1] += h01; Hm[3] += h01; Hm[2] += h02; Hm[6] += h02; Hm[5] += h12; Hm[7] += h12; }
-              for (int rr = 0; rr < 3; ++rr) bv[rr] += om * ((W[rr] * er[0] + W[4 + rr] * er[1]) + W[8 + rr] * er[2]);
+              if (sp[2] <= 0) { t.kind = 0; }
+              else {
+                const double er[3] = {sp[0] - mc[0], sp[1] - mc[1], sp[2] - mc[2]};
+                double om = mc[3];
+                t.e2 = om * ((er[0] * er[0] + er[1] * er[1]) + er[2] * er[2]);
+                t.kind = 1;
+                if (t.e2 > kern) { om *= kern / t.e2; t.kind = 2; }
+                // R^T R is symmetric to the bit (its entries are sums of commuting products): six products instead of nine
+                t.h[0] = om * RtR[0]; t.h[1] = om * RtR[1]; t.h[2] = om * RtR[2]; t.h[3] = om * RtR[4]; t.h[4] = om * RtR[5]; t.h[5] = om * RtR[8];
+                for (int rr = 0; rr < 3; ++rr) t.b[rr] = om * ((W[rr] * er[0] + W[4 + rr] * er[1]) + W[8 + rr] * er[2]);
+              }
+            }
+            __builtin_amdgcn_wave_barrier();     // the previous batch's terms have been read by every lane of the group
+            terms[gl] = t;
+            __builtin_amdgcn_wave_barrier();
+            // every lane adds the batch in list order (its own copy of the accumulators: no broadcast afterwards)
+            const int nb_ = min(RGBD_LM_G, len - j0);
+            for (int u = 0; u < nb_; ++u) {
+              const int kind = __hip_atomic_load(&terms[u].kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              if (kind == 0) { ++n_out; continue; }
+              const volatile RgbdLmTerm& q = terms[u];
+              err += q.e2;
+              if (kind == 2) ++n_out;
+              Hm[0] += q.h[0]; Hm[4] += q.h[3]; Hm[8] += q.h[5];
+              { const double h01 = q.h[1], h02 = q.h[2], h12 = q.h[4]; Hm[1] += h01; Hm[3] += h01; Hm[2] += h02; Hm[6] += h02; Hm[5] += h12; Hm[7] += h12; }
+              bv[0] += q.b[0]; bv[1] += q.b[1]; bv[2] += q.b[2];
             }
           }
           double nb[3] = {-bv[0], -bv[1], -bv[2]}, dx[3];
@@ -591,10 +619,12 @@ __global__ __launch_bounds__(256) void k_rgbd_landmarks(const DevCfg c, const Rg
           }
           err_prev = err;
         }
-        cur.lmu[i] = updates;
       }
-      for (int q = 0; q < 3; ++q) cur.lmw[3 * (size_t)i + q] = world[q];
-      cur.flags[i] = (uint8_t)(fl | RGBD_F_LM | RGBD_F_CHAIN);
+      if (gl == 0) {
+        cur.lmu[i] = updates; cur.lmm[i] = lmm;
+        for (int q = 0; q < 3; ++q) cur.lmw[3 * (size_t)i + q] = world[q];
+        cur.flags[i] = (uint8_t)(fl | RGBD_F_LM | RGBD_F_CHAIN);
+      }
     }
   }
   const int cnt = __popcll(__ballot(active));

@@ -162,7 +162,7 @@ private:
     hipLaunchKernelGGL(k_rgbd_prune, dim3(1), dim3(1024), 0, q, d, bs, rb);
     hipLaunchKernelGGL(k_rgbd_describe_at, dim3(64), dim3(256), 0, q, d, bs, rb);
     hipLaunchKernelGGL(k_rgbd_recover_finish, dim3(1), dim3(1024), 0, q, d, rb);
-    hipLaunchKernelGGL(k_rgbd_landmarks, dim3((d.MAXP + 255) / 256), dim3(256), 0, q, d, rb);
+    hipLaunchKernelGGL(k_rgbd_landmarks, dim3((d.MAXP + RGBD_LM_PTS - 1) / RGBD_LM_PTS), dim3(256), 0, q, d, rb);
     hipLaunchKernelGGL(k_rgbd_finish, dim3(1), dim3(1024), 0, q, d, bs, rb);
   }
 
