@@ -171,7 +171,7 @@ struct DevBuf {
   int32_t* bin_aux;    // [B][2*(nb+1) + NMAX]  per-bin counts, starts, candidate lists
   // history ring for landmark refinement [B][HCAP]
   double* h_pose;      // [..][24]  cam_to_world, world_to_cam
-  double* h_cam;       // [..][MAXP][3]
+  double* h_cam;       // [..][MAXP][4]  camera coordinates and 1 / z
   int32_t* h_prev;     // [..][MAXP]
 };
 __device__ __forceinline__ bool vs_active(const DevBuf& b, int s) { return (b.active[s >> 5] >> (s & 31)) & 1u; }

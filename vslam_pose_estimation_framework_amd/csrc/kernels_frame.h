@@ -52,7 +52,7 @@ __device__ __forceinline__ double* hpose_of(const DevCfg& c, const DevBuf& b, in
   return b.h_pose + ((size_t)s * c.HCAP + (f % c.HCAP)) * 24;
 }
 __device__ __forceinline__ double* hcam_of(const DevCfg& c, const DevBuf& b, int s, int f) {
-  return b.h_cam + ((size_t)s * c.HCAP + (f % c.HCAP)) * (size_t)c.MAXP * 3;
+  return b.h_cam + ((size_t)s * c.HCAP + (f % c.HCAP)) * (size_t)c.MAXP * 4;   // x, y, z, 1 / z per point
 }
 __device__ __forceinline__ int32_t* hprev_of(const DevCfg& c, const DevBuf& b, int s, int f) {
   return b.h_prev + ((size_t)s * c.HCAP + (f % c.HCAP)) * (size_t)c.MAXP;

@@ -395,7 +395,15 @@ __global__ __launch_bounds__(256) void k_recover_brief(const DevCfg c, const Dev
 #endif
 #define VS_LM_NP 48   // world_to_camera of the last VS_LM_NP frames staged in LDS (one copy for all points of the frame)
 template <int NT, int CN>
-struct LmCacheT { static constexpr int kCN = CN; static constexpr int kBatch = NT >= 512 ? 4 : 2; double w2c[VS_LM_NP][12]; double cam[NT][CN][3]; };
+struct LmCacheT { static constexpr int kCN = CN; static constexpr int kBatch = NT >= 512 ? 4 : 2; double w2c[VS_LM_NP][12]; double rtr[VS_LM_NP][9]; double cam[NT][CN][4]; };
+// R^T R of world_to_camera k (J^T J of every measurement taken in that frame: a property of the frame, symmetric to the bit) next to the staged poses
+template <class LC>
+__device__ __forceinline__ void lm_stage_rtr(LC* lc, int f, int hcap, int nthreads) {
+  for (int t = threadIdx.x; t < VS_LM_NP * 9; t += nthreads) {
+    const int k = t / 9, e = t - 9 * k, rr = e / 3, cc = e - 3 * rr;
+    if (f - k >= 0 && k < hcap) { const double* W = lc->w2c[k]; lc->rtr[k][e] = (W[rr] * W[cc] + W[4 + rr] * W[4 + cc]) + W[8 + rr] * W[8 + cc]; }
+  }
+}
 typedef LmCacheT<VS_WG, VS_LM_CN> LmCache;
 template <bool LDS, class LC = LmCache>
 __device__ __forceinline__ bool landmark_point_t(const DevCfg& c, const DevBuf& b, int s, const PtView& cv, int f, int i, LC* lc) {
@@ -414,7 +422,7 @@ __device__ __forceinline__ bool landmark_point_t(const DevCfg& c, const DevBuf& 
       int ff = f, ii = i;
       for (int k = 0; k < len; ++k) {
         double wp[3];
-        tf_apply(hpose_of(c, b, s, ff), hcam_of(c, b, s, ff) + 3 * (size_t)ii, wp);
+        tf_apply(hpose_of(c, b, s, ff), hcam_of(c, b, s, ff) + 4 * (size_t)ii, wp);
         for (int q = 0; q < 3; ++q) acc[q] += wp[q];
         ii = hprev_of(c, b, s, ff)[ii];
         --ff;
@@ -429,21 +437,28 @@ __device__ __forceinline__ bool landmark_point_t(const DevCfg& c, const DevBuf& 
       double err_prev = 0;
       const double kern = c.c.landmark_maximum_error_squared_meters;
       // one measurement of the track: residual, saturated kernel, H += R^T om R, b += R^T om e
-      auto accumulate = [&](const double* W, const double* mc, double* H, double* bv, double& err, int& n_out) {
+      // mc = x, y, z, 1 / z of the measurement (the history ring keeps the inverse depth: one division per measurement, not one per round);
+      // RtR = the staged R^T R of the measurement's frame, or null (computed here)
+      auto accumulate = [&](const double* W, const double* RtR, const double* mc, double* H, double* bv, double& err, int& n_out) {
         double sp[3];
         tf_apply(W, wv, sp);
         if (sp[2] <= 0) {
           ++n_out;
         } else {
           const double e[3] = {sp[0] - mc[0], sp[1] - mc[1], sp[2] - mc[2]};
-          double om = 1 / mc[2];
+          double om = mc[3];
           const double e2 = om * ((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]);
           err += e2;
           if (e2 > kern) { om *= kern / e2; ++n_out; }
-          for (int r = 0; r < 3; ++r) {
-            for (int cc = 0; cc < 3; ++cc) H[3 * r + cc] += om * ((W[r] * W[cc] + W[4 + r] * W[4 + cc]) + W[8 + r] * W[8 + cc]);
-            bv[r] += om * ((W[r] * e[0] + W[4 + r] * e[1]) + W[8 + r] * e[2]);
+          if (RtR) {
+            const double h01 = om * RtR[1], h02 = om * RtR[2], h12 = om * RtR[5];
+            H[0] += om * RtR[0]; H[4] += om * RtR[4]; H[8] += om * RtR[8];
+            H[1] += h01; H[3] += h01; H[2] += h02; H[6] += h02; H[5] += h12; H[7] += h12;
+          } else {
+            for (int r = 0; r < 3; ++r)
+              for (int cc = 0; cc < 3; ++cc) H[3 * r + cc] += om * ((W[r] * W[cc] + W[4 + r] * W[4 + cc]) + W[8 + r] * W[8 + cc]);
           }
+          for (int r = 0; r < 3; ++r) bv[r] += om * ((W[r] * e[0] + W[4 + r] * e[1]) + W[8 + r] * e[2]);
         }
       };
       // Measurement k of the track (frame f - k): index i for k = 0, the trail's entry k - 1 up to k = VS_TRAIL, then the
@@ -468,21 +483,21 @@ __device__ __forceinline__ bool landmark_point_t(const DevCfg& c, const DevBuf& 
       // the first VS_LM_CN_ measurements into the thread's LDS slots, once
       int ncache = 0, ffc = f, iic = i;
       if constexpr (LDS) {
-        double (*slot)[3] = lc->cam[threadIdx.x];
+        double (*slot)[4] = lc->cam[threadIdx.x];
         if (c.trail) {
           const int nc = min(min(len, VS_LM_CN_), n_direct);
-          double mv[VS_LM_CN_][3];
+          double mv[VS_LM_CN_][4];
 #pragma unroll
           for (int k = 0; k < VS_LM_CN_; ++k)
-            if (k < nc) { const double* mc = hcam_of(c, b, s, f - k) + 3 * (size_t)index_at(k); mv[k][0] = mc[0]; mv[k][1] = mc[1]; mv[k][2] = mc[2]; }
+            if (k < nc) { const double* mc = hcam_of(c, b, s, f - k) + 4 * (size_t)index_at(k); mv[k][0] = mc[0]; mv[k][1] = mc[1]; mv[k][2] = mc[2]; mv[k][3] = mc[3]; }
 #pragma unroll
           for (int k = 0; k < VS_LM_CN_; ++k)
-            if (k < nc) { slot[k][0] = mv[k][0]; slot[k][1] = mv[k][1]; slot[k][2] = mv[k][2]; }
+            if (k < nc) { slot[k][0] = mv[k][0]; slot[k][1] = mv[k][1]; slot[k][2] = mv[k][2]; slot[k][3] = mv[k][3]; }
           ncache = nc;
         } else {
           for (int k = 0; k < len && k < VS_LM_CN_; ++k) {
-            const double* mc = hcam_of(c, b, s, ffc) + 3 * (size_t)iic;
-            slot[k][0] = mc[0]; slot[k][1] = mc[1]; slot[k][2] = mc[2];
+            const double* mc = hcam_of(c, b, s, ffc) + 4 * (size_t)iic;
+            slot[k][0] = mc[0]; slot[k][1] = mc[1]; slot[k][2] = mc[2]; slot[k][3] = mc[3];
             ++ncache;
             iic = hprev_of(c, b, s, ffc)[iic];
             --ffc;
@@ -500,29 +515,29 @@ __device__ __forceinline__ bool landmark_point_t(const DevCfg& c, const DevBuf& 
         double err = 0;
         int n_out = 0;
         if constexpr (LDS) {
-          const double (*slot)[3] = lc->cam[threadIdx.x];
-          for (int k = 0; k < ncache; ++k) accumulate(lc->w2c[k], slot[k], H, bv, err, n_out);   // frame f - k
+          const double (*slot)[4] = lc->cam[threadIdx.x];
+          for (int k = 0; k < ncache; ++k) accumulate(lc->w2c[k], lc->rtr[k], slot[k], H, bv, err, n_out);   // frame f - k
         }
         if (c.trail) {
           // directly addressed measurements, four at a time: their (independent) loads are in flight together
           constexpr int NB = LC::kBatch;     // loads in flight together (fewer in the small-register tail kernel)
           for (int k0 = ncache; k0 < n_direct; k0 += NB) {
-            double mc[NB][3];
+            double mc[NB][4];
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
               const int k = min(k0 + u, n_direct - 1);
-              const double* src = hcam_of(c, b, s, f - k) + 3 * (size_t)index_at(k);
-              mc[u][0] = src[0]; mc[u][1] = src[1]; mc[u][2] = src[2];
+              const double* src = hcam_of(c, b, s, f - k) + 4 * (size_t)index_at(k);
+              mc[u][0] = src[0]; mc[u][1] = src[1]; mc[u][2] = src[2]; mc[u][3] = src[3];
             }
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
               const int k = k0 + u;
               if (k < n_direct) {
                 if constexpr (LDS) {
-                  if (k < VS_LM_NP) accumulate(lc->w2c[k], mc[u], H, bv, err, n_out);
-                  else accumulate(hpose_of(c, b, s, f - k) + 12, mc[u], H, bv, err, n_out);
+                  if (k < VS_LM_NP) accumulate(lc->w2c[k], lc->rtr[k], mc[u], H, bv, err, n_out);
+                  else accumulate(hpose_of(c, b, s, f - k) + 12, nullptr, mc[u], H, bv, err, n_out);
                 } else {
-                  accumulate(hpose_of(c, b, s, f - k) + 12, mc[u], H, bv, err, n_out);
+                  accumulate(hpose_of(c, b, s, f - k) + 12, nullptr, mc[u], H, bv, err, n_out);
                 }
               }
             }
@@ -531,7 +546,7 @@ __device__ __forceinline__ bool landmark_point_t(const DevCfg& c, const DevBuf& 
         if (!ended) {
           int ff = ffc, ii = iic;
           for (int k = c.trail ? n_direct : ncache; k < len; ++k) {
-            accumulate(hpose_of(c, b, s, ff) + 12, hcam_of(c, b, s, ff) + 3 * (size_t)ii, H, bv, err, n_out);
+            accumulate(hpose_of(c, b, s, ff) + 12, nullptr, hcam_of(c, b, s, ff) + 4 * (size_t)ii, H, bv, err, n_out);
             ii = hprev_of(c, b, s, ff)[ii];
             --ff;
             if (ii < 0) break;
@@ -550,7 +565,7 @@ __device__ __forceinline__ bool landmark_point_t(const DevCfg& c, const DevBuf& 
             int f2 = f, i2 = i;
             for (int k = 0; k < len; ++k) {
               double wp[3];
-              tf_apply(hpose_of(c, b, s, f2), hcam_of(c, b, s, f2) + 3 * (size_t)i2, wp);
+              tf_apply(hpose_of(c, b, s, f2), hcam_of(c, b, s, f2) + 4 * (size_t)i2, wp);
               for (int q = 0; q < 3; ++q) acc[q] += wp[q];
               i2 = hprev_of(c, b, s, f2)[i2];
               --f2;
@@ -583,7 +598,8 @@ __device__ __forceinline__ void wg_publish_history(const DevCfg& c, const DevBuf
   double* hc = hcam_of(c, b, s, f);
   int32_t* hp = hprev_of(c, b, s, f);
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    for (int k = 0; k < 3; ++k) hc[3 * (size_t)i + k] = cv.cam[3 * (size_t)i + k];
+    { const double x = cv.cam[3 * (size_t)i], y = cv.cam[3 * (size_t)i + 1], z = cv.cam[3 * (size_t)i + 2];
+      reinterpret_cast<double2*>(hc + 4 * (size_t)i)[0] = make_double2(x, y); reinterpret_cast<double2*>(hc + 4 * (size_t)i)[1] = make_double2(z, 1 / z); }   // Measurement::inverse_depth_meters
     const int ip = cv.meta[(size_t)i * META + M_PREV];
     hp[i] = ip;
     if (c.trail) {
@@ -1239,7 +1255,8 @@ __device__ __forceinline__ void wg_stereo_t(const DevCfg& c, const DevBuf& b, in
   double* hc = hcam_of(c, b, s, f);
   int32_t* hp = hprev_of(c, b, s, f);
   for (int j = n_tracked + tid; j < n_final; j += NT) {
-    for (int k = 0; k < 3; ++k) hc[3 * (size_t)j + k] = cv.cam[3 * (size_t)j + k];
+    { const double x = cv.cam[3 * (size_t)j], y = cv.cam[3 * (size_t)j + 1], z = cv.cam[3 * (size_t)j + 2];
+      reinterpret_cast<double2*>(hc + 4 * (size_t)j)[0] = make_double2(x, y); reinterpret_cast<double2*>(hc + 4 * (size_t)j)[1] = make_double2(z, 1 / z); }
     hp[j] = -1;
     if (c.trail) *reinterpret_cast<uint4*>(cv.trail + (size_t)j * VS_TRAIL) = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);   // a track starts here
   }
@@ -1509,6 +1526,8 @@ __global__ VS_FRAME_BOUNDS void k_frame(ConstDevCfg* cp, ConstDevBuf* bp, int ph
     static_assert(sizeof(LmCache) <= VS_ARENA, "landmark measurement cache must fit the LDS arena");
     LmCache* lc = reinterpret_cast<LmCache*>(arena);
     for (int t = tid; t < VS_LM_NP * 12; t += VS_WG) { const int k = t / 12; if (f - k >= 0 && k < c.HCAP) lc->w2c[k][t - 12 * k] = hpose_of(c, b, s, f - k)[12 + t - 12 * k]; }
+    __syncthreads();
+    lm_stage_rtr(lc, f, c.HCAP, VS_WG);
     // The points that carry a landmark (track long enough: creation or refinement) are compacted into a work list first: ~40 % of
     // the frame's points, one per thread in a single round instead of two half-empty ones (a thread's refinement is a serial chain).
     constexpr int LIST_CAP = (VS_ARENA - (int)sizeof(LmCache)) / 2;
@@ -1612,9 +1631,11 @@ __global__ __launch_bounds__(VS_TAIL_WG, 4) void k_tail(ConstDevCfg* cp, ConstDe
     const unsigned long long tu = wall_clock64();
     const PtView cvu = pts_of(c, b, s, pb_cur);
     typedef LmCacheT<VS_TAIL_WG, 1> LC;
-    static_assert(sizeof(LC) + 2048 <= VS_TAIL_ARENA, "landmark cache + work list must fit the tail's arena");
+    static_assert(sizeof(LC) + 1024 <= VS_TAIL_ARENA, "landmark cache + work list must fit the tail's arena");
     LC* lc = reinterpret_cast<LC*>(arena);
     for (int t = tid; t < VS_LM_NP * 12; t += VS_TAIL_WG) { const int k = t / 12; if (f - k >= 0 && k < c.HCAP) lc->w2c[k][t - 12 * k] = hpose_of(c, b, s, f - k)[12 + t - 12 * k]; }
+    __syncthreads();
+    lm_stage_rtr(lc, f, c.HCAP, VS_TAIL_WG);
     constexpr int LIST_CAP = (VS_TAIL_ARENA - (int)sizeof(LC)) / 2;
     uint16_t* work = reinterpret_cast<uint16_t*>(arena + sizeof(LC));
     int active = 0;

@@ -427,7 +427,7 @@ static int create_internal(const vslam_config* cfg, int device, int n_streams, v
   A(al_moving, B * P * 3); A(al_fixed, B * P * 4); A(al_omega, B * P); A(al_weight, B * P); A(al_chi, B * P); A(al_inl, B * P);
   A(rec, B * P * 6); A(rec_desc, B * P * 64);
   A(st_match, B * N * 3); A(sc, B * N * 4); A(bin_occ, B * (size_t)d.rows_bin * d.cols_bin); A(sdist, B * N * 16); A(bin_aux, B * (2 * ((size_t)d.rows_bin * d.cols_bin + 1) + N));
-  A(h_pose, B * Hc * 24); A(h_cam, B * Hc * P * 3); A(h_prev, B * Hc * P);
+  A(h_pose, B * Hc * 24); A(h_cam, B * Hc * P * 4); A(h_prev, B * Hc * P);
 #undef A
   for (int q = 0; q < 2 && e == hipSuccess; ++q) {
     vslam_ctx::ImgSet& t = c->sets[q];
