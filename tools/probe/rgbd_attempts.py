@@ -1,0 +1,22 @@
+"""Which registration paths a jump in the sequence triggers (track_attempts, aligner, break): probe for the RGB-D re-registration tests."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
+import numpy as np
+from _oracle import Oracle
+from test_rgbd_mode import setup
+from vslam_pose_estimation_framework_amd import hip
+from vslam_pose_estimation_framework_amd.capi import RgbdTracker
+o = Oracle()
+which = sys.argv[1] if len(sys.argv) > 1 else "tum"
+scene, cfg, p = setup(o, which, descriptor=0, max_depth=30.0, seed=41)
+if os.environ.get('RGBD_MIN_LM'): cfg.minimum_number_of_landmarks_to_track = int(os.environ['RGBD_MIN_LM'])
+g = hip.load()
+for jump in [int(a) for a in sys.argv[2:]] or [6, 10, 16, 24]:
+    t = RgbdTracker(g, cfg, p)
+    ks = [0, 1, 2, 3, 4, 5, 5 + jump, 6 + jump, 7 + jump]
+    row = []
+    for k in ks:
+        fi, nt = t.process(o.render(scene, k)[0], o.render_depth(scene, k, 2e-3))
+        row.append((k, fi.status, fi.track_attempts, fi.aligner_ran, fi.n_tracked, fi.n_inliers, fi.track_broken, fi.window_pixels))
+    print(jump, row)
+    t.destroy()

@@ -580,7 +580,8 @@ _extra_methods()
 
 
 class RgbdTracker(object):
-    """ctypes view of vslam_rgbd_* (RGB-D mode end to end, host-driven loop inside libvslam_hip.so)."""
+    """ctypes view of vslam_rgbd_* (RGB-D mode end to end inside libvslam_hip.so: the device-resident loop, or the host-driven loop over the
+    stand-alone entry points when VSLAM_RGBD_HOST=1 is set while the tracker is created)."""
 
     def __init__(self, api, cfg, params, device=0):
         self.lib = api.lib
@@ -595,7 +596,11 @@ class RgbdTracker(object):
         if rc != OK:
             raise VslamError(rc, self.lib.vslam_rgbd_last_error(self.h).decode())
 
-    def process(self, left, depth):
+    def reset(self):
+        self._check(self.lib.vslam_rgbd_reset(self.h))
+
+    def process(self, left, depth, cols=None):
+        """left / depth: 2-D arrays; cols: image width when the arrays carry padding columns (row stride = array width)."""
         left = np.ascontiguousarray(left, np.uint8); depth = np.ascontiguousarray(depth, np.uint16)
         self._check(self.lib.vslam_rgbd_process_host(self.h, _p(left, C.c_uint8), C.c_int32(left.shape[1]), _p(depth, C.c_uint16), C.c_int32(depth.shape[1])))
         fi = FrameInfo()
