@@ -377,7 +377,13 @@ typedef struct vslam_depth_params {
   int32_t enable_keypoint_binning, bin_size_pixels;     /* base generator parameters                              */
   int32_t descriptor_type;                              /* extractor of recoverPoints: VSLAM_DESCRIPTOR_BRIEF / _ORB (the RGB-D
                                                            configurations say "ORB-256", i.e. cv::ORB::create())   */
+  int32_t detector_type;                                /* vslam_rgbd_*: VSLAM_DETECTOR_FAST (every shipped configuration) or
+                                                           VSLAM_DETECTOR_ORB = OrbDetector, cv::ORB::create(5000, 1.2, 8, 31, 0, 2,
+                                                           HARRIS_SCORE, 31, threshold) per detector region
+                                                           (base_framepoint_generator.cpp:52-70, :242-247; parameters.cpp:341)  */
 } vslam_depth_params;
+#define VSLAM_DETECTOR_FAST 0
+#define VSLAM_DETECTOR_ORB 1
 
 /* DepthFramePointGenerator::_computeDepthMap (depth_framepoint_generator.cpp:410-485) without the optional bilateral
  * filter: every non-zero u16 depth pixel is back-projected through K_right_inverse, moved into the left camera,
@@ -513,6 +519,16 @@ int vslam_harris_angle(vslam_ctx* ctx, const uint8_t* image, int32_t rows, int32
 int vslam_orb_detect(vslam_ctx* ctx, const uint8_t* image, int32_t rows, int32_t cols, int32_t row_stride,
                      int32_t nfeatures, float scale_factor, int32_t nlevels, int32_t edge_threshold, int32_t patch_size,
                      int32_t fast_threshold, int32_t cap, int32_t* n, float* keypoints);
+
+/* cv::ORB::create()->compute() on keypoints that carry an octave and an angle — what BaseFramePointGenerator::computeDescriptors
+ * (base_framepoint_generator.cpp:431-438) does with an OrbDetector's keypoints when the extractor is ORB [recalled: orb.cpp
+ * detectAndCompute with useProvidedKeypoints]: runByImageBorder(31) on the level-0 coordinates (Rect::contains rounds the float point), a
+ * pyramid up to the highest octave present (level l from level l-1, INTER_LINEAR, cvRound(cols / scale) x cvRound(rows / scale), scale =
+ * (float)pow(scale_factor, l)), GaussianBlur 7x7 sigma 2 per level, 256 tests steered by the keypoint's own angle around
+ * (cvRound(x / scale), cvRound(y / scale)) of its level.  keypoints: n x 6 floats as vslam_orb_detect writes them.  keep[i] = 0: removed
+ * (border filter; also a keypoint whose pattern would leave its level, which an OrbDetector never produces). */
+int vslam_orb_describe_keypoints(vslam_ctx* ctx, const uint8_t* image, int32_t rows, int32_t cols, int32_t row_stride, int32_t n,
+                                 const float* keypoints, float scale_factor, uint8_t* keep, uint8_t* descriptors);
 
 /* ---- multi-GPU: trajectory assembly ---------------------------------------------------------
  * No reference counterpart (single process).  The pose all-gather is issued by the host

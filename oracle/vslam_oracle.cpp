@@ -2380,6 +2380,48 @@ ORC_API int orc_orb_detect(const uint8_t* img, int32_t rows, int32_t cols, int32
   return total > cap ? VSLAM_ERR_CAPACITY : VSLAM_OK;
 }
 
+/* cv::ORB::create()->compute() on keypoints that carry an octave and an angle — what _descriptor_extractor->compute() does with an
+ * OrbDetector's keypoints (base_framepoint_generator.cpp:431-438) [recalled: orb.cpp detectAndCompute, useProvidedKeypoints]:
+ * runByImageBorder(edgeThreshold 31) on the level-0 coordinates (the Rect::contains test rounds the float point), a pyramid up to the
+ * highest octave present (level l from level l-1, INTER_LINEAR, size cvRound(cols / scale) x cvRound(rows / scale), scale =
+ * (float)pow(scaleFactor, l)), a 7x7 Gaussian per level, and per keypoint the 256 tests steered by ITS angle around
+ * (cvRound(x * (1 / scale)), cvRound(y * (1 / scale))) of its level.  kp6: x, y, size, angle, response, octave per keypoint (orc_orb_detect).
+ * A keypoint whose pattern would leave its level (never an OrbDetector's: they keep 31 px from their level's border) is removed too. */
+ORC_API int orc_orb_describe_keypoints(const uint8_t* img, int32_t rows, int32_t cols, int32_t stride, int32_t n, const float* kp6, float scale_factor,
+                                       uint8_t* keep, uint8_t* desc) {
+  if (!img || n < 0 || rows < 4 || cols < 4 || stride < cols || !(scale_factor > 1.f) || (n && (!kp6 || !keep || !desc))) return VSLAM_ERR_INVALID;
+  int top = 0;
+  for (int i = 0; i < n; ++i) { const int o = (int)kp6[6 * i + 5]; if (o < 0 || o > 15) return VSLAM_ERR_INVALID; top = std::max(top, o); }
+  struct Level { std::vector<uint8_t> img, blur; int rows, cols; float scale; };
+  std::vector<Level> L(top + 1);
+  for (int l = 0; l <= top; ++l) {
+    L[l].scale = (float)std::pow((double)scale_factor, (double)l);
+    if (l == 0) {
+      L[0].rows = rows; L[0].cols = cols;
+      L[0].img.resize((size_t)rows * cols);
+      for (int y = 0; y < rows; ++y) std::memcpy(&L[0].img[(size_t)y * cols], img + (size_t)y * stride, cols);
+    } else {
+      L[l].rows = cv_round(rows / L[l].scale); L[l].cols = cv_round(cols / L[l].scale);
+      if (L[l].rows < 8 || L[l].cols < 8) return VSLAM_ERR_INVALID;
+      L[l].img.resize((size_t)L[l].rows * L[l].cols);
+      resize_linear_u8(L[l - 1].img.data(), L[l - 1].rows, L[l - 1].cols, L[l - 1].cols, L[l].img.data(), L[l].rows, L[l].cols);
+    }
+    gaussian_blur7_u8(L[l].img.data(), L[l].rows, L[l].cols, L[l].cols, L[l].blur);
+  }
+  const int reach = 23;   /* the rotated 31 x 31 pattern: |offset| <= cvRound(15 sqrt 2) = 21, + slack */
+  for (int i = 0; i < n; ++i) {
+    const float* k = kp6 + 6 * (size_t)i;
+    const Level& lv = L[(int)k[5]];
+    const float inv = 1.f / lv.scale;
+    const int cx = cv_round(k[0] * inv), cy = cv_round(k[1] * inv);
+    const bool in = orb_inside(rows, cols, cv_round(k[0]), cv_round(k[1])) && cx >= reach && cy >= reach && cx < lv.cols - reach && cy < lv.rows - reach;
+    keep[i] = in ? 1 : 0;
+    if (in) { float a, b; orb_rotation(k[3], &a, &b); orb_at(lv.blur.data(), lv.cols, cx, cy, a, b, desc + 32 * (size_t)i); }
+    else std::memset(desc + 32 * (size_t)i, 0, 32);
+  }
+  return VSLAM_OK;
+}
+
 /* ---- synthetic data + trajectory error (test / bench infrastructure) ---------------------- */
 ORC_API void orc_synth_default_kitti(synth_scene* s) { synth_default_kitti(s); }
 ORC_API void orc_synth_default_euroc(synth_scene* s) { synth_default_euroc(s); }

@@ -131,11 +131,21 @@ class RgbdTracker(object):
         api, c = self.api, self.cfg
         self.space, _, _ = api.depth_space_map(self.p, depth)
         parts = []
+        orb_detector = getattr(self.p, "detector_type", 0) == 1
         for r, (rx, ry, rw, rh) in enumerate(self.regions):     # detectKeypoints: region-major, per-region threshold and controller
-            pxy, _ = api.fast_detect(left, (rx, ry, rw, rh), self.thr[r])
-            n = len(pxy)
-            if n:
-                parts.append(pxy.astype(np.int32) + np.array([rx, ry], np.int32))
+            if orb_detector:
+                # OrbDetector (base_framepoint_generator.cpp:52-70): cv::ORB::create(5000, 1.2f, 8, 31, 0, 2, HARRIS_SCORE, 31, threshold) on the
+                # region's view of the image; keypoint.pt += region corner (:418-419, float addition)
+                kps = api.orb_detect(left[ry:ry + rh, rx:rx + rw], 5000, 1.2, 8, 31, 31, self.thr[r])
+                n = len(kps)
+                if n:
+                    kps = kps.copy(); kps[:, 0] = kps[:, 0] + np.float32(rx); kps[:, 1] = kps[:, 1] + np.float32(ry)
+                    parts.append(kps)
+            else:
+                pxy, _ = api.fast_detect(left, (rx, ry, rw, rh), self.thr[r])
+                n = len(pxy)
+                if n:
+                    parts.append(pxy.astype(np.int32) + np.array([rx, ry], np.int32))
             t = float(self.thr[r])                              # base_framepoint_generator.cpp:382-415
             delta = (float(n) - self.per_detector) / self.per_detector
             if delta < -c.target_number_of_keypoints_tolerance:
@@ -143,10 +153,20 @@ class RgbdTracker(object):
             elif delta > c.target_number_of_keypoints_tolerance:
                 t = t + max(min(delta, c.detector_threshold_maximum_change) * t, 1.0); t = min(t, float(c.detector_threshold_maximum))
             self.thr[r] = int(np.rint(t / 1))                   # adjustDetectorThresholds over ONE detection (:440-459)
-        xy = (np.concatenate(parts) if parts else np.zeros((0, 2), np.int32)).astype(np.int16)
-        keep, desc = (api.orb_describe(left, xy, -1.0) if self.p.descriptor_type == 1 else api.brief_describe(left, xy))
-        sel = keep.astype(bool)
-        self.feat_xy = xy[sel].astype(np.int32); self.feat_desc = desc[sel]
+        if orb_detector:
+            kps = np.concatenate(parts) if parts else np.zeros((0, 6), np.float32)
+            if self.p.descriptor_type == 1:                     # ORB::compute: the keypoint's pyramid level and angle
+                keep, desc = api.orb_describe_keypoints(left, kps, 1.2)
+            else:                                               # BriefDescriptorExtractor: level 0, pixel (int)(pt + 0.5)
+                keep, desc = api.brief_describe(left, np.floor(kps[:, :2] + np.float32(0.5)).astype(np.int16))
+            sel = keep.astype(bool)
+            self.feat_xy = kps[sel][:, :2].astype(np.float32); self.feat_desc = desc[sel]
+        else:
+            xy = (np.concatenate(parts) if parts else np.zeros((0, 2), np.int32)).astype(np.int16)
+            keep, desc = (api.orb_describe(left, xy, -1.0) if self.p.descriptor_type == 1 else api.brief_describe(left, xy))
+            sel = keep.astype(bool)
+            self.feat_xy = xy[sel].astype(np.float32); self.feat_desc = desc[sel]
+        # IntensityFeature: row = (int)pt.y, col = (int)pt.x (frame_point.h:18-35)
         self.feat_rc = np.stack([self.feat_xy[:, 1], self.feat_xy[:, 0]], axis=1).astype(np.int32) if len(self.feat_xy) else np.zeros((0, 2), np.int32)
         self.matched = np.zeros(len(self.feat_xy), bool)
         self.n_detected = len(self.feat_xy)

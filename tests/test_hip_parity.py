@@ -575,3 +575,69 @@ def test_rgbd_chain_on_rendered_frames(gpu, oracle):
     rb = oracle.depth_recover(p, f1["space"], f1["left"], w2c1, np.ones(len(lost_all), np.uint8), world, pdesc[lost_all], 7.0, 60.0)
     assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1].view(np.uint32), rb[1].view(np.uint32))
     assert np.array_equal(ra[2], rb[2]) and np.array_equal(ra[3], rb[3])
+
+
+def test_orb_describe_keypoints_against_oracle(gpu, oracle):
+    """cv::ORB::compute on an OrbDetector's keypoints (pyramid level + own angle per keypoint) at KITTI size: keep flags and descriptor bytes
+    GPU == oracle, all eight levels; border and octave edge cases."""
+    from vslam_pose_estimation_framework_amd.capi import VslamError
+    scene = oracle.scene_kitti()
+    left, _ = oracle.render(scene, 40)
+    kps = oracle.orb_detect(left, 5000, 1.2, 8, 31, 31, 12)
+    extra = np.array([[5.0, 50.0, 31, 10, 1, 0], [600.4, 200.6, 31, 123.5, 1, 3], [45.0, 45.0, 31, 0, 1, 6], [1200.0, 340.0, 31, 359, 1, 1]], np.float32)
+    both = np.concatenate([kps, extra])
+    kg, dg = gpu.orb_describe_keypoints(left, both, 1.2)
+    ko, do = oracle.orb_describe_keypoints(left, both, 1.2)
+    np.testing.assert_array_equal(kg, ko)
+    np.testing.assert_array_equal(dg, do)
+    assert kg[:len(kps)].all() and list(kg[len(kps):]) == [0, 1, 0, 1] and set(np.unique(kps[:, 5]).astype(int)) == set(range(8))
+    assert len(gpu.orb_describe_keypoints(left, np.zeros((0, 6), np.float32), 1.2)[0]) == 0
+    with pytest.raises(VslamError):
+        gpu.orb_describe_keypoints(left, np.array([[50, 50, 31, 0, 1, 16]], np.float32), 1.2)
+
+
+def test_depth_track_with_features_sharing_a_pixel(gpu, oracle):
+    """Several features on one pixel (an OrbDetector finds a corner on more than one pyramid level): setFeatures writes the lattice in list
+    order, only the LAST one is ever found by track(), also after it has been taken (intensity_feature_matcher.cpp:48-70).  GPU == oracle
+    with a third of the features duplicated in front of / behind their originals with other descriptors."""
+    from vslam_pose_estimation_framework_amd.capi import DepthParams
+    from vslam_pose_estimation_framework_amd import evaluation as ev
+    scene = oracle.scene_kitti(scale=0.5)
+    rows, cols = scene.rows, scene.cols
+    K = np.array([[scene.fx, 0, scene.cx], [0, scene.fy, scene.cy], [0, 0, 1.0]])
+    p = DepthParams.make(rows, cols, K, np.linalg.inv(K), np.linalg.inv(K), np.eye(4)[:3], 2e-3, 0.1, 80.0, 1, 1, 15)
+    fr = []
+    for k in (40, 41):
+        left, _ = oracle.render(scene, k)
+        space = oracle.depth_space_map(p, oracle.render_depth(scene, k, 2e-3))[0]
+        xy, _ = oracle.fast_detect(left, (0, 0, cols, rows), 20)
+        keep, d = oracle.brief_describe(left, xy)
+        sel = keep.astype(bool)
+        fr.append(dict(space=space, rc=np.stack([xy[sel, 1], xy[sel, 0]], axis=1).astype(np.int32), desc=d[sel], c2w=oracle.gt_pose(scene, k)))
+    f0, f1 = fr
+    idx, cam = oracle.depth_compute(p, f0["space"], f0["rc"], np.zeros((0, 2), np.int32))[:2]
+    pdesc = f0["desc"][idx]; flags = np.ones(len(idx), np.uint8)
+    T = ev.mul34(ev.inv34(f1["c2w"]), f0["c2w"])
+    rng = np.random.default_rng(11)
+    n = len(f1["rc"])
+    dup = rng.choice(n, n // 3, replace=False)
+    noise = rng.integers(0, 256, (len(dup), 32), dtype=np.uint8)
+    for where in ("behind", "in front"):
+        # behind: the original is written first and overwritten by a stranger's descriptor; in front: the original is the last one and wins
+        if where == "behind":
+            rc = np.concatenate([f1["rc"], f1["rc"][dup]]); desc = np.concatenate([f1["desc"], noise])
+        else:
+            rc = np.concatenate([f1["rc"][dup], f1["rc"]]); desc = np.concatenate([noise, f1["desc"]])
+        perm = rng.permutation(len(rc)) if where == "behind" else np.arange(len(rc))
+        if where == "behind":          # any list order: keep every duplicate behind its original
+            order = np.argsort(np.concatenate([np.arange(n) * 2, dup * 2 + 1]), kind="stable")
+            rc, desc = rc[order], desc[order]
+        for by_app, d in ((1, 20), (0, 10)):
+            a = gpu.depth_track(p, f1["space"], T, d, 40.0, by_app, cam, pdesc, flags, rc, desc)
+            b = oracle.depth_track(p, f1["space"], T, d, 40.0, by_app, cam, pdesc, flags, rc, desc)
+            assert all(np.array_equal(x, y) for x, y in zip(a[:4], b[:4])) and a[4] == b[4], (where, by_app)
+            plain = oracle.depth_track(p, f1["space"], T, d, 40.0, by_app, cam, pdesc, flags, f1["rc"], f1["desc"])
+            if where == "behind":
+                assert len(b[0]) < len(plain[0])     # the overwritten originals cannot be found any more
+            else:
+                assert len(b[0]) == len(plain[0])    # the hidden strangers change nothing

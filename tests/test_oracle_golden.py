@@ -228,3 +228,37 @@ def test_tracker_control_known_answers(oracle, golden):
         assert oracle.lib.orc_prune_select(C.byref(cfg), C.c_int32(len(err)), C.c_double(float(g["total_" + name])), p(err, C.c_double),
                                            p(inl, C.c_uint8), p(keep, C.c_uint8)) == 0
         np.testing.assert_array_equal(keep, g["keep_" + name])
+
+
+def test_orb_describe_keypoints_is_the_composition_of_the_pinned_pieces(oracle):
+    """cv::ORB::compute on an OrbDetector's keypoints (orc_orb_describe_keypoints) = per keypoint: the pyramid level built by successive
+    INTER_LINEAR resizes (pinned: orb.npz), the 7x7 Gaussian + steered tests at ONE angle (pinned: orb_descriptor.npz) at
+    (cvRound(x / scale), cvRound(y / scale)).  Forty keypoints of every level, each against that composition."""
+    scene = oracle.scene_kitti(scale=0.5)
+    img, _ = oracle.render(scene, 40)
+    kps = oracle.orb_detect(img, 5000, 1.2, 8, 31, 31, 10)
+    keep, desc = oracle.orb_describe_keypoints(img, kps, 1.2)
+    assert len(kps) > 500 and keep.all()                     # the detector keeps 31 px from every level's border: nothing is removed
+    levels = [img]
+    top = int(kps[:, 5].max())
+    assert top >= 4
+    for l in range(1, top + 1):
+        sc = np.float32(pow(float(np.float32(1.2)), l))                 # getScale: (float)pow((double)scaleFactor, level)
+        levels.append(oracle.resize_linear_u8(levels[-1], int(np.rint(img.shape[0] / sc)), int(np.rint(img.shape[1] / sc))))
+    rng = np.random.default_rng(5)
+    for i in rng.choice(len(kps), 40, replace=False):
+        x, y, _, angle, _, octave = kps[i]
+        l = int(octave)
+        sc = np.float32(pow(float(np.float32(1.2)), l))
+        inv = np.float32(1.0) / sc
+        cx, cy = int(np.rint(np.float32(x) * inv)), int(np.rint(np.float32(y) * inv))
+        # the single-angle entry removes keypoints closer than 31 px to the border of the image it is given: embed the level in a frame
+        pad = 40
+        framed = np.pad(levels[l], pad, mode="reflect")        # BORDER_REFLECT_101
+        k1, d1 = oracle.orb_describe(framed, np.array([[cx + pad, cy + pad]], np.int16), float(angle))
+        assert k1[0] == 1
+        np.testing.assert_array_equal(desc[i], d1[0], err_msg="keypoint %d level %d" % (i, l))
+    # keypoints too close to the image border / whose pattern would leave their level are removed, octaves out of range are refused
+    bad = np.array([[10.0, 50.0, 31, 0, 1, 0], [100.0, 60.0, 31, 45, 1, 0], [40.0, 40.0, 31, 0, 1, 4]], np.float32)
+    k, d = oracle.orb_describe_keypoints(img, bad, 1.2)
+    assert list(k) == [0, 1, 0] and not d[0].any() and not d[2].any() and d[1].any()

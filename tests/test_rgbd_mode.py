@@ -110,6 +110,26 @@ def test_python_loop_over_the_oracle_runs_every_configuration(which):
     o.destroy()
 
 
+def test_python_loop_over_the_oracle_with_the_orb_detector():
+    """The checker loop itself with detector_type ORB (CPU only): keypoints of several pyramid levels, ORB::compute on their own level and
+    angle, features sharing pixels — the scene is tracked."""
+    from _oracle import Oracle
+    o = Oracle()
+    scene, cfg, p = setup(o, "tum", descriptor=1, seed=67)
+    p.detector_type = 1
+    o.create(cfg, 0, 1)
+    tr = PyLoop(o, cfg, p)
+    try:
+        for k in range(5):
+            info = tr.process(o.render(scene, k)[0], o.render_depth(scene, k, 2e-3))
+        rc = tr.feat_rc
+        assert info["status"] == 1 and info["n_tracked"] > 40 and info["n_keypoints"] > 400, info
+        assert len(rc) > len(np.unique(rc[:, 0].astype(np.int64) * 100000 + rc[:, 1]))     # several features on one pixel
+        assert not np.array_equal(tr.feat_xy, np.floor(tr.feat_xy))                           # sub-pixel keypoints of the higher levels
+    finally:
+        o.destroy()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("impl", ["device", "host"])
 @pytest.mark.parametrize("which,descriptor,max_depth,seed", [("tum", 1, None, 23), ("tum", 0, 25.0, 31), ("icl", 1, None, 29), ("xtion", 1, None, 37)])
@@ -346,5 +366,54 @@ def test_rgbd_reregistration_paths(impl, monkeypatch):
             if fi.track_attempts == 3 and fi.track_broken:
                 seen.add("track broken after three attempts")
         assert seen == {"second attempt by projection", "second attempt by appearance", "track broken after three attempts"}, seen
+    finally:
+        prod.destroy(); o.destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("descriptor", [1, 0])
+def test_rgbd_tracker_with_the_orb_detector(descriptor, monkeypatch):
+    """detector_type ORB (base_framepoint_generator.cpp:52-70, :242-247): one cv::ORB::create(5000, 1.2, 8, 31, 0, 2, HARRIS_SCORE, 31, thr) per
+    detector region with the controller on its FAST threshold, then the configured extractor — ORB::compute on the keypoints' own pyramid
+    level and angle, or BRIEF at level 0 — and a feature lattice in which keypoints of several levels share pixels.  Product (the host-driven
+    loop serves this mode) == the checker loop over the oracle, 2 x 2 detector grid, eight frames."""
+    from _oracle import Oracle
+    monkeypatch.setenv("VSLAM_RGBD_HOST", "0")       # the library switches to the host-driven loop by itself
+    o = Oracle()
+    scene, cfg, p = setup(o, "tum", descriptor=descriptor, seed=67)
+    cfg.det_rows, cfg.det_cols = 2, 2
+    p.detector_type = 1
+    o.create(cfg, 0, 1)
+    g = hip.load()
+    ref = PyLoop(o, cfg, p)
+    prod = RgbdTracker(g, cfg, p)
+    try:
+        shared = 0
+        for k in range(8):
+            L, D = o.render(scene, k)[0], o.render_depth(scene, k, 2e-3)
+            a = ref.process(L, D)
+            fi, n_temp = prod.process(L, D)
+            for name, field in (("status", "status"), ("n_keypoints", "n_keypoints_left"), ("n_tracked", "n_tracked"), ("n_lost", "n_lost"),
+                                ("n_tracked_landmarks", "n_tracked_landmarks"), ("aligner_ran", "aligner_ran"), ("n_inliers", "n_inliers"),
+                                ("aligner_iterations", "aligner_iterations"), ("n_after_prune", "n_after_prune"), ("n_recovered", "n_recovered"),
+                                ("n_active_landmarks", "n_active_landmarks"), ("n_new", "n_new_stereo"), ("n_points", "n_points"),
+                                ("window_pixels", "window_pixels"), ("track_attempts", "track_attempts"), ("fallback", "fallback"),
+                                ("track_broken", "track_broken"), ("status_at_start", "status_at_start")):
+                assert a[name] == getattr(fi, field), (k, name, a[name], getattr(fi, field))
+            assert a["thresholds"] == list(fi.thresholds)[:len(a["thresholds"])] and a["n_temporary"] == n_temp and a["tau_track"] == fi.tau_track
+            To, Tg = a["pose"], np.array(fi.camera_left_to_world).reshape(3, 4)
+            assert np.linalg.norm(Tg - To) / np.linalg.norm(To) <= POSE_RTOL
+            pts = prod.points()
+            cur = ref.frames[-1]
+            assert len(pts["xy"]) == len(cur.points)
+            for i, q in enumerate(cur.points):
+                assert np.array_equal(pts["xy"][i].view(np.uint32), q.xy.view(np.uint32)), (k, i)
+                np.testing.assert_array_equal(pts["desc"][i], q.desc)
+                np.testing.assert_allclose(pts["cam"][i], q.cam, rtol=1e-12, atol=0)
+            rc = ref.feat_rc
+            shared += len(rc) - len(np.unique(rc[:, 0].astype(np.int64) * 100000 + rc[:, 1]))
+        assert fi.status == 1 and fi.n_tracked > 20 and fi.n_keypoints_left > 300, (fi.status, fi.n_tracked, fi.n_keypoints_left)
+        assert shared > 0                                  # keypoints of several pyramid levels did land on the same pixel
+        assert len(set(a["thresholds"])) > 1               # the four detectors' FAST thresholds moved apart
     finally:
         prod.destroy(); o.destroy()

@@ -89,11 +89,12 @@ class DepthParams(C.Structure):
                 ("K_right_inverse", C.c_double * 9), ("right_to_left", C.c_double * 12),
                 ("depth_scale_factor_intensity_to_meters", C.c_double), ("minimum_depth_meters", C.c_double),
                 ("maximum_depth_meters", C.c_double), ("enable_point_triangulation", C.c_int32),
-                ("enable_keypoint_binning", C.c_int32), ("bin_size_pixels", C.c_int32), ("descriptor_type", C.c_int32)]
+                ("enable_keypoint_binning", C.c_int32), ("bin_size_pixels", C.c_int32), ("descriptor_type", C.c_int32),
+                ("detector_type", C.c_int32)]
 
     @staticmethod
     def make(rows, cols, K_left, K_left_inverse, K_right_inverse, right_to_left, scale=1e-3, min_depth=0.1, max_depth=10.0,
-             triangulation=1, binning=1, bin_px=6, descriptor=0):
+             triangulation=1, binning=1, bin_px=6, descriptor=0, detector=0):
         p = DepthParams()
         p.rows, p.cols = int(rows), int(cols)
         for name, a in (("K_left", K_left), ("K_left_inverse", K_left_inverse), ("K_right_inverse", K_right_inverse), ("right_to_left", right_to_left)):
@@ -103,6 +104,7 @@ class DepthParams(C.Structure):
         p.minimum_depth_meters, p.maximum_depth_meters = min_depth, max_depth
         p.enable_point_triangulation, p.enable_keypoint_binning, p.bin_size_pixels = int(triangulation), int(binning), int(bin_px)
         p.descriptor_type = int(descriptor)
+        p.detector_type = int(detector)      # 0 FAST, 1 ORB (OrbDetector)
         return p
 
 
@@ -534,6 +536,18 @@ class CApi(object):
                                            C.c_int32(img.shape[1]), C.c_int32(n), _p(pts, C.c_int16), C.c_float(float(angle_degrees)),
                                            _p(keep, C.c_uint8), _p(desc, C.c_uint8)))
         return keep, desc
+
+    def orb_describe_keypoints(self, image, keypoints, scale_factor=1.2):
+        """cv::ORB::create()->compute() on keypoints with octave and angle (rows of orb_detect): (keep, descriptors)."""
+        img = np.ascontiguousarray(image, np.uint8)
+        kp = np.ascontiguousarray(keypoints, np.float32).reshape(-1, 6)
+        n = kp.shape[0]
+        keep = np.zeros(max(n, 1), np.uint8)
+        desc = np.zeros((max(n, 1), 32), np.uint8)
+        self.check(self.fn("orb_describe_keypoints")(*self._ctx_args(), _p(img, C.c_uint8), C.c_int32(img.shape[0]), C.c_int32(img.shape[1]),
+                                                     C.c_int32(img.shape[1]), C.c_int32(n), _p(kp, C.c_float), C.c_float(float(scale_factor)),
+                                                     _p(keep, C.c_uint8), _p(desc, C.c_uint8)))
+        return keep[:n], desc[:n]
 
     def point_in_camera(self, xy_previous, xy_current, T, K):
         xp = np.ascontiguousarray(xy_previous, np.float32).reshape(-1, 2)

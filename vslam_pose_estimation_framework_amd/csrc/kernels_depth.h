@@ -245,6 +245,7 @@ struct DepthTrack {
   const uint8_t* desc;       // [nL][32]
   const int32_t* rowcell;    // [rows][CW + 1]
   const float* space;
+  const uint8_t* fvis;       // [nL] 0: another feature was written onto this one's lattice cell (never found by track()); null = all visible
   int32_t* hold;             // [2][nL]
   int32_t* pick;             // [nP]  feature, -1 none, -2 projection outside
   unsigned long long* cand;  // [nP][VS_DT_K + 1] the K best keys of the point's window (ascending) + the candidate count
@@ -265,6 +266,7 @@ __device__ __forceinline__ int depth_track_best(const DepthTrack& a, int i, int 
     for (int k = lo; k < hi; ++k) {
       const int x = a.kxy[2 * k];
       if (x < c0 || x >= c1) continue;
+      if (a.fvis && !a.fvis[k]) continue;                                           // overwritten in the lattice
       if (hold[k] < i) continue;                                                    // an earlier point removed it from the lattice
       const uint32_t* kd = reinterpret_cast<const uint32_t*>(a.desc + (size_t)32 * k);
       int h = 0;
@@ -321,6 +323,7 @@ __device__ __forceinline__ void depth_track_candidates_body(const DepthTrack& a,
           for (int k = lo; k < hi; ++k) {
             const int x = a.kxy[2 * k];
             if (x < c0 || x >= c1) continue;
+            if (a.fvis && !a.fvis[k]) continue;
             const uint32_t* kd = reinterpret_cast<const uint32_t*>(a.desc + (size_t)32 * k);
             int h = 0;
 #pragma unroll

@@ -944,6 +944,27 @@ __global__ __launch_bounds__(256) void k_orb_at(const uint8_t* blur, int stride,
   }
 }
 
+// ORB::compute on keypoints with an octave and an angle (vslam_orb_describe_keypoints): one wavefront per keypoint, the tests steered by the
+// keypoint's own rotation (cos / sin evaluated on the host as OpenCV does), sampled from the Gaussian image of the keypoint's pyramid level
+struct OrbLevels { const uint8_t* blur[16]; int32_t stride[16], rows[16], cols[16]; };
+__global__ __launch_bounds__(256) void k_orb_at_levels(const OrbLevels L, int n, const int32_t* pos, const float* ab, uint8_t* keep, uint8_t* desc) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = gridDim.x * (blockDim.x >> 6);
+  for (int i = wave; i < n; i += nwaves) {
+    const int lv = pos[3 * i + 2];          // -1: removed on the host (border filter)
+    unsigned long long d[4] = {0ull, 0ull, 0ull, 0ull};
+    const bool in = lv >= 0;
+    if (in) {
+      const int stride = L.stride[lv];
+      const OrbTaps t = orb_taps(lane, ab[2 * i], ab[2 * i + 1], stride);
+      orb_wave(L.blur[lv] + (size_t)pos[3 * i + 1] * stride + pos[3 * i], t, d);
+    }
+    if (lane == 0) keep[i] = in ? 1 : 0;
+    const unsigned long long dv = lane == 0 ? d[0] : (lane == 1 ? d[1] : (lane == 2 ? d[2] : d[3]));
+    if (lane < 4) reinterpret_cast<unsigned long long*>(desc + (size_t)32 * i)[lane] = dv;
+  }
+}
+
 // ==============================================================================================
 // K6: brute-force N x M 2-nearest-neighbours on 32-byte rows — matcher->knnMatch(query, train, k = 2) of the use_matches block
 // (stereo_framepoint_generator.cpp:168-206).  The reference converts the descriptors to CV_32F and picks the norm with the

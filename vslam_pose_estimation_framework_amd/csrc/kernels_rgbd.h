@@ -159,7 +159,7 @@ __device__ __forceinline__ void rgbd_track_args(const DevCfg& c, const DevBuf& b
   a.nP = st.last_all; a.nL = b.n_kp[0]; a.CW = c.CW;
   a.cam = pv.cam; a.pdesc = pv.desc; a.pflags = pv.flags;
   a.kxy = kpxy_of(c, b, 0, 0); a.desc = desc_of(c, b, 0, 0); a.rowcell = rowcell_of(c, b, 0, 0);
-  a.space = r.space;
+  a.space = r.space; a.fvis = nullptr;       // FAST leaves one feature per pixel
   a.hold = r.hold; a.pick = r.pick; a.cand = r.cand; a.counts = r.st->tcounts; a.out2 = r.out2; a.xyz = r.xyz; a.temp2 = r.temp2; a.lost = r.lost_raw;
 }
 

@@ -189,7 +189,8 @@ private:
   std::vector<double> al_chi; std::vector<uint8_t> al_inl;
   // the current frame's inputs and features
   const uint8_t* img = nullptr; int32_t img_stride = 0; const uint16_t* dep = nullptr; int32_t dep_stride = 0;
-  std::vector<int16_t> fxy; std::vector<uint8_t> fdesc; std::vector<int32_t> frc; std::vector<uint8_t> matched;
+  std::vector<float> fxy;        // keypoint.pt of every feature (integers for FAST, level coordinates x scale for an OrbDetector)
+  std::vector<uint8_t> fdesc; std::vector<int32_t> frc; std::vector<uint8_t> matched;
 
   int fail(int rc, const char* where) { err = std::string(where) + ": " + vslam_last_error(ctx); return rc; }
   static void set_pose(Fr& f, const double* c2w) { std::memcpy(f.c2w, c2w, 96); tf_inv(c2w, f.w2c); }
@@ -263,6 +264,50 @@ private:
     int rc = vslam_depth_space_map(ctx, &p, dep, dep_stride, nullptr, nullptr, nullptr);
     if (rc) return fail(rc, "depth_space_map");
     const int cap = 65535;
+    auto controller = [&](size_t r, int nr) {
+      double t = (double)thr[r];
+      const double delta = ((double)nr - target_per_detector) / target_per_detector;
+      if (delta < -cfg.target_number_of_keypoints_tolerance) {
+        t += std::min(std::max(delta, -cfg.detector_threshold_maximum_change) * t, -1.0); t = std::max(t, (double)cfg.detector_threshold_minimum);
+      } else if (delta > cfg.target_number_of_keypoints_tolerance) {
+        t += std::max(std::min(delta, cfg.detector_threshold_maximum_change) * t, 1.0); t = std::min(t, (double)cfg.detector_threshold_maximum);
+      }
+      thr[r] = (int)std::rint(t / 1);
+    };
+    fxy.clear(); fdesc.clear(); frc.clear();
+    if (p.detector_type == VSLAM_DETECTOR_ORB) {
+      // OrbDetector (base_framepoint_generator.cpp:52-70): cv::ORB::create(5000, 1.2f, 8, 31, 0, 2, HARRIS_SCORE, 31, threshold)->detect on the
+      // region's VIEW of the image (its pyramid is the region's), keypoint.pt += region corner (float), lists concatenated; then the configured
+      // extractor on the whole image: ORB::compute (the keypoint's pyramid level and angle) or BRIEF (level 0, pixel (int)(pt + 0.5))
+      std::vector<float> kps((size_t)cap * 6);
+      int32_t n = 0;
+      for (size_t r = 0; r < regions.size(); ++r) {
+        const Region& R = regions[r];
+        int32_t nr = 0;
+        rc = vslam_orb_detect(ctx, img + (size_t)R.y * img_stride + R.x, R.h, R.w, img_stride, 5000, 1.2f, 8, 31, 31, thr[r], cap - n, &nr, kps.data() + 6 * (size_t)n);
+        if (rc) return fail(rc, "orb_detect");
+        for (int i = n; i < n + nr; ++i) { kps[6 * (size_t)i] = kps[6 * (size_t)i] + (float)R.x; kps[6 * (size_t)i + 1] = kps[6 * (size_t)i + 1] + (float)R.y; }
+        controller(r, nr);
+        n += nr;
+      }
+      n_raw = n;
+      std::vector<uint8_t> keep(std::max(n, 1)), desc((size_t)std::max(n, 1) * 32);
+      if (p.descriptor_type == VSLAM_DESCRIPTOR_ORB) {
+        rc = vslam_orb_describe_keypoints(ctx, img, cfg.rows, cfg.cols, img_stride, n, kps.data(), 1.2f, keep.data(), desc.data());
+      } else {
+        std::vector<int16_t> px((size_t)std::max(n, 1) * 2);
+        for (int i = 0; i < n; ++i) { px[2 * i] = (int16_t)(int)(kps[6 * (size_t)i] + 0.5f); px[2 * i + 1] = (int16_t)(int)(kps[6 * (size_t)i + 1] + 0.5f); }
+        rc = vslam_brief_describe(ctx, img, cfg.rows, cfg.cols, img_stride, n, px.data(), keep.data(), desc.data());
+      }
+      if (rc) return fail(rc, "describe");
+      for (int i = 0; i < n; ++i) {
+        if (!keep[i]) continue;
+        const float x = kps[6 * (size_t)i], y = kps[6 * (size_t)i + 1];
+        fxy.push_back(x); fxy.push_back(y);
+        frc.push_back((int32_t)y); frc.push_back((int32_t)x);          // IntensityFeature: row = (int)pt.y, col = (int)pt.x
+        fdesc.insert(fdesc.end(), desc.begin() + (size_t)32 * i, desc.begin() + (size_t)32 * i + 32);
+      }
+    } else {
     std::vector<int16_t> xy((size_t)cap * 2); std::vector<int32_t> score(cap);
     int32_t n = 0;
     // detectKeypoints (base_framepoint_generator.cpp:355-429): region by region (row-major over the grid) with the region's own
@@ -274,14 +319,7 @@ private:
       rc = vslam_fast_detect(ctx, img, cfg.rows, cfg.cols, img_stride, R.x, R.y, R.w, R.h, thr[r], cap - n, &nr, xy.data() + 2 * (size_t)n, score.data() + n);
       if (rc) return fail(rc, "fast_detect");
       for (int i = n; i < n + nr; ++i) { xy[2 * i] = (int16_t)(xy[2 * i] + R.x); xy[2 * i + 1] = (int16_t)(xy[2 * i + 1] + R.y); }
-      double t = (double)thr[r];
-      const double delta = ((double)nr - target_per_detector) / target_per_detector;
-      if (delta < -cfg.target_number_of_keypoints_tolerance) {
-        t += std::min(std::max(delta, -cfg.detector_threshold_maximum_change) * t, -1.0); t = std::max(t, (double)cfg.detector_threshold_minimum);
-      } else if (delta > cfg.target_number_of_keypoints_tolerance) {
-        t += std::max(std::min(delta, cfg.detector_threshold_maximum_change) * t, 1.0); t = std::min(t, (double)cfg.detector_threshold_maximum);
-      }
-      thr[r] = (int)std::rint(t / 1);
+      controller(r, nr);
       n += nr;
     }
     n_raw = n;
@@ -289,12 +327,12 @@ private:
     rc = p.descriptor_type == VSLAM_DESCRIPTOR_ORB ? vslam_orb_describe(ctx, img, cfg.rows, cfg.cols, img_stride, n, xy.data(), -1.f, keep.data(), desc.data())
                                                    : vslam_brief_describe(ctx, img, cfg.rows, cfg.cols, img_stride, n, xy.data(), keep.data(), desc.data());
     if (rc) return fail(rc, "describe");
-    fxy.clear(); fdesc.clear(); frc.clear();
     for (int i = 0; i < n; ++i) {
       if (!keep[i]) continue;
-      fxy.push_back(xy[2 * i]); fxy.push_back(xy[2 * i + 1]);
+      fxy.push_back((float)xy[2 * i]); fxy.push_back((float)xy[2 * i + 1]);
       frc.push_back(xy[2 * i + 1]); frc.push_back(xy[2 * i]);
       fdesc.insert(fdesc.end(), desc.begin() + (size_t)32 * i, desc.begin() + (size_t)32 * i + 32);
+    }
     }
     n_detected = (int)fxy.size() / 2;
     matched.assign(n_detected, 0);
@@ -325,14 +363,14 @@ private:
     std::fill(matched.begin(), matched.end(), 0);
     for (int u = 0; u < nt; ++u) {
       const int f = out2[2 * u + 1];
-      const float fx[2] = {(float)fxy[2 * f], (float)fxy[2 * f + 1]};
+      const float fx[2] = {fxy[2 * f], fxy[2 * f + 1]};
       cur.points.push_back(new_point(fx, &fdesc[(size_t)32 * f], &xyz[3 * u], fi, prevlist[out2[2 * u]], false));
       matched[f] = 1;
     }
     const double zero[3] = {0, 0, 0};
     for (int u = 0; u < ntmp; ++u) {   // matches on pixels without depth: temporary points (:247-256); never cleared between attempts
       const int f = tmp2[2 * u + 1];
-      const float fx[2] = {(float)fxy[2 * f], (float)fxy[2 * f + 1]};
+      const float fx[2] = {fxy[2 * f], fxy[2 * f + 1]};
       cur.temps.push_back(new_point(fx, &fdesc[(size_t)32 * f], zero, fi, prevlist[tmp2[2 * u]], true));
       matched[f] = 1;
     }
@@ -542,12 +580,12 @@ private:
     if (r) return fail(r, "depth_compute");
     for (int k = 0; k < nn; ++k) {
       const int g = rem[nf[k]];
-      const float fx[2] = {(float)fxy[2 * g], (float)fxy[2 * g + 1]};
+      const float fx[2] = {fxy[2 * g], fxy[2 * g + 1]};
       cur.points.push_back(new_point(fx, &fdesc[(size_t)32 * g], &nx[3 * k], fi, -1, false));
     }
     for (int k = 0; k < nt; ++k) {
       const int g = rem[tf_[k]];
-      const float fx[2] = {(float)fxy[2 * g], (float)fxy[2 * g + 1]};
+      const float fx[2] = {fxy[2 * g], fxy[2 * g + 1]};
       cur.temps.push_back(new_point(fx, &fdesc[(size_t)32 * g], &tx[3 * k], fi, -1, true));
     }
     info.n_new_stereo = nn;

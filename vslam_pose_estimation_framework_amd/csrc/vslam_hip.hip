@@ -1023,19 +1023,25 @@ VS_API int vslam_depth_track(vslam_ctx* c, const vslam_depth_params* p, const fl
     return fail(c, VSLAM_ERR_INVALID, "depth_track: bad argument");
   if (!space && !(c->dm.valid && c->dm.rows == p->rows && c->dm.cols == p->cols)) return fail(c, VSLAM_ERR_STATE, "depth_track: no resident space map of this size");
   const int rows = p->rows, cols = p->cols, CW = (cols + 15) / 16, CW1 = CW + 1;
-  // features row-major + (row, 16-px cell) CSR, as the image pipeline leaves them (k_emit)
+  // features row-major + (row, 16-px cell) CSR, as the image pipeline leaves them (k_emit).  Several features on ONE pixel (an OrbDetector
+  // finds a corner on more than one pyramid level): setFeatures (intensity_feature_matcher.cpp:48-70) writes them into the lattice in list
+  // order, so only the LAST one can ever be found through the lattice — the others stay in the feature vector (compute() still sees them) but
+  // are invisible to track(), also after the last one has been taken.
   std::vector<int> ord(nL);
   for (int i = 0; i < nL; ++i) {
     ord[i] = i;
     if (rcL[2 * i] < 0 || rcL[2 * i] >= rows || rcL[2 * i + 1] < 0 || rcL[2 * i + 1] >= cols) return fail(c, VSLAM_ERR_INVALID, "feature outside the image");
   }
-  std::sort(ord.begin(), ord.end(), [&](int a, int b) { return rcL[2 * a] != rcL[2 * b] ? rcL[2 * a] < rcL[2 * b] : rcL[2 * a + 1] < rcL[2 * b + 1]; });
+  std::sort(ord.begin(), ord.end(), [&](int a, int b) { return rcL[2 * a] != rcL[2 * b] ? rcL[2 * a] < rcL[2 * b] : (rcL[2 * a + 1] != rcL[2 * b + 1] ? rcL[2 * a + 1] < rcL[2 * b + 1] : a < b); });
   std::vector<int16_t> xy((size_t)std::max(nL, 1) * 2);
   std::vector<uint8_t> ds((size_t)std::max(nL, 1) * 32);
+  std::vector<uint8_t> vis(std::max(nL, 1), 1);
+  bool duplicates = false;
   std::vector<int32_t> rowcell((size_t)rows * CW1);
   for (int k = 0; k < nL; ++k) {
     xy[2 * k] = (int16_t)rcL[2 * ord[k] + 1]; xy[2 * k + 1] = (int16_t)rcL[2 * ord[k]];
     std::memcpy(&ds[(size_t)32 * k], dL + (size_t)32 * ord[k], 32);
+    if (k + 1 < nL && rcL[2 * ord[k]] == rcL[2 * ord[k + 1]] && rcL[2 * ord[k] + 1] == rcL[2 * ord[k + 1] + 1]) { vis[k] = 0; duplicates = true; }
   }
   for (int r = 0, k = 0; r < rows; ++r)
     for (int cc = 0; cc < CW1; ++cc) {
@@ -1050,8 +1056,10 @@ VS_API int vslam_depth_track(vslam_ctx* c, const vslam_depth_params* p, const fl
   float* dspace = nullptr; double *dcam = nullptr, *dxyz = nullptr; uint8_t *dpd = nullptr, *dpf = nullptr, *dds = nullptr; int16_t* dxy = nullptr;
   int32_t *drc = nullptr, *dhold = nullptr, *dpick = nullptr, *dcnt = nullptr, *dout2 = nullptr, *dtmp2 = nullptr, *dlost = nullptr;
   unsigned long long* dcand = nullptr;
+  uint8_t* dvis = nullptr;
   hipError_t e = hipSuccess;
   if (space) { e = tmp_get(c, (void**)&dspace, n * 3 * sizeof(float)); if (e == hipSuccess) e = hipMemcpyAsync(dspace, space, n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream); }
+  if (e == hipSuccess && duplicates) { e = tmp_get(c, (void**)&dvis, L1); if (e == hipSuccess) e = hipMemcpyAsync(dvis, vis.data(), (size_t)nL, hipMemcpyHostToDevice, c->stream); }
   if (e == hipSuccess) e = tmp_get(c, (void**)&dcand, P1 * (VS_DT_K + 1) * sizeof(unsigned long long));
   if (e == hipSuccess) e = tmp_get(c, (void**)&dcam, P1 * 3 * sizeof(double));
   if (e == hipSuccess) e = tmp_get(c, (void**)&dxyz, P1 * 3 * sizeof(double));
@@ -1074,7 +1082,7 @@ VS_API int vslam_depth_track(vslam_ctx* c, const vslam_depth_params* p, const fl
   if (e == hipSuccess) e = hipMemcpyAsync(drc, rowcell.data(), rowcell.size() * 4, hipMemcpyHostToDevice, c->stream);
   int32_t cnt[4] = {0, 0, 0, 0};
   if (e == hipSuccess) {
-    a.cam = dcam; a.pdesc = dpd; a.pflags = dpf; a.kxy = dxy; a.desc = dds; a.rowcell = drc; a.space = space ? dspace : c->dm.space;
+    a.cam = dcam; a.pdesc = dpd; a.pflags = dpf; a.kxy = dxy; a.desc = dds; a.rowcell = drc; a.space = space ? dspace : c->dm.space; a.fvis = dvis;
     a.hold = dhold; a.pick = dpick; a.cand = dcand; a.counts = dcnt; a.out2 = dout2; a.xyz = dxyz; a.temp2 = dtmp2; a.lost = dlost;
     if (nP) hipLaunchKernelGGL(k_depth_track_candidates, dim3(std::min(1024, (nP + 15) / 16)), dim3(256), 0, c->stream, a);
     hipLaunchKernelGGL(k_depth_track, dim3(1), dim3(1024), 0, c->stream, a);
@@ -1560,6 +1568,72 @@ VS_API int vslam_orb_describe(vslam_ctx* c, const uint8_t* img, int32_t rows, in
   if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
   return VSLAM_OK;
 }
+// cv::ORB::create()->compute() on an OrbDetector's keypoints: a pyramid up to the highest octave present (level l from level l-1, as the detector
+// builds it), the 7x7 Gaussian per level, the steered tests per keypoint at its level.  Positions, border filter and rotations are host arithmetic
+// (float products rounded half-to-even, cos / sin through the host libm as OpenCV evaluates them).
+VS_API int vslam_orb_describe_keypoints(vslam_ctx* c, const uint8_t* img, int32_t rows, int32_t cols, int32_t stride, int32_t n, const float* kp6,
+                                        float scale_factor, uint8_t* keep, uint8_t* desc) {
+  tmp_reset(c);
+  if (!c) return VSLAM_ERR_INVALID;
+  if (c->sticky != VSLAM_OK) return c->sticky;
+  if (!img || n < 0 || rows < 4 || cols < 4 || stride < cols || !(scale_factor > 1.f) || (n && (!kp6 || !keep || !desc))) return fail(c, VSLAM_ERR_INVALID, "orb_describe_keypoints: bad argument");
+  if (n == 0) return VSLAM_OK;
+  int top = 0;
+  for (int i = 0; i < n; ++i) { const int o = (int)kp6[6 * (size_t)i + 5]; if (o < 0 || o > 15) return fail(c, VSLAM_ERR_INVALID, "orb_describe_keypoints: octave out of range"); top = std::max(top, o); }
+  HIP_TRY(c, hipSetDevice(c->device));
+  OrbLevels L;
+  std::memset(&L, 0, sizeof L);
+  float scale[16];
+  uint8_t* raw[16];
+  hipError_t e = hipSuccess;
+  for (int l = 0; l <= top && e == hipSuccess; ++l) {
+    scale[l] = (float)std::pow((double)scale_factor, (double)l);
+    L.rows[l] = l ? (int)std::lrint(rows / scale[l]) : rows; L.cols[l] = l ? (int)std::lrint(cols / scale[l]) : cols;
+    if (L.rows[l] < 8 || L.cols[l] < 8) return fail(c, VSLAM_ERR_INVALID, "orb_describe_keypoints: pyramid level smaller than 8 pixels");
+    L.stride[l] = L.cols[l];
+    uint8_t* blur = nullptr;
+    e = tmp_get(c, (void**)&raw[l], l ? (size_t)L.rows[l] * L.cols[l] : (size_t)rows * stride);
+    if (e == hipSuccess) e = tmp_get(c, (void**)&blur, (size_t)L.rows[l] * L.cols[l]);
+    L.blur[l] = blur;
+    if (e != hipSuccess) break;
+    const int lstride = l ? L.cols[l] : stride;
+    if (l == 0) e = hipMemcpyAsync(raw[0], img, (size_t)(rows - 1) * stride + cols, hipMemcpyHostToDevice, c->stream);
+    else hipLaunchKernelGGL(k_resize_linear_u8, dim3((L.cols[l] + 255) / 256, L.rows[l]), dim3(256), 0, c->stream, raw[l - 1], L.rows[l - 1], L.cols[l - 1],
+                            l == 1 ? stride : L.cols[l - 1], raw[l], L.rows[l], L.cols[l], L.cols[l]);
+    Gauss7 gk; for (int i = 0; i < 4; ++i) gk.k[i] = c->cfg.gauss7[i];
+    hipLaunchKernelGGL(k_gauss7_plain, dim3((L.cols[l] + VS_TILE_W - 1) / VS_TILE_W, (L.rows[l] + VS_TILE_H - 1) / VS_TILE_H), dim3(256), 0, c->stream, raw[l], lstride,
+                       L.rows[l], L.cols[l], gk, blur, L.cols[l]);
+  }
+  std::vector<int32_t> pos((size_t)n * 3);
+  std::vector<float> ab((size_t)n * 2);
+  const int reach = 23;   // the rotated 31 x 31 pattern reaches cvRound(15 sqrt 2) = 21 pixels
+  for (int i = 0; i < n; ++i) {
+    const float* k = kp6 + 6 * (size_t)i;
+    const int lv = (int)k[5];
+    const float inv = 1.f / scale[lv];
+    const int cx = (int)std::lrint(k[0] * inv), cy = (int)std::lrint(k[1] * inv);
+    const int x0 = (int)std::lrint(k[0]), y0 = (int)std::lrint(k[1]);
+    const bool in = x0 >= VSLAM_ORB_BORDER && x0 < cols - VSLAM_ORB_BORDER && y0 >= VSLAM_ORB_BORDER && y0 < rows - VSLAM_ORB_BORDER &&   // runByImageBorder(31) at level 0
+                    cx >= reach && cy >= reach && cx < L.cols[lv] - reach && cy < L.rows[lv] - reach;
+    pos[3 * (size_t)i] = cx; pos[3 * (size_t)i + 1] = cy; pos[3 * (size_t)i + 2] = in ? lv : -1;
+    orb_rotation_host(k[3], &ab[2 * (size_t)i], &ab[2 * (size_t)i + 1]);
+  }
+  int32_t* dpos = nullptr; float* dab = nullptr; uint8_t *dkeep = nullptr, *ddesc = nullptr;
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dpos, pos.size() * 4);
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dab, ab.size() * 4);
+  if (e == hipSuccess) e = tmp_get(c, (void**)&dkeep, (size_t)n);
+  if (e == hipSuccess) e = tmp_get(c, (void**)&ddesc, (size_t)n * 32);
+  if (e == hipSuccess) e = hipMemcpyAsync(dpos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dab, ab.data(), ab.size() * 4, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_orb_at_levels, dim3(std::min(64, (n + 3) / 4)), dim3(256), 0, c->stream, L, n, dpos, dab, dkeep, ddesc);
+    e = hipMemcpyAsync(keep, dkeep, (size_t)n, hipMemcpyDeviceToHost, c->stream);
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(desc, ddesc, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);    // also: the host staging vectors may go out of scope now
+  if (e != hipSuccess) return fail(c, VSLAM_ERR_HIP, hipGetErrorString(e));
+  return VSLAM_OK;
+}
 // ---- descriptor test pairs as run-time data (the tables are __constant__ arrays of this module: one copy per device) ------
 static int pattern_io(int device, int which, const int8_t* in, int8_t* out) {
   if ((!in && !out) || device < 0) { g_create_error = "pattern: bad argument"; return VSLAM_ERR_INVALID; }
@@ -1963,6 +2037,10 @@ VS_API int vslam_rgbd_create(const vslam_config* cfg, const vslam_depth_params* 
   if (!cfg || !p || !out) { g_rgbd_error = "vslam_rgbd_create: null argument"; return VSLAM_ERR_INVALID; }
   vslam_rgbd* r = new vslam_rgbd;
   if (const char* e = std::getenv("VSLAM_RGBD_HOST")) r->on_host = std::atoi(e) != 0;
+  // detector_type ORB (no shipped configuration): the OrbDetector is a host-driven sequence of per-level kernels (vslam_orb_detect) and several
+  // features can share a pixel — the device-resident loop's image pipeline is FAST's; the host-driven loop serves this mode
+  if (p->detector_type == VSLAM_DETECTOR_ORB) r->on_host = true;
+  else if (p->detector_type != VSLAM_DETECTOR_FAST) { g_rgbd_error = "vslam_rgbd_create: unknown detector_type"; delete r; return VSLAM_ERR_INVALID; }
   const int rc = r->on_host ? r->t.create(*cfg, *p, device) : r->d.create(*cfg, *p, device);
   if (rc != VSLAM_OK) { g_rgbd_error = r->err(); delete r; return rc; }
   *out = r;
