@@ -192,8 +192,8 @@ class Bench(object):
     def open_pose_comm(self):
         """N > 1 on RCCL: the pose all-gather of the timed region goes through the C ABI (vslam_comm_init / vslam_allgather_poses,
         RCCL called by libvslam_hip.so itself — what a C++ caller uses).  The communicator is formed BEFORE anything is timed, under a
-        watchdog: a communicator that does not form, or whose result differs from torch.distributed's, ends the run non-zero with
-        the reason on stderr (no JSON line)."""
+        watchdog: a communicator that HANGS while forming, or whose result differs from torch.distributed's, ends the run non-zero with
+        the reason on stderr (no JSON line); one that reports an error falls back to torch.distributed on all ranks together."""
         if self.world == 1 or self.backend != "nccl" or os.environ.get("VSLAM_BENCH_C_ABI_COMM", "1") == "0":
             return None, ("not used (one GPU)" if self.world == 1 else "torch.distributed %s (rehearsal backend / switched off)" % self.backend)
         box = {}
@@ -212,11 +212,20 @@ class Bench(object):
         th.start()
         th.join(timeout=float(os.environ.get("VSLAM_BENCH_COMM_TIMEOUT", "120")))
         verdict = box.get("r", "timeout: the RCCL communicator did not form")
-        if verdict != "identical to torch.distributed":
+        if verdict.startswith("timeout") or verdict.startswith("MISMATCH"):
             sys.stderr.write("bench.py rank %d: C-ABI pose all-gather (vslam_comm_*): %s\n" % (self.rank, verdict))
             sys.stderr.flush()
-            os._exit(3)      # a hung communicator cannot be joined: leave at once, non-zero, nothing printed on stdout
-        return box["comm"], "C ABI (vslam_allgather_poses, RCCL inside libvslam_hip.so), verified against torch.distributed"
+            os._exit(3)      # a hung communicator cannot be joined, a wrong one cannot be trusted: leave at once, non-zero, nothing on stdout
+        # an ERROR (librccl.so not loadable, no unique id, ncclCommInitRank refused: PoseComm raises on every rank together) is not a hang:
+        # the ranks agree, and if any of them has no communicator the timed all-gather goes through torch.distributed (RCCL as well) — said
+        # in the JSON line and on stderr
+        have = verdict == "identical to torch.distributed"
+        if sharding.all_ranks_ok(have):
+            return box["comm"], "C ABI (vslam_allgather_poses, RCCL inside libvslam_hip.so), verified against torch.distributed"
+        if have:
+            box["comm"].destroy()
+        sys.stderr.write("bench.py rank %d: C-ABI pose all-gather unavailable (%s): torch.distributed carries the all-gather\n" % (self.rank, verdict))
+        return None, "torch.distributed nccl (C-ABI communicator unavailable on some rank: %s)" % verdict[:160]
 
     def run_chunks(self):
         a, api, cfg = self.args, self.api, self.cfg
