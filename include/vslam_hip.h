@@ -474,14 +474,17 @@ int vslam_orb_describe(vslam_ctx* ctx, const uint8_t* image_host, int32_t rows, 
                        const int16_t* xy, float angle_degrees, uint8_t* keep, uint8_t* desc);
 
 /* ---- RGB-D mode end to end: PoseTracker3D with DepthFramePointGenerator + UVDAligner ---------------
- * (slam_assembly.cpp _createDepthTracker; configuration_{icl,tum,xtion}.yaml).  A host-driven loop inside the library
- * (csrc/rgbd_tracker.h): the tracker's control flow and the framepoint / temporary-point / landmark bookkeeping run on the
- * host, every data-parallel step is one of the entry points above on the device.  One sequence per object, detector grid
- * 1 x 1.  cfg carries the tracker / aligner / landmark / detector values, p the depth camera (p->descriptor_type selects the
- * extractor: the RGB-D configurations say "ORB-256").
+ * (slam_assembly.cpp _createDepthTracker; configuration_{icl,tum,xtion}.yaml).  Two implementations inside the library, same results
+ * frame by frame: the device-resident loop (csrc/kernels_rgbd.h + csrc/rgbd_device.h, the default: framepoints, temporary points,
+ * landmarks, history and the tracker's scalars live in HBM; a frame is two copies in, one launch sequence on two HIP streams and one
+ * 1 KB state block out) and the host-driven loop over the stand-alone entry points above (csrc/rgbd_tracker.h: VSLAM_RGBD_HOST=1 in the
+ * environment of vslam_rgbd_create; it also serves p->detector_type = VSLAM_DETECTOR_ORB).  One sequence per object, any detector
+ * grid (configuration_icl.yaml: 2 x 2).  cfg carries the tracker / aligner / landmark / detector values, p the depth camera
+ * (p->descriptor_type selects the extractor: the RGB-D configurations say "ORB-256").  A frame that fails (capacity, HIP error) leaves
+ * the tracker refusing further frames until vslam_rgbd_reset (the reference throws out of compute() and the run ends, app.cpp:128).
  * vslam_rgbd_process_host = PoseTracker3D::compute for one frame: left = 8-bit image, depth = 16-bit depth image (row
  * strides in bytes / in elements).  vslam_rgbd_get_frame_info fills the counters that exist in this mode (n_keypoints_left,
- * n_detected_left, thresholds[0], track_attempts, n_tracked, n_lost, n_tracked_landmarks, aligner_*, n_inliers, n_after_prune,
+ * n_detected_left, thresholds[region], track_attempts, n_tracked, n_lost, n_tracked_landmarks, aligner_*, n_inliers, n_after_prune,
  * n_recovered, n_active_landmarks, n_new_stereo = new points with measured depth, n_points, window_pixels, tau_track, status,
  * poses) and the number of temporary points of the frame.  vslam_rgbd_get_points: Frame::points() as xy (float: recovered
  * points sit at sub-pixel projections), cam, meta = (index of the predecessor in the previous frame's points followed by its
