@@ -260,6 +260,14 @@ def test_config2_one_thousand_frames_full_resolution_one_stream():
     assert stats["tracking_frames"] > 950 and stats["tracked"] > 150 * 1000 and stats["recovered"] > 1000, stats
 
 
+def test_config2_whole_kitti00_length_full_resolution_one_stream():
+    """configs[1] at its FULL size: all 4541 frames of a KITTI-00-shaped sequence at 1241 x 376 as one stream against the oracle — every
+    frame's counters, thresholds, tracker state and pose, the complete comparison every 250 frames (about a minute; the longer
+    multi-sequence runs of configs[2] are tools/full_length_parity.py)."""
+    worst, stats = _long_run([4541], [7], [0.9], full_every=250)
+    assert worst < 1e-10 and stats["tracking_frames"] >= 4530 and stats["tracked"] > 1000000 and stats["recovered"] > 400000, (worst, stats)
+
+
 def test_exact_mode_two_streams_of_different_lengths_full_resolution():
     """Two whole sequences of 420 and 300 frames side by side at 1241 x 376: the shorter stream is switched off when it ends and
     keeps its report and pose log while the longer one runs on."""
