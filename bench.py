@@ -38,7 +38,7 @@ SEQ_FRAMES = KITTI_FRAMES[0]
 EUROC_MH01_FRAMES = 3682   # MH_01_easy stereo pairs
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PMC_SUMMARY = "r03_pmc_traffic.json"   # tools/pmc_traffic.sh (rocprofv3 --pmc, separate passes); carries the source hash of its build
-ATE_NOISE_STUDY = ["r03_ate_noise_seeds16.json", "r03_ate_noise_seeds.json"]   # tools/eval_ate_noise.py: sequential ATE spread under sensor noise vs chunked (16 seeds for the default configuration, 8 seeds for the B x overlap grid)
+ATE_NOISE_STUDY = ["r03_ate_noise_seeds48.json", "r03_ate_noise_seeds16.json", "r03_ate_noise_seeds.json"]   # tools/eval_ate_noise.py: sequential ATE spread under sensor noise vs chunked (48 seeds for the default configuration, 16 for B = 144 / 160, 8 seeds for the B x overlap grid)
 METRIC = "stereo frames/sec on KITTI-00 at 1/2/4/8 MI355X; ATE vs reference"
 KERNELS = ["k_fast_box", "k_emit", "k_brief", "k_track_candidates", "k_frame", "k_recover_brief", "k_update_landmarks", "k_stereo_dist"]
 
