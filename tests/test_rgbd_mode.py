@@ -417,3 +417,40 @@ def test_rgbd_tracker_with_the_orb_detector(descriptor, monkeypatch):
         assert len(set(a["thresholds"])) > 1               # the four detectors' FAST thresholds moved apart
     finally:
         prod.destroy(); o.destroy()
+
+
+@pytest.mark.gpu
+def test_rgbd_device_loop_equals_host_loop_at_full_resolution(monkeypatch):
+    """1241 x 376: ~1800 features and ~1300 framepoints per frame — more than one 1024-thread pass in every single-workgroup kernel of the
+    device-resident loop (track bookkeeping, prune, recovery, compute, list closing).  Both product loops on the same ten frames: frame
+    counters, thresholds, poses and the complete point lists identical."""
+    from _oracle import Oracle
+    o = Oracle()
+    scene, cfg, p = setup(o, "tum", scale=1.0, descriptor=1, seed=71)
+    g = hip.load()
+    frames = [(o.render(scene, k)[0], o.render_depth(scene, k, 2e-3)) for k in range(10)]
+    monkeypatch.setenv("VSLAM_RGBD_HOST", "0")
+    dev = RgbdTracker(g, cfg, p)
+    monkeypatch.setenv("VSLAM_RGBD_HOST", "1")
+    host = RgbdTracker(g, cfg, p)
+    try:
+        for k, (L, D) in enumerate(frames):
+            fa, na = dev.process(L, D)
+            fb, nb = host.process(L, D)
+            for name, _ in fa._fields_:
+                va, vb = getattr(fa, name), getattr(fb, name)
+                if hasattr(va, "__len__"):
+                    va, vb = list(va), list(vb)
+                if name in ("camera_left_to_world", "previous_to_current", "total_error"):
+                    np.testing.assert_allclose(np.array(va), np.array(vb), rtol=1e-9, atol=1e-12, err_msg="%d %s" % (k, name))
+                else:
+                    assert va == vb, (k, name, va, vb)
+            assert na == nb
+            pa, pb = dev.points(), host.points()
+            np.testing.assert_array_equal(pa["xy"].view(np.uint32), pb["xy"].view(np.uint32))
+            np.testing.assert_array_equal(pa["desc"], pb["desc"])
+            np.testing.assert_array_equal(pa["meta"], pb["meta"])
+            np.testing.assert_allclose(pa["cam"], pb["cam"], rtol=1e-12, atol=0)
+        assert fa.status == 1 and fa.n_points > 1024 and fa.n_keypoints_left > 1500 and fa.n_tracked > 600, (fa.n_points, fa.n_keypoints_left, fa.n_tracked)
+    finally:
+        dev.destroy(); host.destroy(); o.destroy()
