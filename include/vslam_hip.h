@@ -495,6 +495,11 @@ void vslam_rgbd_destroy(vslam_rgbd* t);
 int vslam_rgbd_reset(vslam_rgbd* t);
 const char* vslam_rgbd_last_error(const vslam_rgbd* t);
 int vslam_rgbd_process_host(vslam_rgbd* t, const uint8_t* left, int32_t left_row_stride, const uint16_t* depth, int32_t depth_row_stride);
+/* vslam_rgbd_process_host in two halves: submit copies the frame in and enqueues its kernels, wait returns its status (after it the frame's
+ * info and points can be read).  One frame in flight per tracker.  Several trackers — one sequence each, HIP streams of their own — overlap
+ * on the GPU when their frames are submitted before any of them is waited for (tools/probe/rgbd_bench.py --trackers). */
+int vslam_rgbd_submit_host(vslam_rgbd* t, const uint8_t* left, int32_t left_row_stride, const uint16_t* depth, int32_t depth_row_stride);
+int vslam_rgbd_wait(vslam_rgbd* t);
 int vslam_rgbd_get_frame_info(vslam_rgbd* t, vslam_frame_info* out, int32_t* n_temporary);
 int vslam_rgbd_get_points(vslam_rgbd* t, int32_t cap, int32_t* n, float* xy, double* cam, int32_t* meta4, uint8_t* desc);
 

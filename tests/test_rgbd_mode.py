@@ -255,12 +255,14 @@ def _run(prod, frames):
 
 
 @pytest.mark.gpu
-def test_rgbd_device_loop_strides_reset_and_second_tracker(monkeypatch):
+@pytest.mark.parametrize("graph", ["0", "1"])
+def test_rgbd_device_loop_strides_reset_and_second_tracker(graph, monkeypatch):
     """The device-resident loop with padded rows (image stride != width, depth stride != width: the caller's strides are kept on the device / the
     depth image is re-packed), after reset(), and as a second tracker in the same process: every frame's counters and pose identical to the dense
-    first run, bit for bit."""
+    first run, bit for bit.  graph = 1: the frame's launch sequence replayed from a captured hipGraph (captured again when the stride changes)."""
     from _oracle import Oracle
     monkeypatch.setenv("VSLAM_RGBD_HOST", "0")
+    monkeypatch.setenv("VSLAM_RGBD_GRAPH", graph)
     o = Oracle()
     scene, cfg, p = setup(o, "tum", descriptor=1, seed=53)
     g = hip.load()
@@ -454,3 +456,47 @@ def test_rgbd_device_loop_equals_host_loop_at_full_resolution(monkeypatch):
         assert fa.status == 1 and fa.n_points > 1024 and fa.n_keypoints_left > 1500 and fa.n_tracked > 600, (fa.n_points, fa.n_keypoints_left, fa.n_tracked)
     finally:
         dev.destroy(); host.destroy(); o.destroy()
+
+
+@pytest.mark.gpu
+def test_rgbd_three_trackers_in_flight_together(monkeypatch):
+    """Three sequences on one GPU: three tracker objects, every frame submitted for all of them before any is waited for
+    (vslam_rgbd_submit_host / vslam_rgbd_wait) — each tracker's results are those of the same sequence run alone; a second submit without a
+    wait, and a wait without a submit, are refused."""
+    from _oracle import Oracle
+    from vslam_pose_estimation_framework_amd.capi import VslamError, ERR_STATE
+    monkeypatch.setenv("VSLAM_RGBD_HOST", "0")
+    o = Oracle()
+    g = hip.load()
+    worlds = []
+    for i, which in enumerate(("tum", "icl", "xtion")):
+        scene, cfg, p = setup(o, which, seed=83 + i)
+        worlds.append((cfg, p, [(o.render(scene, k)[0], o.render_depth(scene, k, 2e-3)) for k in range(8)]))
+    alone = []
+    for cfg, p, frames in worlds:
+        t = RgbdTracker(g, cfg, p)
+        alone.append(_run(t, frames))
+        t.destroy()
+    trackers = [RgbdTracker(g, cfg, p) for cfg, p, _ in worlds]
+    try:
+        together = [[] for _ in trackers]
+        for f in range(8):
+            for i, t in enumerate(trackers):
+                t.submit(*worlds[i][2][f])
+            if f == 3:
+                with pytest.raises(VslamError) as e:
+                    trackers[0].submit(*worlds[0][2][f])
+                assert e.value.code == ERR_STATE
+            for i, t in enumerate(trackers):
+                fi, nt = t.wait()
+                together[i].append((fi.status, fi.n_keypoints_left, fi.n_tracked, fi.n_lost, fi.n_inliers, fi.aligner_iterations, fi.n_after_prune, fi.n_recovered,
+                                    fi.n_active_landmarks, fi.n_new_stereo, fi.n_points, fi.track_attempts, fi.window_pixels, fi.tau_track, nt,
+                                    list(fi.thresholds)[:4], tuple(fi.camera_left_to_world)))
+        assert together == alone
+        with pytest.raises(VslamError) as e:
+            trackers[1].wait()
+        assert e.value.code == ERR_STATE
+    finally:
+        for t in trackers:
+            t.destroy()
+        o.destroy()

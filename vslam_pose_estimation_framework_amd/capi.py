@@ -622,6 +622,20 @@ class RgbdTracker(object):
         self._check(self.lib.vslam_rgbd_get_frame_info(self.h, C.byref(fi), C.byref(nt)))
         return fi, nt.value
 
+    def submit(self, left, depth):
+        """First half of process(): copies the frame in and enqueues it.  The arrays are kept alive until wait()."""
+        left = np.ascontiguousarray(left, np.uint8); depth = np.ascontiguousarray(depth, np.uint16)
+        self._inflight = (left, depth)
+        self._check(self.lib.vslam_rgbd_submit_host(self.h, _p(left, C.c_uint8), C.c_int32(left.shape[1]), _p(depth, C.c_uint16), C.c_int32(depth.shape[1])))
+
+    def wait(self):
+        self._check(self.lib.vslam_rgbd_wait(self.h))
+        self._inflight = None
+        fi = FrameInfo()
+        nt = C.c_int32()
+        self._check(self.lib.vslam_rgbd_get_frame_info(self.h, C.byref(fi), C.byref(nt)))
+        return fi, nt.value
+
     def points(self):
         cap = int(self.cfg.max_points) * 4
         n = C.c_int32()

@@ -60,6 +60,8 @@ public:
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&q2, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_depth, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_begin, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
+    if (const char* g = std::getenv("VSLAM_RGBD_GRAPH")) use_graph = std::atoi(g) != 0;
     if (e != hipSuccess) { err = std::string("RGB-D mode: ") + hipGetErrorString(e); release(); return VSLAM_ERR_HIP; }
     rb.depth = d_depth;
     return reset();
@@ -80,14 +82,30 @@ public:
     host = s;
     hipError_t e = hipMemcpy(rb.st, &s, sizeof s, hipMemcpyHostToDevice);
     if (e != hipSuccess) { err = hipGetErrorString(e); return VSLAM_ERR_HIP; }
-    failed = false; failed_why.clear();
+    failed = false; failed_why.clear(); pending = false;
     return VSLAM_OK;
   }
 
   int process(const uint8_t* left, int32_t lstride, const uint16_t* depth, int32_t dstride) {
+    const int rc = submit(left, lstride, depth, dstride);
+    return rc != VSLAM_OK ? rc : wait();
+  }
+  // submit(): copies the frame in and enqueues its kernels; returns without waiting.  wait(): the frame's result (and, for the rare frame
+  // whose registration asks for another attempt, the further attempts).  Several trackers — one sequence each, every one on HIP streams of
+  // its own — overlap on the GPU when their frames are submitted before any of them is waited for.
+  int submit(const uint8_t* left, int32_t lstride, const uint16_t* depth, int32_t dstride) {
     if (!left || !depth) { err = "called with empty frame"; return VSLAM_ERR_INVALID; }
     if (failed) { err = "RGB-D tracker: an earlier frame failed (" + failed_why + "); reset() before the next frame"; return VSLAM_ERR_STATE; }
-    const int rc = process_frame(left, lstride, depth, dstride);
+    if (pending) { err = "RGB-D tracker: the previous frame has not been waited for"; return VSLAM_ERR_STATE; }
+    const int rc = submit_frame(left, lstride, depth, dstride);
+    if (rc != VSLAM_OK) { failed = true; failed_why = err; }
+    else pending = true;
+    return rc;
+  }
+  int wait() {
+    if (!pending) { err = "RGB-D tracker: no frame in flight"; return VSLAM_ERR_STATE; }
+    pending = false;
+    const int rc = finish_frame();
     if (rc != VSLAM_OK) { failed = true; failed_why = err; }
     return rc;
   }
@@ -125,10 +143,24 @@ private:
   uint16_t* d_depth = nullptr;
   uint8_t* d_img = nullptr; size_t img_bytes = 0;
   RgbdState* pinned = nullptr;
-  bool depth_pending = false;
+  bool depth_pending = false, pending = false;
+  DevBuf bs;                      // the inner context's buffer table with this frame's image pointers
+  // VSLAM_RGBD_GRAPH=1 (opt-in): the frame's launch sequence (depth map on q2 beside the image pipeline on q, registration, tail, the state
+  // block's copy out) captured once into a hipGraph and replayed — two copies and ONE launch per frame instead of ~22.  Measured on MI355X /
+  // ROCm 7.2 (tools/probe/rgbd_submit_time.py): submit() takes 80 us of host time either way (the two pageable copies; the runtime replays a
+  // graph node by node) and the frame 0.31 against 0.30 ms: the frame is bound by its dependent kernels, not by their launches.  Kept as a
+  // tested switch, captured again when the image stride or buffer changes.
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  bool use_graph = false;
+  int32_t graph_stride = -1;
+  const uint8_t* graph_img = nullptr;
+  hipEvent_t ev_fork = nullptr;
 
   void release() {
     if (pinned) { (void)hipHostFree(pinned); pinned = nullptr; }
+    drop_graph();
+    if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }
     if (q2) { (void)hipStreamDestroy(q2); q2 = nullptr; }
     if (ev_depth) { (void)hipEventDestroy(ev_depth); ev_depth = nullptr; }
     if (ev_begin) { (void)hipEventDestroy(ev_begin); ev_begin = nullptr; }
@@ -166,7 +198,7 @@ private:
     hipLaunchKernelGGL(k_rgbd_finish, dim3(1), dim3(1024), 0, q, d, bs, rb);
   }
 
-  int process_frame(const uint8_t* left, int32_t lstride, const uint16_t* depth, int32_t dstride) {
+  int submit_frame(const uint8_t* left, int32_t lstride, const uint16_t* depth, int32_t dstride) {
     (void)hipSetDevice(ic->device);
     const int rows = p.rows, cols = p.cols;
     // inputs: one contiguous copy each, the caller's strides kept on the device
@@ -181,14 +213,33 @@ private:
     }
     hipError_t e = hipMemcpyAsync(d_img, left, ib, hipMemcpyHostToDevice, q);
     if (e != hipSuccess) return hip_fail(e, "image upload");
-    if (dstride == cols) e = hipMemcpyAsync(d_depth, depth, (size_t)rows * cols * 2, hipMemcpyHostToDevice, q2);
-    else e = hipMemcpy2DAsync(d_depth, (size_t)cols * 2, depth, (size_t)dstride * 2, (size_t)cols * 2, rows, hipMemcpyHostToDevice, q2);
+    // the depth image goes in on the second stream, beside the image's copy (replaying a captured graph: on the first, the graph forks itself)
+    hipStream_t qd = use_graph ? q : q2;
+    if (dstride == cols) e = hipMemcpyAsync(d_depth, depth, (size_t)rows * cols * 2, hipMemcpyHostToDevice, qd);
+    else e = hipMemcpy2DAsync(d_depth, (size_t)cols * 2, depth, (size_t)dstride * 2, (size_t)cols * 2, rows, hipMemcpyHostToDevice, qd);
     if (e != hipSuccess) return hip_fail(e, "depth upload");
-    DevBuf bs = buf_set(ic, 0, 0);
+    bs = buf_set(ic, 0, 0);
     bs.img[0] = d_img; bs.img[1] = d_img; bs.img_row_stride = lstride; bs.img_stream_stride = 0;
+    if (use_graph && (!graph_exec || graph_stride != lstride || graph_img != d_img)) capture_graph(lstride);
+    if (use_graph && graph_exec) {
+      e = hipGraphLaunch(graph_exec, q);
+      if (e != hipSuccess) { ic->sticky = VSLAM_ERR_HIP; return hip_fail(e, "RGB-D frame (graph launch)"); }
+      return VSLAM_OK;
+    }
+    enqueue_first_attempt(false);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(pinned, rb.st, sizeof(RgbdState), hipMemcpyDeviceToHost, q);
+    if (e != hipSuccess) { ic->sticky = VSLAM_ERR_HIP; return hip_fail(e, "RGB-D frame"); }
+    return VSLAM_OK;
+  }
+
+  // everything of a frame's first attempt after the uploads: frame scalars, the space map on q2 beside the image pipeline, registration, tail
+  void enqueue_first_attempt(bool fork) {
+    const int rows = p.rows, cols = p.cols;
     hipLaunchKernelGGL(k_rgbd_begin, dim3(1), dim3(64), 0, q, rb);
-    // _computeDepthMap (once per frame: every initialize() of the frame sees the same depth image), on the second stream beside the image
-    // pipeline; the previous frame has been synchronised, nothing reads the old map any more
+    // _computeDepthMap (once per frame: every initialize() of the frame sees the same depth image) on the second stream, forked after the
+    // uploads and joined before the first reader of the map (the candidate kernel)
+    if (fork) { (void)hipEventRecord(ev_fork, q); (void)hipStreamWaitEvent(q2, ev_fork, 0); }     // inside a capture: q2 joins the graph here
     const size_t npx = (size_t)rows * cols;
     const float f0 = (float)p.maximum_depth_meters;
     uint32_t f0_bits;
@@ -198,14 +249,41 @@ private:
     hipLaunchKernelGGL(k_depth_min, grid, dim3(256), 0, q2, p, d_depth, cols, rb.dkey);
     hipLaunchKernelGGL(k_depth_pick, grid, dim3(256), 0, q2, p, d_depth, cols, f0_bits, rb.dkey, rb.dlast);
     hipLaunchKernelGGL(k_depth_write, grid, dim3(256), 0, q2, p, d_depth, cols, f0_bits, rb.dkey, rb.dlast, rb.space, rb.row_map, rb.col_map);
-    e = hipEventRecord(ev_depth, q2);
-    if (e != hipSuccess) return hip_fail(e, "event");
+    (void)hipEventRecord(ev_depth, q2);
     depth_pending = true;
+    enqueue_attempt(bs);
+    enqueue_tail(bs);
+  }
+
+  void drop_graph() {
+    if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+    if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
+  }
+  // stream capture of enqueue_first_attempt + the state block's copy out; any failure leaves the direct launches in charge
+  void capture_graph(int32_t lstride) {
+    drop_graph();
+    (void)hipStreamSynchronize(q);
+    hipError_t e = hipStreamBeginCapture(q, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) { (void)hipGetLastError(); use_graph = false; return; }
+    enqueue_first_attempt(true);
+    (void)hipMemcpyAsync(pinned, rb.st, sizeof(RgbdState), hipMemcpyDeviceToHost, q);
+    e = hipStreamEndCapture(q, &graph);
+    depth_pending = false;
+    if (e == hipSuccess) e = hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess || !graph_exec) { (void)hipGetLastError(); drop_graph(); use_graph = false; return; }
+    graph_stride = lstride; graph_img = d_img;
+  }
+
+  int finish_frame() {
+    (void)hipSetDevice(ic->device);
+    hipError_t e = hipSuccess;
     for (int attempt = 0; attempt < 3; ++attempt) {
-      enqueue_attempt(bs);
-      enqueue_tail(bs);
-      e = hipGetLastError();
-      if (e == hipSuccess) e = hipMemcpyAsync(pinned, rb.st, sizeof(RgbdState), hipMemcpyDeviceToHost, q);
+      if (attempt) {        // the registration asked for another attempt: initialize() .. aligner .. tail once more
+        enqueue_attempt(bs);
+        enqueue_tail(bs);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(pinned, rb.st, sizeof(RgbdState), hipMemcpyDeviceToHost, q);
+      }
       if (e == hipSuccess) e = hipStreamSynchronize(q);
       if (e != hipSuccess) { ic->sticky = VSLAM_ERR_HIP; return hip_fail(e, "RGB-D frame"); }
       host = *pinned;

@@ -2026,7 +2026,8 @@ VS_API int vslam_set_pose(vslam_ctx* c, int s, const double pose[12]) {
 #include "rgbd_tracker.h"
 #include "rgbd_device.h"
 struct vslam_rgbd {
-  bool on_host = false;
+  bool on_host = false, host_pending = false;
+  int host_rc = 0;
   vs_rgbd::Tracker t;
   vs_rgbd::DeviceTracker d;
   std::string& err() { return on_host ? t.err : d.err; }
@@ -2058,6 +2059,23 @@ VS_API int vslam_rgbd_process_host(vslam_rgbd* r, const uint8_t* left, int32_t l
   const int cols = r->on_host ? r->t.cfg.cols : r->d.cfg.cols;
   if (lstride < cols || dstride < cols) { r->err() = "row stride smaller than image width"; return VSLAM_ERR_INVALID; }
   return r->on_host ? r->t.process(left, lstride, depth, dstride) : r->d.process(left, lstride, depth, dstride);
+}
+VS_API int vslam_rgbd_submit_host(vslam_rgbd* r, const uint8_t* left, int32_t lstride, const uint16_t* depth, int32_t dstride) {
+  if (!r) return VSLAM_ERR_INVALID;
+  if (!left || !depth) { r->err() = "called with empty frame"; return VSLAM_ERR_INVALID; }
+  const int cols = r->on_host ? r->t.cfg.cols : r->d.cfg.cols;
+  if (lstride < cols || dstride < cols) { r->err() = "row stride smaller than image width"; return VSLAM_ERR_INVALID; }
+  if (r->on_host) { r->host_rc = r->t.process(left, lstride, depth, dstride); r->host_pending = true; return r->host_rc; }   // the host-driven loop has nothing to overlap
+  return r->d.submit(left, lstride, depth, dstride);
+}
+VS_API int vslam_rgbd_wait(vslam_rgbd* r) {
+  if (!r) return VSLAM_ERR_INVALID;
+  if (r->on_host) {
+    if (!r->host_pending) { r->t.err = "RGB-D tracker: no frame in flight"; return VSLAM_ERR_STATE; }
+    r->host_pending = false;
+    return r->host_rc;
+  }
+  return r->d.wait();
 }
 VS_API int vslam_rgbd_get_frame_info(vslam_rgbd* r, vslam_frame_info* out, int32_t* n_temporary) {
   if (!r || !out) return VSLAM_ERR_INVALID;
