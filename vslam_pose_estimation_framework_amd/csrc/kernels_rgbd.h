@@ -479,11 +479,13 @@ __global__ __launch_bounds__(1024) void k_rgbd_recover_finish(const DevCfg c, co
 #define RGBD_LM_NP 64     // world_to_camera (and R^T R) of the newest RGBD_LM_NP frames staged in LDS, one copy for the workgroup
 #define RGBD_LM_G 8       // lanes per framepoint
 #define RGBD_LM_PTS (256 / RGBD_LM_G)
+#define RGBD_LM_PRE 64    // measurements of a track kept in LDS across the rounds (each is two dependent HBM loads: trail entry, then the ring)
 struct RgbdPoseLds { double w2c[12]; double rtr[9]; };
 struct RgbdLmTerm { double e2, h[6], b[3]; int kind, pad; };   // kind 0: behind the camera (an outlier, nothing added), 1: inlier, 2: outlier with a saturated kernel
 __global__ __launch_bounds__(256) void k_rgbd_landmarks(const DevCfg c, const RgbdBuf r) {
   __shared__ RgbdPoseLds s_pose[RGBD_LM_NP];
   __shared__ RgbdLmTerm s_term[RGBD_LM_PTS][RGBD_LM_G];
+  __shared__ double s_meas[RGBD_LM_PTS][RGBD_LM_PRE][4];     // the track's newest measurements, fetched once for all Gauss-Newton rounds
   RgbdState& st = *r.st;
   if (!rgbd_tail_on(st)) return;
   const int n = st.n_points;
@@ -544,6 +546,13 @@ __global__ __launch_bounds__(256) void k_rgbd_landmarks(const DevCfg c, const Rg
         const double kern = c.c.landmark_maximum_error_squared_meters;
         double err_prev = 0;
         RgbdLmTerm* terms = s_term[g];
+        // every lane fetches the measurements it will evaluate (list positions gl, gl + 8, ...), all loads in flight together, once
+        double (*meas)[4] = s_meas[g];
+        for (int j = gl; j < len && j < RGBD_LM_PRE; j += RGBD_LM_G) {
+          double mc[4];
+          cam_of(k_at(j), mc);
+          meas[j][0] = mc[0]; meas[j][1] = mc[1]; meas[j][2] = mc[2]; meas[j][3] = mc[3];
+        }
         for (int it = 0; it < c.c.landmark_maximum_number_of_iterations; ++it) {
           double Hm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bv[3] = {0, 0, 0};
           double err = 0;
@@ -556,7 +565,8 @@ __global__ __launch_bounds__(256) void k_rgbd_landmarks(const DevCfg c, const Rg
             if (j < len) {
               const int k = k_at(j);
               double mc[4];
-              cam_of(k, mc);
+              if (j < RGBD_LM_PRE) { mc[0] = meas[j][0]; mc[1] = meas[j][1]; mc[2] = meas[j][2]; mc[3] = meas[j][3]; }     // written by this very lane
+              else cam_of(k, mc);
               const double* W = s_pose[0].w2c;
               const double* RtR = s_pose[0].rtr;
               double rtr_far[9];
@@ -580,20 +590,27 @@ __global__ __launch_bounds__(256) void k_rgbd_landmarks(const DevCfg c, const Rg
                 for (int rr = 0; rr < 3; ++rr) t.b[rr] = om * ((W[rr] * er[0] + W[4 + rr] * er[1]) + W[8 + rr] * er[2]);
               }
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();     // the previous batch's terms have been read by every lane of the group
             terms[gl] = t;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            // every lane adds the batch in list order (its own copy of the accumulators: no broadcast afterwards)
+            // every lane adds the batch in list order (its own copy of the accumulators: no broadcast afterwards); plain LDS loads, so that
+            // the next terms are on their way while one is being added (volatile reads cost one LDS round trip EACH: 88 per batch)
             const int nb_ = min(RGBD_LM_G, len - j0);
-            for (int u = 0; u < nb_; ++u) {
-              const int kind = __hip_atomic_load(&terms[u].kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              if (kind == 0) { ++n_out; continue; }
-              const volatile RgbdLmTerm& q = terms[u];
-              err += q.e2;
-              if (kind == 2) ++n_out;
-              Hm[0] += q.h[0]; Hm[4] += q.h[3]; Hm[8] += q.h[5];
-              { const double h01 = q.h[1], h02 = q.h[2], h12 = q.h[4]; Hm[1] += h01; Hm[3] += h01; Hm[2] += h02; Hm[6] += h02; Hm[5] += h12; Hm[7] += h12; }
-              bv[0] += q.b[0]; bv[1] += q.b[1]; bv[2] += q.b[2];
+#pragma unroll
+            for (int u = 0; u < RGBD_LM_G; ++u) {
+              if (u < nb_) {
+                const RgbdLmTerm q = terms[u];
+                if (q.kind == 0) { ++n_out; }
+                else {
+                  err += q.e2;
+                  if (q.kind == 2) ++n_out;
+                  Hm[0] += q.h[0]; Hm[4] += q.h[3]; Hm[8] += q.h[5];
+                  { const double h01 = q.h[1], h02 = q.h[2], h12 = q.h[4]; Hm[1] += h01; Hm[3] += h01; Hm[2] += h02; Hm[6] += h02; Hm[5] += h12; Hm[7] += h12; }
+                  bv[0] += q.b[0]; bv[1] += q.b[1]; bv[2] += q.b[2];
+                }
+              }
             }
           }
           double nb[3] = {-bv[0], -bv[1], -bv[2]}, dx[3];
