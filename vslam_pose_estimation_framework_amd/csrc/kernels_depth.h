@@ -113,12 +113,13 @@ __device__ __forceinline__ void depth_compute_body(const vslam_depth_params& p, 
                                                    double* temp_xyz, uint8_t* cls, int* sh) {
   const int tid = threadIdx.x;
   const int cols_bin1 = cols_bin + 1;   // rint() can reach the grid size (latent overflow upstream): spare row / column
-  for (int i = tid; i < n_bins; i += 1024) bins[i] = ~0ull;
+  const int NT = blockDim.x;       // 1024 (stand-alone entries) or 512 (device-resident loop on small images)
+  for (int i = tid; i < n_bins; i += NT) bins[i] = ~0ull;
   __syncthreads();
   if (p.enable_keypoint_binning)
-    for (int i = tid; i < nT; i += 1024) bins[depth_bin(p, rcT[2 * i], rcT[2 * i + 1], cols_bin1)] = 0ull;     // :57-63
+    for (int i = tid; i < nT; i += NT) bins[depth_bin(p, rcT[2 * i], rcT[2 * i + 1], cols_bin1)] = 0ull;     // :57-63
   __syncthreads();
-  for (int i = tid; i < nF; i += 1024) {
+  for (int i = tid; i < nF; i += NT) {
     const int row = rcF[2 * i], col = rcF[2 * i + 1];
     const float z = space[3 * ((size_t)row * p.cols + col) + 2];
     uint8_t k = 0;
@@ -135,7 +136,7 @@ __device__ __forceinline__ void depth_compute_body(const vslam_depth_params& p, 
   __syncthreads();
   // temporary points, feature order (:92-100)
   int n_temp = 0;
-  for (int base = 0; base < nF; base += 1024) {
+  for (int base = 0; base < nF; base += NT) {
     const int i = base + tid;
     const int mine = (i < nF && cls[i] == 2) ? 1 : 0;
     int total;
@@ -152,7 +153,7 @@ __device__ __forceinline__ void depth_compute_body(const vslam_depth_params& p, 
   // new points: bin grid row-major (:141-157) or feature order (:160-162)
   int n_new = 0;
   const int n_scan = p.enable_keypoint_binning ? rows_bin * cols_bin : nF;
-  for (int base = 0; base < n_scan; base += 1024) {
+  for (int base = 0; base < n_scan; base += NT) {
     const int j = base + tid;
     int feat = -1;
     if (j < n_scan) {
@@ -367,13 +368,14 @@ __device__ __forceinline__ void depth_track_body(const DepthTrack& a, int* sh, i
   const int tid = threadIdx.x;
   int32_t* hold = a.hold;
   int32_t* next = a.hold + a.nL;
-  for (int k = tid; k < a.nL; k += 1024) hold[k] = 0x7fffffff;
+  const int NT = blockDim.x;
+  for (int k = tid; k < a.nL; k += NT) hold[k] = 0x7fffffff;
   __syncthreads();
   for (int sweep = 0; sweep <= a.nP; ++sweep) {
-    for (int k = tid; k < a.nL; k += 1024) next[k] = 0x7fffffff;
+    for (int k = tid; k < a.nL; k += NT) next[k] = 0x7fffffff;
     if (tid == 0) changed = 0;
     __syncthreads();
-    for (int i = tid; i < a.nP; i += 1024) {
+    for (int i = tid; i < a.nP; i += NT) {
       int f = a.pick[i] == -2 ? -2 : -1;
       if (f != -2) {
         const unsigned long long* list = a.cand + (size_t)i * (VS_DT_K + 1);
@@ -400,7 +402,7 @@ __device__ __forceinline__ void depth_track_body(const DepthTrack& a, int* sh, i
       a.pick[i] = f;
     }
     __syncthreads();
-    for (int k = tid; k < a.nL; k += 1024) if (next[k] != hold[k]) changed = 1;
+    for (int k = tid; k < a.nL; k += NT) if (next[k] != hold[k]) changed = 1;
     __syncthreads();
     const bool again = changed != 0;
     int32_t* t = hold; hold = next; next = t;
@@ -409,7 +411,7 @@ __device__ __forceinline__ void depth_track_body(const DepthTrack& a, int* sh, i
   }
   // outcome of every point under the final holds, lists in the order of the previous points
   int n_trk = 0, n_tmp = 0, n_lost = 0, n_lm = 0;
-  for (int base = 0; base < a.nP; base += 1024) {
+  for (int base = 0; base < a.nP; base += NT) {
     const int i = base + tid;
     int kind = 0;   // 1 tracked, 2 temporary, 3 lost
     int f = -1;
@@ -512,7 +514,8 @@ __global__ __launch_bounds__(256) void k_depth_recover_project(const DepthRecove
 __device__ __forceinline__ void depth_recover_finish_body(const DepthRecover& a, int* sh) {
   const int tid = threadIdx.x;
   int n_rec = 0;
-  for (int base = 0; base < a.n; base += 1024) {
+  const int NT = blockDim.x;
+  for (int base = 0; base < a.n; base += NT) {
     const int i = base + tid;
     int ok = 0;
     if (i < a.n && a.cell[i] >= 0 && a.keep[i]) {

@@ -117,17 +117,17 @@ __global__ void k_rgbd_begin(const RgbdBuf r) {
 // stable partition of the row-major list by region.  First part of k_rgbd_track (1024 threads).
 __device__ __forceinline__ void rgbd_features(const DevCfg& c, const DevBuf& b, const RgbdBuf& r, int* sh) {
   RgbdState& st = *r.st;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, NT = blockDim.x;
   const int n = b.n_kp[0];
   const int16_t* kxy = kpxy_of(c, b, 0, 0);
-  for (int i = tid; i < n; i += 1024) r.matched[i] = 0;
+  for (int i = tid; i < n; i += NT) r.matched[i] = 0;
   if (c.n_regions == 1) {
-    for (int i = tid; i < n; i += 1024) r.order[i] = i;
+    for (int i = tid; i < n; i += NT) r.order[i] = i;
   } else {
     int base = 0;
     for (int q = 0; q < c.n_regions; ++q) {
       const DevRegion R = c.regions[q];
-      for (int i0 = 0; i0 < n; i0 += 1024) {
+      for (int i0 = 0; i0 < n; i0 += NT) {
         const int i = i0 + tid;
         int in = 0;
         if (i < n) { const int x = kxy[2 * i], y = kxy[2 * i + 1]; in = (x >= R.x + 3 && x < R.x + R.w - 3 && y >= R.y + 3 && y < R.y + R.h - 3) ? 1 : 0; }
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(1024) void k_rgbd_track(const DevCfg c, const DevBu
   RgbdState& st = *r.st;
   rgbd_features(c, b, r, sh);          // also on the first frame: compute() walks the features in this order
   if (st.done) return;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, NT = blockDim.x;
   DepthTrack a;
   rgbd_track_args(c, b, r, a);
   depth_track_body(a, sh, &changed);
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(1024) void k_rgbd_track(const DevCfg c, const DevBu
   if (t0 + ntmp > c.MAXP) { ntmp = c.MAXP - t0; if (tid == 0) atomicOr(&st.error_flags, 2); }
   const int16_t* kxy = a.kxy;
   // frame->points().clear(); one framepoint per tracked point (Frame::createFramepoint + setPrevious, frame_point.cpp:43-55)
-  for (int u = tid; u < nt; u += 1024) {
+  for (int u = tid; u < nt; u += NT) {
     const int i = r.out2[2 * u], f = r.out2[2 * u + 1];
     cur.xy[2 * u] = (float)kxy[2 * f]; cur.xy[2 * u + 1] = (float)kxy[2 * f + 1];
     rgbd_copy_desc(cur.desc + (size_t)32 * u, a.desc + (size_t)32 * f);
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(1024) void k_rgbd_track(const DevCfg c, const DevBu
     r.matched[f] = 1;
   }
   // matches on pixels without a depth measurement: temporary points (:247-256); they are NOT cleared between registration attempts
-  for (int u = tid; u < ntmp; u += 1024) {
+  for (int u = tid; u < ntmp; u += NT) {
     const int i = r.temp2[2 * u], f = r.temp2[2 * u + 1], j = t0 + u;
     tp.xy[2 * j] = (float)kxy[2 * f]; tp.xy[2 * j + 1] = (float)kxy[2 * f + 1];
     rgbd_copy_desc(tp.desc + (size_t)32 * j, a.desc + (size_t)32 * f);
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(1024) void k_rgbd_track(const DevCfg c, const DevBu
   __syncthreads();
   // lost list: a previous point an EARLIER attempt of this frame linked is not lost (its next() is set)
   int n_lost = 0;
-  for (int u0 = 0; u0 < nl; u0 += 1024) {
+  for (int u0 = 0; u0 < nl; u0 += NT) {
     const int u = u0 + tid;
     int i = -1, keep = 0;
     if (u < nl) { i = r.lost_raw[u]; keep = (pv.flags[i] & RGBD_F_NEXT) ? 0 : 1; }
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(1024) void k_rgbd_prune(const DevCfg c, const DevBu
   __shared__ int sh[17];
   RgbdState& st = *r.st;
   if (!rgbd_tail_on(st)) return;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, NT = blockDim.x;
   const int n = st.n_points;
   if (tid == 0) st.n_registered = n;
   if (st.frame_count == 0) return;
@@ -383,14 +383,14 @@ __global__ __launch_bounds__(1024) void k_rgbd_prune(const DevCfg c, const DevBu
   if (c.c.enable_landmark_recovery && st.n_lost > 0) {
     DepthRecover a;
     rgbd_recover_args(c, r, a);
-    for (int i = tid; i < a.n; i += 1024) depth_recover_project_one(a, i);
+    for (int i = tid; i < a.n; i += NT) depth_recover_project_one(a, i);
   }
   const RgbdList cur = rgbd_cur(r);
   const bool valid = st.aligner_valid != 0;
   const double kern = c.c.aligner_maximum_error_kernel;
   const double avg = valid ? st.al_total / (double)n : 0;
   int out = 0;
-  for (int u0 = 0; u0 < n; u0 += 1024) {
+  for (int u0 = 0; u0 < n; u0 += NT) {
     const int u = u0 + tid;
     int keep = 0;
     RgbdPoint q;
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(1024) void k_rgbd_recover_finish(const DevCfg c, co
   __shared__ int sh[17];
   RgbdState& st = *r.st;
   if (!rgbd_recover_on(c, st)) return;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, NT = blockDim.x;
   DepthRecover a;
   rgbd_recover_args(c, r, a);
   depth_recover_finish_body(a, sh);
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(1024) void k_rgbd_recover_finish(const DevCfg c, co
   int nr = st.rcount;
   const int n0 = st.n_points;
   if (n0 + nr > c.MAXP) { nr = c.MAXP - n0; if (tid == 0) atomicOr(&st.error_flags, 2); }
-  for (int k = tid; k < nr; k += 1024) {
+  for (int k = tid; k < nr; k += NT) {
     const int i = r.lost[r.ridx[k]], j = n0 + k;
     cur.xy[2 * j] = r.rxy[2 * k]; cur.xy[2 * j + 1] = r.rxy[2 * k + 1];
     rgbd_copy_desc(cur.desc + (size_t)32 * j, r.rrdesc + (size_t)32 * k);
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(1024) void k_rgbd_finish(const DevCfg c, const DevB
   __shared__ int sh[17];
   RgbdState& st = *r.st;
   if (!rgbd_tail_on(st)) return;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, NT = blockDim.x;
   const RgbdList cur = rgbd_cur(r), pv = rgbd_prev(r), tp = r.tmp;
   const int f = st.frame_count;
   // ---- temporary points: midpoint triangulation between the previous and the current keypoint; kept if in front of the camera
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(1024) void k_rgbd_finish(const DevCfg c, const DevB
     for (int k = 0; k < 12; ++k) T[k] = st.prior[k];
     for (int k = 0; k < 9; ++k) K[k] = c.c.K[k];
     int out = 0;
-    for (int u0 = 0; u0 < n; u0 += 1024) {
+    for (int u0 = 0; u0 < n; u0 += NT) {
       const int u = u0 + tid;
       int keep = 0;
       RgbdPoint q;
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(1024) void k_rgbd_finish(const DevCfg c, const DevB
   int nF = 0;
   {
     const int nd = st.n_detected;
-    for (int j0 = 0; j0 < nd; j0 += 1024) {
+    for (int j0 = 0; j0 < nd; j0 += NT) {
       const int j = j0 + tid;
       int fi = -1, rem = 0;
       if (j < nd) { fi = r.order[j]; rem = r.matched[fi] ? 0 : 1; }
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(1024) void k_rgbd_finish(const DevCfg c, const DevB
     }
   }
   const int nT = st.n_points;
-  for (int i = tid; i < nT; i += 1024) { r.rcT[2 * i] = (int32_t)cur.xy[2 * i + 1]; r.rcT[2 * i + 1] = (int32_t)cur.xy[2 * i]; }
+  for (int i = tid; i < nT; i += NT) { r.rcT[2 * i] = (int32_t)cur.xy[2 * i + 1]; r.rcT[2 * i + 1] = (int32_t)cur.xy[2 * i]; }
   __syncthreads();
   const int rows_bin = r.p.enable_keypoint_binning ? r.p.rows / r.p.bin_size_pixels + 1 : 0;
   const int cols_bin = r.p.enable_keypoint_binning ? r.p.cols / r.p.bin_size_pixels + 1 : 0;
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(1024) void k_rgbd_finish(const DevCfg c, const DevB
   if (nT + nn > c.MAXP) { nn = c.MAXP - nT; if (tid == 0) atomicOr(&st.error_flags, 2); }
   if (nT + nn + t0 + nq > c.MAXP) { nq = max(c.MAXP - nT - nn - t0, 0); if (tid == 0) atomicOr(&st.error_flags, 2); }
   const int n_all = min(nT + nn + t0 + nq, c.MAXP);
-  for (int k = tid; k < nn; k += 1024) {
+  for (int k = tid; k < nn; k += NT) {
     const int g = r.remf[r.new_feat[k]], j = nT + k;
     cur.xy[2 * j] = (float)kxy[2 * g]; cur.xy[2 * j + 1] = (float)kxy[2 * g + 1];
     rgbd_copy_desc(cur.desc + (size_t)32 * j, kdesc + (size_t)32 * g);
@@ -726,8 +726,8 @@ __global__ __launch_bounds__(1024) void k_rgbd_finish(const DevCfg c, const DevB
   }
   // ---- the frame's list: framepoints, then the temporary points of track() (triangulated), then compute()'s
   const int np = nT + nn;
-  for (int u = tid; u < t0 && np + u < c.MAXP; u += 1024) { RgbdPoint q; rgbd_load(tp, u, q); rgbd_store(cur, np + u, q); }
-  for (int k = tid; k < nq; k += 1024) {
+  for (int u = tid; u < t0 && np + u < c.MAXP; u += NT) { RgbdPoint q; rgbd_load(tp, u, q); rgbd_store(cur, np + u, q); }
+  for (int k = tid; k < nq; k += NT) {
     const int g = r.remf[r.temp_feat[k]], j = np + t0 + k;
     cur.xy[2 * j] = (float)kxy[2 * g]; cur.xy[2 * j + 1] = (float)kxy[2 * g + 1];
     rgbd_copy_desc(cur.desc + (size_t)32 * j, kdesc + (size_t)32 * g);
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(1024) void k_rgbd_finish(const DevCfg c, const DevB
   // ---- history ring and trails
   {
     double* hc = r.h_cam + (size_t)(f % r.H) * c.MAXP * 4;
-    for (int i = tid; i < n_all; i += 1024) {
+    for (int i = tid; i < n_all; i += NT) {
       const double x = cur.cam[3 * (size_t)i], y = cur.cam[3 * (size_t)i + 1], z = cur.cam[3 * (size_t)i + 2];
       reinterpret_cast<double2*>(hc + 4 * (size_t)i)[0] = make_double2(x, y);
       reinterpret_cast<double2*>(hc + 4 * (size_t)i)[1] = make_double2(z, 1 / z);
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(1024) void k_rgbd_finish(const DevCfg c, const DevB
     if (tid < 12 && f < VS_POSE_LOG) r.pose_log[(size_t)f * 12 + tid] = st.c2w[tid];
     // 16 lanes per point: entry 0 = the predecessor, entries 1.. = the predecessor's trail
     const int lane = tid & 15, g = tid >> 4, TR = r.TR;
-    for (int i = g; i < np; i += 64) {
+    for (int i = g; i < np; i += NT / 16) {
       const int ip = cur.prev[i];
       if (ip < 0 || (cur.flags[i] & RGBD_F_UNREL)) continue;
       const int cnt = min(cur.tlen[i], TR);

@@ -33,6 +33,7 @@ public:
     if (rc != VSLAM_OK) { err = vslam_last_error(nullptr); return rc; }
     q = ic->stream_img;
     const size_t MAXP = ic->cfg.MAXP, NMAX = ic->cfg.NMAX, npx = (size_t)p.rows * p.cols;
+    if (const char* e = std::getenv("VSLAM_RGBD_WG")) { const int v = std::atoi(e); if (v == 256 || v == 512 || v == 1024) wg1 = v; }
     H = std::max(4, std::min(cfg.max_history_frames, 512));   // measurements of a track the landmark refinement can address
     TR = H - 2;
     std::memset(&rb, 0, sizeof rb);
@@ -140,6 +141,7 @@ private:
   hipStream_t q = nullptr, q2 = nullptr;      // q: everything of a frame; q2: the depth image's copy and the space map, beside the image pipeline
   hipEvent_t ev_depth = nullptr, ev_begin = nullptr;
   int H = 0, TR = 0;
+  int wg1 = 1024;                // threads of the single-workgroup kernels (VSLAM_RGBD_WG = 256 | 512 | 1024; measured at 620 x 188, ~700 features: 0.256 / 0.258 / 0.265 ms per frame for 1024 / 512 / 256: their barriers are not what a frame waits for)
   uint16_t* d_depth = nullptr;
   uint8_t* d_img = nullptr; size_t img_bytes = 0;
   RgbdState* pinned = nullptr;
@@ -186,16 +188,16 @@ private:
     }
     if (depth_pending) { (void)hipStreamWaitEvent(q, ev_depth, 0); depth_pending = false; }     // the space map is first read here
     hipLaunchKernelGGL(k_rgbd_track_candidates, dim3(256), dim3(256), 0, q, d, bs, rb);
-    hipLaunchKernelGGL(k_rgbd_track, dim3(1), dim3(1024), 0, q, d, bs, rb);
+    hipLaunchKernelGGL(k_rgbd_track, dim3(1), dim3(wg1), 0, q, d, bs, rb);
     hipLaunchKernelGGL(k_rgbd_align, dim3(1), dim3(VS_WG), 0, q, d, bs, rb);
   }
   void enqueue_tail(const DevBuf& bs) {
     const DevCfg& d = ic->cfg;
-    hipLaunchKernelGGL(k_rgbd_prune, dim3(1), dim3(1024), 0, q, d, bs, rb);
+    hipLaunchKernelGGL(k_rgbd_prune, dim3(1), dim3(wg1), 0, q, d, bs, rb);
     hipLaunchKernelGGL(k_rgbd_describe_at, dim3(64), dim3(256), 0, q, d, bs, rb);
-    hipLaunchKernelGGL(k_rgbd_recover_finish, dim3(1), dim3(1024), 0, q, d, rb);
+    hipLaunchKernelGGL(k_rgbd_recover_finish, dim3(1), dim3(wg1), 0, q, d, rb);
     hipLaunchKernelGGL(k_rgbd_landmarks, dim3((d.MAXP + RGBD_LM_PTS - 1) / RGBD_LM_PTS), dim3(256), 0, q, d, rb);
-    hipLaunchKernelGGL(k_rgbd_finish, dim3(1), dim3(1024), 0, q, d, bs, rb);
+    hipLaunchKernelGGL(k_rgbd_finish, dim3(1), dim3(wg1), 0, q, d, bs, rb);
   }
 
   int submit_frame(const uint8_t* left, int32_t lstride, const uint16_t* depth, int32_t dstride) {
