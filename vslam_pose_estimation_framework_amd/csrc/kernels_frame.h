@@ -788,9 +788,18 @@ __device__ __forceinline__ double align_entry(const AlignRows& R) {
   }
 }
 
-// four accumulators Q0 .. Q0+3 of every lane's measurement: DPP row sums (row_shr 1, 2, 4, 8 inside each 16-lane row; four
-// chains in lockstep fill the two wait states a DPP read needs after a VALU write), lanes 15 / 31 / 47 / 63 put the row
-// totals into LDS (first chunk of measurements) or add them to what is there (further chunks, n > workgroup size)
+// four accumulators Q0 .. Q0+3 of every lane's measurement, summed over each 16-lane row as a REDUCE-SCATTER: inside a quad the lanes first
+// exchange halves (quad_perm [1,0,3,2]: even lanes keep accumulators 0 and 1 and hand over 2 and 3, odd lanes the reverse), then halves of that
+// (quad_perm [2,3,0,1]), so that every lane ends up with ONE accumulator's quad total — 3 transfers instead of 8 —, and only that one value goes
+// through row_shr 4 and 8.  5 value transfers per group instead of 16 (round 2: every accumulator through row_shr 1, 2, 4, 8).  Lanes 12 .. 15 of
+// a row hold the row totals of accumulators 0, 2, 1, 3 and put them into LDS (first chunk of measurements) or add them to what is there.
+#define VS_DPP_F64(dst, src, ctrl)                                                                                   \
+  {                                                                                                                  \
+    const long long bits_ = __double_as_longlong(src);                                                               \
+    const int lo_ = __builtin_amdgcn_update_dpp(0, (int)(bits_ & 0xFFFFFFFFll), ctrl, 0xF, 0xF, true);               \
+    const int hi_ = __builtin_amdgcn_update_dpp(0, (int)(bits_ >> 32), ctrl, 0xF, 0xF, true);                        \
+    dst = __longlong_as_double(((long long)hi_ << 32) | (unsigned)lo_);                                              \
+  }
 template <bool UVD, int Q0>
 __device__ __forceinline__ void align_reduce4(const AlignRows& R, double (*red)[32], int lane, bool first_chunk) {
   double v[4];
@@ -798,24 +807,26 @@ __device__ __forceinline__ void align_reduce4(const AlignRows& R, double (*red)[
   v[1] = Q0 + 1 < NACC ? align_entry<UVD, (Q0 + 1 < NACC ? Q0 + 1 : 0)>(R) : 0.0;
   v[2] = Q0 + 2 < NACC ? align_entry<UVD, (Q0 + 2 < NACC ? Q0 + 2 : 0)>(R) : 0.0;
   v[3] = Q0 + 3 < NACC ? align_entry<UVD, (Q0 + 3 < NACC ? Q0 + 3 : 0)>(R) : 0.0;
-#define VS_DPP4(ctrl)                                                                                     \
-  {                                                                                                       \
-    int lo[4], hi[4];                                                                                     \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                       \
-      const long long bits = __double_as_longlong(v[u]);                                                  \
-      lo[u] = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xFFFFFFFFll), ctrl, 0xF, 0xF, true);           \
-      hi[u] = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), ctrl, 0xF, 0xF, true);                    \
-    }                                                                                                     \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u) v[u] += __longlong_as_double(((long long)hi[u] << 32) | (unsigned)lo[u]); \
-  }
-  VS_DPP4(0x111) VS_DPP4(0x112) VS_DPP4(0x114) VS_DPP4(0x118)
-#undef VS_DPP4
-  if ((lane & 15) == 15) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (Q0 + u < NACC) { if (first_chunk) red[lane >> 4][Q0 + u] = v[u]; else red[lane >> 4][Q0 + u] += v[u]; }
+  const bool odd = lane & 1, hi = lane & 2;
+  // lanes l and l ^ 1: the even one collects accumulators 0, 1, the odd one 2, 3
+  const double keep0 = odd ? v[2] : v[0], keep1 = odd ? v[3] : v[1], send0 = odd ? v[0] : v[2], send1 = odd ? v[1] : v[3];
+  double r0, r1;
+  VS_DPP_F64(r0, send0, 0xB1) VS_DPP_F64(r1, send1, 0xB1)       // quad_perm [1,0,3,2]
+  const double a0 = keep0 + r0, a1 = keep1 + r1;
+  // lanes l and l ^ 2: the lower one keeps the first of its two, the upper one the second
+  const double keep = hi ? a1 : a0, send = hi ? a0 : a1;
+  double r2;
+  VS_DPP_F64(r2, send, 0x4E)                                     // quad_perm [2,3,0,1]
+  double q = keep + r2;                                           // quad total of accumulator {0, 2, 1, 3}[lane & 3]
+  double t;
+  VS_DPP_F64(t, q, 0x114) q += t;                                 // row_shr 4 (lanes 0 .. 3 of the row receive zero)
+  VS_DPP_F64(t, q, 0x118) q += t;                                 // row_shr 8
+  if ((lane & 15) >= 12) {
+    const int idx = Q0 + ((lane & 1) << 1) + ((lane >> 1) & 1);   // lanes 12, 13, 14, 15 -> accumulators 0, 2, 1, 3
+    if (idx < NACC) { if (first_chunk) red[lane >> 4][idx] = q; else red[lane >> 4][idx] += q; }
   }
 }
+#undef VS_DPP_F64
 
 __device__ __forceinline__ void load_align_point(const DevCfg& c, const DevBuf& b, int s, int u, AlignPoint& P) {
   const double* moving = b.al_moving + (size_t)s * c.MAXP * 3;
