@@ -3,8 +3,8 @@
 // as a HOST-DRIVEN loop: the tracker's control flow and the object bookkeeping (framepoints, links, temporary points, landmarks)
 // run here in C++, every data-parallel step is one of the library's own device entry points (vslam_depth_space_map /
 // _compute / _track / _recover, vslam_fast_detect, vslam_brief_describe | vslam_orb_describe, vslam_align_points_uvd,
-// vslam_landmark_update, vslam_point_in_camera).  A fused device version is the follow-up; this one exists so that the
-// icl / tum / xtion configurations run end to end and can be checked frame by frame.  Detector grids of any shape (configuration_icl.yaml:57-58 runs 2 x 2; tum and
+// vslam_landmark_update, vslam_point_in_camera).  The device-resident version of this loop is csrc/rgbd_device.h + kernels_rgbd.h (the
+// default behind vslam_rgbd_*); this one is its cross-check (VSLAM_RGBD_HOST=1) and serves detector_type ORB.  Detector grids of any shape (configuration_icl.yaml:57-58 runs 2 x 2; tum and
 // xtion 1 x 1): one FAST detection, one threshold and one controller per region, keypoints in region-major order.
 //
 // Reference behaviour kept (DESIGN.md "RGB-D mode" lists the citations): initialize() detects and runs the controller on
