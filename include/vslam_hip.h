@@ -500,6 +500,22 @@ int vslam_rgbd_process_host(vslam_rgbd* t, const uint8_t* left, int32_t left_row
  * on the GPU when their frames are submitted before any of them is waited for (tools/probe/rgbd_bench.py --trackers). */
 int vslam_rgbd_submit_host(vslam_rgbd* t, const uint8_t* left, int32_t left_row_stride, const uint16_t* depth, int32_t depth_row_stride);
 int vslam_rgbd_wait(vslam_rgbd* t);
+/* Several sequences in ONE context (device-resident loop only): n_streams independent sequences of the same camera and configuration advance
+ * together, one frame each per call — the launch sequence of a frame serves all of them (one workgroup per sequence in its single-workgroup
+ * kernels, a grid dimension in the wide ones), so a step costs the time of its slowest sequence (tools/probe/rgbd_batch.py).  Images: n_streams
+ * images `left_stream_stride` bytes apart, depth images `depth_stream_stride` ELEMENTS apart.  A sequence that needs another registration attempt
+ * gets it without disturbing the others.  Results per sequence through the *_stream getters. */
+int vslam_rgbd_create_batch(const vslam_config* cfg, const vslam_depth_params* p, int device, int32_t n_streams, vslam_rgbd** out);
+int vslam_rgbd_process_batch_host(vslam_rgbd* t, const uint8_t* left, int32_t left_row_stride, size_t left_stream_stride, const uint16_t* depth,
+                                  int32_t depth_row_stride, size_t depth_stream_stride);
+int vslam_rgbd_submit_batch_host(vslam_rgbd* t, const uint8_t* left, int32_t left_row_stride, size_t left_stream_stride, const uint16_t* depth,
+                                 int32_t depth_row_stride, size_t depth_stream_stride);   /* then vslam_rgbd_wait */
+/* the same with images that are already in HBM (device pointers; the caller orders their producer before this call on the device, e.g.
+ * by a device synchronisation): nothing is copied.  Depth images dense per sequence (depth_stream_stride == rows * depth_row_stride). */
+int vslam_rgbd_submit_batch_device(vslam_rgbd* t, const uint8_t* left_device, int32_t left_row_stride, size_t left_stream_stride,
+                                   const uint16_t* depth_device, int32_t depth_row_stride, size_t depth_stream_stride);
+int vslam_rgbd_get_frame_info_stream(vslam_rgbd* t, int32_t stream, vslam_frame_info* out, int32_t* n_temporary);
+int vslam_rgbd_get_points_stream(vslam_rgbd* t, int32_t stream, int32_t cap, int32_t* n, float* xy, double* cam, int32_t* meta4, uint8_t* desc);
 int vslam_rgbd_get_frame_info(vslam_rgbd* t, vslam_frame_info* out, int32_t* n_temporary);
 int vslam_rgbd_get_points(vslam_rgbd* t, int32_t cap, int32_t* n, float* xy, double* cam, int32_t* meta4, uint8_t* desc);
 

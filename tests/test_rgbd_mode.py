@@ -12,7 +12,7 @@ import pytest
 
 from rgbd_loop import RgbdTracker as PyLoop
 from vslam_pose_estimation_framework_amd import hip
-from vslam_pose_estimation_framework_amd.capi import DepthParams, RgbdTracker
+from vslam_pose_estimation_framework_amd.capi import DepthParams, RgbdBatch, RgbdTracker
 
 POSE_RTOL = 1e-4
 
@@ -500,3 +500,101 @@ def test_rgbd_three_trackers_in_flight_together(monkeypatch):
         for t in trackers:
             t.destroy()
         o.destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which,descriptor", [("tum", 1), ("icl", 0)])
+def test_rgbd_batch_of_sequences_equals_the_sequences_alone(which, descriptor, monkeypatch):
+    """vslam_rgbd_create_batch: five sequences (five worlds, different camera speeds) in ONE context, one launch sequence per step for all of them.
+    Sequence 2 jumps in the middle (lost track: two more registration attempts, breakTrack) and sequence 4 loses its depth image for a frame,
+    while the others track on — every sequence's frame info and complete point lists equal those of the same sequence run alone."""
+    from _oracle import Oracle
+    monkeypatch.setenv("VSLAM_RGBD_HOST", "0")
+    o = Oracle()
+    g = hip.load()
+    n, B = 10, 5
+    worlds = []
+    for i in range(B):
+        scene, cfg, p = setup(o, which, descriptor=descriptor, seed=101 + 13 * i)
+        scene.speed_m = scene.speed_m * (0.7 + 0.15 * i)
+        ks = list(range(n)) if i != 2 else [0, 1, 2, 3, 4, 20, 21, 22, 23, 24]
+        frames = [(o.render(scene, k)[0], o.render_depth(scene, k, 2e-3)) for k in ks]
+        if i == 4:
+            frames[6] = (frames[6][0], np.zeros_like(frames[6][1]))
+        worlds.append(frames)
+    alone, alone_pts = [], []
+    for frames in worlds:
+        t = RgbdTracker(g, cfg, p)
+        rec, pts = [], []
+        for L, D in frames:
+            fi, nt = t.process(L, D)
+            rec.append((fi, nt)); pts.append(t.points())
+        alone.append(rec); alone_pts.append(pts)
+        t.destroy()
+    batch = RgbdBatch(g, cfg, p, B)
+    try:
+        attempts = set()
+        for f in range(n):
+            L = np.stack([worlds[i][f][0] for i in range(B)]); D = np.stack([worlds[i][f][1] for i in range(B)])
+            res = batch.process(L, D)
+            for i, (fi, nt) in enumerate(res):
+                fa, na = alone[i][f]
+                for name, _ in fa._fields_:
+                    va, vb = getattr(fa, name), getattr(fi, name)
+                    if hasattr(va, "__len__"):
+                        va, vb = list(va), list(vb)
+                    assert va == vb, (f, i, name, va, vb)
+                assert na == nt
+                pa, pb = alone_pts[i][f], batch.points(i)
+                for key in ("xy", "cam", "meta", "desc"):
+                    np.testing.assert_array_equal(pa[key], pb[key], err_msg="frame %d sequence %d %s" % (f, i, key))
+                attempts.add((i, fi.track_attempts))
+        assert (2, 3) in attempts                 # the jumping sequence needed all three attempts while the others went on undisturbed
+        assert sum(fi.status == 1 for fi, _ in res) >= 3
+    finally:
+        batch.destroy(); o.destroy()
+
+
+@pytest.mark.gpu
+def test_rgbd_batch_on_device_images_and_strides(monkeypatch):
+    """The batch fed with images that already live in HBM (vslam_rgbd_submit_batch_device: no copy, the kernels read the caller's tensors) and
+    with padded host images (stream and row strides that do not form one dense block): both equal the dense host path, frame by frame."""
+    import torch
+    from _oracle import Oracle
+    monkeypatch.setenv("VSLAM_RGBD_HOST", "0")
+    o = Oracle()
+    g = hip.load()
+    B, n = 3, 8
+    seqs = []
+    for i in range(B):
+        scene, cfg, p = setup(o, "tum", descriptor=1, seed=301 + i)
+        seqs.append([(o.render(scene, k)[0], o.render_depth(scene, k, 2e-3)) for k in range(n)])
+    rows, cols = int(cfg.rows), int(cfg.cols)
+    dev = torch.device("cuda", 0)
+    a, b, c = RgbdBatch(g, cfg, p, B), RgbdBatch(g, cfg, p, B), RgbdBatch(g, cfg, p, B)
+    try:
+        for f in range(n):
+            L = np.stack([seqs[i][f][0] for i in range(B)]); D = np.stack([seqs[i][f][1] for i in range(B)])
+            ra = a.process(L, D)
+            Ld = torch.from_numpy(L).to(dev); Dd = torch.from_numpy(D.view(np.int16)).to(dev)
+            torch.cuda.synchronize()
+            b.submit_device(Ld.data_ptr(), cols, rows * cols, Dd.data_ptr(), cols, rows * cols)
+            rb_ = b.wait()
+            Lp = np.full((B, rows + 3, cols + 20), 9, np.uint8); Lp[:, :rows, :cols] = L        # padded rows AND three spare rows between the sequences
+            Dp = np.full((B, rows + 1, cols + 6), 77, np.uint16); Dp[:, :rows, :cols] = D
+            rc_ = c.process(Lp, Dp)
+            for i in range(B):
+                for other in (rb_, rc_):
+                    fa, fb = ra[i][0], other[i][0]
+                    for name, _ in fa._fields_:
+                        va, vb = getattr(fa, name), getattr(fb, name)
+                        if hasattr(va, "__len__"):
+                            va, vb = list(va), list(vb)
+                        assert va == vb, (f, i, name)
+                    assert ra[i][1] == other[i][1]
+                pa, pb, pc = a.points(i), b.points(i), c.points(i)
+                for key in ("xy", "cam", "meta", "desc"):
+                    np.testing.assert_array_equal(pa[key], pb[key]); np.testing.assert_array_equal(pa[key], pc[key])
+        assert all(fi.status == 1 and fi.n_tracked > 50 for fi, _ in ra)
+    finally:
+        a.destroy(); b.destroy(); c.destroy(); o.destroy()

@@ -648,3 +648,66 @@ class RgbdTracker(object):
         if self.h:
             self.lib.vslam_rgbd_destroy(self.h)
             self.h = None
+
+
+class RgbdBatch(object):
+    """ctypes view of vslam_rgbd_create_batch / _process_batch_host: n_streams sequences of one camera and configuration in one context."""
+
+    def __init__(self, api, cfg, params, n_streams, device=0):
+        self.lib = api.lib
+        self.cfg = cfg.copy()
+        self.n = int(n_streams)
+        self.lib.vslam_rgbd_last_error.restype = C.c_char_p
+        self.h = C.c_void_p()
+        rc = self.lib.vslam_rgbd_create_batch(C.byref(cfg), C.byref(params), C.c_int(device), C.c_int32(self.n), C.byref(self.h))
+        if rc != OK:
+            raise VslamError(rc, self.lib.vslam_rgbd_last_error(None).decode())
+
+    def _check(self, rc):
+        if rc != OK:
+            raise VslamError(rc, self.lib.vslam_rgbd_last_error(self.h).decode())
+
+    def reset(self):
+        self._check(self.lib.vslam_rgbd_reset(self.h))
+
+    def submit(self, left, depth):
+        """left: [n_streams, rows, stride] uint8, depth: [n_streams, rows, stride] uint16 (kept alive until wait())."""
+        left = np.ascontiguousarray(left, np.uint8); depth = np.ascontiguousarray(depth, np.uint16)
+        assert left.shape[0] == self.n and depth.shape[0] == self.n
+        self._inflight = (left, depth)
+        self._check(self.lib.vslam_rgbd_submit_batch_host(self.h, _p(left, C.c_uint8), C.c_int32(left.shape[2]), C.c_size_t(left.shape[1] * left.shape[2]),
+                                                          _p(depth, C.c_uint16), C.c_int32(depth.shape[2]), C.c_size_t(depth.shape[1] * depth.shape[2])))
+
+    def submit_device(self, left_ptr, left_row_stride, left_stream_stride, depth_ptr, depth_row_stride, depth_stream_stride):
+        """Images already in HBM: device addresses (e.g. torch tensors' data_ptr()), strides in bytes / depth in elements."""
+        self._check(self.lib.vslam_rgbd_submit_batch_device(self.h, C.c_void_p(left_ptr), C.c_int32(left_row_stride), C.c_size_t(left_stream_stride),
+                                                            C.c_void_p(depth_ptr), C.c_int32(depth_row_stride), C.c_size_t(depth_stream_stride)))
+
+    def wait(self, infos=True):
+        self._check(self.lib.vslam_rgbd_wait(self.h))
+        self._inflight = None
+        return [self.frame_info(s) for s in range(self.n)] if infos else None
+
+    def process(self, left, depth):
+        self.submit(left, depth)
+        return self.wait()
+
+    def frame_info(self, s):
+        fi = FrameInfo()
+        nt = C.c_int32()
+        self._check(self.lib.vslam_rgbd_get_frame_info_stream(self.h, C.c_int32(s), C.byref(fi), C.byref(nt)))
+        return fi, nt.value
+
+    def points(self, s):
+        cap = int(self.cfg.max_points) * 4
+        n = C.c_int32()
+        xy = np.zeros((cap, 2), np.float32); cam = np.zeros((cap, 3), np.float64); meta = np.zeros((cap, 4), np.int32); desc = np.zeros((cap, 32), np.uint8)
+        self._check(self.lib.vslam_rgbd_get_points_stream(self.h, C.c_int32(s), C.c_int32(cap), C.byref(n), _p(xy, C.c_float), _p(cam, C.c_double), _p(meta, C.c_int32),
+                                                          _p(desc, C.c_uint8)))
+        k = n.value
+        return dict(xy=xy[:k].copy(), cam=cam[:k].copy(), meta=meta[:k].copy(), desc=desc[:k].copy())
+
+    def destroy(self):
+        if self.h:
+            self.lib.vslam_rgbd_destroy(self.h)
+            self.h = None

@@ -43,15 +43,19 @@ __device__ __forceinline__ bool depth_source(const vslam_depth_params& p, const 
   return true;
 }
 
+// (the four kernels take a batch of equally sized images: blockIdx.z — blockIdx.y for the 1-D init — is the image, every array advanced by
+// rows * cols elements per image; the stand-alone entry launches one image)
 __global__ __launch_bounds__(256) void k_depth_init(int n, uint32_t f0_bits, unsigned long long* key, int32_t* last) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) { key[i] = ((unsigned long long)f0_bits << 32) | 0xffffffffull; last[i] = -1; }
+  const size_t zo = (size_t)blockIdx.y * n;
+  if (i < n) { key[zo + i] = ((unsigned long long)f0_bits << 32) | 0xffffffffull; last[zo + i] = -1; }
 }
 
 // min + first in ONE 64-bit atomic per source: key = float bits of the depth << 32 | source index
 __global__ __launch_bounds__(256) void k_depth_min(const vslam_depth_params p, const uint16_t* depth, int stride, unsigned long long* key) {
   const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
   if (c >= p.cols) return;
+  depth += (size_t)blockIdx.z * p.rows * stride; key += (size_t)blockIdx.z * p.rows * p.cols;
   DepthSource s;
   if (!depth_source(p, depth, stride, r, c, s)) return;
   atomicMin(&key[s.dest], ((unsigned long long)__float_as_uint((float)s.pl[2]) << 32) | (unsigned)(r * p.cols + c));
@@ -63,6 +67,7 @@ __global__ __launch_bounds__(256) void k_depth_pick(const vslam_depth_params p, 
                                                     const unsigned long long* key, int32_t* last) {
   const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
   if (c >= p.cols) return;
+  { const size_t zo = (size_t)blockIdx.z * p.rows * p.cols; depth += (size_t)blockIdx.z * p.rows * stride; key += zo; last += zo; }
   DepthSource s;
   if (!depth_source(p, depth, stride, r, c, s)) return;
   const unsigned long long k = key[s.dest];
@@ -79,6 +84,7 @@ __global__ __launch_bounds__(256) void k_depth_write(const vslam_depth_params p,
                                                      int16_t* row_map, int16_t* col_map) {
   const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
   if (c >= p.cols) return;
+  { const size_t zo = (size_t)blockIdx.z * p.rows * p.cols; depth += (size_t)blockIdx.z * p.rows * stride; key += zo; last += zo; space += 3 * zo; row_map += zo; col_map += zo; }
   const int d = r * p.cols + c;
   const unsigned long long k = key[d];
   int win = last[d];

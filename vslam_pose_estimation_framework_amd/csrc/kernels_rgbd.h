@@ -65,6 +65,7 @@ struct RgbdBuf {
   RgbdList fl[2];
   RgbdList tmp;               // temporary points of the frame in flight (trail unused)
   int32_t TR, H;              // trail entries per point, frames of history
+  int32_t MAXP, NMAX, npx, nbins, n_streams;   // capacities per sequence: every array below holds n_streams slices of its per-sequence size
   // features of the last initialize(): the inner context's keypoints / descriptors / CSR of image 0, plus
   int32_t* order;             // [NMAX] feature index (row-major numbering) of the j-th feature in the reference's order
   uint8_t* matched;           // [NMAX]
@@ -86,8 +87,41 @@ struct RgbdBuf {
   double* pose_log;           // [VS_POSE_LOG][12]
 };
 
-__device__ __forceinline__ RgbdList rgbd_cur(const RgbdBuf& r) { return r.fl[r.st->frame_count & 1]; }
-__device__ __forceinline__ RgbdList rgbd_prev(const RgbdBuf& r) { return r.fl[(r.st->frame_count & 1) ^ 1]; }
+// One context tracks n_streams independent sequences (one workgroup per sequence in the single-workgroup kernels, blockIdx.y in the wide ones):
+// the kernels receive the whole table and take their sequence's slice of every array first; the code below that line is written for ONE sequence.
+__device__ __forceinline__ void rgbd_list_at(RgbdList& l, size_t s, size_t P, size_t TR) {
+  l.xy += s * P * 2; l.desc += s * P * 32; l.cam += s * P * 3; l.prev += s * P; l.tlen += s * P; l.flags += s * P;
+  l.lmw += s * P * 3; l.lmu += s * P; l.lmm += s * P;
+  if (l.trail) l.trail += s * P * TR;
+}
+__device__ __forceinline__ RgbdBuf rgbd_stream(const RgbdBuf& a, int stream) {
+  RgbdBuf r = a;
+  const size_t s = (size_t)stream, P = (size_t)a.MAXP, N = (size_t)a.NMAX, X = (size_t)a.npx;
+  r.st += s;
+  rgbd_list_at(r.fl[0], s, P, a.TR); rgbd_list_at(r.fl[1], s, P, a.TR); rgbd_list_at(r.tmp, s, P, a.TR);
+  r.order += s * N; r.matched += s * N;
+  r.depth += s * X; r.dkey += s * X; r.dlast += s * X; r.space += s * X * 3; r.row_map += s * X; r.col_map += s * X;
+  r.hold += s * N * 2; r.pick += s * P; r.cand += s * P * (VS_DT_K + 1); r.out2 += s * P * 2; r.xyz += s * P * 3; r.temp2 += s * P * 2; r.lost_raw += s * P;
+  r.lost += s * P; r.lost_has += s * P; r.lost_lm += s * P * 3; r.lost_desc += s * P * 32;
+  r.rbxy += s * P * 2; r.rkxy += s * P * 2; r.rcell += s * P; r.rkeep += s * P; r.rdesc += s * P * 32; r.ridx += s * P; r.rxy += s * P * 2;
+  r.rrdesc += s * P * 32; r.rxyz += s * P * 3;
+  r.rcF += s * N * 2; r.remf += s * N; r.rcT += s * P * 2; r.bins += s * (size_t)a.nbins; r.cls += s * N; r.new_feat += s * N; r.new_xyz += s * N * 3;
+  r.temp_feat += s * N; r.temp_xyz += s * N * 3;
+  r.weights += s * P;
+  r.h_cam += s * (size_t)a.H * P * 4; r.h_pose += s * (size_t)a.H * 24; r.pose_log += s * (size_t)VS_POSE_LOG * 12;
+  return r;
+}
+// (field by field: indexing r.fl[] with a run-time value would force the whole per-sequence table — a local value since the batch — into scratch)
+__device__ __forceinline__ RgbdList rgbd_pick(const RgbdBuf& r, bool second) {
+  RgbdList l;
+  l.xy = second ? r.fl[1].xy : r.fl[0].xy; l.desc = second ? r.fl[1].desc : r.fl[0].desc; l.cam = second ? r.fl[1].cam : r.fl[0].cam;
+  l.prev = second ? r.fl[1].prev : r.fl[0].prev; l.tlen = second ? r.fl[1].tlen : r.fl[0].tlen; l.flags = second ? r.fl[1].flags : r.fl[0].flags;
+  l.lmw = second ? r.fl[1].lmw : r.fl[0].lmw; l.lmu = second ? r.fl[1].lmu : r.fl[0].lmu; l.lmm = second ? r.fl[1].lmm : r.fl[0].lmm;
+  l.trail = second ? r.fl[1].trail : r.fl[0].trail;
+  return l;
+}
+__device__ __forceinline__ RgbdList rgbd_cur(const RgbdBuf& r) { return rgbd_pick(r, (r.st->frame_count & 1) != 0); }
+__device__ __forceinline__ RgbdList rgbd_prev(const RgbdBuf& r) { return rgbd_pick(r, (r.st->frame_count & 1) == 0); }
 
 __device__ __forceinline__ void rgbd_copy_desc(uint8_t* dst, const uint8_t* src) {
   const uint4 a = reinterpret_cast<const uint4*>(src)[0], b = reinterpret_cast<const uint4*>(src)[1];
@@ -95,8 +129,9 @@ __device__ __forceinline__ void rgbd_copy_desc(uint8_t* dst, const uint8_t* src)
 }
 
 // ---- frame start (PoseTracker3D::compute up to the first initialize) ---------------------------------------------------------------------
-__global__ void k_rgbd_begin(const RgbdBuf r) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ void k_rgbd_begin(const RgbdBuf all) {
+  if (threadIdx.x != 0) return;
+  const RgbdBuf r = rgbd_stream(all, blockIdx.x);
   RgbdState& st = *r.st;
   vslam_frame_info z = {};
   st.info = z;
@@ -115,11 +150,11 @@ __global__ void k_rgbd_begin(const RgbdBuf r) {
 // detectKeypoints concatenates the regions' keypoints in region order (base_framepoint_generator.cpp:355-429); k_emit leaves them row-major.
 // A corner lies in exactly one region's FAST-valid area (the regions overlap by 2-4 px, FAST's border is 3), so the reference's order is a
 // stable partition of the row-major list by region.  First part of k_rgbd_track (1024 threads).
-__device__ __forceinline__ void rgbd_features(const DevCfg& c, const DevBuf& b, const RgbdBuf& r, int* sh) {
+__device__ __forceinline__ void rgbd_features(const DevCfg& c, const DevBuf& b, const RgbdBuf& r, int sq, int* sh) {
   RgbdState& st = *r.st;
   const int tid = threadIdx.x, NT = blockDim.x;
-  const int n = b.n_kp[0];
-  const int16_t* kxy = kpxy_of(c, b, 0, 0);
+  const int n = b.n_kp[2 * sq];
+  const int16_t* kxy = kpxy_of(c, b, sq, 0);
   for (int i = tid; i < n; i += NT) r.matched[i] = 0;
   if (c.n_regions == 1) {
     for (int i = tid; i < n; i += NT) r.order[i] = i;
@@ -141,14 +176,14 @@ __device__ __forceinline__ void rgbd_features(const DevCfg& c, const DevBuf& b, 
   if (tid == 0) {
     st.n_detected = n;
     int raw = 0;
-    for (int q = 0; q < c.n_regions; ++q) raw += b.iinfo[0].raw_count[0][q];
+    for (int q = 0; q < c.n_regions; ++q) raw += b.iinfo[sq].raw_count[0][q];
     st.n_raw = raw;
   }
   __syncthreads();
 }
 
 // ---- _track (pose_tracker_3d.cpp:225-298) around DepthFramePointGenerator::track (:166-287) --------------------------------------------------
-__device__ __forceinline__ void rgbd_track_args(const DevCfg& c, const DevBuf& b, const RgbdBuf& r, DepthTrack& a) {
+__device__ __forceinline__ void rgbd_track_args(const DevCfg& c, const DevBuf& b, const RgbdBuf& r, int sq, DepthTrack& a) {
   const RgbdState& st = *r.st;
   const RgbdList pv = rgbd_prev(r);
   a.p = r.p;
@@ -156,19 +191,22 @@ __device__ __forceinline__ void rgbd_track_args(const DevCfg& c, const DevBuf& b
   a.by_app = st.next_by_app;
   a.d = a.by_app ? c.c.maximum_projection_tracking_distance_pixels : st.win;   // :229-231
   a.tau = c.c.minimum_descriptor_distance_tracking;
-  a.nP = st.last_all; a.nL = b.n_kp[0]; a.CW = c.CW;
+  a.nP = st.last_all; a.nL = b.n_kp[2 * sq]; a.CW = c.CW;
   a.cam = pv.cam; a.pdesc = pv.desc; a.pflags = pv.flags;
-  a.kxy = kpxy_of(c, b, 0, 0); a.desc = desc_of(c, b, 0, 0); a.rowcell = rowcell_of(c, b, 0, 0);
+  a.kxy = kpxy_of(c, b, sq, 0); a.desc = desc_of(c, b, sq, 0); a.rowcell = rowcell_of(c, b, sq, 0);
   a.space = r.space; a.fvis = nullptr;       // FAST leaves one feature per pixel
   a.hold = r.hold; a.pick = r.pick; a.cand = r.cand; a.counts = r.st->tcounts; a.out2 = r.out2; a.xyz = r.xyz; a.temp2 = r.temp2; a.lost = r.lost_raw;
 }
 
-__global__ __launch_bounds__(256) void k_rgbd_track_candidates(const DevCfg c, const DevBuf b, const RgbdBuf r) {
+__global__ __launch_bounds__(256) void k_rgbd_track_candidates(const DevCfg c, const DevBuf b, const RgbdBuf all) {
   __shared__ unsigned long long keys[16][VS_DT_CAP];
   __shared__ int cnt[16];
+  const int sq = blockIdx.y;
+  if (!vs_active(b, sq)) return;
+  const RgbdBuf r = rgbd_stream(all, sq);
   if (r.st->done) return;
   DepthTrack a;
-  rgbd_track_args(c, b, r, a);
+  rgbd_track_args(c, b, r, sq, a);
   depth_track_candidates_body(a, keys, cnt);
 }
 
@@ -200,15 +238,18 @@ __device__ __forceinline__ void rgbd_accept(const DevCfg& c, RgbdState& st) {
   }
 }
 
-__global__ __launch_bounds__(1024) void k_rgbd_track(const DevCfg c, const DevBuf b, const RgbdBuf r) {
+__global__ __launch_bounds__(1024) void k_rgbd_track(const DevCfg c, const DevBuf b, const RgbdBuf all) {
   __shared__ int sh[17];
   __shared__ int changed;
+  const int sq = blockIdx.x;
+  if (!vs_active(b, sq)) return;
+  const RgbdBuf r = rgbd_stream(all, sq);
   RgbdState& st = *r.st;
-  rgbd_features(c, b, r, sh);          // also on the first frame: compute() walks the features in this order
+  rgbd_features(c, b, r, sq, sh);      // also on the first frame: compute() walks the features in this order
   if (st.done) return;
   const int tid = threadIdx.x, NT = blockDim.x;
   DepthTrack a;
-  rgbd_track_args(c, b, r, a);
+  rgbd_track_args(c, b, r, sq, a);
   depth_track_body(a, sh, &changed);
   __syncthreads();
   const RgbdList cur = rgbd_cur(r), pv = rgbd_prev(r), tp = r.tmp;
@@ -292,10 +333,17 @@ __global__ __launch_bounds__(1024) void k_rgbd_track(const DevCfg c, const DevBu
 }
 
 // ---- UVDAligner::initialize (uvd_aligner.cpp:11-69) + converge, then the registration's verdict ------------------------------------------
-__global__ VS_ALIGN_BOUNDS void k_rgbd_align(const DevCfg c, const DevBuf b, const RgbdBuf r) {
+__global__ VS_ALIGN_BOUNDS void k_rgbd_align(const DevCfg c, const DevBuf b, const RgbdBuf all) {
   __shared__ FrameShared sh;
+  const int sq = blockIdx.x;
+  if (!vs_active(b, sq)) return;
+  const RgbdBuf r = rgbd_stream(all, sq);
   RgbdState& st = *r.st;
   if (st.done || !st.do_align) return;
+  double* al_fixed = b.al_fixed + (size_t)sq * c.MAXP * 4;
+  double* al_moving = b.al_moving + (size_t)sq * c.MAXP * 3;
+  double* al_omega = b.al_omega + (size_t)sq * c.MAXP;
+  double* al_weight = b.al_weight + (size_t)sq * c.MAXP;
   const int tid = threadIdx.x;
   const RgbdList cur = rgbd_cur(r), pv = rgbd_prev(r);
   const int n = st.n_points, old = st.wsize, inverse = st.inverse_depth;
@@ -306,16 +354,16 @@ __global__ VS_ALIGN_BOUNDS void k_rgbd_align(const DevCfg c, const DevBuf b, con
     if (cur.flags[u] & RGBD_F_UNREL) { w = 0; wd = 0; }
     else if (inverse) w = c.c.maximum_reliable_depth_meters / z;
     r.weights[u] = w;
-    b.al_fixed[4 * (size_t)u] = (double)cur.xy[2 * u]; b.al_fixed[4 * (size_t)u + 1] = (double)cur.xy[2 * u + 1];
-    b.al_fixed[4 * (size_t)u + 2] = z; b.al_fixed[4 * (size_t)u + 3] = wd;
-    for (int k = 0; k < 3; ++k) b.al_moving[3 * (size_t)u + k] = pv.cam[3 * (size_t)ip + k];    // the current point has no landmark yet (:38)
-    b.al_omega[u] = 1.0; b.al_weight[u] = w;
+    al_fixed[4 * (size_t)u] = (double)cur.xy[2 * u]; al_fixed[4 * (size_t)u + 1] = (double)cur.xy[2 * u + 1];
+    al_fixed[4 * (size_t)u + 2] = z; al_fixed[4 * (size_t)u + 3] = wd;
+    for (int k = 0; k < 3; ++k) al_moving[3 * (size_t)u + k] = pv.cam[3 * (size_t)ip + k];    // the current point has no landmark yet (:38)
+    al_omega[u] = 1.0; al_weight[u] = w;
   }
   double T0[12];
   for (int k = 0; k < 12; ++k) T0[k] = st.prior[k];
   __threadfence_block();
   __syncthreads();
-  wg_align_converge<true>(c, b, 0, sh, n, T0);
+  wg_align_converge<true>(c, b, sq, sh, n, T0);
   __syncthreads();
   if (tid == 0) {
     st.wsize = n;
@@ -371,10 +419,14 @@ __device__ __forceinline__ bool rgbd_recover_on(const DevCfg& c, const RgbdState
 }
 // _prunePoints (:437-472): without a fresh aligner result every tracked point is dropped.  Order-preserving compaction in place, 1024
 // points per pass (a pass reads its points before it writes, and writes never reach the next pass's points).
-__global__ __launch_bounds__(1024) void k_rgbd_prune(const DevCfg c, const DevBuf b, const RgbdBuf r) {
+__global__ __launch_bounds__(1024) void k_rgbd_prune(const DevCfg c, const DevBuf b, const RgbdBuf all) {
   __shared__ int sh[17];
+  const int sq = blockIdx.x;
+  const RgbdBuf r = rgbd_stream(all, sq);
   RgbdState& st = *r.st;
   if (!rgbd_tail_on(st)) return;
+  const double* al_chi = b.al_chi + (size_t)sq * c.MAXP;
+  const uint8_t* al_inl = b.al_inl + (size_t)sq * c.MAXP;
   const int tid = threadIdx.x, NT = blockDim.x;
   const int n = st.n_points;
   if (tid == 0) st.n_registered = n;
@@ -396,7 +448,7 @@ __global__ __launch_bounds__(1024) void k_rgbd_prune(const DevCfg c, const DevBu
     RgbdPoint q;
     if (u < n) {
       rgbd_load(cur, u, q);
-      if (valid) { const double chi = b.al_chi[u]; keep = avg < kern ? (b.al_inl[u] != 0) : (chi != -1 && chi < 100 * kern); }
+      if (valid) { const double chi = al_chi[u]; keep = avg < kern ? (al_inl[u] != 0) : (chi != -1 && chi < 100 * kern); }
     }
     int total;
     const int at = out + block_exclusive_scan(keep, sh, &total);
@@ -408,14 +460,16 @@ __global__ __launch_bounds__(1024) void k_rgbd_prune(const DevCfg c, const DevBu
 }
 
 // descriptors at the projected pixels: BRIEF on the box image / steered ORB tests on the Gaussian image the image pipeline left
-__global__ __launch_bounds__(256) void k_rgbd_describe_at(const DevCfg c, const DevBuf b, const RgbdBuf r) {
+__global__ __launch_bounds__(256) void k_rgbd_describe_at(const DevCfg c, const DevBuf b, const RgbdBuf all) {
+  const int sq = blockIdx.y;
+  const RgbdBuf r = rgbd_stream(all, sq);
   const RgbdState& st = *r.st;
   if (!rgbd_recover_on(c, st)) return;
   const int n = st.n_lost, rows = c.c.rows, cols = c.c.cols;
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
   if (r.p.descriptor_type == VSLAM_DESCRIPTOR_ORB) {
-    const uint8_t* blur = blur_of(c, b, 0, 0);
+    const uint8_t* blur = blur_of(c, b, sq, 0);
     const OrbTaps t = orb_taps(lane, c.orb_cos, c.orb_sin, c.bstride);
     for (int i = wave; i < n; i += nwaves) {
       const int x = r.rbxy[2 * i], y = r.rbxy[2 * i + 1];
@@ -427,7 +481,7 @@ __global__ __launch_bounds__(256) void k_rgbd_describe_at(const DevCfg c, const 
       if (lane < 4) reinterpret_cast<unsigned long long*>(r.rdesc + (size_t)32 * i)[lane] = dv;
     }
   } else {
-    const uint16_t* box = box_of(c, b, 0, 0);
+    const uint16_t* box = box_of(c, b, sq, 0);
     for (int i = wave; i < n; i += nwaves) {
       const int x = r.rbxy[2 * i], y = r.rbxy[2 * i + 1];
       const bool in = x >= VSLAM_BRIEF_BORDER && x < cols - VSLAM_BRIEF_BORDER && y >= VSLAM_BRIEF_BORDER && y < rows - VSLAM_BRIEF_BORDER;
@@ -437,8 +491,9 @@ __global__ __launch_bounds__(256) void k_rgbd_describe_at(const DevCfg c, const 
     }
   }
 }
-__global__ __launch_bounds__(1024) void k_rgbd_recover_finish(const DevCfg c, const RgbdBuf r) {
+__global__ __launch_bounds__(1024) void k_rgbd_recover_finish(const DevCfg c, const RgbdBuf all) {
   __shared__ int sh[17];
+  const RgbdBuf r = rgbd_stream(all, blockIdx.x);
   RgbdState& st = *r.st;
   if (!rgbd_recover_on(c, st)) return;
   const int tid = threadIdx.x, NT = blockDim.x;
@@ -482,14 +537,15 @@ __global__ __launch_bounds__(1024) void k_rgbd_recover_finish(const DevCfg c, co
 #define RGBD_LM_PRE 64    // measurements of a track kept in LDS across the rounds (each is two dependent HBM loads: trail entry, then the ring)
 struct RgbdPoseLds { double w2c[12]; double rtr[9]; };
 struct RgbdLmTerm { double e2, h[6], b[3]; int kind, pad; };   // kind 0: behind the camera (an outlier, nothing added), 1: inlier, 2: outlier with a saturated kernel
-__global__ __launch_bounds__(256) void k_rgbd_landmarks(const DevCfg c, const RgbdBuf r) {
+__global__ __launch_bounds__(256) void k_rgbd_landmarks(const DevCfg c, const RgbdBuf all) {
+  const RgbdBuf r = rgbd_stream(all, blockIdx.y);
   __shared__ RgbdPoseLds s_pose[RGBD_LM_NP];
   __shared__ RgbdLmTerm s_term[RGBD_LM_PTS][RGBD_LM_G];
   __shared__ double s_meas[RGBD_LM_PTS][RGBD_LM_PRE][4];     // the track's newest measurements, fetched once for all Gauss-Newton rounds
   RgbdState& st = *r.st;
   if (!rgbd_tail_on(st)) return;
   const int n = st.n_points;
-  if ((int)(blockIdx.x * RGBD_LM_PTS) >= n) return;
+  if ((int)(blockIdx.x * RGBD_LM_PTS) >= n) return;      // (the grid's x extent is a guess of the host: blocks loop over the points below)
   const int f = st.frame_count, H = r.H;
   for (int t = threadIdx.x; t < RGBD_LM_NP * 12; t += 256) {
     const int k = t / 12, e = t - 12 * k;
@@ -503,9 +559,10 @@ __global__ __launch_bounds__(256) void k_rgbd_landmarks(const DevCfg c, const Rg
   }
   __syncthreads();
   const int g = threadIdx.x / RGBD_LM_G, gl = threadIdx.x % RGBD_LM_G;
-  const int i = blockIdx.x * RGBD_LM_PTS + g;
+  int n_active = 0;
+  for (int i = blockIdx.x * RGBD_LM_PTS + g; i < n; i += gridDim.x * RGBD_LM_PTS) {
   bool active = false;
-  if (i < n) {
+  {
     const RgbdList cur = rgbd_cur(r), pv = rgbd_prev(r);
     const int T = cur.tlen[i], fl = cur.flags[i];
     if (!(T < c.c.minimum_track_length_for_landmark_creation || (fl & RGBD_F_UNREL))) {
@@ -644,15 +701,21 @@ __global__ __launch_bounds__(256) void k_rgbd_landmarks(const DevCfg c, const Rg
       }
     }
   }
-  const int cnt = __popcll(__ballot(active));
-  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&st.n_active, cnt);
+  n_active += active ? 1 : 0;
+  }
+  // (lanes of a wavefront run different numbers of points: a plain per-lane count, summed once)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) n_active += __shfl_xor(n_active, o, 64);
+  if ((threadIdx.x & 63) == 0 && n_active) atomicAdd(&st.n_active, n_active);
 }
 
 // The rest of the frame in one workgroup: temporary points triangulated with the accepted motion (:524-545), status, compute() on the features
 // track() left unmatched (depth_framepoint_generator.cpp:45-164), the frame's list closed (framepoints followed by temporary points), history,
 // trails, frame info.
-__global__ __launch_bounds__(1024) void k_rgbd_finish(const DevCfg c, const DevBuf b, const RgbdBuf r) {
+__global__ __launch_bounds__(1024) void k_rgbd_finish(const DevCfg c, const DevBuf b, const RgbdBuf all) {
   __shared__ int sh[17];
+  const int sq = blockIdx.x;
+  const RgbdBuf r = rgbd_stream(all, sq);
   RgbdState& st = *r.st;
   if (!rgbd_tail_on(st)) return;
   const int tid = threadIdx.x, NT = blockDim.x;
@@ -688,8 +751,8 @@ __global__ __launch_bounds__(1024) void k_rgbd_finish(const DevCfg c, const DevB
     __syncthreads();
   }
   // ---- compute(): unmatched features in the reference's order, the bins the frame's points own
-  const int16_t* kxy = kpxy_of(c, b, 0, 0);
-  const uint8_t* kdesc = desc_of(c, b, 0, 0);
+  const int16_t* kxy = kpxy_of(c, b, sq, 0);
+  const uint8_t* kdesc = desc_of(c, b, sq, 0);
   int nF = 0;
   {
     const int nd = st.n_detected;
@@ -758,11 +821,11 @@ __global__ __launch_bounds__(1024) void k_rgbd_finish(const DevCfg c, const DevB
   }
   __syncthreads();
   if (tid == 0) {
-    st.error_flags |= b.st[0].error_flags & 1;      // keypoint capacity (k_emit)
+    st.error_flags |= b.st[sq].error_flags & 1;     // keypoint capacity (k_emit)
     vslam_frame_info& o = st.info;
     o.frame_index = f + 1; o.status = st.status; o.status_at_start = st.status0;
     o.n_keypoints_left = st.n_detected; o.n_detected_left = st.n_raw;
-    for (int q = 0; q < c.n_regions; ++q) o.thresholds[q] = b.st[0].thr[q];
+    for (int q = 0; q < c.n_regions; ++q) o.thresholds[q] = b.st[sq].thr[q];
     o.track_attempts = st.attempts; o.n_tracked = st.n_registered; o.n_lost = st.n_lost; o.n_tracked_landmarks = st.n_tracked_lm;
     o.aligner_ran = st.aligner_valid ? 1 : 0;
     o.aligner_iterations = st.aligner_valid ? st.al_iterations : 0;

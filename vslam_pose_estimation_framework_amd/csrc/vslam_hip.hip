@@ -2034,7 +2034,15 @@ struct vslam_rgbd {
 };
 static thread_local std::string g_rgbd_error;
 VS_API const char* vslam_rgbd_last_error(const vslam_rgbd* r) { return r ? (r->on_host ? r->t.err.c_str() : r->d.err.c_str()) : g_rgbd_error.c_str(); }
-VS_API int vslam_rgbd_create(const vslam_config* cfg, const vslam_depth_params* p, int device, vslam_rgbd** out) {
+static int rgbd_create(const vslam_config* cfg, const vslam_depth_params* p, int device, int n_streams, vslam_rgbd** out);
+VS_API int vslam_rgbd_wait(vslam_rgbd* r);
+VS_API int vslam_rgbd_get_frame_info(vslam_rgbd* r, vslam_frame_info* out, int32_t* n_temporary);
+VS_API int vslam_rgbd_get_points(vslam_rgbd* r, int32_t cap, int32_t* n, float* xy, double* cam, int32_t* meta4, uint8_t* desc);
+VS_API int vslam_rgbd_create(const vslam_config* cfg, const vslam_depth_params* p, int device, vslam_rgbd** out) { return rgbd_create(cfg, p, device, 1, out); }
+VS_API int vslam_rgbd_create_batch(const vslam_config* cfg, const vslam_depth_params* p, int device, int32_t n_streams, vslam_rgbd** out) {
+  return rgbd_create(cfg, p, device, n_streams, out);
+}
+static int rgbd_create(const vslam_config* cfg, const vslam_depth_params* p, int device, int n_streams, vslam_rgbd** out) {
   if (!cfg || !p || !out) { g_rgbd_error = "vslam_rgbd_create: null argument"; return VSLAM_ERR_INVALID; }
   vslam_rgbd* r = new vslam_rgbd;
   if (const char* e = std::getenv("VSLAM_RGBD_HOST")) r->on_host = std::atoi(e) != 0;
@@ -2042,7 +2050,8 @@ VS_API int vslam_rgbd_create(const vslam_config* cfg, const vslam_depth_params* 
   // features can share a pixel — the device-resident loop's image pipeline is FAST's; the host-driven loop serves this mode
   if (p->detector_type == VSLAM_DETECTOR_ORB) r->on_host = true;
   else if (p->detector_type != VSLAM_DETECTOR_FAST) { g_rgbd_error = "vslam_rgbd_create: unknown detector_type"; delete r; return VSLAM_ERR_INVALID; }
-  const int rc = r->on_host ? r->t.create(*cfg, *p, device) : r->d.create(*cfg, *p, device);
+  if (r->on_host && n_streams != 1) { g_rgbd_error = "vslam_rgbd_create_batch: the host-driven loop (VSLAM_RGBD_HOST=1, detector_type ORB) tracks one sequence per object"; delete r; return VSLAM_ERR_INVALID; }
+  const int rc = r->on_host ? r->t.create(*cfg, *p, device) : r->d.create(*cfg, *p, device, n_streams);
   if (rc != VSLAM_OK) { g_rgbd_error = r->err(); delete r; return rc; }
   *out = r;
   return VSLAM_OK;
@@ -2077,6 +2086,40 @@ VS_API int vslam_rgbd_wait(vslam_rgbd* r) {
   }
   return r->d.wait();
 }
+VS_API int vslam_rgbd_submit_batch_host(vslam_rgbd* r, const uint8_t* left, int32_t lstride, size_t left_stream_stride, const uint16_t* depth, int32_t dstride,
+                                        size_t depth_stream_stride) {
+  if (!r) return VSLAM_ERR_INVALID;
+  if (r->on_host) { r->t.err = "batch entry points need the device-resident loop"; return VSLAM_ERR_STATE; }
+  if (!left || !depth) { r->d.err = "called with empty frame"; return VSLAM_ERR_INVALID; }
+  if (lstride < r->d.cfg.cols || dstride < r->d.cfg.cols) { r->d.err = "row stride smaller than image width"; return VSLAM_ERR_INVALID; }
+  return r->d.submit(left, lstride, depth, dstride, left_stream_stride, depth_stream_stride);
+}
+VS_API int vslam_rgbd_process_batch_host(vslam_rgbd* r, const uint8_t* left, int32_t lstride, size_t left_stream_stride, const uint16_t* depth, int32_t dstride,
+                                         size_t depth_stream_stride) {
+  const int rc = vslam_rgbd_submit_batch_host(r, left, lstride, left_stream_stride, depth, dstride, depth_stream_stride);
+  return rc != VSLAM_OK ? rc : vslam_rgbd_wait(r);
+}
+VS_API int vslam_rgbd_submit_batch_device(vslam_rgbd* r, const uint8_t* left, int32_t lstride, size_t left_stream_stride, const uint16_t* depth, int32_t dstride,
+                                          size_t depth_stream_stride) {
+  if (!r) return VSLAM_ERR_INVALID;
+  if (r->on_host) { r->t.err = "device images need the device-resident loop"; return VSLAM_ERR_STATE; }
+  if (!left || !depth) { r->d.err = "called with empty frame"; return VSLAM_ERR_INVALID; }
+  if (lstride < r->d.cfg.cols || dstride < r->d.cfg.cols) { r->d.err = "row stride smaller than image width"; return VSLAM_ERR_INVALID; }
+  return r->d.submit(left, lstride, depth, dstride, left_stream_stride, depth_stream_stride, true);
+}
+VS_API int vslam_rgbd_get_frame_info_stream(vslam_rgbd* r, int32_t stream, vslam_frame_info* out, int32_t* n_temporary) {
+  if (!r || !out) return VSLAM_ERR_INVALID;
+  if (r->on_host) return stream == 0 ? vslam_rgbd_get_frame_info(r, out, n_temporary) : VSLAM_ERR_INVALID;
+  if (stream < 0 || stream >= r->d.B) { r->d.err = "stream index out of range"; return VSLAM_ERR_INVALID; }
+  *out = r->d.hosts[stream].info;
+  if (n_temporary) *n_temporary = r->d.hosts[stream].n_temporary;
+  return VSLAM_OK;
+}
+VS_API int vslam_rgbd_get_points_stream(vslam_rgbd* r, int32_t stream, int32_t cap, int32_t* n, float* xy, double* cam, int32_t* meta4, uint8_t* desc) {
+  if (!r || !n) return VSLAM_ERR_INVALID;
+  if (r->on_host) return stream == 0 ? vslam_rgbd_get_points(r, cap, n, xy, cam, meta4, desc) : VSLAM_ERR_INVALID;
+  return r->d.get_points(stream, cap, n, xy, cam, meta4, desc);
+}
 VS_API int vslam_rgbd_get_frame_info(vslam_rgbd* r, vslam_frame_info* out, int32_t* n_temporary) {
   if (!r || !out) return VSLAM_ERR_INVALID;
   if (r->on_host) { *out = r->t.info; if (n_temporary) *n_temporary = r->t.n_temporary; return VSLAM_OK; }
@@ -2086,7 +2129,7 @@ VS_API int vslam_rgbd_get_frame_info(vslam_rgbd* r, vslam_frame_info* out, int32
 }
 VS_API int vslam_rgbd_get_points(vslam_rgbd* r, int32_t cap, int32_t* n, float* xy, double* cam, int32_t* meta4, uint8_t* desc) {
   if (!r || !n) return VSLAM_ERR_INVALID;
-  if (!r->on_host) return r->d.get_points(cap, n, xy, cam, meta4, desc);
+  if (!r->on_host) return r->d.get_points(0, cap, n, xy, cam, meta4, desc);
   if (r->t.info.frame_index == 0) { *n = 0; return VSLAM_OK; }
   const vs_rgbd::Fr& f = r->t.current();
   *n = (int32_t)f.points.size();
