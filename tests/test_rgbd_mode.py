@@ -255,18 +255,27 @@ def _run(prod, frames):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("graph", ["0", "1"])
+@pytest.mark.parametrize("graph", ["0", "1", "general-depth", "gated-depth"])
 def test_rgbd_device_loop_strides_reset_and_second_tracker(graph, monkeypatch):
     """The device-resident loop with padded rows (image stride != width, depth stride != width: the caller's strides are kept on the device / the
     depth image is re-packed), after reset(), and as a second tracker in the same process: every frame's counters and pose identical to the dense
     first run, bit for bit.  graph = 1: the frame's launch sequence replayed from a captured hipGraph (captured again when the stride changes)."""
     from _oracle import Oracle
     monkeypatch.setenv("VSLAM_RGBD_HOST", "0")
-    monkeypatch.setenv("VSLAM_RGBD_GRAPH", graph)
+    monkeypatch.setenv("VSLAM_RGBD_GRAPH", graph if graph in ("0", "1") else "0")
+    # the space map: the direct pass (default where every depth pixel projects onto itself), the general z-buffer alone, and the general passes
+    # opened behind the direct one as if a crossing source had been seen — all three must give the first run's results
     o = Oracle()
     scene, cfg, p = setup(o, "tum", descriptor=1, seed=53)
     g = hip.load()
     frames = [(o.render(scene, k)[0], o.render_depth(scene, k, 2e-3)) for k in range(10)]
+    ref = RgbdTracker(g, cfg, p)                   # the default paths (created before the switches below are set)
+    baseline = _run(ref, frames)
+    ref.destroy()
+    if graph == "general-depth":
+        monkeypatch.setenv("VSLAM_RGBD_DEPTH_DIRECT", "0")
+    if graph == "gated-depth":
+        monkeypatch.setenv("VSLAM_RGBD_DEPTH_FORCE_CROSS", "1")
     padded = []
     for L, D in frames:
         Lp = np.full((cfg.rows, cfg.cols + 12), 7, np.uint8); Lp[:, :cfg.cols] = L
@@ -276,6 +285,7 @@ def test_rgbd_device_loop_strides_reset_and_second_tracker(graph, monkeypatch):
     b = RgbdTracker(g, cfg, p)
     try:
         first = _run(a, frames)
+        assert first == baseline
         assert first[-1][0] == 1 and first[-1][2] > 50
         a.reset()
         # padded rows: process() passes the array width as the stride, the image width comes from the configuration

@@ -52,6 +52,7 @@ struct DevCfg {
   int32_t NMAX, MAXP, HCAP;
   int32_t trail;           // 1: framepoints carry the indices of their track's last VS_TRAIL predecessors (MAXP <= 65535)
   int32_t n_streams;
+  int32_t mono;            // 1: one image per stream (RGB-D mode): the tile kernels' grid z is the stream, not 2 * stream + side
   // ORB extractor: the rotation of the pattern by the FAST keypoints' angle (-1 degree), evaluated on the host exactly as
   // OpenCV does — angle *= (float)(CV_PI/180.f); (float)cos(angle), (float)sin(angle) — and the fixed-point Gaussian taps
   float orb_cos, orb_sin;

@@ -30,12 +30,24 @@ __device__ __forceinline__ bool depth_source(const vslam_depth_params& p, const 
   const double ph[3] = {c * dm, r * dm, dm};
   double pr[3], px[3];
   const double* Ki = p.K_right_inverse;
-  for (int i = 0; i < 3; ++i) pr[i] = (Ki[3 * i] * ph[0] + Ki[3 * i + 1] * ph[1]) + Ki[3 * i + 2] * ph[2];   // :454
   const double* T = p.right_to_left;
+  const double* K = p.K_left;
+  // Pinhole matrices and a depth image registered to the colour image (identity offset) — every shipped RGB-D configuration: the products with
+  // the structural zeros are exact zeros and x + 0 == x, so leaving them out gives the same bits as the full triple product below with a
+  // third of its multiplications (uniform branch: the parameters are kernel arguments)
+  const bool plain = Ki[1] == 0 && Ki[3] == 0 && Ki[6] == 0 && Ki[7] == 0 && Ki[8] == 1 && K[1] == 0 && K[3] == 0 && K[6] == 0 && K[7] == 0 && K[8] == 1 &&
+                     T[0] == 1 && T[1] == 0 && T[2] == 0 && T[3] == 0 && T[4] == 0 && T[5] == 1 && T[6] == 0 && T[7] == 0 && T[8] == 0 && T[9] == 0 && T[10] == 1 && T[11] == 0;
+  if (plain) {
+    pr[0] = Ki[0] * ph[0] + Ki[2] * ph[2]; pr[1] = Ki[4] * ph[1] + Ki[5] * ph[2]; pr[2] = ph[2];
+    s.pl[0] = pr[0]; s.pl[1] = pr[1]; s.pl[2] = pr[2];
+    if (s.pl[2] <= 0) return false;
+    px[0] = K[0] * s.pl[0] + K[2] * s.pl[2]; px[1] = K[4] * s.pl[1] + K[5] * s.pl[2]; px[2] = s.pl[2];
+  } else {
+  for (int i = 0; i < 3; ++i) pr[i] = (Ki[3 * i] * ph[0] + Ki[3 * i + 1] * ph[1]) + Ki[3 * i + 2] * ph[2];   // :454
   for (int i = 0; i < 3; ++i) s.pl[i] = ((T[4 * i] * pr[0] + T[4 * i + 1] * pr[1]) + T[4 * i + 2] * pr[2]) + T[4 * i + 3];   // :456
   if (s.pl[2] <= 0) return false;                                                           // :458-460
-  const double* K = p.K_left;
   for (int i = 0; i < 3; ++i) px[i] = (K[3 * i] * s.pl[0] + K[3 * i + 1] * s.pl[1]) + K[3 * i + 2] * s.pl[2];   // :462
+  }
   const double u = px[0] / px[2], v = px[1] / px[2];                                        // :463
   const double ru = round(u), rv = round(v);                                                // :466-467 (half away from zero)
   if (!(rv >= 0 && rv < p.rows && ru >= 0 && ru < p.cols)) return false;                    // :470-474
@@ -52,50 +64,93 @@ __global__ __launch_bounds__(256) void k_depth_init(int n, uint32_t f0_bits, uns
 }
 
 // min + first in ONE 64-bit atomic per source: key = float bits of the depth << 32 | source index
-__global__ __launch_bounds__(256) void k_depth_min(const vslam_depth_params p, const uint16_t* depth, int stride, unsigned long long* key) {
-  const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+// gate (may be null): one int per image; the kernel skips an image whose entry is 0 (k_depth_direct found that the general z-buffer is not needed)
+__global__ __launch_bounds__(256) void k_depth_min(const vslam_depth_params p, const uint16_t* depth, int stride, unsigned long long* key, const int32_t* gate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= p.cols) return;
+  if (gate && !gate[blockIdx.z]) return;
   depth += (size_t)blockIdx.z * p.rows * stride; key += (size_t)blockIdx.z * p.rows * p.cols;
-  DepthSource s;
-  if (!depth_source(p, depth, stride, r, c, s)) return;
-  atomicMin(&key[s.dest], ((unsigned long long)__float_as_uint((float)s.pl[2]) << 32) | (unsigned)(r * p.cols + c));
+  for (int r = blockIdx.y; r < p.rows; r += gridDim.y) {     // (a gated launch uses a few row blocks only: it almost never has work)
+    DepthSource s;
+    if (!depth_source(p, depth, stride, r, c, s)) continue;
+    atomicMin(&key[s.dest], ((unsigned long long)__float_as_uint((float)s.pl[2]) << 32) | (unsigned)(r * p.cols + c));
+  }
 }
 
 // "last": only sources that tie the minimum float, lie strictly below it as doubles and are not the first one already
 // recorded — with one source per destination (the usual case) no atomic is issued here at all
 __global__ __launch_bounds__(256) void k_depth_pick(const vslam_depth_params p, const uint16_t* depth, int stride, uint32_t f0_bits,
-                                                    const unsigned long long* key, int32_t* last) {
-  const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+                                                    const unsigned long long* key, int32_t* last, const int32_t* gate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= p.cols) return;
+  if (gate && !gate[blockIdx.z]) return;
   { const size_t zo = (size_t)blockIdx.z * p.rows * p.cols; depth += (size_t)blockIdx.z * p.rows * stride; key += zo; last += zo; }
-  DepthSource s;
-  if (!depth_source(p, depth, stride, r, c, s)) return;
-  const unsigned long long k = key[s.dest];
-  const uint32_t m = (uint32_t)(k >> 32);
-  if (__float_as_uint((float)s.pl[2]) != m) return;
-  const int idx = r * p.cols + c;
-  if (!(s.pl[2] < (double)__uint_as_float(m))) return;
-  if (m < f0_bits && (uint32_t)idx == (uint32_t)k) return;   // the first source wins anyway unless a later one passes
-  atomicMax(&last[s.dest], idx);
+  for (int r = blockIdx.y; r < p.rows; r += gridDim.y) {
+    DepthSource s;
+    if (!depth_source(p, depth, stride, r, c, s)) continue;
+    const unsigned long long k = key[s.dest];
+    const uint32_t m = (uint32_t)(k >> 32);
+    if (__float_as_uint((float)s.pl[2]) != m) continue;
+    const int idx = r * p.cols + c;
+    if (!(s.pl[2] < (double)__uint_as_float(m))) continue;
+    if (m < f0_bits && (uint32_t)idx == (uint32_t)k) continue;   // the first source wins anyway unless a later one passes
+    atomicMax(&last[s.dest], idx);
+  }
 }
 
+// rearm: the z-buffer entries are put back to their initial values once read (the device-resident loop initialises them once and lets every
+// frame leave them ready for the next: one kernel and one pass over the buffers less per frame)
 __global__ __launch_bounds__(256) void k_depth_write(const vslam_depth_params p, const uint16_t* depth, int stride, uint32_t f0_bits,
-                                                     const unsigned long long* key, const int32_t* last, float* space,
-                                                     int16_t* row_map, int16_t* col_map) {
+                                                     unsigned long long* key, int32_t* last, float* space,
+                                                     int16_t* row_map, int16_t* col_map, int rearm, const int32_t* gate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= p.cols) return;
+  if (gate && !gate[blockIdx.z]) return;
+  { const size_t zo = (size_t)blockIdx.z * p.rows * p.cols; depth += (size_t)blockIdx.z * p.rows * stride; key += zo; last += zo; space += 3 * zo; row_map += zo; col_map += zo; }
+  for (int r = blockIdx.y; r < p.rows; r += gridDim.y) {
+    const int d = r * p.cols + c;
+    const unsigned long long k = key[d];
+    int win = last[d];
+    if (rearm) { key[d] = ((unsigned long long)f0_bits << 32) | 0xffffffffull; last[d] = -1; }
+    if ((uint32_t)(k >> 32) < f0_bits && (uint32_t)k != 0xffffffffu) win = max(win, (int)(uint32_t)k);
+    float o[3] = {0.f, 0.f, __uint_as_float(f0_bits)};                                       // :428-432
+    int sr = -1, sc = -1;
+    if (win >= 0) {
+      sr = win / p.cols; sc = win - sr * p.cols;
+      DepthSource s;
+      depth_source(p, depth, stride, sr, sc, s);
+      o[0] = (float)s.pl[0]; o[1] = (float)s.pl[1]; o[2] = (float)s.pl[2];                  // :480-482
+    }
+    space[3 * (size_t)d] = o[0]; space[3 * (size_t)d + 1] = o[1]; space[3 * (size_t)d + 2] = o[2];
+    row_map[d] = (int16_t)sr; col_map[d] = (int16_t)sc;                                      // :483-484
+  }
+}
+
+// The z-buffer without a z-buffer: when every source pixel projects onto ITSELF (a depth image registered to the colour image and one camera
+// matrix: every shipped RGB-D configuration) a destination has at most one source, and the three passes above reduce, per pixel, to
+//     the source wins iff fl(z) < F0, or fl(z) == F0 and z < F0 as doubles          (min: key = (fl(z), index) when fl(z) <= F0; pick: the tie case)
+// One pass, no atomics (the three passes are bound by 64-bit atomics: 430 + 160 + 240 us for 256 images of 620 x 188).  Whether the premise
+// holds is CHECKED, not assumed: a source that lands on another pixel raises its image's flag, and the general passes — gated on that flag —
+// then recompute the image from scratch.
+__global__ __launch_bounds__(256) void k_depth_direct(const vslam_depth_params p, const uint16_t* depth, int stride, uint32_t f0_bits, float* space,
+                                                      int16_t* row_map, int16_t* col_map, int32_t* cross) {
   const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
   if (c >= p.cols) return;
-  { const size_t zo = (size_t)blockIdx.z * p.rows * p.cols; depth += (size_t)blockIdx.z * p.rows * stride; key += zo; last += zo; space += 3 * zo; row_map += zo; col_map += zo; }
+  { const size_t zo = (size_t)blockIdx.z * p.rows * p.cols; depth += (size_t)blockIdx.z * p.rows * stride; space += 3 * zo; row_map += zo; col_map += zo; }
   const int d = r * p.cols + c;
-  const unsigned long long k = key[d];
-  int win = last[d];
-  if ((uint32_t)(k >> 32) < f0_bits && (uint32_t)k != 0xffffffffu) win = max(win, (int)(uint32_t)k);
+  DepthSource s;
   float o[3] = {0.f, 0.f, __uint_as_float(f0_bits)};                                       // :428-432
   int sr = -1, sc = -1;
-  if (win >= 0) {
-    sr = win / p.cols; sc = win - sr * p.cols;
-    DepthSource s;
-    depth_source(p, depth, stride, sr, sc, s);
-    o[0] = (float)s.pl[0]; o[1] = (float)s.pl[1]; o[2] = (float)s.pl[2];                  // :480-482
+  if (depth_source(p, depth, stride, r, c, s)) {
+    if (s.dest != d) {
+      if (!__hip_atomic_load(&cross[blockIdx.z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&cross[blockIdx.z], 1);
+    } else {
+      const uint32_t zb = __float_as_uint((float)s.pl[2]);
+      if (zb < f0_bits || (zb == f0_bits && s.pl[2] < (double)__uint_as_float(f0_bits))) {
+        o[0] = (float)s.pl[0]; o[1] = (float)s.pl[1]; o[2] = (float)s.pl[2];               // :480-482
+        sr = r; sc = c;
+      }
+    }
   }
   space[3 * (size_t)d] = o[0]; space[3 * (size_t)d + 1] = o[1]; space[3 * (size_t)d + 2] = o[2];
   row_map[d] = (int16_t)sr; col_map[d] = (int16_t)sc;                                      // :483-484

@@ -85,6 +85,7 @@ struct RgbdBuf {
   double* h_cam;              // [H][MAXP][4] camera coordinates and 1 / z (Measurement::inverse_depth_meters, divided once)
   double* h_pose;             // [H][24] camera_to_world, world_to_camera
   double* pose_log;           // [VS_POSE_LOG][12]
+  int32_t* cross;             // [n_streams] k_depth_direct: some depth pixel of the image projects onto another pixel (the general z-buffer runs)
 };
 
 // One context tracks n_streams independent sequences (one workgroup per sequence in the single-workgroup kernels, blockIdx.y in the wide ones):
@@ -109,6 +110,7 @@ __device__ __forceinline__ RgbdBuf rgbd_stream(const RgbdBuf& a, int stream) {
   r.temp_feat += s * N; r.temp_xyz += s * N * 3;
   r.weights += s * P;
   r.h_cam += s * (size_t)a.H * P * 4; r.h_pose += s * (size_t)a.H * 24; r.pose_log += s * (size_t)VS_POSE_LOG * 12;
+  r.cross += s;
   return r;
 }
 // (field by field: indexing r.fl[] with a run-time value would force the whole per-sequence table — a local value since the batch — into scratch)
@@ -842,5 +844,6 @@ __global__ __launch_bounds__(1024) void k_rgbd_finish(const DevCfg c, const DevB
     st.last_points = np; st.last_all = n_all;
     st.frame_count = f + 1;
     st.tail_done = 1;
+    *r.cross = 0;              // the space map has been consumed: the next frame's k_depth_direct starts from "no crossing source"
   }
 }

@@ -37,6 +37,7 @@ public:
     int rc = create_internal(&in, device, B, &ic);
     if (rc != VSLAM_OK) { err = vslam_last_error(nullptr); return rc; }
     q = ic->stream_img;
+    ic->cfg.mono = 1;                             // the tile kernels run ONE image per sequence (grid z = sequences); k_emit's one-image controller
     const size_t MAXP = ic->cfg.MAXP, NMAX = ic->cfg.NMAX, npx = (size_t)p.rows * p.cols, nB = (size_t)B;
     if (const char* e = std::getenv("VSLAM_RGBD_WG")) { const int v = std::atoi(e); if (v == 256 || v == 512 || v == 1024) wg1 = v; }
     H = std::max(4, std::min(cfg.max_history_frames, 512));   // measurements of a track the landmark refinement can address
@@ -62,7 +63,7 @@ public:
     A(&rb.rrdesc, MAXP * 32); A(&rb.rxyz, MAXP * 3);
     A(&rb.rcF, NMAX * 2); A(&rb.remf, NMAX); A(&rb.rcT, MAXP * 2); A(&rb.bins, nbins); A(&rb.cls, NMAX);
     A(&rb.new_feat, NMAX); A(&rb.new_xyz, NMAX * 3); A(&rb.temp_feat, NMAX); A(&rb.temp_xyz, NMAX * 3);
-    A(&rb.weights, MAXP);
+    A(&rb.weights, MAXP); A(&rb.cross, 1);
     A(&rb.h_cam, (size_t)H * MAXP * 4); A(&rb.h_pose, (size_t)H * 24); A(&rb.pose_log, (size_t)VS_POSE_LOG * 12);
     if (e == hipSuccess) e = hipHostMalloc((void**)&pinned, sizeof(RgbdState) * nB, hipHostMallocDefault);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&q2, hipStreamNonBlocking);
@@ -71,6 +72,13 @@ public:
     if (const char* g = std::getenv("VSLAM_RGBD_GRAPH")) use_graph = std::atoi(g) != 0;
     if (e != hipSuccess) { err = std::string("RGB-D mode: ") + hipGetErrorString(e); release(); return VSLAM_ERR_HIP; }
     rb.depth = d_depth;
+    {   // the premise of k_depth_direct, as kernels_depth.h depth_source tests it
+      const double* Ki = p.K_right_inverse; const double* K = p.K_left; const double* T = p.right_to_left;
+      depth_plain = Ki[1] == 0 && Ki[3] == 0 && Ki[6] == 0 && Ki[7] == 0 && Ki[8] == 1 && K[1] == 0 && K[3] == 0 && K[6] == 0 && K[7] == 0 && K[8] == 1 &&
+                    T[0] == 1 && T[1] == 0 && T[2] == 0 && T[3] == 0 && T[4] == 0 && T[5] == 1 && T[6] == 0 && T[7] == 0 && T[8] == 0 && T[9] == 0 && T[10] == 1 && T[11] == 0;
+      if (const char* e2 = std::getenv("VSLAM_RGBD_DEPTH_DIRECT")) depth_plain = depth_plain && std::atoi(e2) != 0;
+      if (const char* e3 = std::getenv("VSLAM_RGBD_DEPTH_FORCE_CROSS")) force_cross = std::atoi(e3) != 0;
+    }
     hosts.resize(B);
     return reset();
   }
@@ -92,6 +100,15 @@ public:
     host = s;
     hipError_t e = hipMemcpy(rb.st, hosts.data(), sizeof(RgbdState) * (size_t)B, hipMemcpyHostToDevice);
     if (e != hipSuccess) { err = hipGetErrorString(e); return VSLAM_ERR_HIP; }
+    {   // the space maps' z-buffers: initialised here, every frame's k_depth_write puts them back
+      const size_t npx = (size_t)p.rows * p.cols;
+      const float f0 = (float)p.maximum_depth_meters;
+      uint32_t f0_bits;
+      std::memcpy(&f0_bits, &f0, 4);
+      hipLaunchKernelGGL(k_depth_init, dim3((unsigned)((npx + 255) / 256), B), dim3(256), 0, q, (int)npx, f0_bits, rb.dkey, rb.dlast);
+      (void)hipMemsetAsync(rb.cross, 0, sizeof(int32_t) * (size_t)B, q);
+      if (hipStreamSynchronize(q) != hipSuccess) { err = "RGB-D reset: space-map buffers"; return VSLAM_ERR_HIP; }
+    }
     failed = false; failed_why.clear(); pending = false;
     return VSLAM_OK;
   }
@@ -163,7 +180,7 @@ private:
   const uint16_t* depth_src = nullptr; int32_t depth_src_stride = 0;   // what the space-map kernels read this frame: d_depth, or the caller's device images
   uint8_t* d_img = nullptr; size_t img_stream = 0;     // [B][img_stream] bytes, the caller's row stride kept
   RgbdState* pinned = nullptr;   // [B]
-  bool depth_pending = false, pending = false;
+  bool depth_pending = false, pending = false, depth_plain = false, force_cross = false;
   DevBuf bs;                      // the inner context's buffer table with this frame's image pointers
   // VSLAM_RGBD_GRAPH=1 (opt-in): the frame's launch sequence (depth map on q2 beside the image pipeline on q, registration, tail, the state
   // block's copy out) captured once into a hipGraph and replayed — two copies and ONE launch per frame instead of ~22.  Measured on MI355X /
@@ -192,16 +209,16 @@ private:
     for (int s = 0; s < B; ++s) b.active[s >> 5] |= 1u << (s & 31);
   }
 
-  // initialize() .. registration of one attempt: the image pipeline (both of its image slots point at the ONE image of a sequence: its
-  // controller then averages two identical detections, which is the single detection of this mode), track, aligner.  Sequences whose bit in
+  // initialize() .. registration of one attempt: the image pipeline on ONE image per sequence (DevCfg::mono: grid z = sequences; k_emit with
+  // its one-image controller), track, aligner.  Sequences whose bit in
   // b.active is cleared are skipped by every kernel.
   void enqueue_attempt(const DevBuf& b) {
     const DevCfg& d = ic->cfg;
-    const dim3 g1(d.TX, (d.c.rows + VS_TILE_H - 1) / VS_TILE_H, 2 * B);
+    const dim3 g1(d.TX, (d.c.rows + VS_TILE_H - 1) / VS_TILE_H, B);
     hipLaunchKernelGGL(k_fast_box, g1, dim3(256), VS_FB_DYN_LDS, q, d, b);
     const bool orb = d.c.descriptor_type == VSLAM_DESCRIPTOR_ORB;
-    hipLaunchKernelGGL(k_emit, dim3(B, 2), dim3(512), 0, q, d, b, orb ? (int)VSLAM_ORB_BORDER : (int)VSLAM_BRIEF_BORDER, 1);
-    const dim3 g3((d.c.cols + VS_BT_W - 1) / VS_BT_W, (d.c.rows + VS_BT_H - 1) / VS_BT_H, 2 * B);
+    hipLaunchKernelGGL(k_emit, dim3(B, 1), dim3(512), 0, q, d, b, orb ? (int)VSLAM_ORB_BORDER : (int)VSLAM_BRIEF_BORDER, 2);
+    const dim3 g3((d.c.cols + VS_BT_W - 1) / VS_BT_W, (d.c.rows + VS_BT_H - 1) / VS_BT_H, B);
     if (orb) {
       Gauss7 gk; for (int i = 0; i < 4; ++i) gk.k[i] = d.gauss7[i];
       hipLaunchKernelGGL(k_gauss7, g1, dim3(256), 0, q, d, b, gk);
@@ -293,16 +310,23 @@ private:
     // _computeDepthMap (once per frame: every initialize() of the frame sees the same depth image) on the second stream, joined before the
     // first reader of the map (the candidate kernel)
     if (fork) { (void)hipEventRecord(ev_fork, q); (void)hipStreamWaitEvent(q2, ev_fork, 0); }     // inside a capture: q2 joins the graph here
-    const size_t npx = (size_t)rows * cols;
     const float f0 = (float)p.maximum_depth_meters;
     uint32_t f0_bits;
     std::memcpy(&f0_bits, &f0, 4);
     const dim3 grid((cols + 255) / 256, rows, B);
-    hipLaunchKernelGGL(k_depth_init, dim3((unsigned)((npx + 255) / 256), B), dim3(256), 0, q2, (int)npx, f0_bits, rb.dkey, rb.dlast);
     if (depth_src != d_depth) { (void)hipEventRecord(ev_fork, q); (void)hipStreamWaitEvent(q2, ev_fork, 0); }   // device images: whatever wrote them was ordered before q
-    hipLaunchKernelGGL(k_depth_min, grid, dim3(256), 0, q2, p, depth_src, depth_src_stride, rb.dkey);
-    hipLaunchKernelGGL(k_depth_pick, grid, dim3(256), 0, q2, p, depth_src, depth_src_stride, f0_bits, rb.dkey, rb.dlast);
-    hipLaunchKernelGGL(k_depth_write, grid, dim3(256), 0, q2, p, depth_src, depth_src_stride, f0_bits, rb.dkey, rb.dlast, rb.space, rb.row_map, rb.col_map);
+    // pinhole matrices, identity offset: one direct pass; the general three passes stay enqueued behind it and skip every image whose depth
+    // pixels all landed on themselves (k_depth_direct checks that and raises rb.cross[image] otherwise)
+    const int32_t* gate = nullptr;
+    if (depth_plain) {
+      if (force_cross) (void)hipMemsetAsync(rb.cross, 1, sizeof(int32_t) * (size_t)B, q2);     // test switch: the general passes run behind the direct one
+      hipLaunchKernelGGL(k_depth_direct, grid, dim3(256), 0, q2, p, depth_src, depth_src_stride, f0_bits, rb.space, rb.row_map, rb.col_map, rb.cross);
+      gate = rb.cross;
+    }
+    const dim3 ggrid((cols + 255) / 256, gate ? std::min(rows, 4) : rows, B);     // gated: a token grid (the kernels loop over the rows); it almost never has work
+    hipLaunchKernelGGL(k_depth_min, ggrid, dim3(256), 0, q2, p, depth_src, depth_src_stride, rb.dkey, gate);
+    hipLaunchKernelGGL(k_depth_pick, ggrid, dim3(256), 0, q2, p, depth_src, depth_src_stride, f0_bits, rb.dkey, rb.dlast, gate);
+    hipLaunchKernelGGL(k_depth_write, ggrid, dim3(256), 0, q2, p, depth_src, depth_src_stride, f0_bits, rb.dkey, rb.dlast, rb.space, rb.row_map, rb.col_map, 1, gate);   // leaves the z-buffer initialised for the next frame
     (void)hipEventRecord(ev_depth, q2);
     depth_pending = true;
     enqueue_attempt(bs);

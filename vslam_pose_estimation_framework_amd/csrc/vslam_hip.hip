@@ -949,9 +949,9 @@ VS_API int vslam_depth_space_map(vslam_ctx* c, const vslam_depth_params* p, cons
   std::memcpy(&f0_bits, &f0, 4);
   const dim3 grid((p->cols + 255) / 256, p->rows);
   hipLaunchKernelGGL(k_depth_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (int)n, f0_bits, m.key, m.last);
-  hipLaunchKernelGGL(k_depth_min, grid, dim3(256), 0, c->stream, *p, m.depth, p->cols, m.key);
-  hipLaunchKernelGGL(k_depth_pick, grid, dim3(256), 0, c->stream, *p, m.depth, p->cols, f0_bits, m.key, m.last);
-  hipLaunchKernelGGL(k_depth_write, grid, dim3(256), 0, c->stream, *p, m.depth, p->cols, f0_bits, m.key, m.last, m.space, m.row_map, m.col_map);
+  hipLaunchKernelGGL(k_depth_min, grid, dim3(256), 0, c->stream, *p, m.depth, p->cols, m.key, (const int32_t*)nullptr);
+  hipLaunchKernelGGL(k_depth_pick, grid, dim3(256), 0, c->stream, *p, m.depth, p->cols, f0_bits, m.key, m.last, (const int32_t*)nullptr);
+  hipLaunchKernelGGL(k_depth_write, grid, dim3(256), 0, c->stream, *p, m.depth, p->cols, f0_bits, m.key, m.last, m.space, m.row_map, m.col_map, 0, (const int32_t*)nullptr);
   HIP_TRY(c, hipGetLastError());
   if (space) HIP_TRY(c, hipMemcpyAsync(space, m.space, n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   if (row_map) HIP_TRY(c, hipMemcpyAsync(row_map, m.row_map, n * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
