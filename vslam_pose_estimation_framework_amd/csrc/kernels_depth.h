@@ -134,26 +134,37 @@ __global__ __launch_bounds__(256) void k_depth_write(const vslam_depth_params p,
 // then recompute the image from scratch.
 __global__ __launch_bounds__(256) void k_depth_direct(const vslam_depth_params p, const uint16_t* depth, int stride, uint32_t f0_bits, float* space,
                                                       int16_t* row_map, int16_t* col_map, int32_t* cross) {
-  const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
-  if (c >= p.cols) return;
+  __shared__ float tile[256 * 3];
+  const int c = blockIdx.x * 256 + threadIdx.x;
   { const size_t zo = (size_t)blockIdx.z * p.rows * p.cols; depth += (size_t)blockIdx.z * p.rows * stride; space += 3 * zo; row_map += zo; col_map += zo; }
-  const int d = r * p.cols + c;
-  DepthSource s;
-  float o[3] = {0.f, 0.f, __uint_as_float(f0_bits)};                                       // :428-432
-  int sr = -1, sc = -1;
-  if (depth_source(p, depth, stride, r, c, s)) {
-    if (s.dest != d) {
-      if (!__hip_atomic_load(&cross[blockIdx.z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&cross[blockIdx.z], 1);
-    } else {
-      const uint32_t zb = __float_as_uint((float)s.pl[2]);
-      if (zb < f0_bits || (zb == f0_bits && s.pl[2] < (double)__uint_as_float(f0_bits))) {
-        o[0] = (float)s.pl[0]; o[1] = (float)s.pl[1]; o[2] = (float)s.pl[2];               // :480-482
-        sr = r; sc = c;
+  const int c0 = blockIdx.x * 256, nvalid = min(256, p.cols - c0) * 3;
+  // a workgroup walks down its 256-column strip (a workgroup per row segment is 144 k workgroups of 256 pixels for 256 small images: the
+  // dispatch, not the arithmetic, was the cost)
+  for (int r = blockIdx.y; r < p.rows; r += gridDim.y) {
+    const int d = r * p.cols + c;
+    DepthSource s;
+    float o[3] = {0.f, 0.f, __uint_as_float(f0_bits)};                                       // :428-432
+    int sr = -1, sc = -1;
+    if (c < p.cols && depth_source(p, depth, stride, r, c, s)) {
+      if (s.dest != d) {
+        if (!__hip_atomic_load(&cross[blockIdx.z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&cross[blockIdx.z], 1);
+      } else {
+        const uint32_t zb = __float_as_uint((float)s.pl[2]);
+        if (zb < f0_bits || (zb == f0_bits && s.pl[2] < (double)__uint_as_float(f0_bits))) {
+          o[0] = (float)s.pl[0]; o[1] = (float)s.pl[1]; o[2] = (float)s.pl[2];               // :480-482
+          sr = r; sc = c;
+        }
       }
     }
+    // the three floats of a pixel through LDS: the workgroup's 256 x 3 floats leave as three fully coalesced rows of stores instead of three
+    // stride-12-byte ones
+    __syncthreads();
+    tile[3 * threadIdx.x] = o[0]; tile[3 * threadIdx.x + 1] = o[1]; tile[3 * threadIdx.x + 2] = o[2];
+    __syncthreads();
+    float* out = space + 3 * ((size_t)r * p.cols + c0);
+    for (int k = threadIdx.x; k < nvalid; k += 256) out[k] = tile[k];
+    if (c < p.cols) { row_map[d] = (int16_t)sr; col_map[d] = (int16_t)sc; }                  // :483-484
   }
-  space[3 * (size_t)d] = o[0]; space[3 * (size_t)d + 1] = o[1]; space[3 * (size_t)d + 2] = o[2];
-  row_map[d] = (int16_t)sr; col_map[d] = (int16_t)sc;                                      // :483-484
 }
 
 // ---- compute ----------------------------------------------------------------------------------------------------

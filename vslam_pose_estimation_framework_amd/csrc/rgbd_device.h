@@ -320,7 +320,8 @@ private:
     const int32_t* gate = nullptr;
     if (depth_plain) {
       if (force_cross) (void)hipMemsetAsync(rb.cross, 1, sizeof(int32_t) * (size_t)B, q2);     // test switch: the general passes run behind the direct one
-      hipLaunchKernelGGL(k_depth_direct, grid, dim3(256), 0, q2, p, depth_src, depth_src_stride, f0_bits, rb.space, rb.row_map, rb.col_map, rb.cross);
+      const dim3 dgrid((cols + 255) / 256, std::min(rows, std::max(8, 4096 / B)), B);      // one sequence: a workgroup per row segment; many: workgroups walk down their strip
+      hipLaunchKernelGGL(k_depth_direct, dgrid, dim3(256), 0, q2, p, depth_src, depth_src_stride, f0_bits, rb.space, rb.row_map, rb.col_map, rb.cross);
       gate = rb.cross;
     }
     const dim3 ggrid((cols + 255) / 256, gate ? std::min(rows, 4) : rows, B);     // gated: a token grid (the kernels loop over the rows); it almost never has work
