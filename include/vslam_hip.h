@@ -497,12 +497,12 @@ const char* vslam_rgbd_last_error(const vslam_rgbd* t);
 int vslam_rgbd_process_host(vslam_rgbd* t, const uint8_t* left, int32_t left_row_stride, const uint16_t* depth, int32_t depth_row_stride);
 /* vslam_rgbd_process_host in two halves: submit copies the frame in and enqueues its kernels, wait returns its status (after it the frame's
  * info and points can be read).  One frame in flight per tracker.  Several trackers — one sequence each, HIP streams of their own — overlap
- * on the GPU when their frames are submitted before any of them is waited for (tools/probe/rgbd_bench.py --trackers). */
+ * on the GPU when their frames are submitted before any of them is waited for (tests/validation/rgbd_bench.py --trackers). */
 int vslam_rgbd_submit_host(vslam_rgbd* t, const uint8_t* left, int32_t left_row_stride, const uint16_t* depth, int32_t depth_row_stride);
 int vslam_rgbd_wait(vslam_rgbd* t);
 /* Several sequences in ONE context (device-resident loop only): n_streams independent sequences of the same camera and configuration advance
  * together, one frame each per call — the launch sequence of a frame serves all of them (one workgroup per sequence in its single-workgroup
- * kernels, a grid dimension in the wide ones), so a step costs the time of its slowest sequence (tools/probe/rgbd_batch.py).  Images: n_streams
+ * kernels, a grid dimension in the wide ones), so a step costs the time of its slowest sequence (tests/validation/rgbd_batch.py).  Images: n_streams
  * images `left_stream_stride` bytes apart, depth images `depth_stream_stride` ELEMENTS apart.  A sequence that needs another registration attempt
  * gets it without disturbing the others.  Results per sequence through the *_stream getters. */
 int vslam_rgbd_create_batch(const vslam_config* cfg, const vslam_depth_params* p, int device, int32_t n_streams, vslam_rgbd** out);

@@ -263,7 +263,7 @@ def test_config2_one_thousand_frames_full_resolution_one_stream():
 def test_config2_whole_kitti00_length_full_resolution_one_stream():
     """configs[1] at its FULL size: all 4541 frames of a KITTI-00-shaped sequence at 1241 x 376 as one stream against the oracle — every
     frame's counters, thresholds, tracker state and pose, the complete comparison every 250 frames (about a minute; the longer
-    multi-sequence runs of configs[2] are tools/full_length_parity.py)."""
+    multi-sequence runs of configs[2] are tests/validation/full_length_parity.py)."""
     worst, stats = _long_run([4541], [7], [0.9], full_every=250)
     assert worst < 1e-10 and stats["tracking_frames"] >= 4530 and stats["tracked"] > 1000000 and stats["recovered"] > 400000, (worst, stats)
 

@@ -1,5 +1,5 @@
 """ATE of the chunked (frame-sharded) GPU run vs the sequential GPU run vs the CPU oracle, all against the synthetic
-ground truth of the KITTI-00-shaped sequence.  Usage: python tools/eval_ate.py [frames] [streams] [overlaps...]"""
+ground truth of the KITTI-00-shaped sequence.  Usage: python tests/validation/eval_ate.py [frames] [streams] [overlaps...]"""
 import json, os, sys, time
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np, torch

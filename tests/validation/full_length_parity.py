@@ -6,7 +6,7 @@ the complete comparison (keypoints, descriptors, framepoint tuples, landmarks, a
   full_length_parity.py config3    sequences 00 + 02 + 05 + 06 as four streams of their own lengths (configs[2]: one GPU's view)
 Prints one JSON line."""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from test_hip_configs import _long_run
 from vslam_pose_estimation_framework_amd import buildinfo

@@ -1,6 +1,6 @@
 """One whole KITTI-00-length synthetic sequence (4541 frames, full resolution, configuration_kitti.yaml values) through the HIP path
 and through the CPU oracle: every frame's counters, thresholds, tracker state and pose compared.  Prints one JSON line.
-Usage: python tools/probe/full_sequence_parity.py [frames]"""
+Usage: python tests/validation/full_sequence_parity.py [frames]"""
 import json, os, sys, time
 sys.path.insert(0, os.getcwd())
 sys.path.insert(0, os.path.join(os.getcwd(), "tests"))

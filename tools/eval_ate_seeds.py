@@ -1,6 +1,6 @@
 """Is the chunked (frame-sharded) trajectory systematically worse than the sequential one?  Open-loop drift is a random
 walk: one sequence gives one realization of it, and two runs of equal quality differ by far more than 1 % in ATE.  This
-tool repeats the comparison of tools/eval_ate.py over several scene seeds (same path, different texture / noise, i.e.
+tool repeats the comparison of tests/validation/eval_ate.py over several scene seeds (same path, different texture / noise, i.e.
 different keypoints) and reports the distribution of ATE(chunked) / ATE(sequential).
 Usage: python tools/eval_ate_seeds.py [streams] [overlap] [seeds...]"""
 import json, os, sys

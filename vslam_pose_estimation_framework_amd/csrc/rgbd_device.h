@@ -184,7 +184,7 @@ private:
   DevBuf bs;                      // the inner context's buffer table with this frame's image pointers
   // VSLAM_RGBD_GRAPH=1 (opt-in): the frame's launch sequence (depth map on q2 beside the image pipeline on q, registration, tail, the state
   // block's copy out) captured once into a hipGraph and replayed — two copies and ONE launch per frame instead of ~22.  Measured on MI355X /
-  // ROCm 7.2 (tools/probe/rgbd_submit_time.py): submit() takes 80 us of host time either way (the two pageable copies; the runtime replays a
+  // ROCm 7.2 (tests/validation/rgbd_submit_time.py): submit() takes 80 us of host time either way (the two pageable copies; the runtime replays a
   // graph node by node) and the frame 0.31 against 0.30 ms: the frame is bound by its dependent kernels, not by their launches.  Kept as a
   // tested switch, captured again when the image stride or buffer changes.
   hipGraph_t graph = nullptr;

@@ -19,7 +19,7 @@ _torch_checked = False
 
 def _initialise_torch_first():
     """A process that uses both PyTorch-ROCm and this library holds TWO ROCm runtimes: torch's wheel bundles its own libamdhip64 /
-    libhsa-runtime64, libvslam_hip.so links the system's (/opt/rocm).  Measured on this image (tools/probe/torch_after_hip.py):
+    libhsa-runtime64, libvslam_hip.so links the system's (/opt/rocm).  Measured on this image (tests/validation/torch_after_hip.py):
     when the system runtime creates a context first, torch's later fails with "No HIP GPUs are available"; the other way round
     both work.  So when torch is installed its GPU context is initialised before the library's first HIP call."""
     global _torch_checked
