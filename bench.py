@@ -6,7 +6,7 @@ streams a GPU owns.
 
 --mode chunks (default; BASELINE.json configs[1]): KITTI-00-shaped synthetic sequence (1241x376, 4541 frames),
   configuration_kitti.yaml values (bin 15 -> target 2158 keypoints per image), cut into B contiguous chunks that start
-  `overlap` frames early.  The chunks run as a steady-state pipeline: stream s is `phase_s` frames into
+  `overlap` frames early (default 6, see --overlap).  The chunks run as a steady-state pipeline: stream s is `phase_s` frames into
   its chunk when the timed region starts and restarts (vslam_reset_stream, asynchronous) whenever its chunk ends, so ANY
   window of K steps sees the stationary mix of warm-up and unique frames.  `value` counts only the unique frames
   (frames inside their chunk's own range) produced inside the timed region.  With N GPUs every rank owns B further
@@ -38,7 +38,7 @@ SEQ_FRAMES = KITTI_FRAMES[0]
 EUROC_MH01_FRAMES = 3682   # MH_01_easy stereo pairs
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PMC_SUMMARY = "r03_pmc_traffic.json"   # tools/pmc_traffic.sh (rocprofv3 --pmc, separate passes); carries the source hash of its build
-ATE_NOISE_STUDY = ["r03_ate_noise_seeds48.json", "r03_ate_noise_seeds16.json", "r03_ate_noise_seeds.json"]   # tools/eval_ate_noise.py: sequential ATE spread under sensor noise vs chunked (48 seeds for the default configuration, 16 for B = 144 / 160, 8 seeds for the B x overlap grid)
+ATE_NOISE_STUDY = ["r03_ate_noise_seeds48.json", "r03_ate_noise_overlaps48.json", "r03_ate_noise_seeds16.json", "r03_ate_noise_seeds.json"]   # tools/eval_ate_noise.py: sequential ATE spread under sensor noise vs chunked (48 seeds for the default configuration and for B = 160 at overlaps 2 .. 8, 16 for B = 144 / 160, 8 seeds for the B x overlap grid)
 METRIC = "stereo frames/sec on KITTI-00 at 1/2/4/8 MI355X; ATE vs reference"
 KERNELS = ["k_fast_box", "k_emit", "k_brief", "k_track_candidates", "k_frame", "k_recover_brief", "k_update_landmarks", "k_stereo_dist"]
 
@@ -633,7 +633,7 @@ def main():
     ap.add_argument("--streams", type=int, default=int(os.environ.get("VSLAM_BENCH_STREAMS", "160")))
     ap.add_argument("--scene", choices=["kitti", "euroc"], default="kitti", help="euroc: MH_01-shaped 752x480 scene with configuration_euroc.yaml values (not the headline workload)")
     ap.add_argument("--speed", type=float, default=0.0, help="camera speed of the synthetic scene in m/frame (0 = the scene's default 0.9; slower = more of the points tracked)")
-    ap.add_argument("--overlap", type=int, default=10, help="warm-up frames per chunk (SURVEY.md 8e default)")
+    ap.add_argument("--overlap", type=int, default=6, help="warm-up frames per chunk.  SURVEY.md 8e proposed 10 without data; measured (48 sensor-noise seeds each, profiles/r03_ate_noise_overlaps48.json + r03_ate_noise_seeds48.json): 2, 3, 4, 5, 6, 8 and 10 all lie inside the sequential run's own ATE spread (|Welch t| <= 1.3), so the default is three times the two frames a chunk needs before its poses are aligned against landmarks")
     ap.add_argument("--cpu-frames", type=int, default=240)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU leg (0 = min(nproc, 16): the box's CPU share)")
     ap.add_argument("--exact-frames", type=int, default=1200, help="frames per sequence of the exact-mode legs (0 = whole sequences)")
