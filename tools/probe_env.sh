@@ -5,7 +5,7 @@ OUT=gpurun_out/$TAG; mkdir -p $OUT
 i=0
 for E in "$@"; do
   i=$((i+1))
-  env $E timeout -k 10 200 python bench.py --no-cpu --no-exact --no-pcie --no-ate --steps 39 > $OUT/e$i.json 2> $OUT/e$i.err
+  env $E timeout -k 10 200 python bench.py --no-cpu --no-exact --no-pcie --no-ate --steps 35 > $OUT/e$i.json 2> $OUT/e$i.err
   python - $OUT/e$i.json "$E" <<'PY'
 import json,sys
 try:

@@ -4,8 +4,8 @@ TAG=$1; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 for L in "$@"; do
   n=$(basename $L .so)
-  VSLAM_HIP_LIB=$PWD/vslam_pose_estimation_framework_amd/csrc/$L VSLAM_IMG_STREAMS=0 timeout -k 10 200 python bench.py --no-cpu --no-exact --no-pcie --no-ate --steps 39 > $OUT/$n.b2b.json 2> $OUT/$n.b2b.err
-  VSLAM_HIP_LIB=$PWD/vslam_pose_estimation_framework_amd/csrc/$L timeout -k 10 200 python bench.py --no-cpu --no-exact --no-pcie --no-ate --steps 39 > $OUT/$n.ovl.json 2> $OUT/$n.ovl.err
+  VSLAM_HIP_LIB=$PWD/vslam_pose_estimation_framework_amd/csrc/$L VSLAM_IMG_STREAMS=0 timeout -k 10 200 python bench.py --no-cpu --no-exact --no-pcie --no-ate --steps 35 > $OUT/$n.b2b.json 2> $OUT/$n.b2b.err
+  VSLAM_HIP_LIB=$PWD/vslam_pose_estimation_framework_amd/csrc/$L timeout -k 10 200 python bench.py --no-cpu --no-exact --no-pcie --no-ate --steps 35 > $OUT/$n.ovl.json 2> $OUT/$n.ovl.err
   python - $OUT/$n <<'PY'
 import json,sys
 for mode in ("b2b","ovl"):
