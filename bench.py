@@ -190,12 +190,19 @@ class Bench(object):
 
     # ------------------------------------------------------------------------------------------------------------------
     def open_pose_comm(self):
-        """N > 1 on RCCL: the pose all-gather of the timed region goes through the C ABI (vslam_comm_init / vslam_allgather_poses,
-        RCCL called by libvslam_hip.so itself — what a C++ caller uses).  The communicator is formed BEFORE anything is timed, under a
+        """N > 1 on RCCL with VSLAM_BENCH_C_ABI_COMM=1: the pose all-gather of the timed region goes through the C ABI (vslam_comm_init /
+        vslam_allgather_poses, RCCL called by libvslam_hip.so itself — what a C++ caller uses); by default torch.distributed (RCCL as
+        well) carries it.  The communicator is formed BEFORE anything is timed, under a
         watchdog: a communicator that HANGS while forming, or whose result differs from torch.distributed's, ends the run non-zero with
         the reason on stderr (no JSON line); one that reports an error falls back to torch.distributed on all ranks together."""
-        if self.world == 1 or self.backend != "nccl" or os.environ.get("VSLAM_BENCH_C_ABI_COMM", "1") == "0":
-            return None, ("not used (one GPU)" if self.world == 1 else "torch.distributed %s (rehearsal backend / switched off)" % self.backend)
+        if self.world == 1:
+            return None, "not used (one GPU)"
+        if self.backend != "nccl":
+            return None, "torch.distributed %s (rehearsal backend)" % self.backend
+        if os.environ.get("VSLAM_BENCH_C_ABI_COMM", "0") != "1":
+            # opt-in: this pipeline's GPU boxes have ONE card, so a communicator of vslam_comm_* with more than one rank has never
+            # formed on hardware; a path that has never run must not be able to end the measurement (its hang = exit 3, no JSON line)
+            return None, "torch.distributed nccl (RCCL); the C-ABI all-gather (vslam_allgather_poses) is opt-in: VSLAM_BENCH_C_ABI_COMM=1"
         box = {}
 
         def form():
