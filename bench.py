@@ -155,6 +155,8 @@ class Bench(object):
         self.scene = self.sy.scene_euroc(seed=seed) if self.euroc else self.sy.scene_kitti(seed=seed)
         if args.speed > 0:
             self.scene.speed_m = args.speed
+        if args.contrast > 0:
+            self.scene.contrast = args.contrast
         self.api = hip.load()
         self.cfg = synth.config_for_scene(self.api, self.scene, "euroc" if self.euroc else "kitti")
         if not self.euroc or args.bin != 15:
@@ -338,7 +340,7 @@ class Bench(object):
                        "parallelism": "frame-sharded chunks, %d per GPU x %d GPU (%s scaling)" % (B, world, a.scaling),
                        "mean_keypoints_per_image": round(stats["N"], 1), "mean_points_per_frame": round(stats["P"], 1),
                        "mean_tracked": round(stats["M"], 1), "mean_aligner_iterations": round(stats["I"], 1),
-                       "scene_speed_m_per_frame": round(float(self.scene.speed_m), 3), "error_flags": flags},
+                       "scene_speed_m_per_frame": round(float(self.scene.speed_m), 3), "scene_contrast": round(float(self.scene.contrast), 3), "error_flags": flags},
             "roofline": roof,
             "kernels": kern,
             "chronometers_s": {k: round(v, 4) for k, v in chrono.items()},
@@ -639,6 +641,7 @@ def main():
     ap.add_argument("--bin", type=int, default=15, help="bin_size_pixels (15: ~2158 kp/image, 22: ~1026, 11: ~3955)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("VSLAM_BENCH_STREAMS", "160")))
     ap.add_argument("--scene", choices=["kitti", "euroc"], default="kitti", help="euroc: MH_01-shaped 752x480 scene with configuration_euroc.yaml values (not the headline workload)")
+    ap.add_argument("--contrast", type=float, default=0.0, help="texture contrast of the synthetic scene (0 = the scene's default 1.0; 2.0: ~60 %% more corners, stereo points and tracks per frame: with --speed 0.3 --bin 11 a workload of the size SURVEY.md 8(d) assumed; not the headline)")
     ap.add_argument("--speed", type=float, default=0.0, help="camera speed of the synthetic scene in m/frame (0 = the scene's default 0.9; slower = more of the points tracked)")
     ap.add_argument("--overlap", type=int, default=6, help="warm-up frames per chunk.  SURVEY.md 8e proposed 10 without data; measured (48 sensor-noise seeds each, profiles/r03_ate_noise_overlaps48.json + r03_ate_noise_seeds48.json): 2, 3, 4, 5, 6, 8 and 10 all lie inside the sequential run's own ATE spread (|Welch t| <= 1.3), so the default is three times the two frames a chunk needs before its poses are aligned against landmarks")
     ap.add_argument("--cpu-frames", type=int, default=240)
