@@ -33,7 +33,9 @@
 #else
 #define VS_FRAME_BOUNDS __launch_bounds__(VS_WG)
 #endif
+#ifndef VS_TRAIL
 #define VS_TRAIL 32           // predecessors a framepoint knows by index (64 B per point): the landmark refinement reads its measurements without chasing the per-frame `prev` links
+#endif
 #ifndef VS_ARENA
 #define VS_ARENA (128 * 1024) // bytes of LDS scratch the frame kernel stages hot index arrays in (one frame workgroup per CU)
 #endif

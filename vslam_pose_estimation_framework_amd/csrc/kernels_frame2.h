@@ -588,6 +588,191 @@ __device__ __forceinline__ bool landmark_point(const DevCfg& c, const DevBuf& b,
   return landmark_point_t<false, LmCache>(c, b, s, cv, f, i, (LmCache*)nullptr);
 }
 
+// Landmark::update of a LONG track by a team of eight lanes (fused frame kernel).  One lane per landmark walks a chain of ~65
+// dependent fp64 operations per measurement and round; the longest track of the frame (dozens of measurements, three rounds)
+// kept the phase waiting for one wavefront.  Only the thirteen ADDITIONS into H, b and the error have to happen in the list's
+// order: the eight lanes evaluate eight consecutive measurements at once (projection, residual, kernel, om * R^T R, om * R^T e),
+// park the terms in LDS, and every lane adds the eight terms in list order into its own copy of the sums — the same operations on
+// the same operands in the same order as landmark_point_t's serial loop, an eighth of the multiplications on the critical path.
+// Measurements beyond the trail (k >= n_direct: only reachable through the `prev` links) follow serially on every lane alike.
+#ifndef VS_LM_TEAMS
+#define VS_LM_TEAMS 1
+#endif
+#define VS_LM_TEAM_G 8          // lanes per team
+#ifndef VS_LM_TEAM_WAVES
+#define VS_LM_TEAM_WAVES 2      // wavefronts of the workgroup that run teams when the frame has long tracks (16 teams at a time)
+#endif
+#ifndef VS_LM_TEAM_MIN
+#define VS_LM_TEAM_MIN 9        // measurements from which a track goes to a team
+#endif
+struct LmTerm { double e2, h[6], b[3]; int kind, pad; };   // kind 0: behind the camera (outlier, nothing added), 1: inlier, 2: outlier with the saturated kernel
+#define VS_LM_TEAM_LDS (VS_LM_TEAM_WAVES * (64 / VS_LM_TEAM_G) * VS_LM_TEAM_G * (int)sizeof(LmTerm))
+// classification used by the work lists: an update (not a creation) of a track with VS_LM_TEAM_MIN or more measurements
+__device__ __forceinline__ bool landmark_is_long(const DevCfg& c, const int32_t* m) {
+  return m[M_LMUP] != 0 && min(m[M_TLEN] + 1, c.HCAP) >= VS_LM_TEAM_MIN && c.trail;
+}
+__device__ __forceinline__ bool landmark_team(const DevCfg& c, const DevBuf& b, int s, const PtView& cv, int f, int i, LmCache* lc, LmTerm* terms, int gl) {
+  const double* w2c_cur = hpose_of(c, b, s, f) + 12;
+  int32_t* m = cv.meta + (size_t)i * META;
+  const int tlen = m[M_TLEN];
+  const int lmup0 = m[M_LMUP];
+  int len = tlen + 1;
+  if (len > c.HCAP) { len = c.HCAP; if (gl == 0) atomicOr(&b.st[s].error_flags, 4); }
+  double wpos[3];
+  double wv[3] = {cv.lm[3 * (size_t)i], cv.lm[3 * (size_t)i + 1], cv.lm[3 * (size_t)i + 2]};
+  for (int q = 0; q < 3; ++q) wpos[q] = wv[q];
+  const double kern = c.c.landmark_maximum_error_squared_meters;
+  // directly addressed measurements (landmark_point_t's n_direct)
+  const uint16_t* tr = cv.trail + (size_t)i * VS_TRAIL;
+  int n_direct = 1;
+  bool ended = false;
+  {
+    const int want = min(len, VS_TRAIL + 1);
+    for (int q0 = 0; q0 < VS_TRAIL && n_direct < want && !ended; q0 += 8) {
+      const uint4 v = *reinterpret_cast<const uint4*>(tr + q0);
+      const uint32_t wv4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const uint32_t ent = (wv4[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+        if (!ended && n_direct < want) { if (ent == 0xFFFFu) ended = true; else ++n_direct; }
+      }
+    }
+  }
+  // this lane's measurements of the directly addressed part (k = gl, gl + 8, ...) into its LDS slots, all loads in flight, once
+  constexpr int NG = LmCache::kCN;                       // groups whose measurements have a slot (k < 8 * NG)
+  double (*slot)[4] = lc->cam[threadIdx.x];
+  {
+    double mv[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int k = VS_LM_TEAM_G * g + gl;
+      if (k < n_direct) {
+        const double* mc = hcam_of(c, b, s, f - k) + 4 * (size_t)(k == 0 ? i : (int)tr[k - 1]);
+        mv[g][0] = mc[0]; mv[g][1] = mc[1]; mv[g][2] = mc[2]; mv[g][3] = mc[3];
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+      if (VS_LM_TEAM_G * g + gl < n_direct) { slot[g][0] = mv[g][0]; slot[g][1] = mv[g][1]; slot[g][2] = mv[g][2]; slot[g][3] = mv[g][3]; }
+  }
+  // where the link walk continues after the directly addressed measurements
+  int ffc = f, iic = i;
+  if (!ended && n_direct < len) { ffc = f - (n_direct - 1); iic = hprev_of(c, b, s, ffc)[n_direct == 1 ? i : (int)tr[n_direct - 2]]; --ffc; if (iic < 0) ended = true; }
+  else ended = true;
+  double err_prev = 0;
+  for (int it = 0; it < c.c.landmark_maximum_number_of_iterations; ++it) {
+    double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bv[3] = {0, 0, 0};
+    double err = 0;
+    int n_out = 0;
+    for (int k0 = 0; k0 < n_direct; k0 += VS_LM_TEAM_G) {
+      const int k = k0 + gl;
+      LmTerm t;
+      t.kind = -1;
+      if (k < n_direct) {
+        double mc[4];
+        const int g = k0 / VS_LM_TEAM_G;
+        if (g < NG) { mc[0] = slot[g][0]; mc[1] = slot[g][1]; mc[2] = slot[g][2]; mc[3] = slot[g][3]; }
+        else { const double* src = hcam_of(c, b, s, f - k) + 4 * (size_t)tr[k - 1]; mc[0] = src[0]; mc[1] = src[1]; mc[2] = src[2]; mc[3] = src[3]; }
+        const double* W;
+        double rtr_far[9];
+        const double* RtR;
+        if (k < VS_LM_NP) { W = lc->w2c[k]; RtR = lc->rtr[k]; }
+        else {
+          W = hpose_of(c, b, s, f - k) + 12;
+          for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) rtr_far[3 * r + cc] = (W[r] * W[cc] + W[4 + r] * W[4 + cc]) + W[8 + r] * W[8 + cc];
+          RtR = rtr_far;
+        }
+        double sp[3];
+        tf_apply(W, wv, sp);
+        if (sp[2] <= 0) { t.kind = 0; }
+        else {
+          const double e[3] = {sp[0] - mc[0], sp[1] - mc[1], sp[2] - mc[2]};
+          double om = mc[3];
+          t.e2 = om * ((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]);
+          t.kind = 1;
+          if (t.e2 > kern) { om *= kern / t.e2; t.kind = 2; }
+          t.h[0] = om * RtR[0]; t.h[1] = om * RtR[1]; t.h[2] = om * RtR[2]; t.h[3] = om * RtR[4]; t.h[4] = om * RtR[5]; t.h[5] = om * RtR[8];
+          for (int r = 0; r < 3; ++r) t.b[r] = om * ((W[r] * e[0] + W[4 + r] * e[1]) + W[8 + r] * e[2]);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();     // the previous batch's terms have been read by every lane of the team
+      terms[gl] = t;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int nb_ = min(VS_LM_TEAM_G, n_direct - k0);
+#pragma unroll
+      for (int u = 0; u < VS_LM_TEAM_G; ++u) {
+        if (u < nb_) {
+          const LmTerm q = terms[u];
+          if (q.kind == 0) { ++n_out; }
+          else {
+            err += q.e2;
+            if (q.kind == 2) ++n_out;
+            H[0] += q.h[0]; H[4] += q.h[3]; H[8] += q.h[5];
+            { const double h01 = q.h[1], h02 = q.h[2], h12 = q.h[4]; H[1] += h01; H[3] += h01; H[2] += h02; H[6] += h02; H[5] += h12; H[7] += h12; }
+            bv[0] += q.b[0]; bv[1] += q.b[1]; bv[2] += q.b[2];
+          }
+        }
+      }
+    }
+    if (!ended) {
+      // beyond the trail: the serial loop of landmark_point_t, on every lane of the team alike
+      int ff = ffc, ii = iic;
+      for (int k = n_direct; k < len; ++k) {
+        const double* W = hpose_of(c, b, s, ff) + 12;
+        const double* mc = hcam_of(c, b, s, ff) + 4 * (size_t)ii;
+        double sp[3];
+        tf_apply(W, wv, sp);
+        if (sp[2] <= 0) {
+          ++n_out;
+        } else {
+          const double e[3] = {sp[0] - mc[0], sp[1] - mc[1], sp[2] - mc[2]};
+          double om = mc[3];
+          const double e2 = om * ((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]);
+          err += e2;
+          if (e2 > kern) { om *= kern / e2; ++n_out; }
+          for (int r = 0; r < 3; ++r)
+            for (int cc = 0; cc < 3; ++cc) H[3 * r + cc] += om * ((W[r] * W[cc] + W[4 + r] * W[4 + cc]) + W[8 + r] * W[8 + cc]);
+          for (int r = 0; r < 3; ++r) bv[r] += om * ((W[r] * e[0] + W[4 + r] * e[1]) + W[8 + r] * e[2]);
+        }
+        ii = hprev_of(c, b, s, ff)[ii];
+        --ff;
+        if (ii < 0) break;
+      }
+    }
+    double nb[3] = {-bv[0], -bv[1], -bv[2]}, dx[3];
+    full_piv_solve_regs<3>(H, nb, dx);
+    for (int q = 0; q < 3; ++q) wv[q] += dx[q];
+    if (fabs(err - err_prev) < 1e-5 || it == 999) {
+      const int n_in = len - n_out;
+      if (n_in > lmup0) {
+        for (int q = 0; q < 3; ++q) wpos[q] = wv[q];
+        if (gl == 0) m[M_LMUP] = n_in;
+      } else if (n_in < n_out) {
+        double acc[3] = {0, 0, 0};
+        int f2 = f, i2 = i;
+        for (int k = 0; k < len; ++k) {
+          double wp[3];
+          tf_apply(hpose_of(c, b, s, f2), hcam_of(c, b, s, f2) + 4 * (size_t)i2, wp);
+          for (int q = 0; q < 3; ++q) acc[q] += wp[q];
+          i2 = hprev_of(c, b, s, f2)[i2];
+          --f2;
+          if (i2 < 0) break;
+        }
+        for (int q = 0; q < 3; ++q) wpos[q] = acc[q] / (double)len;
+      }
+      break;
+    }
+    err_prev = err;
+  }
+  if (gl == 0) {
+    for (int q = 0; q < 3; ++q) cv.lm[3 * (size_t)i + q] = wpos[q];
+    tf_apply(w2c_cur, wpos, cv.camlm + 3 * (size_t)i);
+  }
+  return true;
+}
+
 // Besides the history ring (camera coordinates and `prev` link of every point of frame f), every point gets its trail: the
 // indices of its track's points in frames f-1 .. f-VS_TRAIL (its predecessor, then the predecessor's own trail shifted by one;
 // 0xFFFF where the track starts before that).  The landmark refinement then addresses its measurements directly instead of
@@ -1530,24 +1715,52 @@ __global__ VS_FRAME_BOUNDS void k_frame(ConstDevCfg* cp, ConstDevBuf* bp, int ph
     lm_stage_rtr(lc, f, c.HCAP, VS_WG);
     // The points that carry a landmark (track long enough: creation or refinement) are compacted into a work list first: ~40 % of
     // the frame's points, one per thread in a single round instead of two half-empty ones (a thread's refinement is a serial chain).
+#if VS_LM_TEAMS
+    static_assert(sizeof(LmCache) + VS_LM_TEAM_LDS + 4096 <= VS_ARENA, "landmark cache + team terms must leave room for the work lists");
+    constexpr int LIST_CAP = (VS_ARENA - (int)sizeof(LmCache) - VS_LM_TEAM_LDS) / 2;
+    LmTerm* team_terms = reinterpret_cast<LmTerm*>(arena + VS_ARENA - VS_LM_TEAM_LDS);
+#else
     constexpr int LIST_CAP = (VS_ARENA - (int)sizeof(LmCache)) / 2;
+#endif
     uint16_t* work = reinterpret_cast<uint16_t*>(arena + sizeof(LmCache));
     const bool listed = sh.n_cur <= LIST_CAP && sh.n_cur <= 65535;
-    if (tid == 0) sh.flag = 0;
+    if (tid == 0) { sh.flag = 0; sh.n_proj = 0; }       // n_proj (recovery is over): the count of long tracks
     __syncthreads();
     if (listed) {
+      // short tracks (one lane each) from the front of the list, long ones (a team of eight lanes each) from its end
       for (int i0 = 0; i0 < sh.n_cur; i0 += VS_WG) {
         const int i = i0 + tid;
-        const bool need = i < sh.n_cur && cvu.meta[(size_t)i * META + M_TLEN] >= c.c.minimum_track_length_for_landmark_creation;
-        const unsigned long long m = __ballot(need);
-        int base = 0;
+        const int32_t* mi = cvu.meta + (size_t)min(i, sh.n_cur - 1) * META;
+        const bool need = i < sh.n_cur && mi[M_TLEN] >= c.c.minimum_track_length_for_landmark_creation;
+#if VS_LM_TEAMS
+        const bool lng = need && landmark_is_long(c, mi);
+#else
+        const bool lng = false;
+#endif
+        const unsigned long long m = __ballot(need && !lng), ml = __ballot(lng);
+        int base = 0, basel = 0;
         if ((tid & 63) == 0 && m) base = atomicAdd(&sh.flag, __popcll(m));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (need) work[base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)i;
+        if ((tid & 63) == 0 && ml) basel = atomicAdd(&sh.n_proj, __popcll(ml));
+        base = __builtin_amdgcn_readfirstlane(base); basel = __builtin_amdgcn_readfirstlane(basel);
+        if (need && !lng) work[base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)i;
+        if (lng) work[LIST_CAP - 1 - (basel + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ml >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ml, 0u)))] = (uint16_t)i;
       }
       __syncthreads();
       const int n_work = sh.flag;
+#if VS_LM_TEAMS
+      const int n_long = sh.n_proj;
+      const int team_waves = min(VS_LM_TEAM_WAVES, (n_long + 64 / VS_LM_TEAM_G - 1) / (64 / VS_LM_TEAM_G));
+      const int wv_ = tid >> 6;
+      if (wv_ < team_waves) {
+        const int team = tid / VS_LM_TEAM_G, gl = tid % VS_LM_TEAM_G;
+        for (int q = team; q < n_long; q += team_waves * (64 / VS_LM_TEAM_G))
+          active += (landmark_team(c, b, s, cvu, f, work[LIST_CAP - 1 - q], lc, team_terms + team * VS_LM_TEAM_G, gl) && gl == 0) ? 1 : 0;
+      } else {
+        for (int q = tid - 64 * team_waves; q < n_work; q += VS_WG - 64 * team_waves) active += landmark_point_t<true>(c, b, s, cvu, f, work[q], lc) ? 1 : 0;
+      }
+#else
       for (int q = tid; q < n_work; q += VS_WG) active += landmark_point_t<true>(c, b, s, cvu, f, work[q], lc) ? 1 : 0;
+#endif
     } else {
       for (int i = tid; i < sh.n_cur; i += VS_WG) active += landmark_point_t<true>(c, b, s, cvu, f, i, lc) ? 1 : 0;
     }
