@@ -434,7 +434,7 @@ class Bench(object):
         my_len = [lengths[i] for i in mine] + [0] * (B - len(mine))
         total_steps = max(load) if max(len(r) for r in ranks) == 1 else max(lengths)
         K = min(steps, total_steps) if steps > 0 else total_steps
-        Wm = min(max(0, warmup), 8)
+        Wm = min(max(0, warmup), 128, K)
         KB = K
         cfg.max_history_frames = min(K + Wm + 2, 512)
         api = api or hip.load()
@@ -672,10 +672,10 @@ def main():
             torch.cuda.empty_cache()
             if not args.no_exact:
                 # exact mode (whole sequence per stream, results identical to the sequential reference run)
-                one, api1, _ = b.run_sequences([0], args.exact_frames, 2, label="KITTI-00-shaped alone: ONE stream, the literal drop-in")
+                one, api1, _ = b.run_sequences([0], args.exact_frames, 100, label="KITTI-00-shaped alone: ONE stream, the literal drop-in")
                 api1.destroy()
                 torch.cuda.empty_cache()
-                allseq, api2, _ = b.run_sequences(list(range(11)), args.exact_frames, 2, label="KITTI 00-10 lengths as 11 streams")
+                allseq, api2, _ = b.run_sequences(list(range(11)), args.exact_frames, 100, label="KITTI 00-10 lengths as 11 streams")
                 api2.destroy()
                 out["exact_mode"] = {"single_sequence": one, "eleven_sequences": allseq}
                 if "cpu_baseline" in out:
