@@ -52,6 +52,15 @@ def test_run_kitti_folder_end_to_end(tmp_path):
     run_kitti.run(str(seq), out_tum, "tum", log=lambda *_: None, max_frames=5)
     rows = [ln.split() for ln in open(out_tum).read().splitlines()]
     assert len(rows) == 5 and all(len(r) == 8 for r in rows)
+    # frame-sharded mode on the same folder: 3 chunks with 3 warm-up frames side by side, chained at the seams; every frame gets a
+    # pose, the first chunk is the sequential run itself, and the whole trajectory stays close to it (approximate at the seams)
+    out_ch = str(tmp_path / "traj_chunks.txt")
+    rc = run_kitti.run(str(seq), out_ch, "kitti", str(tmp_path / "gt.txt"), log=lambda *_: None, chunks=3, overlap=3)
+    assert rc["frames"] == n and rc["error_flags"] == 0
+    ch = io.read_trajectory_kitti(out_ch).reshape(n, 12)
+    assert np.abs(ch[:6] - ref[:6]).max() < 1e-6      # chunk 0 = frames 0 .. 5, no seam before it
+    assert np.abs(ch.reshape(n, 3, 4)[:, :, 3] - ref.reshape(n, 3, 4)[:, :, 3]).max() < 0.25
+    assert rc["ate_rmse_aligned"] < 0.5
 
 
 @pytest.mark.gpu
