@@ -334,7 +334,7 @@ class Bench(object):
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "frames_processed": int(frames), "unique_frames_timed": int(unique), "raw_pairs_per_s": round(frames / elapsed, 1),
             "config": {"workload": what + "chunks as a steady-state pipeline (streams staggered over the %d-step chunk job, restart when a chunk ends)" % J,
-                       "mode": "chunks", "streams_per_gpu": B, "chunk_frames": L, "chunk_overlap": overlap, "chunk_job_steps": J,
+                       "mode": "chunks", "streams_per_gpu": B, "chunk_frames": L, "chunk_overlap": overlap, "chunk_overlap_note": "warm-up frames per chunk; SURVEY.md 8e proposed 10 without data, the 48-seed ATE study (profiles/r03_ate_noise_overlaps48.json) finds 2 .. 10 equivalent; the same command at 2 / 4 / 6 / 10: profiles/r03_bench_overlap_sweep.json", "chunk_job_steps": J,
                        "preroll_steps": preroll, "frames_per_step": int(frames // K),
                        "unique_frame_fraction": round(unique / frames, 4),
                        "parallelism": "frame-sharded chunks, %d per GPU x %d GPU (%s scaling)" % (B, world, a.scaling),
