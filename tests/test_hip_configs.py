@@ -244,6 +244,9 @@ def _long_run(lengths, seeds, speeds, full_every):
                         stats["tracked"] += fg.n_tracked; stats["recovered"] += fg.n_recovered; stats["tracking_frames"] += fg.status == 1
                         if k % full_every == full_every - 1 or k == lengths[s] - 1:
                             compare_frame(o, g, s, k, "long run")
+                            tl = g.points(s)["meta"][:, 3]            # track lengths: which refinement paths the run exercised
+                            stats["longest_track"] = max(stats.get("longest_track", 0), int(tl.max()) if len(tl) else 0)
+                            stats["tracks_of_9_or_more"] = stats.get("tracks_of_9_or_more", 0) + int((tl >= 8).sum())
         assert worst <= 1e-4, worst                         # north_star: pose within 1e-4 relative Frobenius, over the whole run
         for s in range(n_streams):
             pg, po = g.poses(s, 0, lengths[s]), o.poses(s, 0, lengths[s])
@@ -258,6 +261,9 @@ def test_config2_one_thousand_frames_full_resolution_one_stream():
     """configs[1] (KITTI-00-shaped, bin 15, one sequence = one stream: the literal drop-in) over 1000 frames at 1241 x 376."""
     worst, stats = _long_run([1000], [7], [0.9], full_every=125)
     assert stats["tracking_frames"] > 950 and stats["tracked"] > 150 * 1000 and stats["recovered"] > 1000, stats
+    # the landmark refinement's three ways through a track were all taken: one lane (short tracks), teams of eight lanes (nine and
+    # more measurements), and the serial remainder behind the 32-entry trail
+    assert stats["tracks_of_9_or_more"] > 50 and stats["longest_track"] > 34, stats
 
 
 def test_config2_whole_kitti00_length_full_resolution_one_stream():
