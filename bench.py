@@ -274,7 +274,7 @@ class Bench(object):
         preroll = J
         run_steps(preroll + W)
         api.synchronize()
-        pose_send = torch.zeros((K, B, 12), dtype=torch.float64, device=self.dev)
+        pose_send = torch.zeros((K, job["streams_padded"], 12), dtype=torch.float64, device=self.dev)    # same shape on every rank (a strong plan can be ragged)
         allgather(pose_send)                          # untimed: RCCL sets its all-gather channels up on first use
         self.barrier()
         torch.cuda.synchronize()
@@ -306,7 +306,7 @@ class Bench(object):
         self.run_steps, self.counter = run_steps, counter
         if rank != 0:
             return None
-        traffic, traffic_note = pmc_traffic(dom, a.streams if a.scaling == "weak" else B)
+        traffic, traffic_note = pmc_traffic(dom, B)
         achieved = abytes[dom] / dom_avg_s / 1e9
         if self.euroc:
             what = ("EuRoC-MH_01-shaped synthetic stereo (752x480, 3682 frames, 6-DoF), configuration_euroc.yaml values (2x2 FAST detectors, "
@@ -334,7 +334,7 @@ class Bench(object):
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "frames_processed": int(frames), "unique_frames_timed": int(unique), "raw_pairs_per_s": round(frames / elapsed, 1),
             "config": {"workload": what + "chunks as a steady-state pipeline (streams staggered over the %d-step chunk job, restart when a chunk ends)" % J,
-                       "mode": "chunks", "streams_per_gpu": B, "chunk_frames": L, "chunk_overlap": overlap, "chunk_overlap_note": "warm-up frames per chunk; SURVEY.md 8e proposed 10 without data, the 48-seed ATE study (profiles/r03_ate_noise_overlaps48.json) finds 2 .. 10 equivalent; the same command at 2 / 4 / 6 / 10: profiles/r03_bench_overlap_sweep.json", "chunk_job_steps": J,
+                       "mode": "chunks", "streams_per_gpu": B, "chunks_planned": int(a.streams), "chunk_frames": L, "chunk_overlap": overlap, "chunk_overlap_note": "warm-up frames per chunk; SURVEY.md 8e proposed 10 without data, the 48-seed ATE study (profiles/r03_ate_noise_overlaps48.json) finds 2 .. 10 equivalent; the same command at 2 / 4 / 6 / 10: profiles/r03_bench_overlap_sweep.json", "chunk_job_steps": J,
                        "preroll_steps": preroll, "frames_per_step": int(frames // K),
                        "unique_frame_fraction": round(unique / frames, 4),
                        "parallelism": "frame-sharded chunks, %d per GPU x %d GPU (%s scaling)" % (B, world, a.scaling),
@@ -369,7 +369,7 @@ class Bench(object):
         for s in range(B):
             i0 = (-(k0 + job["phase"][s])) % J            # the step at which stream s starts its chunk over
             chunks.append(rec[i0:i0 + J, s].reshape(J, 3, 4))
-        traj = sharding.assemble_trajectory(chunks, job["plan"])
+        traj = sharding.assemble_trajectory(chunks, job["plan"][:B])     # (the planned chunks behind the end of the sequence are empty and were not run)
         gt = np.array([self.sy.gt_pose(self.scene, k) for k in range(total)])
         seq_api = hip.load()
         cfg.max_history_frames = 512

@@ -162,7 +162,10 @@ def test_chunk_job_accounting_single_rank():
     for total, B, ov in ((4541, 144, 10), (4541, 36, 40), (3682, 144, 10), (100, 7, 3)):
         job = sharding.chunk_job(total, B, ov)
         J = job["J"]
-        assert J == job["L"] + ov and job["n_streams"] == B and job["plan"] == sharding.plan_chunks(total, B, ov)[0]
+        live = sum(1 for (st, fi, en) in job["plan"] if en > fi)     # chunks behind the end of the sequence get no stream
+        assert J == job["L"] + ov and job["n_streams"] == live <= B and job["plan"] == sharding.plan_chunks(total, B, ov)[0]
+        assert live == -(-total // job["L"]) and job["streams_padded"] == live
+        B = live
         for k0 in (0, 5, J, 3 * J + 1):
             assert sharding.chunk_job_unique_frames(job, k0, J) == total
         # every stream restarts exactly once per J steps, at the step its chunk frame index wraps to 0
@@ -176,9 +179,9 @@ def test_chunk_job_accounting_single_rank():
         got = []
         for r in range(world):
             job = sharding.chunk_job(4541, 144, 10, r, world, "strong")
-            assert job["n_streams"] == 144 // world and job["plan"] == sharding.plan_chunks(4541, 144, 10)[0]
+            assert job["n_streams"] <= job["streams_padded"] == -(-142 // world) and job["plan"] == sharding.plan_chunks(4541, 144, 10)[0]
             got += job["chunk_ids"]
-        assert got == list(range(144))
+        assert got == list(range(142))         # 4541 frames in chunks of 32: 142 live chunks of the 144 planned
 
 
 def _bench_accounting_worker(rank, world, port, scaling, q):
@@ -194,7 +197,7 @@ def _bench_accounting_worker(rank, world, port, scaling, q):
     ok = sharding.all_ranks_ok(rank == 0)            # one rank reporting a failure makes every rank see it
     ok_all = sharding.all_ranks_ok(True)
     # the [K][B][12] per-step pose blocks come back rank-major from the single all-gather
-    send = torch.full((K, job["n_streams"], 12), float(rank), dtype=torch.float64)
+    send = torch.full((K, job["streams_padded"], 12), float(rank), dtype=torch.float64)
     allp = sharding.gather_poses(send)
     q.put((rank, t.tolist(), ok, ok_all, tuple(allp.shape), float(allp[K:].mean()) if world > 1 else 0.0))
     dist.destroy_process_group()
@@ -217,9 +220,9 @@ def test_bench_accounting_two_ranks_gloo(scaling):
         assert p.exitcode == 0
     for rank, (unique, frames), ok, ok_all, shape, mean_other in res:
         if scaling == "weak":
-            assert unique == 2 * 4541 and frames == 2 * 144 * 42 and shape == (2 * 42, 144, 12)
+            assert unique == 2 * 4541 and frames == 2 * 142 * 42 and shape == (2 * 42, 142, 12)      # 142 live chunks of the 144 planned
         else:
-            assert unique == 4541 and frames == 144 * 42 and shape == (2 * 42, 72, 12)
+            assert unique == 4541 and frames == 142 * 42 and shape == (2 * 42, 71, 12)
         assert ok is False and ok_all is True
         assert mean_other == 1.0
 

@@ -31,21 +31,27 @@ def chunk_job(seq_frames, streams, overlap, rank=0, world=1, scaling="weak"):
            `streams` chunks: per-GPU work is fixed.
     strong ONE `seq_frames`-frame sequence: the plan of `streams` chunks is the single-GPU plan and rank r runs chunks
            r*streams/world .. (r+1)*streams/world - 1 of it (the assembled trajectory does not depend on the GPU count).
+    Chunks that lie behind the end of the sequence (ceil effects) are dropped: n_streams can be smaller than `streams`.
     Stream s is `phase[s]` frames into its chunk when the pipeline starts and restarts whenever its chunk job of J = L + overlap
     steps ends.  Returns a dict: L, J, n_streams (of this rank), chunk_ids (global chunk of every local stream), plan (the
-    global (start, first_unique, end) list), starts / first_unique / end_unique / phase per local stream."""
+    global (start, first_unique, end) list), starts / first_unique / end_unique / phase per local stream, streams_padded (the largest
+    n_streams over the ranks: the row length of the pose blocks the ranks all-gather)."""
     if scaling not in ("weak", "strong"):
         raise ValueError("scaling must be weak or strong")
     n_chunks = int(streams)
     plan, L = plan_chunks(seq_frames, n_chunks, overlap)
+    # chunks behind the end of the sequence are empty (4541 frames in 160 chunks of 29: chunks 157 .. 159) and get no stream: the
+    # plan, and with it the assembled trajectory, is the one of `streams` chunks; only the live ones are run
+    n_live = min(n_chunks, -(-int(seq_frames) // L))
     if scaling == "weak":
-        ids = list(range(n_chunks))
+        ids = list(range(n_live))
+        per = n_live
     else:
-        per = -(-n_chunks // world)
-        ids = list(range(rank * per, min((rank + 1) * per, n_chunks)))
+        per = -(-n_live // world)
+        ids = list(range(rank * per, min((rank + 1) * per, n_live)))
     J = L + overlap
     B = len(ids)
-    job = {"L": L, "J": J, "n_streams": B, "chunk_ids": ids, "plan": plan, "scaling": scaling, "seq_frames": seq_frames,
+    job = {"L": L, "J": J, "n_streams": B, "streams_padded": per, "chunk_ids": ids, "plan": plan, "scaling": scaling, "seq_frames": seq_frames,
            "starts": [], "first_unique": [], "end_unique": [], "phase": []}
     for s, c in enumerate(ids):
         job["starts"].append(max(0, c * L - overlap))         # every chunk job is J steps long: the same pipeline period for all
