@@ -182,6 +182,10 @@ def test_chunk_job_accounting_single_rank():
             assert job["n_streams"] <= job["streams_padded"] == -(-142 // world) and job["plan"] == sharding.plan_chunks(4541, 144, 10)[0]
             got += job["chunk_ids"]
         assert got == list(range(142))         # 4541 frames in chunks of 32: 142 live chunks of the 144 planned
+    # a ragged strong plan (157 live chunks on 8 ranks: 7 x 20 + 17): every rank sends pose blocks of the same row length
+    jobs = [sharding.chunk_job(4541, 160, 6, r, 8, "strong") for r in range(8)]
+    assert [j["n_streams"] for j in jobs] == [20] * 7 + [17] and all(j["streams_padded"] == 20 for j in jobs)
+    assert sum(sharding.chunk_job_unique_frames(j, 3, j["J"]) for j in jobs) == 4541
 
 
 def _bench_accounting_worker(rank, world, port, scaling, q):
