@@ -28,6 +28,47 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (0 = one whole chunk job / whole sequences)")
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mode", choices=["chunks", "sequences"], default="chunks")
+    ap.add_argument("--sequences", default="", help="--mode sequences: comma-separated KITTI sequence numbers")
+    ap.add_argument("--bin", type=int, default=15, help="bin_size_pixels (15: ~2158 kp/image, 22: ~1026, 11: ~3955)")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("VSLAM_BENCH_STREAMS", "160")))
+    ap.add_argument("--scene", choices=["kitti", "euroc"], default="kitti", help="euroc: MH_01-shaped 752x480 scene with configuration_euroc.yaml values (not the headline workload)")
+    ap.add_argument("--contrast", type=float, default=0.0, help="texture contrast of the synthetic scene (0 = the scene's default 1.0; 2.0: ~60 %% more corners, stereo points and tracks per frame: with --speed 0.3 --bin 11 a workload of the size SURVEY.md 8(d) assumed; not the headline)")
+    ap.add_argument("--speed", type=float, default=0.0, help="camera speed of the synthetic scene in m/frame (0 = the scene's default 0.9; slower = more of the points tracked)")
+    ap.add_argument("--overlap", type=int, default=6, help="warm-up frames per chunk.  SURVEY.md 8e proposed 10 without data; measured (48 sensor-noise seeds each, profiles/r03_ate_noise_overlaps48.json + r03_ate_noise_seeds48.json): 2, 3, 4, 5, 6, 8 and 10 all lie inside the sequential run's own ATE spread (|Welch t| <= 1.3), so the default is three times the two frames a chunk needs before its poses are aligned against landmarks")
+    ap.add_argument("--cpu-frames", type=int, default=240)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU leg (0 = min(nproc, 16): the box's CPU share)")
+    ap.add_argument("--exact-frames", type=int, default=1200, help="frames per sequence of the exact-mode legs (0 = whole sequences)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="chunks at N > 1: weak = one KITTI-00-shaped sequence per GPU (per-GPU work fixed); strong = the ONE sequence's chunk plan spread over the GPUs")
+    ap.add_argument("--no-ate", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-exact", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true")
+    ap.add_argument("--no-shim", action="store_true")
+    ap.add_argument("--only-shim", action="store_true", help="print the shim_path block alone (one JSON line) and stop")
+    return ap.parse_args(argv)
+
+
+def self_launch():
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset) and N > 1: start N ranks of this script, one per
+    GPU, and relay rank 0's JSON line.  Runs BEFORE torch / libvslam_hip.so are imported: the parent never touches the GPU.  Under a
+    launcher, WORLD_SIZE must equal --gpus (exit 2 otherwise)."""
+    from vslam_pose_estimation_framework_amd import launch       # standard library only
+    args = parse_args()
+    if launch.check_world(args.gpus) is None and args.gpus > 1:
+        sys.exit(launch.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    return args
+
+
+ARGS = self_launch() if __name__ == "__main__" else None
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -139,6 +180,9 @@ class Bench(object):
         # one rank per GPU (RCCL).  VSLAM_BENCH_BACKEND=gloo is a rehearsal aid only: several ranks on the one GPU of a
         # test box, same code path, the single all-gather staged through the host
         self.backend = os.environ.get("VSLAM_BENCH_BACKEND", "nccl")
+        if self.backend == "nccl" and self.world > torch.cuda.device_count():
+            raise SystemExit("bench.py: %d ranks on RCCL need %d GPUs, this node shows %d (one process per GPU; VSLAM_BENCH_BACKEND=gloo "
+                             "rehearses several ranks on one card)" % (self.world, self.world, torch.cuda.device_count()))
         self.dev_index = local_rank if self.backend == "nccl" else local_rank % torch.cuda.device_count()
         torch.cuda.set_device(self.dev_index)
         self.dev = torch.device("cuda", self.dev_index)
@@ -192,19 +236,18 @@ class Bench(object):
 
     # ------------------------------------------------------------------------------------------------------------------
     def open_pose_comm(self):
-        """N > 1 on RCCL with VSLAM_BENCH_C_ABI_COMM=1: the pose all-gather of the timed region goes through the C ABI (vslam_comm_init /
-        vslam_allgather_poses, RCCL called by libvslam_hip.so itself — what a C++ caller uses); by default torch.distributed (RCCL as
-        well) carries it.  The communicator is formed BEFORE anything is timed, under a
-        watchdog: a communicator that HANGS while forming, or whose result differs from torch.distributed's, ends the run non-zero with
-        the reason on stderr (no JSON line); one that reports an error falls back to torch.distributed on all ranks together."""
+        """N > 1 on RCCL: the pose all-gather of the timed region goes through the C ABI (vslam_comm_init / vslam_allgather_poses, RCCL
+        called by libvslam_hip.so itself — what a C++ caller uses).  The communicator is formed BEFORE anything is timed, in a worker
+        thread under a time limit, and its result on a probe block is compared with torch.distributed's.  Whatever goes wrong on any
+        rank (librccl.so not loadable, ncclCommInitRank refused, no communicator inside the limit, a result that differs), the ranks
+        agree over torch.distributed and ALL of them let torch.distributed (RCCL as well) carry the timed all-gather; the JSON line
+        and stderr say which path ran and why.  VSLAM_BENCH_C_ABI_COMM=0 skips the attempt."""
         if self.world == 1:
             return None, "not used (one GPU)"
         if self.backend != "nccl":
             return None, "torch.distributed %s (rehearsal backend)" % self.backend
-        if os.environ.get("VSLAM_BENCH_C_ABI_COMM", "0") != "1":
-            # opt-in: this pipeline's GPU boxes have ONE card, so a communicator of vslam_comm_* with more than one rank has never
-            # formed on hardware; a path that has never run must not be able to end the measurement (its hang = exit 3, no JSON line)
-            return None, "torch.distributed nccl (RCCL); the C-ABI all-gather (vslam_allgather_poses) is opt-in: VSLAM_BENCH_C_ABI_COMM=1"
+        if os.environ.get("VSLAM_BENCH_C_ABI_COMM", "1") == "0":
+            return None, "torch.distributed nccl (RCCL); the C-ABI all-gather was switched off: VSLAM_BENCH_C_ABI_COMM=0"
         box = {}
 
         def form():
@@ -212,29 +255,24 @@ class Bench(object):
                 torch.cuda.set_device(self.dev_index)
                 comm = sharding.PoseComm(self.api, self.rank, self.world, self.dev_index)
                 probe = torch.arange(2 * 3 * 12, dtype=torch.float64, device=self.dev).reshape(2, 3, 12) + 1000.0 * self.rank
-                got, ref = comm.allgather(probe), sharding.gather_poses(probe)
+                got = comm.allgather(probe)
+                want = torch.cat([probe - 1000.0 * self.rank + 1000.0 * r for r in range(self.world)])     # rank-major blocks
                 box["comm"] = comm
-                box["r"] = "identical to torch.distributed" if torch.equal(got, ref) else "MISMATCH against torch.distributed"
+                box["r"] = "ok" if torch.equal(got, want) else "MISMATCH against the expected rank-major blocks"
             except Exception as e:
                 box["r"] = "failed: %s" % str(e)[:300]
         th = threading.Thread(target=form, daemon=True)
         th.start()
-        th.join(timeout=float(os.environ.get("VSLAM_BENCH_COMM_TIMEOUT", "120")))
-        verdict = box.get("r", "timeout: the RCCL communicator did not form")
-        if verdict.startswith("timeout") or verdict.startswith("MISMATCH"):
-            sys.stderr.write("bench.py rank %d: C-ABI pose all-gather (vslam_comm_*): %s\n" % (self.rank, verdict))
-            sys.stderr.flush()
-            os._exit(3)      # a hung communicator cannot be joined, a wrong one cannot be trusted: leave at once, non-zero, nothing on stdout
-        # an ERROR (librccl.so not loadable, no unique id, ncclCommInitRank refused: PoseComm raises on every rank together) is not a hang:
-        # the ranks agree, and if any of them has no communicator the timed all-gather goes through torch.distributed (RCCL as well) — said
-        # in the JSON line and on stderr
-        have = verdict == "identical to torch.distributed"
+        th.join(timeout=float(os.environ.get("VSLAM_BENCH_COMM_TIMEOUT", "90")))
+        verdict = box.get("r", "timeout: the RCCL communicator did not form inside the limit (the worker thread is abandoned)")
+        have = verdict == "ok"
         if sharding.all_ranks_ok(have):
-            return box["comm"], "C ABI (vslam_allgather_poses, RCCL inside libvslam_hip.so), verified against torch.distributed"
+            return box["comm"], "C ABI (vslam_allgather_poses: RCCL called by libvslam_hip.so), probe block verified"
         if have:
             box["comm"].destroy()
-        sys.stderr.write("bench.py rank %d: C-ABI pose all-gather unavailable (%s): torch.distributed carries the all-gather\n" % (self.rank, verdict))
-        return None, "torch.distributed nccl (C-ABI communicator unavailable on some rank: %s)" % verdict[:160]
+        sys.stderr.write("bench.py rank %d: C-ABI pose all-gather not used (%s): torch.distributed carries the all-gather\n" % (self.rank, verdict))
+        sys.stderr.flush()
+        return None, "torch.distributed nccl (RCCL); C-ABI communicator unavailable on some rank, this rank: %s" % verdict[:160]
 
     def run_chunks(self):
         a, api, cfg = self.args, self.api, self.cfg
@@ -546,6 +584,40 @@ class Bench(object):
                 "note": "pinned host images, one hipMemcpyAsync per side and step; PCIe-bound, never `value`"}
 
     # ------------------------------------------------------------------------------------------------------------------
+    def shim_leg(self, frames=320, warmup=20):
+        """The real drop-in path: shim/proslam_hip_plugin.h's HipStereoFramePointGenerator / HipStereoUVAligner driven
+        as PoseTracker3D::compute drives its plug-ins (initialize -> track -> aligner -> prune / recoverPoints -> compute), one
+        stream, HOST images (cv::Mat of the Frame), host objects materialised — tests/cpp/bench_shim.cpp, a separate C++ process
+        built against the declaration stubs.  Never `value`."""
+        cfg = self.cfg
+        exe = os.path.join(ROOT, "tests", "cpp", "bench_shim")
+        if not os.path.exists(exe):
+            subprocess.check_call(["make", "-C", os.path.dirname(exe), "-s", "bench_shim"])
+        n = frames + warmup
+        Ls = torch.empty((n, 1, cfg.rows, self.stride), dtype=torch.uint8, device=self.dev)
+        Rs = torch.empty_like(Ls)
+        self.render(self.scene, 0, n, Ls, Rs, 0, 1)
+        torch.cuda.synchronize()
+        both = torch.stack([Ls[:, 0, :, :cfg.cols], Rs[:, 0, :, :cfg.cols]], dim=1).contiguous().cpu().numpy()      # [n][2][rows][cols], dense rows like a cv::Mat
+        del Ls, Rs
+        import tempfile
+        with tempfile.NamedTemporaryFile(prefix="vslam_shim_", suffix=".bin", dir=os.environ.get("TMPDIR", "/tmp"), delete=False) as fh:
+            both.tofile(fh)
+            path = fh.name
+        try:
+            p = subprocess.run([exe, path, str(cfg.rows), str(cfg.cols), str(cfg.cols), str(n), str(cfg.bin_size_pixels), str(warmup)],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
+        finally:
+            os.unlink(path)
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        if p.returncode != 0 or not lines:
+            return {"error": "bench_shim rc %d: %s" % (p.returncode, (p.stderr or p.stdout)[-300:])}
+        out = json.loads(lines[-1])
+        out["what"] = ("shim/proslam_hip_plugin.h driven like PoseTracker3D::compute (tests/cpp/bench_shim.cpp, stubs of the reference headers), ONE stream, "
+                       "host images %dx%d, bin %d, host objects materialised; the fused figure beside it is vslam_process_host on the same images" % (cfg.cols, cfg.rows, cfg.bin_size_pixels))
+        return out
+
+    # ------------------------------------------------------------------------------------------------------------------
     def cpu_leg(self):
         """The oracle (a port of the reference path) on bounded samples of the same images, on this host's cores."""
         a, cfg, B, J = self.args, self.cfg, self.B, self.J
@@ -632,29 +704,11 @@ class Bench(object):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=0, help="timed steps (0 = one whole chunk job / whole sequences)")
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--mode", choices=["chunks", "sequences"], default="chunks")
-    ap.add_argument("--sequences", default="", help="--mode sequences: comma-separated KITTI sequence numbers")
-    ap.add_argument("--bin", type=int, default=15, help="bin_size_pixels (15: ~2158 kp/image, 22: ~1026, 11: ~3955)")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("VSLAM_BENCH_STREAMS", "160")))
-    ap.add_argument("--scene", choices=["kitti", "euroc"], default="kitti", help="euroc: MH_01-shaped 752x480 scene with configuration_euroc.yaml values (not the headline workload)")
-    ap.add_argument("--contrast", type=float, default=0.0, help="texture contrast of the synthetic scene (0 = the scene's default 1.0; 2.0: ~60 %% more corners, stereo points and tracks per frame: with --speed 0.3 --bin 11 a workload of the size SURVEY.md 8(d) assumed; not the headline)")
-    ap.add_argument("--speed", type=float, default=0.0, help="camera speed of the synthetic scene in m/frame (0 = the scene's default 0.9; slower = more of the points tracked)")
-    ap.add_argument("--overlap", type=int, default=6, help="warm-up frames per chunk.  SURVEY.md 8e proposed 10 without data; measured (48 sensor-noise seeds each, profiles/r03_ate_noise_overlaps48.json + r03_ate_noise_seeds48.json): 2, 3, 4, 5, 6, 8 and 10 all lie inside the sequential run's own ATE spread (|Welch t| <= 1.3), so the default is three times the two frames a chunk needs before its poses are aligned against landmarks")
-    ap.add_argument("--cpu-frames", type=int, default=240)
-    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU leg (0 = min(nproc, 16): the box's CPU share)")
-    ap.add_argument("--exact-frames", type=int, default=1200, help="frames per sequence of the exact-mode legs (0 = whole sequences)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="chunks at N > 1: weak = one KITTI-00-shaped sequence per GPU (per-GPU work fixed); strong = the ONE sequence's chunk plan spread over the GPUs")
-    ap.add_argument("--no-ate", action="store_true")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-exact", action="store_true")
-    ap.add_argument("--no-pcie", action="store_true")
-    args = ap.parse_args()
+    args = ARGS if ARGS is not None else parse_args()
     b = Bench(args)
+    if args.only_shim:
+        print(json.dumps(b.shim_leg()), flush=True)
+        return
     if args.mode == "sequences":
         out = b.main_sequences()
     else:
@@ -664,6 +718,8 @@ def main():
                 out["ate"] = b.ate_leg()
             if not args.no_pcie:
                 out["pcie_inclusive"] = b.pcie_leg()
+            if not args.no_shim and not b.euroc:
+                out["shim_path"] = b.shim_leg()
             if not args.no_cpu:
                 out["cpu_baseline"] = b.cpu_leg()
                 out["speedup_vs_cpu_port"] = round(out["value"] / out["cpu_baseline"]["value"], 1)

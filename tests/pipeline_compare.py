@@ -12,25 +12,33 @@ INT_FIELDS = ["frame_index", "status", "status_at_start", "n_keypoints_left", "n
               "track_broken", "fallback", "window_pixels", "error_flags"]
 
 
-def compare_frame(o, g, s, k, tag=""):
-    fo, fg = o.frame_info(s), g.frame_info(s)
+def compare_frame(o, g, s, k, tag="", sg=None, identical=False):
+    """Stream s of the checker `o` against stream sg (default: s) of `g` after the same frame.  identical: `o` is another HIP
+    context that ran the same images (one stream alone, say): every float must then be equal bit for bit as well."""
+    sg = s if sg is None else sg
+    s_o = s
+    fo, fg = o.frame_info(s_o), g.frame_info(sg)
     for name in INT_FIELDS:
         assert getattr(fo, name) == getattr(fg, name), "%s frame %d stream %d: %s oracle=%s hip=%s" % (
             tag, k, s, name, getattr(fo, name), getattr(fg, name))
     assert list(fo.thresholds) == list(fg.thresholds)
     assert fo.tau_track == fg.tau_track and fo.tau_triangulation == fg.tau_triangulation
     for side in (0, 1):
-        xo, so, do = o.keypoints(s, side)
-        xg, sg, dg = g.keypoints(s, side)
+        xo, sco, do = o.keypoints(s_o, side)
+        xg, scg, dg = g.keypoints(sg, side)
         # oracle order is detector-region-major, the device order is image row-major: same for 1x1 grids
         io = np.lexsort((xo[:, 0], xo[:, 1]))
         ig = np.lexsort((xg[:, 0], xg[:, 1]))
         np.testing.assert_array_equal(xo[io], xg[ig])
-        np.testing.assert_array_equal(so[io], sg[ig])
+        np.testing.assert_array_equal(sco[io], scg[ig])
         np.testing.assert_array_equal(do[io], dg[ig])
-    po, pg = o.points(s), g.points(s)
+    po, pg = o.points(s_o), g.points(sg)
     np.testing.assert_array_equal(po["kp"], pg["kp"])
     np.testing.assert_array_equal(po["meta"], pg["meta"])
+    if identical:
+        np.testing.assert_array_equal(pg["cam"], po["cam"])
+        np.testing.assert_array_equal(pg["lm"], po["lm"])
+        assert list(fo.camera_left_to_world) == list(fg.camera_left_to_world) and list(fo.previous_to_current) == list(fg.previous_to_current)
     np.testing.assert_allclose(pg["cam"], po["cam"], rtol=1e-13, atol=0)
     np.testing.assert_allclose(pg["lm"], po["lm"], rtol=1e-6, atol=1e-6)
     To = np.array(fo.camera_left_to_world).reshape(3, 4)
@@ -40,11 +48,14 @@ def compare_frame(o, g, s, k, tag=""):
     Pg = np.array(fg.previous_to_current).reshape(3, 4)
     assert np.linalg.norm(Pg - Po) / np.linalg.norm(Po) <= POSE_RTOL
     if fo.aligner_ran:
-        ao, ag = o.aligner_result(s), g.aligner_result(s)
+        ao, ag = o.aligner_result(s_o), g.aligner_result(sg)
         np.testing.assert_array_equal(ao["inlier"], ag["inlier"])
         np.testing.assert_allclose(ag["chi"], ao["chi"], rtol=1e-6, atol=1e-6)
+        if identical:
+            np.testing.assert_array_equal(ag["chi"], ao["chi"])
+            np.testing.assert_array_equal(ag["H"], ao["H"])
         assert fo.aligner_iterations == fg.aligner_iterations
-    np.testing.assert_array_equal(o.aligner_weights_of(s), g.aligner_weights_of(s))   # persistent _weights_translation
+    np.testing.assert_array_equal(o.aligner_weights_of(s_o), g.aligner_weights_of(sg))   # persistent _weights_translation
 
 
 def create_hip(cfg, n_streams, split=None):

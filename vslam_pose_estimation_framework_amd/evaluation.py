@@ -192,3 +192,83 @@ def trajectory_analyzer(tum_path, asl_path, skip=0):
     T, log = align_robust_icp(meas, ref)
     moved = meas @ T[:3, :3].T + T[:3, 3]
     return {"correspondences": len(meas), "raw_rmse": raw, "optimal_rmse": rmse(moved, ref), "transform": T, "iterations": log}
+
+
+# ---- relative errors: metrics that resolve a seam ------------------------------------------------------------------------------
+# ATE of open-loop odometry is a random walk in the measurement noise (29 % run-to-run spread of the sequential
+# pipeline alone), so it cannot carry a 1 % criterion.  The KITTI odometry benchmark's own metric — translation / rotation error of
+# sub-trajectories, relative to their length — and the relative-pose error of single frame-to-frame motions do not accumulate.
+KITTI_LENGTHS_M = (100.0, 200.0, 300.0, 400.0, 500.0, 600.0, 700.0, 800.0)
+
+
+def _rotation_angle(R):
+    return float(np.arccos(max(-1.0, min(1.0, 0.5 * (np.trace(R) - 1.0)))))
+
+
+def relative_pose(poses, i, j):
+    """Motion from frame i to frame j in frame i's coordinates: inv(T_i) T_j (camera-to-world poses)."""
+    return mul34(inv34(poses[i]), poses[j])
+
+
+def kitti_relative_errors(est_poses, gt_poses, lengths=KITTI_LENGTHS_M, step=10):
+    """The KITTI odometry devkit's evaluation (evaluate_odometry.cpp calcSequenceErrors, restated from its published definition): for
+    every `step`-th first frame and every sub-trajectory length, the last frame is the first one whose ground-truth path length
+    from the first frame reaches the length; error = inv(gt motion) * estimated motion; t_err = |translation| / length,
+    r_err = rotation angle / length.  Returns {"t_rel_percent", "r_rel_deg_per_m", "segments", "per_length": {len: (t %, r deg/m, n)}}."""
+    est = np.asarray(est_poses, float).reshape(-1, 3, 4)
+    gt = np.asarray(gt_poses, float).reshape(-1, 3, 4)
+    n = min(len(est), len(gt))
+    dist = np.concatenate([[0.0], np.cumsum(np.linalg.norm(np.diff(gt[:n, :, 3], axis=0), axis=1))])
+    per = {}
+    t_all, r_all = [], []
+    for L in lengths:
+        t_l, r_l = [], []
+        for first in range(0, n, step):
+            last = int(np.searchsorted(dist, dist[first] + L, side="left"))
+            if last >= n:
+                break
+            err = mul34(inv34(relative_pose(gt, first, last)), relative_pose(est, first, last))
+            t_l.append(np.linalg.norm(err[:, 3]) / L)
+            r_l.append(_rotation_angle(err[:, :3]) / L)
+        if t_l:
+            per[float(L)] = (100.0 * float(np.mean(t_l)), float(np.degrees(np.mean(r_l))), len(t_l))
+            t_all += t_l
+            r_all += r_l
+    if not t_all:
+        return {"t_rel_percent": None, "r_rel_deg_per_m": None, "segments": 0, "per_length": {}}
+    return {"t_rel_percent": 100.0 * float(np.mean(t_all)), "r_rel_deg_per_m": float(np.degrees(np.mean(r_all))), "segments": len(t_all), "per_length": per}
+
+
+def relative_pose_errors(est_poses, ref_poses, frames, delta=1):
+    """Relative-pose error of the motions frame-delta -> frame, for the given frames: (translation errors in m, rotation errors in
+    rad) of inv(ref motion) * est motion.  `ref` is the ground truth, or another run of the same images."""
+    est = np.asarray(est_poses, float).reshape(-1, 3, 4)
+    ref = np.asarray(ref_poses, float).reshape(-1, 3, 4)
+    te, re = [], []
+    for f in frames:
+        if f - delta < 0 or f >= min(len(est), len(ref)):
+            continue
+        err = mul34(inv34(relative_pose(ref, f - delta, f)), relative_pose(est, f - delta, f))
+        te.append(np.linalg.norm(err[:, 3]))
+        re.append(_rotation_angle(err[:, :3]))
+    return np.array(te), np.array(re)
+
+
+def seam_frames(plan):
+    """First own frame of every chunk but the first (sharding.plan_chunks): the motions frame-1 -> frame cross a seam."""
+    return [first for c, (start, first, end) in enumerate(plan) if c > 0 and end > first]
+
+
+def seam_report(chunked, sequential, gt, plan):
+    """Does a seam cost accuracy?  Relative-pose error against the ground truth of the frame-to-frame motions AT the seams, for the
+    chunked run and for the sequential run at the very same frames (rms), their ratio, and the chunked run's seam motions against
+    the sequential run's own."""
+    seams = seam_frames(plan)
+    tc, rc = relative_pose_errors(chunked, gt, seams)
+    ts, rs = relative_pose_errors(sequential, gt, seams)
+    td, rd = relative_pose_errors(chunked, sequential, seams)
+    rms = lambda v: float(np.sqrt(np.mean(np.square(v)))) if len(v) else None      # noqa: E731
+    return {"seams": len(seams), "chunked_rpe_trans_rms_m": rms(tc), "sequential_rpe_trans_rms_m": rms(ts),
+            "chunked_rpe_rot_rms_deg": None if not len(rc) else float(np.degrees(rms(rc))), "sequential_rpe_rot_rms_deg": None if not len(rs) else float(np.degrees(rms(rs))),
+            "rpe_trans_ratio": None if not len(tc) or rms(ts) == 0 else rms(tc) / rms(ts), "rpe_rot_ratio": None if not len(rc) or rms(rs) == 0 else rms(rc) / rms(rs),
+            "chunked_vs_sequential_trans_rms_m": rms(td), "chunked_vs_sequential_rot_rms_deg": None if not len(rd) else float(np.degrees(rms(rd)))}

@@ -48,6 +48,11 @@ def chunk_job(seq_frames, streams, overlap, rank=0, world=1, scaling="weak"):
         per = n_live
     else:
         per = -(-n_live // world)
+        if (world - 1) * per >= n_live:
+            # a rank without a chunk would create no context and leave its peers waiting in the collectives: every rank computes the
+            # same plan, so every rank raises here, before anything is launched
+            raise ValueError("strong chunk plan: %d live chunks (of %d planned) over %d ranks leaves rank %d and above without a chunk; "
+                             "use more --streams or fewer GPUs" % (n_live, n_chunks, world, -(-n_live // per)))
         ids = list(range(rank * per, min((rank + 1) * per, n_live)))
     J = L + overlap
     B = len(ids)
