@@ -605,14 +605,24 @@ class Bench(object):
             both.tofile(fh)
             path = fh.name
         try:
-            p = subprocess.run([exe, path, str(cfg.rows), str(cfg.cols), str(cfg.cols), str(n), str(cfg.bin_size_pixels), str(warmup)],
-                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
+            cmd = [exe, path, str(cfg.rows), str(cfg.cols), str(cfg.cols), str(n), str(cfg.bin_size_pixels), str(warmup)]
+            prof = os.environ.get("VSLAM_SHIM_ROCPROF")        # profiling aid: per-kernel device time of the shim loop (tools/profile_shim.sh)
+            if prof:
+                cmd = ["rocprofv3", "--kernel-trace", "--stats", "-d", prof, "-o", "shim", "--output-format", "csv", "--"] + cmd
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
+            lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            if p.returncode != 0 or not lines:
+                return {"error": "bench_shim rc %d: %s" % (p.returncode, (p.stderr or p.stdout)[-300:])}
+            out = json.loads(lines[-1])
+            # the same loop with the frame's images in pinned memory (vslam_host_alloc): no staging copy on the way to the device
+            p2 = subprocess.run([exe, path, str(cfg.rows), str(cfg.cols), str(cfg.cols), str(n), str(cfg.bin_size_pixels), str(warmup), "1"],
+                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
+            l2 = [ln for ln in p2.stdout.splitlines() if ln.startswith("{")]
+            if p2.returncode == 0 and l2:
+                r2 = json.loads(l2[-1])
+                out["pinned_images"] = {k: r2[k] for k in ("ms_per_frame", "frames_per_s", "stage_ms", "fused_host_images_ms_per_frame", "last_frame_identical_to_fused")}
         finally:
             os.unlink(path)
-        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-        if p.returncode != 0 or not lines:
-            return {"error": "bench_shim rc %d: %s" % (p.returncode, (p.stderr or p.stdout)[-300:])}
-        out = json.loads(lines[-1])
         out["what"] = ("shim/proslam_hip_plugin.h driven like PoseTracker3D::compute (tests/cpp/bench_shim.cpp, stubs of the reference headers), ONE stream, "
                        "host images %dx%d, bin %d, host objects materialised; the fused figure beside it is vslam_process_host on the same images" % (cfg.cols, cfg.rows, cfg.bin_size_pixels))
         return out

@@ -223,6 +223,7 @@ int vslam_prune_recover(vslam_ctx* ctx);
 int vslam_update_points(vslam_ctx* ctx);
 /* StereoFramePointGenerator::compute (…:135-462). */
 int vslam_stereo_new(vslam_ctx* ctx);
+int vslam_compute(vslam_ctx* ctx);          /* vslam_update_points + vslam_stereo_new in ONE launch (the shim's compute())  */
 /* Tracker-owned state the reference pokes through setters
  * (setProjectionTrackingDistancePixels, setMaximumDescriptorDistanceTracking,
  * base_framepoint_generator.h:166-167; Frame::setRobotToWorld; Frame::setStatus). */
@@ -260,6 +261,56 @@ int vslam_get_track_result(vslam_ctx* ctx, int stream, int32_t cap, int32_t* n_t
                            int32_t* lost);
 int vslam_get_frame_points(vslam_ctx* ctx, int stream, int in_progress, int32_t cap, int32_t* n, int16_t* kp, int32_t* meta,
                            double* cam, double* lm, uint8_t* desc);
+/* Pinned (page-locked) host memory.  Host images handed to vslam_process_host / vslam_frame_begin from ordinary (pageable) memory
+ * are staged through a pinned buffer of the context first (one memcpy per image, ~30 us per 467 KB); images that already live in
+ * memory from vslam_host_alloc (e.g. the cv::Mat a loader decodes into, constructed on such a buffer) are copied to the device
+ * directly and asynchronously. */
+int vslam_host_alloc(void** out, size_t bytes);
+void vslam_host_free(void* p);
+
+/* ---- stage views: zero-copy read-back for a host that keeps the reference's object model --------------------------------------
+ * The reference's tracker reads its plug-ins' results after every virtual call (pose_tracker_3d.cpp:32-222: keypoints after
+ * initialize(), the tracked list after track(), errors()/inliers() after converge(), Frame::points() after recoverPoints() and
+ * compute()).  A vslam_view_* call packs exactly the live elements of that stage's results into a pinned host buffer owned by the
+ * context (one small kernel, the GPU writes host memory directly) and synchronises the stream's frame queue ONCE; the pointers it
+ * returns stay valid until the next vslam_view_* call on the context (one report buffer per context).  Same data, same order and
+ * same meaning as the vslam_get_* calls above, which copy array by array. */
+typedef struct vslam_keypoints_view {
+  int32_t n[2];                /* left, right                                           */
+  const int16_t* xy[2];        /* n * (x, y), image row-major                           */
+  const uint8_t* score[2];     /* n FAST scores (KeyPoint::response)                    */
+  const uint8_t* desc[2];      /* n * 32 descriptor bytes                               */
+} vslam_keypoints_view;
+typedef struct vslam_track_view {
+  int32_t n_tracked, n_lost, n_tracked_landmarks;
+  const int32_t* tracked4;     /* as vslam_get_track_result out4                        */
+  const int32_t* lost;
+} vslam_track_view;
+typedef struct vslam_aligner_view {
+  int32_t n, n_inliers, n_outliers, iterations, converged;
+  double total_error;
+  const double* chi;           /* StereoUVAligner::errors()                             */
+  const uint8_t* inlier;       /* StereoUVAligner::inliers()                            */
+  double T[12], H[36];
+} vslam_aligner_view;
+typedef struct vslam_points_view {
+  int32_t n;
+  int32_t first_full;          /* meta / cam / desc are filled for points first_full .. n-1: 0 for the finished frame; for the frame in
+                                  assembly (in_progress = 1) the number of survivors of the prune — those are objects the caller already
+                                  holds, only the recovered points behind them are new                                                  */
+  const int16_t* kp;           /* n * (xL, yL, xR, yR), every point                     */
+  const int32_t* meta;         /* n * 6, the layout of vslam_get_points                 */
+  const double* cam;           /* n * 3                                                 */
+  const uint8_t* desc;         /* n * 64 (left | right); in_progress = 1 only, else NULL (the finished frame's new points carry the
+                                  descriptors of the caller's own features)             */
+  vslam_frame_info info;       /* the stream's report as of this stage                  */
+  /* in-kernel chronometers of the stream, accumulated seconds (the tracker-side five of vslam_get_timers) */
+  double seconds_tracking, seconds_pose_optimization, seconds_point_recovery, seconds_landmark_optimization, seconds_point_triangulation;
+} vslam_points_view;
+int vslam_view_keypoints(vslam_ctx* ctx, int stream, vslam_keypoints_view* out);            /* after vslam_frame_begin    */
+int vslam_view_track(vslam_ctx* ctx, int stream, vslam_track_view* out);                    /* after vslam_track          */
+int vslam_view_aligner(vslam_ctx* ctx, int stream, vslam_aligner_view* out);                /* after vslam_align          */
+int vslam_view_points(vslam_ctx* ctx, int stream, int in_progress, vslam_points_view* out); /* after vslam_prune_recover (1) / vslam_stereo_new (0) */
 /* StereoUVAligner::_weights_translation as the stream's last initialize() left it (stereouv_aligner.cpp:22,57-61): the
  * vector is a MEMBER of the aligner, `resize(n, 1)` keeps the elements it already holds, and they are rewritten only while
  * enable_inverse_depth_as_information is set — so Localizing frames (flag off, pose_tracker_3d.cpp:124) reuse the weights the

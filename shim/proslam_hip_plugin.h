@@ -18,10 +18,10 @@
 // every materialisation step below checks the counts and throws on divergence.  Open loop only (loop closing rewrites
 // host poses the device does not see).
 #pragma once
+#include <algorithm>
 #include <cstring>
 #include <stdexcept>
 #include <string>
-#include <unordered_map>
 #include <vector>
 
 #include "aligners/stereouv_aligner.h"
@@ -29,6 +29,27 @@
 #include "vslam_hip.h"
 
 namespace proslam {
+
+// host-time breakdown of the plug-in calls (tests/cpp/bench_shim.cpp builds with -DPROSLAM_HIP_PROFILE); compiled out otherwise
+#ifdef PROSLAM_HIP_PROFILE
+#include <chrono>
+struct HipProfile {
+  enum { BEGIN_CALL, KEYPOINTS_WAIT, KEYPOINTS_HOST, TRACK_CALL, TRACK_WAIT, TRACK_HOST, ALIGN_CALL, ALIGN_WAIT, ALIGN_HOST, PRUNE_CALL, PRUNE_WAIT, PRUNE_HOST,
+         COMPUTE_CALL, COMPUTE_WAIT, COMPUTE_HOST, CHRONO, N };
+  static double* acc() { static double a[N] = {0}; return a; }
+  static const char* name(int i) {
+    static const char* n[N] = {"begin_call", "keypoints_wait", "keypoints_host", "track_call", "track_wait", "track_host", "align_call", "align_wait", "align_host",
+                               "prune_call", "prune_wait", "prune_host", "compute_call", "compute_wait", "compute_host", "chronometers"};
+    return n[i];
+  }
+  int k; std::chrono::steady_clock::time_point t0;
+  explicit HipProfile(int k_) : k(k_), t0(std::chrono::steady_clock::now()) {}
+  ~HipProfile() { acc()[k] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+#define HIP_PROFILE(K) HipProfile hip_profile_##K(HipProfile::K)
+#else
+#define HIP_PROFILE(K) do {} while (0)
+#endif
 
 inline void hipCheck(vslam_ctx* ctx, int rc, const char* where) {
   if (rc != VSLAM_OK) throw std::runtime_error(std::string(where) + "|" + vslam_last_error(ctx));
@@ -114,22 +135,19 @@ public:
   //! StereoUVAligner::converge (:210-264): one launch; results into the base-class members the tracker reads
   //! (errors(), inliers(), numberOfInliers(), totalError(), previousToCurrent(): base_aligner.h:37-48)
   void converge() override {
-    hipCheck(_hip->ctx, vslam_align(_hip->ctx, _parameters->enable_inverse_depth_as_information ? 1 : 0), "HipStereoUVAligner::converge");
-    std::vector<double> chi(_number_of_measurements + 1);
-    std::vector<uint8_t> inl(_number_of_measurements + 1);
-    double T[12], H[36];
-    int32_t n = 0;
-    hipCheck(_hip->ctx, vslam_get_aligner_result(_hip->ctx, 0, (int32_t)_number_of_measurements, &n, chi.data(), inl.data(), T, H), "HipStereoUVAligner::converge");
+    { HIP_PROFILE(ALIGN_CALL); hipCheck(_hip->ctx, vslam_align(_hip->ctx, _parameters->enable_inverse_depth_as_information ? 1 : 0), "HipStereoUVAligner::converge"); }
+    vslam_aligner_view v;      // one packed read-back, one synchronisation (include/vslam_hip.h: stage views)
+    { HIP_PROFILE(ALIGN_WAIT); hipCheck(_hip->ctx, vslam_view_aligner(_hip->ctx, 0, &v), "HipStereoUVAligner::converge"); }
+    HIP_PROFILE(ALIGN_HOST);
+    const int32_t n = v.n;
     if (n != (int32_t)_number_of_measurements) throw std::runtime_error("HipStereoUVAligner::converge|host and device disagree on the number of measurements");
-    vslam_frame_info info;
-    hipCheck(_hip->ctx, vslam_get_frame_info(_hip->ctx, 0, &info), "HipStereoUVAligner::converge");
-    _errors.assign(chi.begin(), chi.begin() + n);
+    _errors.assign(v.chi, v.chi + n);
     _inliers.resize(n);
-    for (int32_t u = 0; u < n; ++u) _inliers[u] = inl[u] != 0;
-    _number_of_inliers = (Count)info.n_inliers; _number_of_outliers = (Count)info.n_outliers; _total_error = info.total_error;
-    _has_system_converged = info.aligner_converged != 0;
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) _previous_to_current.matrix()(i, j) = T[4 * i + j];
-    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) { _H(i, j) = H[6 * i + j]; _information_matrix(i, j) = H[6 * i + j]; }
+    for (int32_t u = 0; u < n; ++u) _inliers[u] = v.inlier[u] != 0;
+    _number_of_inliers = (Count)v.n_inliers; _number_of_outliers = (Count)v.n_outliers; _total_error = v.total_error;
+    _has_system_converged = v.converged != 0;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) _previous_to_current.matrix()(i, j) = v.T[4 * i + j];
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) { _H(i, j) = v.H[6 * i + j]; _information_matrix(i, j) = v.H[6 * i + j]; }
   }
 
   //! a new track() invalidates the previous converge(): PoseTracker3D::_prunePoints would otherwise read the stale
@@ -200,7 +218,7 @@ public:
     double pose[12];
     hipToArray(frame_->cameraLeftToWorld(), pose);
     hipCheck(_hip->ctx, vslam_set_pose(_hip->ctx, 0, pose), "HipStereoFramePointGenerator::initialize");
-    hipCheck(_hip->ctx, vslam_frame_begin(_hip->ctx, L.data, R.data, (int32_t)static_cast<size_t>(L.step), 0, 0), "HipStereoFramePointGenerator::initialize");
+    { HIP_PROFILE(BEGIN_CALL); hipCheck(_hip->ctx, vslam_frame_begin(_hip->ctx, L.data, R.data, (int32_t)static_cast<size_t>(L.step), 0, 0), "HipStereoFramePointGenerator::initialize"); }
     _pruned = false;
     downloadKeypoints(frame_);   // Frame::keypointsLeft/Right + descriptorsLeft/Right for downstream consumers
   }
@@ -213,8 +231,9 @@ public:
     _hip->status = frame_->status() == Frame::Localizing ? VSLAM_LOCALIZING : VSLAM_TRACKING;
     _hip->window_pixels = _projection_tracking_distance_pixels;
     _hip->tau_track = _maximum_descriptor_distance_tracking;
-    pushState(camera_left_previous_in_current_);
-    hipCheck(_hip->ctx, vslam_track(_hip->ctx, track_by_appearance_ ? 1 : 0), "HipStereoFramePointGenerator::track");
+    { HIP_PROFILE(TRACK_CALL);
+      pushState(camera_left_previous_in_current_);
+      hipCheck(_hip->ctx, vslam_track(_hip->ctx, track_by_appearance_ ? 1 : 0), "HipStereoFramePointGenerator::track"); }
     materializeTrackedPoints(frame_, frame_previous_, lost_points_);
     if (_hip->aligner) _hip->aligner->invalidate((Count)frame_->points().size());
   }
@@ -232,10 +251,8 @@ public:
   void compute(Frame* frame_) override {
     if (!frame_) throw std::runtime_error("HipStereoFramePointGenerator::compute|called with empty frame");
     if (!_pruned) pruneOnDevice(frame_);     // recovery disabled or no previous frame: _prunePoints alone
-    hipCheck(_hip->ctx, vslam_update_points(_hip->ctx), "HipStereoFramePointGenerator::compute");
-    hipCheck(_hip->ctx, vslam_stereo_new(_hip->ctx), "HipStereoFramePointGenerator::compute");
-    materializeNewPoints(frame_);  // Frame::createFramepoint(feature_left, feature_right, distance, xyz)
-    updateChronometers();
+    { HIP_PROFILE(COMPUTE_CALL); hipCheck(_hip->ctx, vslam_compute(_hip->ctx), "HipStereoFramePointGenerator::compute"); }   // landmark update + stereo sweep, one launch
+    materializeNewPoints(frame_);  // Frame::createFramepoint(feature_left, feature_right, distance, xyz); chronometers
   }
 
   HipContext* hip() { return _hip; }
@@ -247,12 +264,13 @@ private:
   //! base_framepoint_generator.h:232-233) and _point_triangulation (stereo_framepoint_generator.h:81) from the generator
   //! (slam_assembly.cpp:709-719); CREATE_CHRONOMETER makes the members protected (definitions.h:144-146), so they are set here
   //! from the device's own clocks: accumulated seconds since the context was created, like CHRONOMETER_STOP accumulates
-  void updateChronometers() {
-    double seconds[8];
-    hipCheck(_hip->ctx, vslam_get_timers(_hip->ctx, seconds), "HipStereoFramePointGenerator|timers");
-    _time_consumption_seconds_keypoint_detection = seconds[0];
-    _time_consumption_seconds_descriptor_extraction = seconds[1];
-    _time_consumption_seconds_point_triangulation = seconds[2];
+  void updateChronometers(const vslam_points_view& view_) {
+    HIP_PROFILE(CHRONO);
+    double ms[8]; int32_t launches[8];
+    hipCheck(_hip->ctx, vslam_get_kernel_times(_hip->ctx, ms, launches), "HipStereoFramePointGenerator|timers");
+    _time_consumption_seconds_keypoint_detection = (ms[0] + ms[1]) * 1e-3;     // FAST / NMS + emission / threshold controller
+    _time_consumption_seconds_descriptor_extraction = ms[2] * 1e-3;
+    _time_consumption_seconds_point_triangulation = view_.seconds_point_triangulation;
   }
   void pushState(const TransformMatrix3D& prior_) const {
     double prior[12];
@@ -266,6 +284,7 @@ private:
     return PointCoordinates(1 / c.K[0] * (xL - c.K[2]) * z, 1 / c.K[4] * ((yL + yR) / 2.0 - c.K[5]) * z, z);
   }
   void pruneOnDevice(Frame* frame_) const {
+    HIP_PROFILE(PRUNE_CALL);
     double pose[12];
     hipToArray(frame_->cameraLeftToWorld(), pose);   // Frame::setRobotToWorld happened on the host (pose_tracker_3d.cpp:151-152,175)
     hipCheck(_hip->ctx, vslam_set_pose(_hip->ctx, 0, pose), "HipStereoFramePointGenerator|prune");
@@ -273,41 +292,69 @@ private:
     _pruned = true;
   }
 
-  //! vslam_get_keypoints -> cv::KeyPoint(x, y, 7, -1, score) + 1x32 CV_8U descriptor rows (frame.h:64-67) and the
-  //! IntensityFeature vectors (frame_point.h:18-35) the framepoints are created from
-  void downloadSide(int side_, std::vector<cv::KeyPoint>& keypoints_, cv::Mat& descriptors_, std::vector<IntensityFeature>& features_,
-                    std::unordered_map<uint32_t, uint32_t>& pixel_to_feature_) const {
-    const int32_t cap = _hip->config.max_keypoints;
-    std::vector<int16_t> xy((size_t)cap * 2);
-    std::vector<int32_t> score(cap);
-    std::vector<uint8_t> desc((size_t)cap * VSLAM_DESC_BYTES);
-    int32_t n = 0;
-    hipCheck(_hip->ctx, vslam_get_keypoints(_hip->ctx, 0, side_, cap, &n, xy.data(), score.data(), desc.data()), "HipStereoFramePointGenerator|keypoints");
+  //! IntensityFeature objects (frame_point.h:18-35: a cv::KeyPoint copy + a cv::Mat row header each) are what
+  //! Frame::createFramepoint takes; only the features that end up in a framepoint (~1 in 3) need one, so they are made on first
+  //! use.  The store is reserved for every feature up front: pointers handed out stay valid for the frame.
+  struct LazyFeatures {
+    std::vector<IntensityFeature> store;
+    std::vector<int32_t> slot;
+    const std::vector<cv::KeyPoint>* keypoints = nullptr;
+    const cv::Mat* descriptors = nullptr;
+    void reset(const std::vector<cv::KeyPoint>& keypoints_, const cv::Mat& descriptors_) {
+      keypoints = &keypoints_; descriptors = &descriptors_;
+      store.clear(); store.reserve(keypoints_.size());
+      slot.assign(keypoints_.size(), -1);
+    }
+    int32_t size() const { return (int32_t)slot.size(); }
+    const IntensityFeature* get(int32_t i) {
+      if (slot[i] < 0) { slot[i] = (int32_t)store.size(); store.emplace_back((*keypoints)[i], descriptors->row(i), (size_t)i); }
+      return &store[slot[i]];
+    }
+  };
+  //! one stage view -> cv::KeyPoint(x, y, 7, -1, score) + n x 32 CV_8U descriptor rows (frame.h:64-67).  The device lists are
+  //! image row-major: (row << 16 | col) rises strictly, so the feature at a pixel is found by bisection (compute() needs it for
+  //! the new points)
+  void materializeSide(const vslam_keypoints_view& view_, int side_, std::vector<cv::KeyPoint>& keypoints_, cv::Mat& descriptors_,
+                       LazyFeatures& features_, std::vector<uint32_t>& pixel_keys_) const {
+    const int32_t n = view_.n[side_];
+    const int16_t* xy = view_.xy[side_];
+    const uint8_t* score = view_.score[side_];
     keypoints_.resize(n);
     descriptors_ = cv::Mat(n > 0 ? n : 1, VSLAM_DESC_BYTES, CV_8UC1);
-    features_.resize(n);
-    pixel_to_feature_.clear();
+    if (n > 0) std::memcpy(descriptors_.ptr<uint8_t>(0), view_.desc[side_], (size_t)n * VSLAM_DESC_BYTES);   // freshly created Mat: dense rows
+    pixel_keys_.resize(n);
+    uint32_t last = 0;
     for (int32_t i = 0; i < n; ++i) {
       keypoints_[i] = cv::KeyPoint((float)xy[2 * i], (float)xy[2 * i + 1], 7.f, -1.f, (float)score[i]);   // FAST: size 7, no angle
-      std::memcpy(descriptors_.ptr<uint8_t>(i), &desc[(size_t)VSLAM_DESC_BYTES * i], VSLAM_DESC_BYTES);
-      features_[i] = IntensityFeature(keypoints_[i], descriptors_.row(i), (size_t)i);
-      pixel_to_feature_[((uint32_t)(uint16_t)xy[2 * i + 1] << 16) | (uint16_t)xy[2 * i]] = (uint32_t)i;
+      const uint32_t key = ((uint32_t)(uint16_t)xy[2 * i + 1] << 16) | (uint16_t)xy[2 * i];
+      if (i && key <= last) throw std::runtime_error("HipStereoFramePointGenerator|keypoints are not in image row-major order");
+      pixel_keys_[i] = last = key;
     }
+    features_.reset(keypoints_, descriptors_);
   }
   void downloadKeypoints(Frame* frame_) {
-    downloadSide(0, frame_->keypointsLeft(), frame_->descriptorsLeft(), _features_left, _pixel_left);
-    downloadSide(1, frame_->keypointsRight(), frame_->descriptorsRight(), _features_right, _pixel_right);
+    vslam_keypoints_view view;
+    { HIP_PROFILE(KEYPOINTS_WAIT); hipCheck(_hip->ctx, vslam_view_keypoints(_hip->ctx, 0, &view), "HipStereoFramePointGenerator|keypoints"); }
+    HIP_PROFILE(KEYPOINTS_HOST);
+    materializeSide(view, 0, frame_->keypointsLeft(), frame_->descriptorsLeft(), _features_left, _pixel_left);
+    materializeSide(view, 1, frame_->keypointsRight(), frame_->descriptorsRight(), _features_right, _pixel_right);
     _number_of_detected_keypoints = (Count)_features_left.size();
+  }
+  static int32_t featureAt(const std::vector<uint32_t>& pixel_keys_, int16_t x_, int16_t y_) {
+    const uint32_t key = ((uint32_t)(uint16_t)y_ << 16) | (uint16_t)x_;
+    const auto it = std::lower_bound(pixel_keys_.begin(), pixel_keys_.end(), key);
+    return it != pixel_keys_.end() && *it == key ? (int32_t)(it - pixel_keys_.begin()) : -1;
   }
 
   //! the tracked list of the device -> Frame::createFramepoint(left, right, distance, xyz, previous) in the order of the
   //! previous points, FramePoint::setEpipolarOffset, the lost list, the tracking statistics (:632-668)
   void materializeTrackedPoints(Frame* frame_, Frame* previous_, FramePointPointerVector& lost_) {
     FramePointPointerVector& previous_points(previous_->points());
-    const int32_t cap = (int32_t)previous_points.size() + 1;
-    std::vector<int32_t> out4((size_t)cap * 4), lost(cap);
-    int32_t n_tracked = 0, n_lost = 0;
-    hipCheck(_hip->ctx, vslam_get_track_result(_hip->ctx, 0, cap, &n_tracked, out4.data(), &n_lost, lost.data()), "HipStereoFramePointGenerator::track");
+    vslam_track_view view;
+    { HIP_PROFILE(TRACK_WAIT); hipCheck(_hip->ctx, vslam_view_track(_hip->ctx, 0, &view), "HipStereoFramePointGenerator::track"); }
+    HIP_PROFILE(TRACK_HOST);
+    const int32_t n_tracked = view.n_tracked, n_lost = view.n_lost;
+    const int32_t* out4 = view.tracked4;
     FramePointPointerVector& points(frame_->points());
     points.resize(n_tracked);
     _number_of_tracked_landmarks = 0;
@@ -316,8 +363,8 @@ private:
       const int32_t ip = out4[4 * u], fl = out4[4 * u + 1], fr = out4[4 * u + 2], dist = out4[4 * u + 3];
       if (ip < 0 || ip >= (int32_t)previous_points.size() || fl < 0 || fl >= (int32_t)_features_left.size() || fr < 0 || fr >= (int32_t)_features_right.size())
         throw std::runtime_error("HipStereoFramePointGenerator::track|host and device frames diverged");
-      const IntensityFeature* feature_left = &_features_left[fl];
-      const IntensityFeature* feature_right = &_features_right[fr];
+      const IntensityFeature* feature_left = _features_left.get(fl);
+      const IntensityFeature* feature_right = _features_right.get(fr);
       FramePoint* point_previous = previous_points[ip];
       FramePoint* framepoint = frame_->createFramepoint(feature_left, feature_right, (real)dist,
                                                         pointInLeftCamera(feature_left->keypoint.pt.x, feature_left->keypoint.pt.y,
@@ -329,7 +376,10 @@ private:
       if (point_previous->landmark()) ++_number_of_tracked_landmarks;
     }
     lost_.resize(n_lost);
-    for (int32_t u = 0; u < n_lost; ++u) lost_[u] = previous_points[lost[u]];
+    for (int32_t u = 0; u < n_lost; ++u) {
+      if (view.lost[u] < 0 || view.lost[u] >= (int32_t)previous_points.size()) throw std::runtime_error("HipStereoFramePointGenerator::track|bad lost index");
+      lost_[u] = previous_points[view.lost[u]];
+    }
     previous_->setAverageDescriptorDistanceTracking(accumulated_descriptor_distance / n_tracked);
   }
 
@@ -338,16 +388,14 @@ private:
   void materializeRecoveredPoints(Frame* frame_) const {
     Frame* previous = frame_->previous();
     if (!previous) return;
-    const int32_t cap = _hip->config.max_points;
-    std::vector<int16_t> kp((size_t)cap * 4);
-    std::vector<int32_t> meta((size_t)cap * 6);
-    std::vector<double> cam((size_t)cap * 3);
-    std::vector<uint8_t> desc((size_t)cap * 64);
-    int32_t n = 0;
-    hipCheck(_hip->ctx, vslam_get_frame_points(_hip->ctx, 0, 1, cap, &n, kp.data(), meta.data(), cam.data(), nullptr, desc.data()), "HipStereoFramePointGenerator::recoverPoints");
+    vslam_points_view view;
+    { HIP_PROFILE(PRUNE_WAIT); hipCheck(_hip->ctx, vslam_view_points(_hip->ctx, 0, 1, &view), "HipStereoFramePointGenerator::recoverPoints"); }
+    HIP_PROFILE(PRUNE_HOST);
+    const int32_t n = view.n;
+    const int16_t* kp = view.kp; const int32_t* meta = view.meta; const double* cam = view.cam; const uint8_t* desc = view.desc;
     FramePointPointerVector& points(frame_->points());
     const int32_t n_kept = (int32_t)points.size();
-    if (n < n_kept) throw std::runtime_error("HipStereoFramePointGenerator::recoverPoints|host and device frames diverged (prune)");
+    if (n < n_kept || view.first_full != n_kept) throw std::runtime_error("HipStereoFramePointGenerator::recoverPoints|host and device frames diverged (prune)");
     for (int32_t i = 0; i < n_kept; ++i)
       if (points[i]->keypointLeft().pt.x != (float)kp[4 * i] || points[i]->keypointLeft().pt.y != (float)kp[4 * i + 1])
         throw std::runtime_error("HipStereoFramePointGenerator::recoverPoints|host and device frames diverged (prune order)");
@@ -370,32 +418,33 @@ private:
 
   //! the finished device frame = the host list so far + the new stereo points in emission order
   void materializeNewPoints(Frame* frame_) {
-    const int32_t cap = _hip->config.max_points;
-    std::vector<int16_t> kp((size_t)cap * 4);
-    std::vector<int32_t> meta((size_t)cap * 6);
-    std::vector<double> cam((size_t)cap * 3);
-    int32_t n = 0;
-    hipCheck(_hip->ctx, vslam_get_frame_points(_hip->ctx, 0, 0, cap, &n, kp.data(), meta.data(), cam.data(), nullptr, nullptr), "HipStereoFramePointGenerator::compute");
+    vslam_points_view view;
+    { HIP_PROFILE(COMPUTE_WAIT); hipCheck(_hip->ctx, vslam_view_points(_hip->ctx, 0, 0, &view), "HipStereoFramePointGenerator::compute"); }
+    HIP_PROFILE(COMPUTE_HOST);
+    const int32_t n = view.n;
+    const int16_t* kp = view.kp; const int32_t* meta = view.meta; const double* cam = view.cam;
     FramePointPointerVector& points(frame_->points());
     const int32_t n_old = (int32_t)points.size();
     if (n < n_old) throw std::runtime_error("HipStereoFramePointGenerator::compute|host and device frames diverged");
     points.resize(n);
     for (int32_t i = n_old; i < n; ++i) {
-      const auto fl = _pixel_left.find(((uint32_t)(uint16_t)kp[4 * i + 1] << 16) | (uint16_t)kp[4 * i]);
-      const auto fr = _pixel_right.find(((uint32_t)(uint16_t)kp[4 * i + 3] << 16) | (uint16_t)kp[4 * i + 2]);
-      if (fl == _pixel_left.end() || fr == _pixel_right.end()) throw std::runtime_error("HipStereoFramePointGenerator::compute|new point without a feature");
-      FramePoint* framepoint = frame_->createFramepoint(&_features_left[fl->second], &_features_right[fr->second], (real)meta[6 * i],
+      const int32_t fl = featureAt(_pixel_left, kp[4 * i], kp[4 * i + 1]), fr = featureAt(_pixel_right, kp[4 * i + 2], kp[4 * i + 3]);
+      if (fl < 0 || fr < 0) throw std::runtime_error("HipStereoFramePointGenerator::compute|new point without a feature");
+      FramePoint* framepoint = frame_->createFramepoint(_features_left.get(fl), _features_right.get(fr), (real)meta[6 * i],
                                                         PointCoordinates(cam[3 * i], cam[3 * i + 1], cam[3 * i + 2]));
       framepoint->setEpipolarOffset(meta[6 * i + 1]);
       points[i] = framepoint;
     }
+    _last_info = view.info;
+    updateChronometers(view);
   }
 
   HipContext* _hip;
   mutable bool _pruned = false;
   bool _timers_enabled = false;
-  std::vector<IntensityFeature> _features_left, _features_right;            // keypoints + descriptors of the current frame
-  std::unordered_map<uint32_t, uint32_t> _pixel_left, _pixel_right;        // (row << 16 | col) -> feature (one feature per pixel)
+  LazyFeatures _features_left, _features_right;                            // keypoints + descriptors of the current frame
+  std::vector<uint32_t> _pixel_left, _pixel_right;                         // (row << 16 | col) of feature i, strictly rising
+  vslam_frame_info _last_info;                                             // the device's report of the frame last finished
 };
 
 }  // namespace proslam

@@ -3,7 +3,9 @@
 // materialised (Frame::keypoints / descriptors / points(), FramePoint links) — against the fused one-stream device path
 // (vslam_process_host) on the same host images.  Built against the declaration stubs (tests/shim_stubs/): the reference's own
 // headers need OpenCV / Eigen / srrg, absent here.
-//   bench_shim <images.bin> <rows> <cols> <row_stride> <n_frames> <bin_size> [warmup]
+//   bench_shim <images.bin> <rows> <cols> <row_stride> <n_frames> <bin_size> [warmup] [pinned]
+// pinned = 1: each frame's two images are first placed in pinned buffers from vslam_host_alloc (outside the timed region — what a
+// loader that decodes into such buffers gives the tracker), so the upload is a direct asynchronous copy.
 // images.bin: n_frames x (left image, right image), each rows x row_stride bytes.  Prints one JSON line.
 #include <algorithm>
 #include <cstdio>
@@ -16,6 +18,7 @@ int main(int argc, char** argv) {
   if (argc < 7) { std::fprintf(stderr, "usage: bench_shim <images.bin> <rows> <cols> <row_stride> <n_frames> <bin_size> [warmup]\n"); return 2; }
   const int rows = std::atoi(argv[2]), cols = std::atoi(argv[3]), stride = std::atoi(argv[4]), n_frames = std::atoi(argv[5]), bin = std::atoi(argv[6]);
   const int warmup = argc > 7 ? std::atoi(argv[7]) : 20;
+  const bool pinned = argc > 8 && std::atoi(argv[8]) != 0;
   const size_t img = (size_t)rows * stride;
   std::vector<uint8_t> data((size_t)n_frames * 2 * img);
   FILE* f = std::fopen(argv[1], "rb");
@@ -49,14 +52,19 @@ int main(int argc, char** argv) {
     h.window = generator_parameters.maximum_projection_tracking_distance_pixels; h.tau = generator_parameters.minimum_descriptor_distance_tracking;
     std::vector<double> frame_s;
     double total = 0, points = 0, tracked = 0, keypoints = 0;
+    uint8_t* pin[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // [frame parity][side]
+    if (pinned) for (int q = 0; q < 4; ++q) hipCheck(nullptr, vslam_host_alloc((void**)&pin[q / 2][q % 2], img), "pinned image buffer");
     for (int k = 0; k < n_frames; ++k) {
       if (k == warmup) for (double& s : h.seconds) s = 0;
+      uint8_t* L = &data[(size_t)(2 * k) * img]; uint8_t* R = &data[(size_t)(2 * k + 1) * img];
+      if (pinned) { std::memcpy(pin[k & 1][0], L, img); std::memcpy(pin[k & 1][1], R, img); L = pin[k & 1][0]; R = pin[k & 1][1]; }
       const auto t0 = std::chrono::steady_clock::now();
-      Frame* frame = h.step(&data[(size_t)(2 * k) * img], &data[(size_t)(2 * k + 1) * img], rows, cols, (size_t)stride);
+      Frame* frame = h.step(L, R, rows, cols, (size_t)stride);
       const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       if (k >= warmup) { frame_s.push_back(dt); total += dt; points += frame->points().size(); tracked += h.tracked_points; keypoints += frame->keypointsLeft().size(); }
     }
     const vslam_frame_info shim_info = generator.frameInfo();
+    for (int q = 0; q < 4; ++q) vslam_host_free(pin[q / 2][q % 2]);
     // the fused one-stream path on the same host images (what exact_mode.single_sequence times with device-resident images)
     vslam_ctx* fused = nullptr;
     hipCheck(nullptr, vslam_create(&hip.config, 0, 1, &fused), "fused context");
@@ -78,8 +86,12 @@ int main(int argc, char** argv) {
     std::printf("{\"frames\": %d, \"warmup\": %d, \"ms_per_frame\": %.4f, \"frames_per_s\": %.1f, \"median_ms\": %.4f, \"min_ms\": %.4f, \"max_ms\": %.4f, \"stage_ms\": {", n, warmup,
                 total / n * 1e3, n / total, frame_s[n / 2] * 1e3, frame_s[0] * 1e3, frame_s[n - 1] * 1e3);
     for (int q = 0; q < Harness::T_STAGES; ++q) std::printf("%s\"%s\": %.4f", q ? ", " : "", names[q], h.seconds[q] / n * 1e3);
+#ifdef PROSLAM_HIP_PROFILE
+    std::printf("}, \"host_breakdown_ms\": {");      // accumulated over ALL frames (warm-up included)
+    for (int q = 0; q < HipProfile::N; ++q) std::printf("%s\"%s\": %.4f", q ? ", " : "", HipProfile::name(q), HipProfile::acc()[q] / n_frames * 1e3);
+#endif
     std::printf("}, \"mean_keypoints_left\": %.1f, \"mean_points\": %.1f, \"mean_tracked\": %.1f, \"fused_host_images_ms_per_frame\": %.4f, \"shim_over_fused\": %.3f, "
-                "\"last_frame_identical_to_fused\": %s}\n", keypoints / n, points / n, tracked / n, fused_total / n * 1e3, (total / n) / (fused_total / n), same ? "true" : "false");
+                "\"last_frame_identical_to_fused\": %s, \"host_images\": \"%s\"}\n", keypoints / n, points / n, tracked / n, fused_total / n * 1e3, (total / n) / (fused_total / n), same ? "true" : "false", pinned ? "pinned (vslam_host_alloc)" : "pageable");
     return same ? 0 : 1;
   } catch (const std::exception& e) {
     std::fprintf(stderr, "bench_shim: %s\n", e.what());

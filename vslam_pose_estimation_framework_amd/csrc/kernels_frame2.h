@@ -2,6 +2,7 @@
 // stereo sweep + binning, and the PoseTracker3D control flow that strings the stages together.
 #pragma once
 #include "kernels_frame.h"
+#include "kernels_report.h"
 #include <type_traits>
 
 // write one framepoint (Frame::createFramepoint, types/frame.cpp:61-84) from a left/right feature pair
@@ -1923,13 +1924,19 @@ __global__ __launch_bounds__(VS_WG) void k_recover_alone(const DevCfg c, const D
 // Stage-granular entry points: the same device functions, one reference virtual per launch, with the
 // control flow left to the caller (shim/proslam_hip_plugin.h keeps the reference's PoseTracker3D logic).
 // ==============================================================================================
-enum { VS_STAGE_TRACK = 1, VS_STAGE_ALIGN = 2, VS_STAGE_PRUNE_RECOVER = 3, VS_STAGE_UPDATE = 4, VS_STAGE_STEREO = 5 };
+enum { VS_STAGE_TRACK = 1, VS_STAGE_ALIGN = 2, VS_STAGE_PRUNE_RECOVER = 3, VS_STAGE_UPDATE = 4, VS_STAGE_STEREO = 5, VS_STAGE_COMPUTE = 6 /* UPDATE then STEREO */ };
 
 // WorldMap::createFrame + the bookkeeping PoseTracker3D::compute does before initialize() (:36-77)
-__global__ __launch_bounds__(256) void k_begin(const DevCfg c, const DevBuf b) {
+// the caller's setters folded into a stage launch (StageIo): applied by one lane before anything reads the stream state
+__device__ __forceinline__ void stage_apply_set(StreamState& st, const StageIo& io) {
+  if (io.set_flags & 1) { st.status = io.status; st.win = io.win; st.tau_track = io.tau; for (int k = 0; k < 12; ++k) st.prior[k] = io.prior[k]; }
+  if (io.set_flags & 2) { for (int k = 0; k < 12; ++k) st.pose[k] = io.pose[k]; }
+}
+__global__ __launch_bounds__(256) void k_begin(const DevCfg c, const DevBuf b, const StageIo io) {
   const int s = b.s0 + blockIdx.x, tid = threadIdx.x;
   if (!vs_active(b, s)) return;
   StreamState& st = b.st[s];
+  if (io.set_flags) { if (tid == 0) stage_apply_set(st, io); __syncthreads(); }
   const int f = st.frame_count;
   if (st.has_prev) {
     const PtView pv = pts_of(c, b, s, st.cur);
@@ -1947,22 +1954,23 @@ __global__ __launch_bounds__(256) void k_begin(const DevCfg c, const DevBuf b) {
   }
 }
 
-__global__ __launch_bounds__(VS_WG) void k_stage(const DevCfg c, const DevBuf b, int stage, int arg) {
+__global__ __launch_bounds__(VS_WG) void k_stage(const DevCfg c, const DevBuf b, int stage, int arg, const StageIo io) {
   __shared__ FrameShared sh;
   __shared__ __align__(16) unsigned char arena[VS_ARENA];
   const int s = b.s0 + blockIdx.x, tid = threadIdx.x;
   if (!vs_active(b, s)) return;
   StreamState& st = b.st[s];
   vslam_frame_info& info = b.info[s];
+  if (io.set_flags) { if (tid == 0) stage_apply_set(st, io); __syncthreads(); }
   const int f = st.frame_count;
   const int pb_prev = st.cur, pb_cur = st.cur ^ 1;
+  const bool has_prev = st.has_prev != 0;
   if (tid == 0) {
     sh.n_trk = st.n_trk; sh.n_lost = st.n_lost; sh.n_lm = st.n_tracked_landmarks; sh.n_cur = st.n_cur; sh.n_cand = 0;
     sh.E = st.al_total_error; sh.inl = st.al_inliers; sh.outl = st.al_outliers; sh.its = 0; sh.conv = 0; sh.flag = 0;
   }
   __syncthreads();
-  if (stage == VS_STAGE_TRACK) {
-    if (!st.has_prev) return;
+  if (stage == VS_STAGE_TRACK && has_prev) {
     const double tau = st.tau_track;
     const unsigned long long t0 = wall_clock64();
     wg_track_resolve(c, b, s, sh, pb_prev, arena, st.win, tau, st.tau_tri, arg);
@@ -1973,8 +1981,7 @@ __global__ __launch_bounds__(VS_WG) void k_stage(const DevCfg c, const DevBuf b,
       info.n_tracked = sh.n_trk; info.n_lost = sh.n_lost; info.n_tracked_landmarks = sh.n_lm; info.track_attempts = st.track_calls;
       info.aligner_ran = 0;
     }
-  } else if (stage == VS_STAGE_ALIGN) {
-    if (!st.has_prev) return;
+  } else if (stage == VS_STAGE_ALIGN && has_prev) {
     double T0[12];
     for (int k = 0; k < 12; ++k) T0[k] = st.prior[k];
     const unsigned long long t0 = wall_clock64();
@@ -1991,41 +1998,60 @@ __global__ __launch_bounds__(VS_WG) void k_stage(const DevCfg c, const DevBuf b,
   } else if (stage == VS_STAGE_PRUNE_RECOVER) {
     if (tid == 0) set_pose(c, b, s, f, st.pose);   // Frame::setRobotToWorld happened on the host side
     __syncthreads();
-    if (!st.has_prev) return;
-    wg_prune(c, b, s, sh, pb_prev, pb_cur, st.aligner_valid != 0);
-    const int n_after = sh.n_cur;
-    int n_rec = 0;
-    const unsigned long long t0 = wall_clock64();
-    if (arg) { wg_recover(c, b, s, sh, pb_prev, pb_cur, hpose_of(c, b, s, f) + 12, st.tau_gen, st.tau_tri, arena); n_rec = sh.flag; }
-    if (tid == 0) {
-      if (arg) st.ticks[2] += wall_clock64() - t0;
-      st.n_cur = sh.n_cur; st.n_after_prune = n_after; st.n_recovered = n_rec;
-      info.n_after_prune = n_after; info.n_recovered = n_rec; info.n_points = sh.n_cur;
+    if (has_prev) {
+      wg_prune(c, b, s, sh, pb_prev, pb_cur, st.aligner_valid != 0);
+      const int n_after = sh.n_cur;
+      int n_rec = 0;
+      const unsigned long long t0 = wall_clock64();
+      if (arg) { wg_recover(c, b, s, sh, pb_prev, pb_cur, hpose_of(c, b, s, f) + 12, st.tau_gen, st.tau_tri, arena); n_rec = sh.flag; }
+      if (tid == 0) {
+        if (arg) st.ticks[2] += wall_clock64() - t0;
+        st.n_cur = sh.n_cur; st.n_after_prune = n_after; st.n_recovered = n_rec;
+        info.n_after_prune = n_after; info.n_recovered = n_rec; info.n_points = sh.n_cur;
+      }
     }
-  } else if (stage == VS_STAGE_UPDATE) {
-    const unsigned long long t0 = wall_clock64();
-    wg_update_points(c, b, s, sh, pb_cur, f);
-    if (tid == 0) { st.n_active = sh.n_lm; info.n_active_landmarks = sh.n_lm; st.ticks[3] += wall_clock64() - t0; }
-  } else if (stage == VS_STAGE_STEREO) {
-    const unsigned long long t0 = wall_clock64();
-    wg_stereo(c, b, s, sh, pb_cur, st.tau_tri, f, arena, VS_ARENA);
-    if (tid == 0) {
-      st.ticks[4] += wall_clock64() - t0;
-      const double* c2w = hpose_of(c, b, s, f);
-      *pts_of(c, b, s, pb_cur).n = sh.n_cur;
-      st.n_cur = sh.n_cur; st.n_new = sh.n_cand;
-      st.n_tracked_landmarks_prev = st.n_active;
-      st.frame_count = f + 1; st.has_prev = 1; st.cur = pb_cur;
-      info.frame_index = f + 1; info.status = st.status;
-      info.n_keypoints_left = b.n_kp[s * 2]; info.n_keypoints_right = b.n_kp[s * 2 + 1];
-      int rl = 0, rr = 0;
-      for (int r = 0; r < c.n_regions; ++r) { rl += b.iinfo[s].raw_count[0][r]; rr += b.iinfo[s].raw_count[1][r]; info.thresholds[r] = b.iinfo[s].thr_after[r]; }
-      info.n_detected_left = rl; info.n_detected_right = rr;
-      info.n_new_stereo = sh.n_cand; info.n_points = sh.n_cur; info.window_pixels = st.win; info.error_flags = st.error_flags;
-      info.tau_track = st.tau_track; info.tau_triangulation = st.tau_tri;
-      for (int k = 0; k < 12; ++k) { info.camera_left_to_world[k] = c2w[k]; info.previous_to_current[k] = st.prior[k]; }
-      if (f < VS_POSE_LOG) { double* pl = b.pose_log + ((size_t)s * VS_POSE_LOG + f) * 12; for (int k = 0; k < 12; ++k) pl[k] = c2w[k]; }
+  } else if (stage == VS_STAGE_UPDATE || stage == VS_STAGE_STEREO || stage == VS_STAGE_COMPUTE) {
+    if (stage != VS_STAGE_STEREO) {
+      const unsigned long long t0 = wall_clock64();
+      wg_update_points(c, b, s, sh, pb_cur, f);
+      if (tid == 0) { st.n_active = sh.n_lm; info.n_active_landmarks = sh.n_lm; st.ticks[3] += wall_clock64() - t0; }
     }
+    if (stage == VS_STAGE_COMPUTE) {     // the two launches of compute() in one: the shared scalars start over as a new launch would read them
+      __syncthreads();
+      if (tid == 0) { sh.n_lm = st.n_tracked_landmarks; sh.n_cand = 0; sh.flag = 0; sh.n_cur = st.n_cur; }
+      __syncthreads();
+    }
+    if (stage != VS_STAGE_UPDATE) {
+      const unsigned long long t0 = wall_clock64();
+      wg_stereo(c, b, s, sh, pb_cur, st.tau_tri, f, arena, VS_ARENA);
+      if (tid == 0) {
+        st.ticks[4] += wall_clock64() - t0;
+        const double* c2w = hpose_of(c, b, s, f);
+        *pts_of(c, b, s, pb_cur).n = sh.n_cur;
+        st.n_cur = sh.n_cur; st.n_new = sh.n_cand;
+        st.n_tracked_landmarks_prev = st.n_active;
+        st.frame_count = f + 1; st.has_prev = 1; st.cur = pb_cur;
+        info.frame_index = f + 1; info.status = st.status;
+        info.n_keypoints_left = b.n_kp[s * 2]; info.n_keypoints_right = b.n_kp[s * 2 + 1];
+        int rl = 0, rr = 0;
+        for (int r = 0; r < c.n_regions; ++r) { rl += b.iinfo[s].raw_count[0][r]; rr += b.iinfo[s].raw_count[1][r]; info.thresholds[r] = b.iinfo[s].thr_after[r]; }
+        info.n_detected_left = rl; info.n_detected_right = rr;
+        info.n_new_stereo = sh.n_cand; info.n_points = sh.n_cur; info.window_pixels = st.win; info.error_flags = st.error_flags;
+        info.tau_track = st.tau_track; info.tau_triangulation = st.tau_tri;
+        for (int k = 0; k < 12; ++k) { info.camera_left_to_world[k] = c2w[k]; info.previous_to_current[k] = st.prior[k]; }
+        if (f < VS_POSE_LOG) { double* pl = b.pose_log + ((size_t)s * VS_POSE_LOG + f) * 12; for (int k = 0; k < 12; ++k) pl[k] = c2w[k]; }
+      }
+    }
+  }
+  if (io.report && s == io.report_stream) {
+    // the stage's results for the caller, packed by this workgroup into the pinned host buffer (kernels_report.h): the host
+    // synchronises the frame queue once and reads them there
+    __threadfence();
+    __syncthreads();
+    report_body(c, b, s, io.report, io.report_in_progress, io.seq, io.L, io.out, (size_t)tid, (size_t)blockDim.x, true, tid, (int)blockDim.x);
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) report_publish(io.out, io.seq);
   }
 }
 

@@ -13,6 +13,7 @@
 #include "kernels_depth.h"
 #include "kernels_orb.h"
 #include "kernels_landmark.h"
+#include "kernels_report.h"
 
 #define VS_API extern "C" __attribute__((visibility("default")))
 
@@ -52,6 +53,8 @@ struct vslam_ctx {
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   struct EvRec { hipEvent_t a, b; int k; bool count; };
   std::vector<EvRec> evrec;
+  struct EvShared { hipEvent_t a, b; int k; };      // interval whose start event belongs to an EvRec (only b returns to the pool)
+  std::vector<EvShared> evshared;
   std::vector<hipEvent_t> evpool;
   double kern_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int kern_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -67,6 +70,20 @@ struct vslam_ctx {
   // (tmp_get / tmp_reset below) — hipMalloc and hipFree cost tens of microseconds each, hipFree synchronises the device, and the
   // host-driven RGB-D loop would pay ~60 of them per frame
   struct Tmp { std::vector<std::pair<char*, size_t>> blocks; size_t used = 0; } tmp;
+  // stage reports (kernels_report.h): pinned, device-mapped host buffer the report kernel packs a stage's results into; pinned
+  // staging of the stage path's host images (a pageable hipMemcpyAsync of 2 x 467 KB costs ~0.24 ms of host time)
+  unsigned char* report = nullptr; unsigned char* report_dev = nullptr; ReportLayout rl;
+  unsigned int* report_done = nullptr;                 // arrival counter of the multi-block report kernel (device)
+  // stage path of a one-stream context: the image pipeline runs on the frame queue itself (the caller waits for every stage, so a
+  // second queue buys no overlap and costs an event round trip per frame) and is timed by three events instead of two per kernel
+  hipStream_t img_override = nullptr;
+  bool img_on_frm_queue = false;
+  int report_seq = 0;                                  // stamps every report launch; the header carries it back
+  int report_have = 0, report_have_ip = 0, report_have_stream = -1, report_have_seq = -1;   // what the LAST launch on the frame queue packed (0: nothing)
+  // setters of a one-stream context wait here for the next stage launch (StageIo); flush_pending() launches them on their own
+  struct Pending { int flags = 0; int status = 0, win = 0; double tau = 0; double prior[12], pose[12]; } pend;
+  unsigned char* pin_img[2] = {nullptr, nullptr}; size_t pin_img_bytes = 0;     // [step parity]: left | right
+  hipEvent_t pin_ev[2] = {nullptr, nullptr}; bool pin_used[2] = {false, false};
   int split = 0;   // 0: one frame launch; 1: three phase launches with wide recovery / landmark kernels in between (measured slower);
                    // 2: two phase launches around the wide recovery kernel (faster for few streams: VS_SPLIT2_MAX_STREAMS)
   int sticky = VSLAM_OK;
@@ -96,6 +113,7 @@ static hipError_t tmp_get(vslam_ctx* c, void** p, size_t bytes) {
   bytes = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
   auto& T = c->tmp;
   if (T.blocks.empty() || T.used + bytes > T.blocks.back().second) {
+    (void)hipSetDevice(c->device);     // the caller's thread may have another device current (torch switches it)
     const size_t want = std::max<size_t>(bytes, T.blocks.empty() ? ((size_t)1 << 20) : 2 * T.blocks.back().second);
     void* q = nullptr;
     const hipError_t e = hipMalloc(&q, want);
@@ -115,6 +133,7 @@ static void tmp_reset(vslam_ctx* c) {
   if (!c) return;
   auto& T = c->tmp;
   if (T.blocks.size() > 1) {
+    (void)hipSetDevice(c->device);     // entries call tmp_reset first: the merged block must live on the context's device
     size_t total = 0;
     for (auto& b : T.blocks) { total += b.second; (void)hipFree(b.first); }
     T.blocks.clear();
@@ -137,12 +156,19 @@ static hipEvent_t ev_get(vslam_ctx* c) {
 }
 struct KernelTimer {
   vslam_ctx* c; int k; hipStream_t st; bool count; hipEvent_t a = nullptr;
-  KernelTimer(vslam_ctx* c_, int k_, hipStream_t st_, bool count_ = true) : c(c_), k(k_), st(st_), count(count_) { if (c->timers) { a = ev_get(c); (void)hipEventRecord(a, st); } }
+  KernelTimer(vslam_ctx* c_, int k_, hipStream_t st_, bool count_ = true, bool enabled_ = true) : c(c_), k(k_), st(st_), count(count_) { if (c->timers && enabled_) { a = ev_get(c); (void)hipEventRecord(a, st); } }
   ~KernelTimer() { if (a) { hipEvent_t b = ev_get(c); (void)hipEventRecord(b, st); c->evrec.push_back({a, b, k, count}); } }
 };
 static void sync_all(vslam_ctx* c);
+static int flush_pending(vslam_ctx* c);
 static void harvest_events(vslam_ctx* c) {
   sync_all(c);
+  for (auto& r : c->evshared) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { c->kern_ms[r.k] += ms; c->kern_n[r.k] += 1; }
+    c->evpool.push_back(r.b);
+  }
+  c->evshared.clear();
   for (auto& r : c->evrec) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { c->kern_ms[r.k] += ms; if (r.count) c->kern_n[r.k] += 1; }
@@ -512,6 +538,8 @@ VS_API void vslam_destroy(vslam_ctx* c) {
   for (void* p : c->allocs) (void)hipFree(p);
   tmp_free(c);
   depth_map_free(c);
+  if (c->report) (void)hipHostFree(c->report);
+  for (int q = 0; q < 2; ++q) { if (c->pin_img[q]) (void)hipHostFree(c->pin_img[q]); if (c->pin_ev[q]) (void)hipEventDestroy(c->pin_ev[q]); }
   for (int i = 0; i < 6; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   harvest_events(c);
   for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
@@ -615,28 +643,41 @@ static int launch_image_pipeline(vslam_ctx* c) {
   const int set = c->parity;
   for (auto& g : c->groups) {
     const DevBuf bs = buf_set(c, set, g.s0);
-    hipStream_t st = set ? g.st_img2 : g.st_img;
+    hipStream_t st = c->img_override ? c->img_override : (set ? g.st_img2 : g.st_img);
+    if (!c->img_override && c->img_on_frm_queue) {
+      // the last frame's image pipeline ran on the frame queue (stage path) and left no event behind: a caller that switches to
+      // the fused path mid-sequence pays one synchronisation here, once
+      HIP_TRY(c, hipStreamSynchronize(g.st_frm));
+      c->img_on_frm_queue = false;
+    }
+    if (c->img_override) c->img_on_frm_queue = true;
+    const bool coarse = c->img_override != nullptr;     // stage path: detection = [k_fast_box .. k_emit], extraction = k_brief: three events
     // the image products of this set were last read by the frame kernel two steps ago; the detector thresholds come
     // from the controller in k_emit of the previous step (other image stream)
     if (g.frm_pending[set] && st != g.st_frm) HIP_TRY(c, hipStreamWaitEvent(st, g.ev_frm[set], 0));
-    if (g.emit_pending[set ^ 1] && g.st_img != g.st_img2) HIP_TRY(c, hipStreamWaitEvent(st, g.ev_emit[set ^ 1], 0));
+    if (g.emit_pending[set ^ 1] && (g.st_img != g.st_img2 || c->img_override)) HIP_TRY(c, hipStreamWaitEvent(st, g.ev_emit[set ^ 1], 0));
     dim3 g1(d.TX, (d.c.rows + VS_TILE_H - 1) / VS_TILE_H, 2 * g.n);
-    { KernelTimer t(c, 0, st); hipLaunchKernelGGL(k_fast_box, g1, dim3(256), VS_FB_DYN_LDS, st, c->cfg, bs); }
     const bool orb = d.c.descriptor_type == VSLAM_DESCRIPTOR_ORB;
-    { KernelTimer t(c, 1, st); hipLaunchKernelGGL(k_emit, dim3(g.n, 2), dim3(512), 0, st, c->cfg, bs, orb ? (int)VSLAM_ORB_BORDER : (int)VSLAM_BRIEF_BORDER, 1); }
-    if (g.st_img != g.st_img2) { HIP_TRY(c, hipEventRecord(g.ev_emit[set], st)); g.emit_pending[set] = true; }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (coarse && c->timers) { e0 = ev_get(c); (void)hipEventRecord(e0, st); }
+    { KernelTimer t(c, 0, st, true, !coarse); hipLaunchKernelGGL(k_fast_box, g1, dim3(256), VS_FB_DYN_LDS, st, c->cfg, bs); }
+    { KernelTimer t(c, 1, st, true, !coarse); hipLaunchKernelGGL(k_emit, dim3(g.n, 2), dim3(512), 0, st, c->cfg, bs, orb ? (int)VSLAM_ORB_BORDER : (int)VSLAM_BRIEF_BORDER, 1); }
+    if (e0) { e1 = ev_get(c); (void)hipEventRecord(e1, st); c->evrec.push_back({e0, e1, 0, true}); c->kern_n[1] += 1; }
+    if (g.st_img != g.st_img2 && !c->img_override) { HIP_TRY(c, hipEventRecord(g.ev_emit[set], st)); g.emit_pending[set] = true; }
+    else g.emit_pending[set] = false;
     if (orb) {   // cv::ORB::create() as extractor: Gaussian image (in the box image's memory), steered tests per keypoint
-      KernelTimer t(c, 2, st);
+      KernelTimer t(c, 2, st, true, !coarse);
       Gauss7 gk; for (int i = 0; i < 4; ++i) gk.k[i] = d.gauss7[i];
       hipLaunchKernelGGL(k_gauss7, g1, dim3(256), 0, st, c->cfg, bs, gk);
       hipLaunchKernelGGL(k_orb_describe, dim3((d.c.cols + VS_BT_W - 1) / VS_BT_W, (d.c.rows + VS_BT_H - 1) / VS_BT_H, 2 * g.n), dim3(256), 0, st, c->cfg, bs, d.orb_cos, d.orb_sin);
     } else {
       dim3 g3((d.c.cols + VS_BT_W - 1) / VS_BT_W, (d.c.rows + VS_BT_H - 1) / VS_BT_H, 2 * g.n);
-      KernelTimer t(c, 2, st); hipLaunchKernelGGL(k_brief, g3, dim3(256), 0, st, c->cfg, bs);
+      KernelTimer t(c, 2, st, true, !coarse); hipLaunchKernelGGL(k_brief, g3, dim3(256), 0, st, c->cfg, bs);
     }
+    if (e1) { hipEvent_t e2 = ev_get(c); (void)hipEventRecord(e2, st); hipEvent_t e1b = e1; c->evshared.push_back({e1b, e2, 2}); }
     // left-right descriptor distances of the first epipolar pass: a product of the images alone, so it is computed
     // here, wide, instead of inside the per-stream frame workgroup
-    { KernelTimer t(c, 7, st); hipLaunchKernelGGL(k_stereo_dist, dim3((d.NMAX + 255) / 256, g.n), dim3(256), 0, st, c->cfg, bs); }
+    { KernelTimer t(c, 7, st, true, !coarse); hipLaunchKernelGGL(k_stereo_dist, dim3((d.NMAX + 255) / 256, g.n), dim3(256), 0, st, c->cfg, bs); }
     HIP_TRY(c, hipGetLastError());
     if (st != g.st_frm) { HIP_TRY(c, hipEventRecord(g.ev_img[set], st)); HIP_TRY(c, hipStreamWaitEvent(g.st_frm, g.ev_img[set], 0)); }
   }
@@ -708,7 +749,39 @@ static int upload_images(vslam_ctx* c, const uint8_t* L, const uint8_t* R, int32
   const size_t dense = (size_t)c->B * c->cfg.c.rows * c->cfg.c.cols;
   const bool ordered = c->B == 1 || image_stride >= (size_t)c->cfg.c.rows * row_stride;
   if (c->groups.size() == 1 && ordered && span <= (size_t)c->B * c->up_stream_stride && span <= dense + dense / 8) {
-    hipStream_t st = c->parity ? c->groups[0].st_img2 : c->groups[0].st_img;
+    hipStream_t st = c->img_override ? c->img_override : (c->parity ? c->groups[0].st_img2 : c->groups[0].st_img);
+    // A small pageable source (the literal drop-in: one cv::Mat pair per call) goes through pinned memory of the context: the
+    // runtime's own staging of a pageable hipMemcpyAsync costs ~0.12 ms of host time per 467 KB image here, a memcpy into a pinned
+    // buffer + a true asynchronous copy ~0.03 ms; the left image's DMA runs while the right one is being staged.
+    if (span <= ((size_t)4 << 20)) {
+      hipPointerAttribute_t at;
+      const bool pinned = hipPointerGetAttributes(&at, L) == hipSuccess && at.type == hipMemoryTypeHost;
+      if (!pinned) {
+        (void)hipGetLastError();   // "invalid value" for a plain malloc'ed pointer is the expected answer, not an error of this call
+        const size_t half = (span + 255) & ~(size_t)255;
+        if (c->pin_img_bytes < 2 * half) {
+          for (int q = 0; q < 2; ++q) {
+            if (c->pin_ev[q]) HIP_TRY(c, hipEventSynchronize(c->pin_ev[q]));
+            if (c->pin_img[q]) { (void)hipHostFree(c->pin_img[q]); c->pin_img[q] = nullptr; }
+            void* h = nullptr;
+            HIP_TRY(c, hipHostMalloc(&h, 2 * half, hipHostMallocDefault));
+            c->pin_img[q] = (unsigned char*)h;
+            if (!c->pin_ev[q]) HIP_TRY(c, hipEventCreateWithFlags(&c->pin_ev[q], hipEventDisableTiming));
+          }
+          c->pin_img_bytes = 2 * half;
+        } else if (c->pin_used[c->parity]) {
+          HIP_TRY(c, hipEventSynchronize(c->pin_ev[c->parity]));     // the copy that last read this staging buffer (two frames ago)
+        }
+        unsigned char* stage = c->pin_img[c->parity];
+        std::memcpy(stage, L, span);
+        HIP_TRY(c, hipMemcpyAsync(c->upload[c->parity][0], stage, span, hipMemcpyHostToDevice, st));
+        std::memcpy(stage + half, R, span);
+        HIP_TRY(c, hipMemcpyAsync(c->upload[c->parity][1], stage + half, span, hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipEventRecord(c->pin_ev[c->parity], st));
+        c->pin_used[c->parity] = true;
+        return set_images_device(c, c->upload[c->parity][0], c->upload[c->parity][1], row_stride, image_stride);
+      }
+    }
     HIP_TRY(c, hipMemcpyAsync(c->upload[c->parity][0], L, span, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->upload[c->parity][1], R, span, hipMemcpyHostToDevice, st));
     return set_images_device(c, c->upload[c->parity][0], c->upload[c->parity][1], row_stride, image_stride);
@@ -741,6 +814,8 @@ VS_API int vslam_process_device(vslam_ctx* c, const uint8_t* L, const uint8_t* R
   if (c->sticky != VSLAM_OK) return c->sticky;
   int rc = set_images_device(c, L, R, row_stride, image_stride);
   if (rc != VSLAM_OK) return rc;
+  rc = flush_pending(c);
+  if (rc != VSLAM_OK) return rc;
   rc = launch_image_pipeline(c);
   if (rc != VSLAM_OK) return rc;
   return launch_frame(c);
@@ -751,6 +826,8 @@ VS_API int vslam_process_host(vslam_ctx* c, const uint8_t* L, const uint8_t* R, 
   HIP_TRY(c, hipSetDevice(c->device));
   int rc = upload_images(c, L, R, row_stride, image_stride);
   if (rc != VSLAM_OK) return rc;
+  rc = flush_pending(c);
+  if (rc != VSLAM_OK) return rc;
   rc = launch_image_pipeline(c);
   if (rc != VSLAM_OK) return rc;
   return launch_frame(c);
@@ -760,6 +837,7 @@ VS_API int vslam_process_host(vslam_ctx* c, const uint8_t* L, const uint8_t* R, 
 static int check_stream(vslam_ctx* c, int s) {
   if (!c) return VSLAM_ERR_INVALID;
   if (s < 0 || s >= c->B) return fail(c, VSLAM_ERR_INVALID, "stream index out of range");
+  { int rc = flush_pending(c); if (rc) return rc; }
   sync_all(c);   // read-back: every group's queued work must have finished
   return VSLAM_OK;
 }
@@ -1586,10 +1664,12 @@ VS_API int vslam_orb_describe_keypoints(vslam_ctx* c, const uint8_t* img, int32_
   float scale[16];
   uint8_t* raw[16];
   hipError_t e = hipSuccess;
-  for (int l = 0; l <= top && e == hipSuccess; ++l) {
+  for (int l = 0; l <= top; ++l) {      // every level is validated BEFORE the first launch: an error return must not leave kernels running on the arena
     scale[l] = (float)std::pow((double)scale_factor, (double)l);
     L.rows[l] = l ? (int)std::lrint(rows / scale[l]) : rows; L.cols[l] = l ? (int)std::lrint(cols / scale[l]) : cols;
     if (L.rows[l] < 8 || L.cols[l] < 8) return fail(c, VSLAM_ERR_INVALID, "orb_describe_keypoints: pyramid level smaller than 8 pixels");
+  }
+  for (int l = 0; l <= top && e == hipSuccess; ++l) {
     L.stride[l] = L.cols[l];
     uint8_t* blur = nullptr;
     e = tmp_get(c, (void**)&raw[l], l ? (size_t)L.rows[l] * L.cols[l] : (size_t)rows * stride);
@@ -1808,7 +1888,7 @@ VS_API int vslam_track_match(vslam_ctx* c, const double T[12], int32_t d, double
     }
     if (e == hipSuccess) {
       hipLaunchKernelGGL(k_track_candidates, dim3(16, 1), dim3(256), 0, t->stream, t->cfg, t->buf, by_appearance ? 1 : 0);
-      hipLaunchKernelGGL(k_stage, dim3(1), dim3(VS_WG), 0, t->stream, t->cfg, t->buf, (int)VS_STAGE_TRACK, by_appearance ? 1 : 0);
+      hipLaunchKernelGGL(k_stage, dim3(1), dim3(VS_WG), 0, t->stream, t->cfg, t->buf, (int)VS_STAGE_TRACK, by_appearance ? 1 : 0, StageIo{});
       e = hipMemcpyAsync(&st, t->buf.st, sizeof st, hipMemcpyDeviceToHost, t->stream);
       if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
     }
@@ -1851,7 +1931,7 @@ VS_API int vslam_stereo_match(vslam_ctx* c, double tau_tri, int32_t nL, const in
     }
     if (e == hipSuccess) {
       hipLaunchKernelGGL(k_stereo_dist, dim3((t->cfg.NMAX + 255) / 256, 1), dim3(256), 0, t->stream, t->cfg, t->buf);
-      hipLaunchKernelGGL(k_stage, dim3(1), dim3(VS_WG), 0, t->stream, t->cfg, t->buf, (int)VS_STAGE_STEREO, 0);
+      hipLaunchKernelGGL(k_stage, dim3(1), dim3(VS_WG), 0, t->stream, t->cfg, t->buf, (int)VS_STAGE_STEREO, 0, StageIo{});
       e = hipMemcpyAsync(&st, t->buf.st, sizeof st, hipMemcpyDeviceToHost, t->stream);
       if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
     }
@@ -1948,13 +2028,41 @@ VS_API int vslam_stereo_recover(vslam_ctx* c, const uint8_t* imgL, const uint8_t
 }
 
 // ---- stage entry points (the reference's plug-in virtuals; control flow stays with the caller) ----------
-static int launch_begin(vslam_ctx* c) {
-  for (auto& g : c->groups) hipLaunchKernelGGL(k_begin, dim3(g.n), dim3(256), 0, g.st_frm, c->cfg, buf_set(c, c->last_set, g.s0));
+static StageIo stage_io(vslam_ctx* c, int report, int in_progress) {
+  StageIo io;
+  std::memset(&io, 0, sizeof io);
+  if (c->B == 1 && c->pend.flags) {
+    io.set_flags = c->pend.flags; io.status = c->pend.status; io.win = c->pend.win; io.tau = c->pend.tau;
+    std::memcpy(io.prior, c->pend.prior, sizeof io.prior); std::memcpy(io.pose, c->pend.pose, sizeof io.pose);
+    c->pend.flags = 0;
+  }
+  c->report_have = 0;
+  if (report && c->report) {
+    io.report = report; io.report_in_progress = in_progress; io.report_stream = 0; io.seq = ++c->report_seq; io.L = c->rl; io.out = c->report_dev;
+    c->report_have = report; c->report_have_ip = in_progress; c->report_have_stream = 0; c->report_have_seq = io.seq;
+  }
+  return io;
+}
+// setters that were not folded into a stage launch (the next launch is not a stage kernel, or a getter reads the state)
+static int flush_pending(vslam_ctx* c) {
+  if (!c->pend.flags) return VSLAM_OK;
+  const int fl = c->pend.flags;
+  c->pend.flags = 0;
+  hipStream_t q = c->groups[0].st_frm;
+  if (fl & 1) { D12 p; std::memcpy(p.v, c->pend.prior, sizeof p.v); hipLaunchKernelGGL(k_set_tracker_state, dim3(1), dim3(1), 0, q, c->buf, 0, c->pend.status, c->pend.win, c->pend.tau, p); }
+  if (fl & 2) { D12 p; std::memcpy(p.v, c->pend.pose, sizeof p.v); hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(1), 0, q, c->buf, 0, p); }
   HIP_TRY(c, hipGetLastError());
   return VSLAM_OK;
 }
-static int launch_stage(vslam_ctx* c, int stage, int arg) {
-  for (auto& g : c->groups) hipLaunchKernelGGL(k_stage, dim3(g.n), dim3(VS_WG), 0, g.st_frm, c->cfg, buf_set(c, c->last_set, g.s0), stage, arg);
+static int launch_begin(vslam_ctx* c) {
+  const StageIo io = stage_io(c, 0, 0);
+  for (auto& g : c->groups) hipLaunchKernelGGL(k_begin, dim3(g.n), dim3(256), 0, g.st_frm, c->cfg, buf_set(c, c->last_set, g.s0), io);
+  HIP_TRY(c, hipGetLastError());
+  return VSLAM_OK;
+}
+static int launch_stage(vslam_ctx* c, int stage, int arg, int report = 0, int in_progress = 0) {
+  const StageIo io = stage_io(c, report, in_progress);
+  for (auto& g : c->groups) hipLaunchKernelGGL(k_stage, dim3(g.n), dim3(VS_WG), 0, g.st_frm, c->cfg, buf_set(c, c->last_set, g.s0), stage, arg, io);
   HIP_TRY(c, hipGetLastError());
   return VSLAM_OK;
 }
@@ -1962,18 +2070,30 @@ VS_API int vslam_frame_begin(vslam_ctx* c, const uint8_t* L, const uint8_t* R, i
   if (!c) return VSLAM_ERR_INVALID;
   if (c->sticky != VSLAM_OK) return c->sticky;
   HIP_TRY(c, hipSetDevice(c->device));
+  c->img_override = (c->B == 1 && c->groups.size() == 1) ? c->groups[0].st_frm : nullptr;
   int rc = on_device ? set_images_device(c, L, R, row_stride, image_stride) : upload_images(c, L, R, row_stride, image_stride);
+  if (rc == VSLAM_OK) rc = launch_image_pipeline(c);
+  c->img_override = nullptr;
   if (rc != VSLAM_OK) return rc;
-  rc = launch_image_pipeline(c);
-  if (rc == VSLAM_OK) rc = launch_begin(c);
+  rc = launch_begin(c);
   c->frame_begun = rc == VSLAM_OK;
+  if (rc == VSLAM_OK && c->report) {
+    // a caller that reads stage views wants the keypoints next (initialize() fills Frame::keypoints / descriptors): packed right
+    // behind k_begin, no host round trip in between
+    const vslam_ctx::Group& g = c->groups[0];
+    const int seq = ++c->report_seq;
+    hipLaunchKernelGGL(k_report, dim3(32), dim3(256), 0, g.st_frm, c->cfg, buf_set(c, c->last_set, g.s0), 0, (int)VS_REPORT_KEYPOINTS, 0, seq, c->rl, c->report_dev, c->report_done);
+    HIP_TRY(c, hipGetLastError());
+    c->report_have = VS_REPORT_KEYPOINTS; c->report_have_ip = 0; c->report_have_stream = 0; c->report_have_seq = seq;
+  }
   return rc;
 }
 VS_API int vslam_frame_finish(vslam_ctx* c) {
   if (!c) return VSLAM_ERR_INVALID;
   if (!c->frame_begun) return fail(c, VSLAM_ERR_STATE, "vslam_frame_finish called before vslam_frame_begin");
   c->frame_begun = false;
-  return launch_frame(c);
+  int rc = flush_pending(c);
+  return rc == VSLAM_OK ? launch_frame(c) : rc;
 }
 #define NEED_FRAME(name) if (!c) return VSLAM_ERR_INVALID; if (!c->frame_begun) return fail(c, VSLAM_ERR_STATE, name " called before vslam_frame_begin")
 VS_API int vslam_frame_restore(vslam_ctx* c) {
@@ -1984,25 +2104,42 @@ VS_API int vslam_frame_restore(vslam_ctx* c) {
 }
 VS_API int vslam_track(vslam_ctx* c, int by_appearance) {
   NEED_FRAME("vslam_track");
+  { int rc = flush_pending(c); if (rc) return rc; }     // the candidate kernel reads prior / window / distance before the stage kernel runs
   for (auto& g : c->groups) {
     const int gx = cand_blocks(c, g.n);
     hipLaunchKernelGGL(k_track_candidates, dim3(gx, g.n), dim3(256), 0, g.st_frm, c->cfg, buf_set(c, c->last_set, g.s0), by_appearance ? 1 : 0);
   }
-  return launch_stage(c, VS_STAGE_TRACK, by_appearance ? 1 : 0);
+  return launch_stage(c, VS_STAGE_TRACK, by_appearance ? 1 : 0, VS_REPORT_TRACK);
 }
-VS_API int vslam_align(vslam_ctx* c, int inverse_depth) { NEED_FRAME("vslam_align"); return launch_stage(c, VS_STAGE_ALIGN, inverse_depth); }
-VS_API int vslam_prune_recover(vslam_ctx* c) { NEED_FRAME("vslam_prune_recover"); return launch_stage(c, VS_STAGE_PRUNE_RECOVER, c->cfg.c.enable_landmark_recovery); }
+VS_API int vslam_align(vslam_ctx* c, int inverse_depth) { NEED_FRAME("vslam_align"); return launch_stage(c, VS_STAGE_ALIGN, inverse_depth, VS_REPORT_ALIGNER); }
+VS_API int vslam_prune_recover(vslam_ctx* c) { NEED_FRAME("vslam_prune_recover"); return launch_stage(c, VS_STAGE_PRUNE_RECOVER, c->cfg.c.enable_landmark_recovery, VS_REPORT_POINTS, 1); }
 VS_API int vslam_update_points(vslam_ctx* c) { NEED_FRAME("vslam_update_points"); return launch_stage(c, VS_STAGE_UPDATE, 0); }
 VS_API int vslam_stereo_new(vslam_ctx* c) {
   NEED_FRAME("vslam_stereo_new");
   c->frame_begun = false;  // compute() is the last call PoseTracker3D::compute makes on a frame
-  int rc = launch_stage(c, VS_STAGE_STEREO, 0);
+  int rc = launch_stage(c, VS_STAGE_STEREO, 0, VS_REPORT_POINTS, 0);
   return rc == VSLAM_OK ? frame_done(c) : rc;
 }
+VS_API int vslam_compute(vslam_ctx* c) {     // vslam_update_points + vslam_stereo_new in one launch
+  NEED_FRAME("vslam_compute");
+  c->frame_begun = false;
+  int rc = launch_stage(c, VS_STAGE_COMPUTE, 0, VS_REPORT_POINTS, 0);
+  return rc == VSLAM_OK ? frame_done(c) : rc;
+}
+// the setters are queued on the stream's frame queue, in order with the stage launches around them: no synchronisation
+static int check_stream_index(vslam_ctx* c, int s) {
+  if (!c) return VSLAM_ERR_INVALID;
+  if (s < 0 || s >= c->B) return fail(c, VSLAM_ERR_INVALID, "stream index out of range");
+  return VSLAM_OK;
+}
 VS_API int vslam_set_tracker_state(vslam_ctx* c, int s, int status, const double prior[12], int win, double tau) {
-  int rc = check_stream(c, s);
+  int rc = check_stream_index(c, s);
   if (rc) return rc;
   if (!prior) return fail(c, VSLAM_ERR_INVALID, "null prior");
+  if (c->B == 1) {      // rides with the next stage launch (StageIo)
+    c->pend.flags |= 1; c->pend.status = status; c->pend.win = win; c->pend.tau = tau; std::memcpy(c->pend.prior, prior, sizeof c->pend.prior);
+    return VSLAM_OK;
+  }
   D12 p;
   std::memcpy(p.v, prior, sizeof p.v);
   hipLaunchKernelGGL(k_set_tracker_state, dim3(1), dim3(1), 0, c->groups[group_of(c, s)].st_frm, c->buf, s, status, win, tau, p);
@@ -2010,13 +2147,139 @@ VS_API int vslam_set_tracker_state(vslam_ctx* c, int s, int status, const double
   return VSLAM_OK;
 }
 VS_API int vslam_set_pose(vslam_ctx* c, int s, const double pose[12]) {
-  int rc = check_stream(c, s);
+  int rc = check_stream_index(c, s);
   if (rc) return rc;
   if (!pose) return fail(c, VSLAM_ERR_INVALID, "null pose");
+  if (c->B == 1) { c->pend.flags |= 2; std::memcpy(c->pend.pose, pose, sizeof c->pend.pose); return VSLAM_OK; }
   D12 p;
   std::memcpy(p.v, pose, sizeof p.v);
   hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(1), 0, c->groups[group_of(c, s)].st_frm, c->buf, s, p);
   HIP_TRY(c, hipGetLastError());
+  return VSLAM_OK;
+}
+
+
+// ---- pinned host memory for the caller's images -------------------------------------------------------------------------------------
+VS_API int vslam_host_alloc(void** out, size_t bytes) {
+  if (!out || !bytes) return VSLAM_ERR_INVALID;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, VSLAM_ERR_HIP, "vslam_host_alloc: hipHostMalloc failed"); }
+  *out = p;
+  return VSLAM_OK;
+}
+VS_API void vslam_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+// ---- stage views: one report kernel + one synchronisation of the stream's frame queue per stage (kernels_report.h) -------------
+static uint32_t rl_take(uint32_t* off, size_t bytes) { const uint32_t o = *off; *off = (uint32_t)((o + bytes + 63) & ~(size_t)63); return o; }
+static int report_ready(vslam_ctx* c) {
+  if (c->report) return VSLAM_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  ReportLayout& L = c->rl;
+  uint32_t off = (uint32_t)((sizeof(ReportHeader) + 255) & ~(size_t)255);
+  const size_t N = c->cfg.NMAX, P = c->cfg.MAXP;
+  for (int d = 0; d < 2; ++d) { L.kp_xy[d] = rl_take(&off, N * 4); L.kp_score[d] = rl_take(&off, N); L.desc[d] = rl_take(&off, N * 32); }
+  L.trk = rl_take(&off, P * 16); L.lost = rl_take(&off, P * 4);
+  L.chi = rl_take(&off, P * 8); L.inl = rl_take(&off, P);
+  L.p_kp = rl_take(&off, P * 8); L.p_meta = rl_take(&off, P * 24); L.p_cam = rl_take(&off, P * 24); L.p_desc = rl_take(&off, P * 64);
+  L.total = off;
+  void* h = nullptr;
+  HIP_TRY(c, hipHostMalloc(&h, L.total, hipHostMallocMapped));
+  void* d = nullptr;
+  if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return fail(c, VSLAM_ERR_HIP, "hipHostGetDevicePointer(report buffer)"); }
+  std::memset(h, 0, L.total);
+  if (dalloc(c, &c->report_done, 1) != hipSuccess || hipMemset(c->report_done, 0, sizeof(unsigned int)) != hipSuccess) { (void)hipHostFree(h); return fail(c, VSLAM_ERR_HIP, "report counter"); }
+  c->report = (unsigned char*)h; c->report_dev = (unsigned char*)d;
+  return VSLAM_OK;
+}
+// packs `what` of stream s and waits for it: everything queued on the stream's frame queue before (the image pipeline is ordered
+// before it by the frame's event) has finished when this returns
+static int report_run(vslam_ctx* c, int s, int what, int in_progress, const ReportHeader** hdr) {
+  int rc = check_stream_index(c, s);
+  if (rc) return rc;
+  if (c->sticky != VSLAM_OK) return c->sticky;
+  rc = report_ready(c);
+  if (rc) return rc;
+  const vslam_ctx::Group& g = c->groups[group_of(c, s)];
+  int seq = c->report_have_seq;
+  const bool folded = c->report_have == what && c->report_have_ip == in_progress && c->report_have_stream == s && !c->pend.flags;
+  if (!folded) {      // the stage was launched before the report buffer existed, or something else ran since: pack it now
+    rc = flush_pending(c);
+    if (rc) return rc;
+    seq = ++c->report_seq;
+    const int blocks = what == VS_REPORT_KEYPOINTS ? 32 : (what == VS_REPORT_POINTS ? 16 : 4);
+    hipLaunchKernelGGL(k_report, dim3(blocks), dim3(256), 0, g.st_frm, c->cfg, buf_set(c, c->last_set, g.s0), s, what, in_progress, seq, c->rl, c->report_dev, c->report_done);
+    HIP_TRY(c, hipGetLastError());
+    c->report_have = what; c->report_have_ip = in_progress; c->report_have_stream = s; c->report_have_seq = seq;
+  }
+  // the report's completion flag (its seq, stored last with system-scope release) is polled in the pinned buffer: the caller's
+  // thread sees the stage end a few microseconds after the kernel's last store instead of waiting for the runtime's own
+  // completion path (~10-15 us per synchronisation, five per frame).  Bounded: after ~20 ms without the flag the queue is
+  // synchronised the ordinary way (an inactive stream never writes a report: that is the STATE error below)
+  const ReportHeader* h = reinterpret_cast<const ReportHeader*>(c->report);
+  bool seen = false;
+  for (long spin = 0; spin < 4000000L; ++spin) {
+    if (__atomic_load_n(&h->seq, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
+    __builtin_ia32_pause();
+  }
+  if (!seen) HIP_TRY(c, hipStreamSynchronize(g.st_frm));
+  *hdr = h;
+  if (__atomic_load_n(&h->seq, __ATOMIC_ACQUIRE) != seq || h->what != what) return fail(c, VSLAM_ERR_STATE, "stage report is stale (the stream is inactive?)");
+  if ((*hdr)->info.error_flags) c->err = "device buffer capacity exceeded (error_flags != 0)";
+  return VSLAM_OK;
+}
+VS_API int vslam_view_keypoints(vslam_ctx* c, int s, vslam_keypoints_view* out) {
+  if (!c || !out) return VSLAM_ERR_INVALID;
+  const ReportHeader* h = nullptr;
+  int rc = report_run(c, s, VS_REPORT_KEYPOINTS, 0, &h);
+  if (rc) return rc;
+  for (int d = 0; d < 2; ++d) {
+    out->n[d] = std::min(h->n_kp[d], c->cfg.NMAX);
+    out->xy[d] = reinterpret_cast<const int16_t*>(c->report + c->rl.kp_xy[d]);
+    out->score[d] = c->report + c->rl.kp_score[d];
+    out->desc[d] = c->report + c->rl.desc[d];
+  }
+  return VSLAM_OK;
+}
+VS_API int vslam_view_track(vslam_ctx* c, int s, vslam_track_view* out) {
+  if (!c || !out) return VSLAM_ERR_INVALID;
+  const ReportHeader* h = nullptr;
+  int rc = report_run(c, s, VS_REPORT_TRACK, 0, &h);
+  if (rc) return rc;
+  out->n_tracked = h->n_trk; out->n_lost = h->n_lost; out->n_tracked_landmarks = h->n_tracked_landmarks;
+  out->tracked4 = reinterpret_cast<const int32_t*>(c->report + c->rl.trk);
+  out->lost = reinterpret_cast<const int32_t*>(c->report + c->rl.lost);
+  return VSLAM_OK;
+}
+VS_API int vslam_view_aligner(vslam_ctx* c, int s, vslam_aligner_view* out) {
+  if (!c || !out) return VSLAM_ERR_INVALID;
+  const ReportHeader* h = nullptr;
+  int rc = report_run(c, s, VS_REPORT_ALIGNER, 0, &h);
+  if (rc) return rc;
+  out->n = h->al_n; out->n_inliers = h->al_inliers; out->n_outliers = h->al_outliers; out->iterations = h->al_iterations;
+  out->converged = h->al_converged; out->total_error = h->al_total_error;
+  out->chi = reinterpret_cast<const double*>(c->report + c->rl.chi);
+  out->inlier = c->report + c->rl.inl;
+  std::memcpy(out->T, h->al_T, sizeof out->T);
+  std::memcpy(out->H, h->al_H, sizeof out->H);
+  return VSLAM_OK;
+}
+VS_API int vslam_view_points(vslam_ctx* c, int s, int in_progress, vslam_points_view* out) {
+  if (!c || !out) return VSLAM_ERR_INVALID;
+  const ReportHeader* h = nullptr;
+  int rc = report_run(c, s, VS_REPORT_POINTS, in_progress ? 1 : 0, &h);
+  if (rc) return rc;
+  out->n = h->n_points;
+  out->kp = reinterpret_cast<const int16_t*>(c->report + c->rl.p_kp);
+  out->meta = reinterpret_cast<const int32_t*>(c->report + c->rl.p_meta);
+  out->cam = reinterpret_cast<const double*>(c->report + c->rl.p_cam);
+  out->desc = in_progress ? c->report + c->rl.p_desc : nullptr;
+  out->first_full = in_progress ? std::min(h->n_after_prune, h->n_points) : 0;
+  out->info = h->info;
+  // the generator's chronometers from the same report (no further copy): accumulated seconds like vslam_get_timers
+  const double inv = 1e-8;
+  out->seconds_tracking = (double)h->ticks[0] * inv; out->seconds_pose_optimization = (double)h->ticks[1] * inv;
+  out->seconds_point_recovery = (double)h->ticks[2] * inv; out->seconds_landmark_optimization = (double)h->ticks[3] * inv;
+  out->seconds_point_triangulation = (double)h->ticks[4] * inv;
   return VSLAM_OK;
 }
 
