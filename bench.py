@@ -78,8 +78,9 @@ KITTI_FRAMES = [4541, 1101, 4661, 801, 271, 2761, 1101, 1101, 4071, 1591, 1201] 
 SEQ_FRAMES = KITTI_FRAMES[0]
 EUROC_MH01_FRAMES = 3682   # MH_01_easy stereo pairs
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PMC_SUMMARY = "r03_pmc_traffic.json"   # tools/pmc_traffic.sh (rocprofv3 --pmc, separate passes); carries the source hash of its build
-ATE_NOISE_STUDY = ["r03_ate_noise_seeds48.json", "r03_ate_noise_overlaps48.json", "r03_ate_noise_seeds16.json", "r03_ate_noise_seeds.json"]   # tools/eval_ate_noise.py: sequential ATE spread under sensor noise vs chunked (48 seeds for the default configuration and for B = 160 at overlaps 2 .. 8, 16 for B = 144 / 160, 8 seeds for the B x overlap grid)
+PMC_SUMMARY = "r04_pmc_traffic.json"   # tools/pmc_traffic.sh (rocprofv3 --pmc, separate passes); carries the source hash of its build
+SQ_SUMMARY = "r04_sq_counters.json"    # tools/pmc_sq.sh (SQ / GRBM counters per kernel, kernels serialised on one HIP stream); carries the source hash as well
+ATE_NOISE_STUDY = ["r04_ate_noise_rel48.json", "r03_ate_noise_seeds48.json", "r03_ate_noise_overlaps48.json", "r03_ate_noise_seeds16.json", "r03_ate_noise_seeds.json"]   # tools/eval_ate_noise.py: sequential ATE spread under sensor noise vs chunked (48 seeds for the default configuration and for B = 160 at overlaps 2 .. 8, 16 for B = 144 / 160, 8 seeds for the B x overlap grid)
 METRIC = "stereo frames/sec on KITTI-00 at 1/2/4/8 MI355X; ATE vs reference"
 KERNELS = ["k_fast_box", "k_emit", "k_brief", "k_track_candidates", "k_frame", "k_recover_brief", "k_update_landmarks", "k_stereo_dist"]
 
@@ -122,6 +123,9 @@ def algorithmic_bytes(cfg, B, stats):
     # one launch of the fused frame kernel also does the recovery descriptors and the landmark refinement (their own kernels when
     # the frame is split into phase launches).  SURVEY.md 8(d) lists neither: they are reported separately, never inside `frac`.
     extra = {"k_frame": (per_frame["k_recover_brief"] + per_frame["k_update_landmarks"]) * B} if stats.get("fused", True) else {}
+    # SURVEY.md 8(d) asks for BOTH figures of the frame path: with the aligner's I·M·64 "re-read per iteration" term and without it
+    # (those re-reads are register / LDS resident: M < 512 lanes, one measurement per lane, nothing of them reaches HBM)
+    extra["k_frame_hbm_only"] = (per_frame["k_frame"] - I * M * 64) * B
     return {k: v * B for k, v in per_frame.items()}, extra
 
 
@@ -150,6 +154,29 @@ def kernel_report(api, cfg, B, stats, launches_per_step_hint):
     dom = max(ktimes.items(), key=lambda kv: kv[1][0])[0]
     dom_avg_s = ktimes[dom][0] / max(ktimes[dom][1], 1) * 1e-3
     return kern, dom, dom_avg_s, abytes, extra
+
+
+def sq_utilisation():
+    """Per-kernel VALU / SALU issue utilisation from the committed SQ counter summary (tools/pmc_sq.sh), only when it was recorded on
+    THIS build.  valu_util = SQ_ACTIVE_INST_VALU / (32 x GRBM_GUI_ACTIVE): SQ_ACTIVE_INST_VALU counts quad-cycles (4 shader cycles, what
+    one wave64 VALU instruction holds its SIMD's issue for), GRBM_GUI_ACTIVE is summed over the 8 XCDs, the chip has 1024 SIMDs:
+    busy SIMD-cycles 4 x ACTIVE over available SIMD-cycles (GRBM / 8) x 1024.  salu_util = SQ_INSTS_SALU / (32 x GRBM_GUI_ACTIVE): one
+    scalar instruction per cycle and CU (256 CUs).  Each kernel alone on the chip (the counters need serialised kernels)."""
+    try:
+        sq = json.load(open(os.path.join(ROOT, "profiles", SQ_SUMMARY)))
+    except (OSError, ValueError):
+        return {}, "no counter file profiles/%s" % SQ_SUMMARY
+    here = buildinfo.source_sha16()
+    if sq.get("source_sha16") != here:
+        return {}, "profiles/%s was recorded on source %s, this build is %s: not reported" % (SQ_SUMMARY, sq.get("source_sha16"), here)
+    out = {}
+    for k, c in sq.get("per_kernel", {}).items():
+        g = c.get("GRBM_GUI_ACTIVE", 0.0)
+        if g > 0 and "SQ_ACTIVE_INST_VALU" in c and "SQ_INSTS_SALU" in c:
+            out[k] = {"valu_util": round(c["SQ_ACTIVE_INST_VALU"] / (32.0 * g), 4), "salu_util": round(c["SQ_INSTS_SALU"] / (32.0 * g), 4)}
+            if "SQ_ACTIVE_INST_LDS" in c:
+                out[k]["lds_util"] = round(c["SQ_ACTIVE_INST_LDS"] / (32.0 * g), 4)
+    return out, None
 
 
 def pmc_traffic(kernel, streams):
@@ -360,8 +387,21 @@ class Bench(object):
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(abytes[dom]), "avg_launch_ms": round(dom_avg_s * 1e3, 4),
                 "algorithmic_bytes": "SURVEY.md 8(d) rows of the kernel x the %d frames one launch processes" % B}
+        roof["achieved_hbm_only"] = round(extra["k_frame_hbm_only"] / dom_avg_s / 1e9, 2) if dom == "k_frame" else roof["achieved"]
+        roof["frac_hbm_only"] = round(roof["achieved_hbm_only"] / HBM_PEAK_GBS, 5)
+        roof["frac_note"] = ("frac: SURVEY.md 8(d) bytes including the aligner's I*M*64 per-iteration re-reads; frac_hbm_only: without them (they are "
+                             "register / LDS resident and never reach HBM).  The step is VALU / SALU issue-bound, not HBM-bound: see kernels{}.valu_util")
+        if traffic is not None:
+            roof["traffic_over_algorithmic"] = round(traffic / abytes[dom], 3)
+            roof["traffic_counters"] = "FETCH_SIZE + WRITE_SIZE as reported; wide (16 B/lane) reads are tallied at half their bytes on gfx950, the kernel's loads are of mixed width: FETCH is a lower bound"
         if traffic_note:
             roof["traffic_note"] = traffic_note
+        util, util_note = sq_utilisation()
+        for k_, u_ in util.items():
+            if k_ in kern:
+                kern[k_].update(u_)
+        if util_note:
+            roof["utilisation_note"] = util_note
         if dom in extra:      # what the fused launch does beyond 8(d)'s rows, labelled and kept out of `frac`
             roof["achieved_incl_recovery"] = round((abytes[dom] + extra[dom]) / dom_avg_s / 1e9, 2)
             roof["achieved_incl_recovery_note"] = ("+ recovery descriptors (projected landmarks x (64 + 2 x 512 box taps x 2 B)) and landmark "
@@ -441,6 +481,15 @@ class Bench(object):
                              "the reference tool's own alignment (trajectory_analyzer.cpp:212-309 as restated in evaluation.py)",
                "chunked_is": "the timed configuration itself: %d chunks of %d frames + %d warm-up frames, chained at the seams" % (B, job["L"], self.args.overlap),
                "sequential_is": "the same images as ONE stream (exact mode: identical to the CPU port to rounding), %.2f s for the whole sequence" % seq_s}
+        # metrics that can resolve a seam (ATE is a random walk in the noise): KITTI's relative errors over 100 .. 800 m sub-trajectories
+        # and the relative-pose error of the frame-to-frame motions AT the seams, chunked against sequential at the very same frames
+        kc, ks = ev.kitti_relative_errors(traj, gt), ev.kitti_relative_errors(seq, gt)
+        out["kitti_relative"] = {"chunked": {"t_rel_percent": round(kc["t_rel_percent"], 4), "r_rel_deg_per_m": round(kc["r_rel_deg_per_m"], 6)},
+                                 "sequential": {"t_rel_percent": round(ks["t_rel_percent"], 4), "r_rel_deg_per_m": round(ks["r_rel_deg_per_m"], 6)},
+                                 "t_rel_chunked_over_sequential": round(kc["t_rel_percent"] / ks["t_rel_percent"], 4),
+                                 "r_rel_chunked_over_sequential": round(kc["r_rel_deg_per_m"] / ks["r_rel_deg_per_m"], 4), "segments": kc["segments"],
+                                 "definition": "KITTI odometry devkit: mean over sub-trajectories of 100 .. 800 m starting every 10 frames (evaluation.kitti_relative_errors)"}
+        out["seam"] = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in ev.seam_report(traj, seq, gt, job["plan"]).items()}
         key = "B%d_ov%d" % (self.args.streams, self.args.overlap)
         for name in ATE_NOISE_STUDY:      # where single runs sit in the pipeline's own spread under sensor noise (tools/eval_ate_noise.py)
             try:
@@ -457,6 +506,13 @@ class Bench(object):
                 out["noise_study"].update({"chunked_mean": round(c["mean"], 3), "chunked_std": round(c["std"], 3),
                                            "mean_shift_in_sequential_sigmas": round(c["mean_shift_in_sequential_sigmas"], 3),
                                            "welch_t": round(c["welch_t"], 3), "chunked_runs_inside_sequential_range": c["inside_sequential_range"]})
+                for m in ("t_rel", "r_rel"):          # the study's relative errors (r04 onwards)
+                    if m in full and key in full[m]["chunked"]:
+                        q = full[m]["chunked"][key]
+                        out["noise_study"][m] = {"sequential_mean": round(full[m]["sequential"]["mean"], 5), "chunked_mean": round(q["mean"], 5),
+                                                 "ratio_of_means": round(q["ratio_of_means"], 4), "welch_t": round(q["welch_t"], 3)}
+                if "seam" in full and key in full["seam"]:
+                    out["noise_study"]["seam"] = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in full["seam"][key].items()}
             break
         return out
 

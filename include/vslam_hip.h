@@ -513,8 +513,8 @@ int vslam_gaussian_blur7_u8(vslam_ctx* ctx, const uint8_t* image, int32_t rows, 
  * orb_pattern) calls these once before the first frame; maps, relocalization data and Hamming thresholds tuned on OpenCV
  * descriptors then keep their meaning.
  *   BRIEF pair i = {y1, x1, y2, x2}: bit i (byte i / 8, MSB first) = box9x9(p + (x1, y1)) < box9x9(p + (x2, y2)); |.| <= 24.
- *   ORB   pair i = {x1, y1, x2, y2}: bit i (byte i / 8, LSB first) = I(c + R (x1, y1)) < I(c + R (x2, y2)); |.| <= 15 and
- *   x^2 + y^2 <= 15^2 (the rotated point must stay inside the 16 px margin the tiles stage).
+ *   ORB   pair i = {x1, y1, x2, y2}: bit i (byte i / 8, LSB first) = I(c + R (x1, y1)) < I(c + R (x2, y2)); |x|, |y| <= 15, the
+ *   31 x 31 patch (OpenCV's bit_pattern_31_, whose points reach radius 17.7, fits).
  * The tables live in the device's constant memory: the setting holds for every context on `device` in this process.  Call
  * them while no frame is in flight.  vslam_get_*_pattern returns the table in effect (256 * 4 bytes). */
 int vslam_set_brief_pattern(int device, const int8_t* pairs_y1x1y2x2 /* 256 * 4 */);

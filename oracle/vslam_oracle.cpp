@@ -1686,7 +1686,7 @@ ORC_API int orc_set_brief_pattern(int, const int8_t* pairs) {
 }
 ORC_API int orc_set_orb_pattern(int, const int8_t* pairs) {
   if (!pairs) return VSLAM_ERR_INVALID;
-  for (int i = 0; i < 512; ++i) if (pairs[2 * i] * pairs[2 * i] + pairs[2 * i + 1] * pairs[2 * i + 1] > 225) return VSLAM_ERR_INVALID;
+  for (int i = 0; i < 1024; ++i) if (pairs[i] < -15 || pairs[i] > 15) return VSLAM_ERR_INVALID;     /* a 31 x 31 patch, as the HIP library checks it */
   std::memcpy(kOrbPattern, pairs, 1024);
   return VSLAM_OK;
 }

@@ -26,8 +26,9 @@ def test_frame_kernel_bytes_are_the_survey_rows(bench):
     assert ab["k_frame"] == pytest.approx(per_frame * 160)
     assert ab["k_fast_box"] == 2 * 1241 * 376 * 160                                               # each image byte once
     assert extra["k_frame"] > 0 and "k_fast_box" not in extra                                     # recovery taps etc.: separate, never in frac
+    assert extra["k_frame_hbm_only"] == pytest.approx((per_frame - I * M * 64) * 160)            # 8(d)'s second figure: without the aligner re-reads
     ab2, extra2 = bench.algorithmic_bytes(cfg, 160, dict(stats, fused=False))
-    assert ab2["k_frame"] == ab["k_frame"] and extra2 == {}
+    assert ab2["k_frame"] == ab["k_frame"] and set(extra2) == {"k_frame_hbm_only"}
 
 
 def test_counter_file_is_tied_to_the_build(bench, monkeypatch, tmp_path):
@@ -62,3 +63,23 @@ def test_source_hash_follows_the_sources(tmp_path, monkeypatch):
     extra.write_text("// changed")
     monkeypatch.setattr(buildinfo, "source_files", lambda: files + [str(extra)])
     assert buildinfo.source_sha16() != a
+
+
+def test_sq_utilisation_formula_and_build_tie(bench, monkeypatch, tmp_path):
+    from vslam_pose_estimation_framework_amd import buildinfo
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    # k_fast_box of profiles/r03l_sq_counters.json: 142.7 M quad-cycles of VALU issue, 5.18 M GRBM cycles summed over 8 XCDs
+    rec = {"source_sha16": buildinfo.source_sha16(), "per_kernel": {"k_fast_box": {"SQ_ACTIVE_INST_VALU": 142686400.2, "SQ_INSTS_SALU": 86842098.2,
+                                                                                  "SQ_ACTIVE_INST_LDS": 24865027.2, "GRBM_GUI_ACTIVE": 5177150.3}}}
+    (prof / bench.SQ_SUMMARY).write_text(json.dumps(rec))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    util, note = bench.sq_utilisation()
+    assert note is None
+    # 4 x 142.7 M busy SIMD-cycles over (5.18 M / 8) x 1024 available: 86 %
+    assert util["k_fast_box"]["valu_util"] == pytest.approx(4 * 142686400.2 / (5177150.3 / 8 * 1024), rel=1e-3)
+    assert 0.85 < util["k_fast_box"]["valu_util"] < 0.87 and 0.5 < util["k_fast_box"]["salu_util"] < 0.55
+    rec["source_sha16"] = "0" * 16
+    (prof / bench.SQ_SUMMARY).write_text(json.dumps(rec))
+    util, note = bench.sq_utilisation()
+    assert util == {} and "recorded on source" in note

@@ -11,12 +11,13 @@ from vslam_pose_estimation_framework_amd.capi import VslamError
 def other_tables(seed=5):
     rng = np.random.default_rng(seed)
     brief = rng.integers(-24, 25, size=(256, 4)).astype(np.int8)
-    pts = []
-    while len(pts) < 512:
-        x, y = rng.integers(-15, 16, size=2)
-        if x * x + y * y <= 169:
-            pts.append((x, y))
-    orb = np.array(pts, np.int8).reshape(256, 4)
+    # the whole 31 x 31 patch, corners included: OpenCV's bit_pattern_31_ holds points such as (7, -12, 12, -13) — radius 17.7 —
+    # which a radius-15 rule refused; the extremes are put in by hand so that every run exercises them
+    orb = rng.integers(-15, 16, size=(256, 4)).astype(np.int8)
+    orb[0] = (7, -12, 12, -13)
+    orb[1] = (15, 15, -15, -15)
+    orb[2] = (-15, 15, 15, -15)
+    orb[3] = (0, 15, 15, 0)
     return brief, orb
 
 
@@ -40,7 +41,7 @@ def test_oracle_pattern_is_data():
         bad = brief1.copy(); bad[3, 1] = 25
         with pytest.raises(VslamError):
             o.set_pattern("brief", bad)
-        bad = orb1.copy(); bad[7, 0] = 15; bad[7, 1] = 15
+        bad = orb1.copy(); bad[7, 0] = 16
         with pytest.raises(VslamError):
             o.set_pattern("orb", bad)
     finally:

@@ -6,8 +6,10 @@ set -e
 cp gpurun_out/prof_$T/stats/*/*kernel_stats.csv profiles/${T}_kernel_stats.csv
 cp gpurun_out/prof_$T/knn/*/*kernel_stats.csv profiles/${T}_knn2_kernel_stats.csv
 cp gpurun_out/pmc_$T/summary.json profiles/${T}_pmc_traffic.json
-cp gpurun_out/pmc_$T/summary.json profiles/r03_pmc_traffic.json
+cp gpurun_out/pmc_$T/summary.json profiles/r04_pmc_traffic.json
+cp gpurun_out/sq_$T/summary.json profiles/r04_sq_counters.json
+[ -f gpurun_out/pmcph_$T/summary.json ] && cp gpurun_out/pmcph_$T/summary.json profiles/${T}_pmc_traffic_phases.json
 cp gpurun_out/sq_$T/summary.json profiles/${T}_sq_counters.json
 cp gpurun_out/prof_$T/build.json profiles/${T}_build.json
 [ -f gpurun_out/bench_$T.json ] && cp gpurun_out/bench_$T.json profiles/${T}_bench_driver_cmd.json
-ls -la profiles/${T}_* profiles/r03_pmc_traffic.json
+ls -la profiles/${T}_* profiles/r04_pmc_traffic.json

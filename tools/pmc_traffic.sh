@@ -7,7 +7,7 @@ OUT=$PWD/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -- python3 bench.py --no-cpu --no-exact --no-pcie --no-ate --steps 8 > $OUT/$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -- python3 bench.py --no-cpu --no-exact --no-pcie --no-ate --no-shim --steps 8 > $OUT/$C.log 2>&1
 done
 python3 - "$OUT" << 'PY'
 import csv, glob, json, os, sys, collections
@@ -29,6 +29,6 @@ streams = None
 for line in open(out + "/FETCH_SIZE.log"):          # the bench line of the profiled run says how many streams it ran
     if line.startswith("{") and "streams_per_gpu" in line:
         streams = json.loads(line)["config"]["streams_per_gpu"]
-json.dump({"streams": streams, "source_sha16": buildinfo.source_sha16(), "library_sha16": buildinfo.library_sha16(), "command": "python3 bench.py --no-cpu --no-exact --no-pcie --no-ate --steps 8", "counters": "FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes, kernel-trace only; KB per launch as reported (see MI355X_MICROARCH.md for the fetch under-count of wide loads)", "per_launch_KB": res}, open(out + "/summary.json", "w"), indent=1)
+json.dump({"streams": streams, "source_sha16": buildinfo.source_sha16(), "library_sha16": buildinfo.library_sha16(), "command": "python3 bench.py --no-cpu --no-exact --no-pcie --no-ate --no-shim --steps 8", "counters": "FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes, kernel-trace only; KB per launch as reported (see MI355X_MICROARCH.md for the fetch under-count of wide loads)", "per_launch_KB": res}, open(out + "/summary.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY

@@ -1,6 +1,6 @@
 """Per-stream, per-step phase durations of k_frame (in-kernel clocks; build the library with
 `make -C vslam_pose_estimation_framework_amd/csrc clean all EXTRA=-DVS_PROFILE_PHASES` first): where the slowest stream of a step spends
-its time.  Usage: python tools/dbg_tail.py [B] [K]"""
+its time.  Usage: python tools/probe/phase_clocks_per_stream.py [B] [K]"""
 import sys, os, ctypes as C
 sys.path.insert(0, os.getcwd())
 import torch, numpy as np

@@ -8,7 +8,7 @@ TAG=${1:-r03}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --no-cpu --no-exact --no-pcie --no-ate --steps 35 > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --no-cpu --no-exact --no-pcie --no-ate --no-shim --steps 35 > $OUT/stats.log 2>&1
 echo "stats rc=$?"
 bash tools/pmc_traffic.sh $TAG > $OUT/pmc_traffic.log 2>&1; echo "traffic rc=$?"
 bash tools/pmc_sq.sh $TAG > $OUT/pmc_sq.log 2>&1; echo "sq rc=$?"

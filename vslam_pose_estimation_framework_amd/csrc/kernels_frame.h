@@ -17,7 +17,7 @@
 #include "kernels_image.h"
 #include "dev_math.h"
 
-// Fine-grained phase clocks of the frame kernel (tools/dbg_tail.py): compiled in only with -DVS_PROFILE_PHASES, every
+// Fine-grained phase clocks of the frame kernel (tools/probe/phase_clocks_per_stream.py): compiled in only with -DVS_PROFILE_PHASES, every
 // stamp is a global read-modify-write by thread 0 and costs about a microsecond.
 #ifdef VS_PROFILE_PHASES
 #define VS_PHASE_BEGIN(var) unsigned long long var = wall_clock64()
@@ -916,7 +916,12 @@ __device__ __forceinline__ void wg_one_round(const DevCfg& c, const DevBuf& b, i
     const int u = base + tid;
     const bool have = u < n;
     AlignRows R;
-    if (base == 0) {
+    // a wavefront without a measurement in this chunk (M ~ 240 of 512 lanes: half of them) skips the rows as well as the sums: it
+    // would add exact zeros, and its ~600 fp64 instructions would share a SIMD's issue with a wavefront that does have work
+    const bool wave_has = base + w * 64 < n;
+    if (!wave_has) {
+      if (base == 0) { chi_reg[0] = -1; inl_reg[0] = 0; }
+    } else if (base == 0) {
       align_rows<UVD>(c, T, cache[0], have, ignore_outliers, R, &chi_reg[0], &inl_reg[0]);   // stored after the last round
     } else {
       AlignPoint P;
@@ -926,7 +931,7 @@ __device__ __forceinline__ void wg_one_round(const DevCfg& c, const DevBuf& b, i
       align_rows<UVD>(c, T, P, have, ignore_outliers, R, &chi_w, &inl_w);
       if (have) { chi_o[u] = chi_w; inl_o[u] = inl_w; }
     }
-    if (base + w * 64 < n) {   // waves without a measurement in this chunk would add exact zeros
+    if (wave_has) {   // waves without a measurement in this chunk would add exact zeros
       double (*red)[32] = sh.red4[w];
       const bool fc = base == 0;
       align_reduce4<UVD, 0>(R, red, lane, fc);  align_reduce4<UVD, 4>(R, red, lane, fc);  align_reduce4<UVD, 8>(R, red, lane, fc);
@@ -957,8 +962,9 @@ __device__ __forceinline__ void wg_one_round_lds(const DevCfg& c, const DevBuf& 
     if (have) { if (u < cap) P = lp[u]; else load_align_point(c, b, s, u, P); }
     AlignRows R;
     double chi_w; uint8_t inl_w;
-    align_rows<UVD>(c, sh.T, P, have, ignore_outliers, R, &chi_w, &inl_w);
-    if (base + w * 64 < n) {
+    const bool wave_has = base + w * 64 < n;      // see wg_one_round
+    if (wave_has) align_rows<UVD>(c, sh.T, P, have, ignore_outliers, R, &chi_w, &inl_w);
+    if (wave_has) {
       double (*red)[32] = sh.red4[w];
       const bool fc = base == 0;
       align_reduce4<UVD, 0>(R, red, lane, fc);  align_reduce4<UVD, 4>(R, red, lane, fc);  align_reduce4<UVD, 8>(R, red, lane, fc);

@@ -1,4 +1,6 @@
-// rgbd_tracker.h — RGB-D mode: PoseTracker3D with a DepthFramePointGenerator and a UVDAligner plugged in
+// rgbd_tracker.h — WHY IT SHIPS IN THE PRODUCT LIBRARY: it is the only RGB-D loop that serves detector_type ORB (the device-resident
+// loop of rgbd_device.h runs the FAST detector grid only) and the independent second implementation the device loop is fuzzed against.
+// RGB-D mode: PoseTracker3D with a DepthFramePointGenerator and a UVDAligner plugged in
 // (slam_assembly.cpp _createDepthTracker; pose_tracker_3d.cpp:32-566; depth_framepoint_generator.cpp:24-407; uvd_aligner.cpp),
 // as a HOST-DRIVEN loop: the tracker's control flow and the object bookkeeping (framepoints, links, temporary points, landmarks)
 // run here in C++, every data-parallel step is one of the library's own device entry points (vslam_depth_space_map /

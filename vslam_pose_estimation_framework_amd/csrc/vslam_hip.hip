@@ -1723,8 +1723,11 @@ static int pattern_io(int device, int which, const int8_t* in, int8_t* out) {
       if (which == 0) {
         for (int k = 0; k < 4; ++k) if (q[k] < -VSLAM_BRIEF_PATCH_HALF || q[k] > VSLAM_BRIEF_PATCH_HALF) { g_create_error = "brief pattern: offset beyond the 48 px patch"; return VSLAM_ERR_INVALID; }
       } else {
-        for (int h = 0; h < 2; ++h)
-          if (q[2 * h] * q[2 * h] + q[2 * h + 1] * q[2 * h + 1] > 15 * 15) { g_create_error = "orb pattern: point beyond radius 15"; return VSLAM_ERR_INVALID; }
+        // a 31 x 31 patch: |x|, |y| <= 15 (OpenCV's bit_pattern_31_ reaches (12, -13), radius 17.7).  Where the reach matters: the
+        // tiled extractor (k_orb_describe) stages a 16 px margin and rotates by the FAST keypoints' fixed -1 degree, so a rotated,
+        // rounded offset is at most rint(15 cos 1 + 15 sin 1) = 15; the kernels that rotate by arbitrary angles gather from the
+        // whole image behind the 31 px border, and 15 sqrt 2 < 22.
+        for (int k = 0; k < 4; ++k) if (q[k] < -15 || q[k] > 15) { g_create_error = "orb pattern: offset beyond the 31 px patch (|x|, |y| <= 15)"; return VSLAM_ERR_INVALID; }
       }
     }
   }
