@@ -547,7 +547,8 @@ int vslam_rgbd_reset(vslam_rgbd* t);
 const char* vslam_rgbd_last_error(const vslam_rgbd* t);
 int vslam_rgbd_process_host(vslam_rgbd* t, const uint8_t* left, int32_t left_row_stride, const uint16_t* depth, int32_t depth_row_stride);
 /* vslam_rgbd_process_host in two halves: submit copies the frame in and enqueues its kernels, wait returns its status (after it the frame's
- * info and points can be read).  One frame in flight per tracker.  Several trackers — one sequence each, HIP streams of their own — overlap
+ * info and points can be read; between submit and wait the getters return VSLAM_ERR_STATE: the frame in flight is rewriting the lists they
+ * would copy).  One frame in flight per tracker.  Several trackers — one sequence each, HIP streams of their own — overlap
  * on the GPU when their frames are submitted before any of them is waited for (tests/validation/rgbd_bench.py --trackers). */
 int vslam_rgbd_submit_host(vslam_rgbd* t, const uint8_t* left, int32_t left_row_stride, const uint16_t* depth, int32_t depth_row_stride);
 int vslam_rgbd_wait(vslam_rgbd* t);

@@ -497,6 +497,9 @@ def test_rgbd_three_trackers_in_flight_together(monkeypatch):
                 with pytest.raises(VslamError) as e:
                     trackers[0].submit(*worlds[0][2][f])
                 assert e.value.code == ERR_STATE
+                with pytest.raises(VslamError) as e:          # the frame in flight is rewriting the lists: not readable before wait()
+                    trackers[0].points()
+                assert e.value.code == ERR_STATE
             for i, t in enumerate(trackers):
                 fi, nt = t.wait()
                 together[i].append((fi.status, fi.n_keypoints_left, fi.n_tracked, fi.n_lost, fi.n_inliers, fi.aligner_iterations, fi.n_after_prune, fi.n_recovered,
@@ -506,6 +509,7 @@ def test_rgbd_three_trackers_in_flight_together(monkeypatch):
         with pytest.raises(VslamError) as e:
             trackers[1].wait()
         assert e.value.code == ERR_STATE
+        trackers[2].submit(*worlds[2][2][0])          # destroyed with a frame in flight: release() drains its queues first
     finally:
         for t in trackers:
             t.destroy()

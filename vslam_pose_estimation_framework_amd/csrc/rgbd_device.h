@@ -142,8 +142,11 @@ public:
     return rc;
   }
 
+  bool frame_in_flight() const { return pending; }
   int get_points(int stream, int32_t cap, int32_t* n, float* xy, double* cam, int32_t* meta4, uint8_t* desc) {
     if (stream < 0 || stream >= B) { err = "stream index out of range"; return VSLAM_ERR_INVALID; }
+    // a frame between submit() and wait() is rewriting the lists these copies read (and flags of the previous list): not readable
+    if (pending) { err = "RGB-D tracker: a frame is in flight (call vslam_rgbd_wait first)"; return VSLAM_ERR_STATE; }
     const RgbdState& hs = hosts[stream];
     if (hs.frame_count == 0) { *n = 0; return VSLAM_OK; }
     const int np = hs.last_points;
@@ -195,6 +198,10 @@ private:
   hipEvent_t ev_fork = nullptr;
 
   void release() {
+    // an un-waited frame may still be copying into `pinned` and running on q / q2: both queues drain before anything is freed
+    if (q) (void)hipStreamSynchronize(q);
+    if (q2) (void)hipStreamSynchronize(q2);
+    pending = false;
     if (pinned) { (void)hipHostFree(pinned); pinned = nullptr; }
     drop_graph();
     if (ev_fork) { (void)hipEventDestroy(ev_fork); ev_fork = nullptr; }

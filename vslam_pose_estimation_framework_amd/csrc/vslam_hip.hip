@@ -2377,6 +2377,7 @@ VS_API int vslam_rgbd_get_frame_info_stream(vslam_rgbd* r, int32_t stream, vslam
   if (!r || !out) return VSLAM_ERR_INVALID;
   if (r->on_host) return stream == 0 ? vslam_rgbd_get_frame_info(r, out, n_temporary) : VSLAM_ERR_INVALID;
   if (stream < 0 || stream >= r->d.B) { r->d.err = "stream index out of range"; return VSLAM_ERR_INVALID; }
+  if (r->d.frame_in_flight()) { r->d.err = "RGB-D tracker: a frame is in flight (call vslam_rgbd_wait first)"; return VSLAM_ERR_STATE; }
   *out = r->d.hosts[stream].info;
   if (n_temporary) *n_temporary = r->d.hosts[stream].n_temporary;
   return VSLAM_OK;
@@ -2389,6 +2390,7 @@ VS_API int vslam_rgbd_get_points_stream(vslam_rgbd* r, int32_t stream, int32_t c
 VS_API int vslam_rgbd_get_frame_info(vslam_rgbd* r, vslam_frame_info* out, int32_t* n_temporary) {
   if (!r || !out) return VSLAM_ERR_INVALID;
   if (r->on_host) { *out = r->t.info; if (n_temporary) *n_temporary = r->t.n_temporary; return VSLAM_OK; }
+  if (r->d.frame_in_flight()) { r->d.err = "RGB-D tracker: a frame is in flight (call vslam_rgbd_wait first)"; return VSLAM_ERR_STATE; }
   *out = r->d.host.info;
   if (n_temporary) *n_temporary = r->d.host.n_temporary;
   return VSLAM_OK;
