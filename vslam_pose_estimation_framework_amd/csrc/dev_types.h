@@ -114,6 +114,11 @@ struct ImgInfo {
 #define VS_MAX_STREAMS 4096   // streams per context (one bit each in DevBuf::active)
 struct DevBuf {
   int32_t s0;          // first stream of the launch (streams are processed in independent groups)
+  // Workgroup b of a launch runs on XCD (q0 + b) % 8, where q0 belongs to the hardware queue (HIP stream) — measured: constant from
+  // launch to launch, idle or busy, different for different HIP streams (tools/probe/xcd_map.hip).  xcd_rot = (q0 - s0) & 7 of the
+  // queue THIS launch goes to (calibrated when the context is created), so that the relabelling below puts stream s on the SAME
+  // physical XCD s % 8 in every kernel of the step, whichever queue it is launched on.  Speed only: any value is a valid permutation.
+  int32_t xcd_rot;
   // one bit per stream: a cleared bit makes every kernel skip the stream (its sequence has ended while other streams of
   // the context still run: whole sequences of different lengths per stream, SURVEY.md 8e exact mode).  By value in the
   // kernel arguments: a scalar load from the kernarg segment, no global round trip in the wide kernels.
@@ -178,3 +183,6 @@ struct DevBuf {
   int32_t* h_prev;     // [..][MAXP]
 };
 __device__ __forceinline__ bool vs_active(const DevBuf& b, int s) { return (b.active[s >> 5] >> (s & 31)) & 1u; }
+// one-workgroup-per-stream grids: block i of n works on local stream xcd_local_stream(i, n, rot) — inside every aligned group of eight
+// blocks (which covers the eight XCDs once) the block on physical XCD x takes the stream with (s0 + stream) % 8 == x; a bijection on 0 .. n-1
+__device__ __forceinline__ int xcd_local_stream(int i, int n, int rot) { return i < ((n >> 3) << 3) ? ((i & ~7) | ((i + rot) & 7)) : i; }

@@ -246,11 +246,11 @@ __device__ __forceinline__ void candidates_wave(const DevCfg& c, const DevBuf& b
 // grid the blocks of ONE stream land on all eight and every L2 fetches that stream's descriptors, keypoints and row / cell CSR.
 // Re-labelled, the gridDim.x blocks of stream s all run on XCD s mod 8 — the XCD its frame workgroup (block s of k_frame) and
 // its two k_emit workgroups run on, whose L2 then already holds / will want the same lines.  Speed only, never correctness.
-__device__ __forceinline__ void xcd_stream_block(int* bx, int* sy) {
+__device__ __forceinline__ void xcd_stream_block(int* bx, int* sy, int rot = 0) {
   const int gx = gridDim.x, ns = gridDim.y;
   const int lin = blockIdx.y * gx + blockIdx.x, per = (ns >> 3) * gx;      // blocks per XCD among the first 8 * (ns / 8) streams
   *bx = blockIdx.x; *sy = blockIdx.y;
-  if (lin < (per << 3)) { const int x = lin & 7, j = lin >> 3, q = j / gx; *sy = x + 8 * q; *bx = j - q * gx; }
+  if (lin < (per << 3)) { const int x = (lin + rot) & 7, j = lin >> 3, q = j / gx; *sy = x + 8 * q; *bx = j - q * gx; }   // rot: dev_types.h xcd_rot
 }
 
 __global__ __launch_bounds__(256, 8) void k_track_candidates(const DevCfg c, const DevBuf b, int mode) {
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256, 8) void k_track_candidates(const DevCfg c, con
   // mode 0/1: stage path, window and distance exactly as set through vslam_set_tracker_state
   __shared__ CandWave cw[256 / VS_CGL];
   int bx, sy;
-  xcd_stream_block(&bx, &sy);
+  xcd_stream_block(&bx, &sy, b.xcd_rot);
   const int s = b.s0 + sy;
   if (!vs_active(b, s)) return;
   const StreamState& st = b.st[s];

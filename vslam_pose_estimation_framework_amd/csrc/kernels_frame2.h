@@ -360,7 +360,7 @@ __device__ __forceinline__ void wg_recover(const DevCfg& c, const DevBuf& b, int
 // fused path: BRIEF of the projected lost points of ALL streams, one wavefront each
 __global__ __launch_bounds__(256) void k_recover_brief(const DevCfg c, const DevBuf b) {
   int bx, sy;
-  xcd_stream_block(&bx, &sy);
+  xcd_stream_block(&bx, &sy, b.xcd_rot);
   const int s = b.s0 + sy;
   if (!vs_active(b, s)) return;
   const StreamState& st = b.st[s];
@@ -1459,7 +1459,7 @@ __device__ __forceinline__ void wg_stereo(const DevCfg& c, const DevBuf& b, int 
 // wg_stereo's step A reads.  One thread per left feature.
 __global__ __launch_bounds__(256) void k_stereo_dist(const DevCfg c, const DevBuf b) {
   int bx, sy;
-  xcd_stream_block(&bx, &sy);
+  xcd_stream_block(&bx, &sy, b.xcd_rot);
   const int s = b.s0 + sy;
   if (!vs_active(b, s)) return;
   const int i = bx * blockDim.x + threadIdx.x;
@@ -1509,7 +1509,7 @@ __global__ VS_FRAME_BOUNDS void k_frame(ConstDevCfg* cp, ConstDevBuf* bp, int ph
 #ifdef VS_FRAME_PRIO
   __builtin_amdgcn_s_setprio(VS_FRAME_PRIO);   // co-scheduled builds: the latency-bound frame wavefronts issue ahead of the image kernels' wavefronts on their SIMD
 #endif
-  const int s = b.s0 + blockIdx.x, tid = threadIdx.x;
+  const int s = b.s0 + xcd_local_stream(blockIdx.x, gridDim.x, b.xcd_rot), tid = threadIdx.x;
   if (!vs_active(b, s)) return;
   StreamState& st = b.st[s];
   vslam_frame_info& info = b.info[s];
@@ -1822,7 +1822,7 @@ __global__ __launch_bounds__(VS_TAIL_WG, 4) void k_tail(ConstDevCfg* cp, ConstDe
   __shared__ TailShared sh;
   __shared__ __align__(16) unsigned char arena[VS_TAIL_ARENA];
   __builtin_amdgcn_s_setprio(2);
-  const int s = b.s0 + blockIdx.x, tid = threadIdx.x;
+  const int s = b.s0 + xcd_local_stream(blockIdx.x, gridDim.x, b.xcd_rot), tid = threadIdx.x;
   if (!vs_active(b, s)) return;
   StreamState& st = b.st[s];
   vslam_frame_info& info = b.info[s];
@@ -1933,7 +1933,7 @@ __device__ __forceinline__ void stage_apply_set(StreamState& st, const StageIo& 
   if (io.set_flags & 2) { for (int k = 0; k < 12; ++k) st.pose[k] = io.pose[k]; }
 }
 __global__ __launch_bounds__(256) void k_begin(const DevCfg c, const DevBuf b, const StageIo io) {
-  const int s = b.s0 + blockIdx.x, tid = threadIdx.x;
+  const int s = b.s0 + xcd_local_stream(blockIdx.x, gridDim.x, b.xcd_rot), tid = threadIdx.x;
   if (!vs_active(b, s)) return;
   StreamState& st = b.st[s];
   if (io.set_flags) { if (tid == 0) stage_apply_set(st, io); __syncthreads(); }
@@ -1957,7 +1957,7 @@ __global__ __launch_bounds__(256) void k_begin(const DevCfg c, const DevBuf b, c
 __global__ __launch_bounds__(VS_WG) void k_stage(const DevCfg c, const DevBuf b, int stage, int arg, const StageIo io) {
   __shared__ FrameShared sh;
   __shared__ __align__(16) unsigned char arena[VS_ARENA];
-  const int s = b.s0 + blockIdx.x, tid = threadIdx.x;
+  const int s = b.s0 + xcd_local_stream(blockIdx.x, gridDim.x, b.xcd_rot), tid = threadIdx.x;
   if (!vs_active(b, s)) return;
   StreamState& st = b.st[s];
   vslam_frame_info& info = b.info[s];

@@ -82,13 +82,14 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* sh, int* total) 
 // leaves in that L2 (corner masks, keypoints, row / cell CSR, descriptors) is what the next one reads.  gridDim.z = 2 * streams
 // (z = 2 * stream + side).  Speed only, never correctness.
 // mono: one image per stream (RGB-D mode: gridDim.z = streams, the returned z is the stream) instead of two (z = 2 * stream + side)
-__device__ __forceinline__ void xcd_tile(int* tx, int* ty, int* tz, int mono = 0) {
+__device__ __forceinline__ void xcd_tile(int* tx, int* ty, int* tz, int mono = 0, int rot = 0) {
   const int gx = gridDim.x, gy = gridDim.y;
   const int tps = mono ? gx * gy : gx * gy * 2;         // tiles of one stream (both images)
   const int ns = mono ? gridDim.z : gridDim.z >> 1;
   int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
   const int per = (ns >> 3) * tps;                      // tiles per XCD among the first 8 * (ns / 8) streams
-  if (lin < (per << 3)) { const int x = lin & 7, j = lin >> 3, q = j / tps; lin = (x + 8 * q) * tps + (j - q * tps); }
+  // block lin runs on physical XCD (lin + q0) % 8 (q0: the queue's); rot = (q0 - s0) & 7 makes x the stream's residue class
+  if (lin < (per << 3)) { const int x = (lin + rot) & 7, j = lin >> 3, q = j / tps; lin = (x + 8 * q) * tps + (j - q * tps); }
   *tx = lin % gx;
   const int r = lin / gx;
   *ty = r % gy;
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256, 8) void k_fast_box(const DevCfg c, const DevBu
   __shared__ unsigned long long lmask[VS_TILE_H];
   __shared__ int qn;
   int tx, ty, tz;
-  xcd_tile(&tx, &ty, &tz, c.mono);
+  xcd_tile(&tx, &ty, &tz, c.mono, b.xcd_rot);
   const int s = b.s0 + (c.mono ? tz : (tz >> 1)), side = c.mono ? 0 : (tz & 1);
   if (!vs_active(b, s)) return;
   const int x0 = tx * VS_TILE_W, y0 = ty * VS_TILE_H;
@@ -424,7 +425,8 @@ __global__ __launch_bounds__(512, 4) void k_emit(const DevCfg c, const DevBuf b,
   __shared__ int sh_wave[8], sh_total;
   __shared__ int sh_cnt[VSLAM_MAX_REGIONS];
   __shared__ int sh_last;
-  const int s = b.s0 + blockIdx.x, tid = threadIdx.x;
+  // block (i, side) is the (side * gridDim.x + i)-th of the launch: both images of stream s on physical XCD s % 8 (dev_types.h xcd_rot)
+  const int s = b.s0 + xcd_local_stream(blockIdx.x, gridDim.x, (b.xcd_rot + blockIdx.y * gridDim.x) & 7), tid = threadIdx.x;
   if (!vs_active(b, s)) return;
   const int rows = c.c.rows, cols = c.c.cols, TX = c.TX, CW = c.CW;
   StreamState& st = b.st[s];
@@ -614,7 +616,7 @@ __global__ __launch_bounds__(256) void k_brief(const DevCfg c, const DevBuf b) {
   __shared__ __align__(16) uint16_t reg[VS_BT_RH * VS_BT_RW];
   __shared__ int row_lo[VS_BT_H], row_off[VS_BT_H + 1];
   int tx, ty, tz;
-  xcd_tile(&tx, &ty, &tz, c.mono);
+  xcd_tile(&tx, &ty, &tz, c.mono, b.xcd_rot);
   const int s = b.s0 + (c.mono ? tz : (tz >> 1)), side = c.mono ? 0 : (tz & 1);
   if (!vs_active(b, s)) return;
   const int x0 = tx * VS_BT_W, y0 = ty * VS_BT_H;
@@ -804,7 +806,7 @@ __global__ __launch_bounds__(256) void k_gauss7(const DevCfg c, const DevBuf b, 
   __shared__ uint8_t src[VS_TILE_H + 6][72];
   __shared__ uint16_t hs[VS_TILE_H + 6][VS_TILE_W];
   int tx, ty, tz;
-  xcd_tile(&tx, &ty, &tz, c.mono);
+  xcd_tile(&tx, &ty, &tz, c.mono, b.xcd_rot);
   const int s = b.s0 + (c.mono ? tz : (tz >> 1)), side = c.mono ? 0 : (tz & 1);
   if (!vs_active(b, s)) return;
   gauss7_tile(b.img[side] + (size_t)s * b.img_stream_stride, b.img_row_stride, c.c.rows, c.c.cols, tx * VS_TILE_W, ty * VS_TILE_H, g,
@@ -852,7 +854,7 @@ __global__ __launch_bounds__(256) void k_orb_describe(const DevCfg c, const DevB
   __shared__ __align__(16) uint8_t reg[VS_OT_RH * VS_OT_RW];
   __shared__ int row_lo[VS_BT_H], row_off[VS_BT_H + 1];
   int tx, ty, tz;
-  xcd_tile(&tx, &ty, &tz, c.mono);
+  xcd_tile(&tx, &ty, &tz, c.mono, b.xcd_rot);
   const int s = b.s0 + (c.mono ? tz : (tz >> 1)), side = c.mono ? 0 : (tz & 1);
   if (!vs_active(b, s)) return;
   const int x0 = tx * VS_BT_W, y0 = ty * VS_BT_H;

@@ -38,7 +38,8 @@ struct vslam_ctx {
   // delays its own group, the other groups' kernels fill the idle CUs
   // st_img: image pipeline of even steps (and uploads), st_img2: image pipeline of odd steps, so that BRIEF of step t
   // overlaps FAST of step t+1 (FAST(t+1) only waits for the threshold controller in k_emit(t))
-  struct Group { int s0, n; hipStream_t st_frm, st_img, st_img2; hipEvent_t ev_img[2], ev_frm[2], ev_emit[2]; bool frm_pending[2], emit_pending[2]; };
+  struct Group { int s0, n; hipStream_t st_frm, st_img, st_img2; hipEvent_t ev_img[2], ev_frm[2], ev_emit[2]; bool frm_pending[2], emit_pending[2];
+                 int q0_frm = 0, q0_img = 0, q0_img2 = 0; };   // XCD that block 0 of a launch on the queue runs on (calibrate_queues)
   std::vector<Group> groups;
   std::string err;
   std::vector<void*> allocs;
@@ -77,6 +78,8 @@ struct vslam_ctx {
   // stage path of a one-stream context: the image pipeline runs on the frame queue itself (the caller waits for every stage, so a
   // second queue buys no overlap and costs an event round trip per frame) and is timed by three events instead of two per kernel
   hipStream_t img_override = nullptr;
+  bool xcd_affinity = true;      // VSLAM_XCD_AFFINITY=0: block ids as the runtime deals them (measurement aid)
+  int xcd_skew = 0;              // VSLAM_XCD_SKEW=k: the image queues' streams k XCDs away from their frame workgroups (measurement aid)
   bool img_on_frm_queue = false;
   int report_seq = 0;                                  // stamps every report launch; the header carries it back
   int report_have = 0, report_have_ip = 0, report_have_stream = -1, report_have_seq = -1;   // what the LAST launch on the frame queue packed (0: nothing)
@@ -185,9 +188,10 @@ static int group_of(const vslam_ctx* c, int s) {
   for (size_t i = 0; i < c->groups.size(); ++i) if (s >= c->groups[i].s0 && s < c->groups[i].s0 + c->groups[i].n) return (int)i;
   return 0;
 }
-static DevBuf buf_set(const vslam_ctx* c, int set, int s0 = 0) {
+static DevBuf buf_set(const vslam_ctx* c, int set, int s0 = 0, int q0 = 0) {
   DevBuf b = c->buf;
   b.s0 = s0;
+  b.xcd_rot = c->xcd_affinity ? ((q0 - s0) & 7) : 0;     // dev_types.h: stream s on physical XCD s % 8 whatever queue the launch goes to
   const vslam_ctx::ImgSet& q = c->sets[set];
   b.box = q.box; b.score8 = q.score8; b.mask = q.mask; b.kp_xy = q.kp_xy; b.kp_score = q.kp_score; b.desc = q.desc;
   b.n_kp = q.n_kp; b.rowcell = q.rowcell; b.used = q.used; b.sdist = q.sdist; b.iinfo = q.iinfo;
@@ -305,7 +309,7 @@ static void fresh_stream_state(const vslam_ctx* c, StreamState& x) {
 static int upload_buffer_tables(vslam_ctx* c) {
   const size_t G = c->groups.size();
   std::vector<DevBuf> hb(2 * G);
-  for (int q = 0; q < 2; ++q) for (size_t g = 0; g < G; ++g) hb[q * G + g] = buf_set(c, q, c->groups[g].s0);
+  for (int q = 0; q < 2; ++q) for (size_t g = 0; g < G; ++g) hb[q * G + g] = buf_set(c, q, c->groups[g].s0, c->groups[g].q0_frm);
   HIP_TRY(c, hipMemcpy(c->d_bufs, hb.data(), sizeof(DevBuf) * 2 * G, hipMemcpyHostToDevice));
   return VSLAM_OK;
 }
@@ -379,6 +383,29 @@ static void scratch_put(vslam_ctx* parent, vslam_ctx* t) {
     }
   vslam_destroy(t);
 }
+// Workgroup b of a launch runs on XCD (q0 + b) % 8 with q0 a property of the hardware queue behind the HIP stream (constant from launch
+// to launch, idle or loaded: tools/probe/xcd_map.hip).  One one-block launch per queue reads it.
+__global__ void k_xcc_probe(int* out) {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  if (threadIdx.x == 0) *out = (int)(v & 7u);
+}
+static int calibrate_queues(vslam_ctx* c) {
+  if (const char* e = getenv("VSLAM_XCD_AFFINITY")) c->xcd_affinity = atoi(e) != 0;
+  if (const char* e = getenv("VSLAM_XCD_SKEW")) c->xcd_skew = atoi(e) & 7;
+  int* d = nullptr;
+  if (hipMalloc(&d, 3 * sizeof(int)) != hipSuccess) return VSLAM_OK;     // affinity is an optimisation: without it rot stays 0
+  for (auto& g : c->groups) {
+    int h[3] = {0, 0, 0};
+    hipStream_t q[3] = {g.st_frm, g.st_img, g.st_img2};
+    bool ok = true;
+    for (int k = 0; k < 3 && ok; ++k) { hipLaunchKernelGGL(k_xcc_probe, dim3(1), dim3(64), 0, q[k], d + k); ok = hipStreamSynchronize(q[k]) == hipSuccess; }
+    if (ok && hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) { g.q0_frm = h[0]; g.q0_img = (h[1] + c->xcd_skew) & 7; g.q0_img2 = (h[2] + c->xcd_skew) & 7; }
+  }
+  (void)hipFree(d);
+  return VSLAM_OK;
+}
+
 static int create_internal(const vslam_config* cfg, int device, int n_streams, vslam_ctx** out) {
   if (!cfg || !out || n_streams < 1) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: null argument or n_streams < 1");
   if (n_streams > VS_MAX_STREAMS) return fail(nullptr, VSLAM_ERR_INVALID, "vslam_create: more than 4096 streams in one context");
@@ -491,6 +518,7 @@ static int create_internal(const vslam_config* cfg, int device, int n_streams, v
   {
     // the frame kernel's view of the configuration and of the buffer table (image pointers excluded: it never reads them)
     const size_t G = c->groups.size();
+    calibrate_queues(c);
     e = dalloc(c, &c->d_cfg, 1);
     if (e == hipSuccess) e = dalloc(c, &c->d_bufs, 2 * G);
     if (e == hipSuccess) e = hipMemcpy(c->d_cfg, &c->cfg, sizeof(DevCfg), hipMemcpyHostToDevice);
@@ -627,6 +655,7 @@ VS_API int vslam_set_hip_stream(vslam_ctx* c, void* s) {
   c->groups.push_back(q);
   c->stream = q.st_frm; c->stream_img = q.st_img;
   c->own_stream = false;
+  calibrate_queues(c);      // the caller's queue has its own first XCD
   // the frame kernel's buffer table for the single group
   return upload_buffer_tables(c);
 }
@@ -642,8 +671,8 @@ static int launch_image_pipeline(vslam_ctx* c) {
   const DevCfg& d = c->cfg;
   const int set = c->parity;
   for (auto& g : c->groups) {
-    const DevBuf bs = buf_set(c, set, g.s0);
     hipStream_t st = c->img_override ? c->img_override : (set ? g.st_img2 : g.st_img);
+    const DevBuf bs = buf_set(c, set, g.s0, c->img_override ? g.q0_frm : (set ? g.q0_img2 : g.q0_img));
     if (!c->img_override && c->img_on_frm_queue) {
       // the last frame's image pipeline ran on the frame queue (stage path) and left no event behind: a caller that switches to
       // the fused path mid-sequence pays one synchronisation here, once
@@ -703,7 +732,7 @@ static int cand_blocks(const vslam_ctx* c, int n_streams) {
 static int launch_frame(vslam_ctx* c) {
   size_t gi = 0;
   for (auto& g : c->groups) {
-    const DevBuf bs = buf_set(c, c->last_set, g.s0);
+    const DevBuf bs = buf_set(c, c->last_set, g.s0, g.q0_frm);
     ConstDevCfg* kc = (ConstDevCfg*)c->d_cfg;
     ConstDevBuf* kb = (ConstDevBuf*)(c->d_bufs + c->last_set * c->groups.size() + gi++);
     const int gx = cand_blocks(c, g.n);
@@ -2059,13 +2088,13 @@ static int flush_pending(vslam_ctx* c) {
 }
 static int launch_begin(vslam_ctx* c) {
   const StageIo io = stage_io(c, 0, 0);
-  for (auto& g : c->groups) hipLaunchKernelGGL(k_begin, dim3(g.n), dim3(256), 0, g.st_frm, c->cfg, buf_set(c, c->last_set, g.s0), io);
+  for (auto& g : c->groups) hipLaunchKernelGGL(k_begin, dim3(g.n), dim3(256), 0, g.st_frm, c->cfg, buf_set(c, c->last_set, g.s0, g.q0_frm), io);
   HIP_TRY(c, hipGetLastError());
   return VSLAM_OK;
 }
 static int launch_stage(vslam_ctx* c, int stage, int arg, int report = 0, int in_progress = 0) {
   const StageIo io = stage_io(c, report, in_progress);
-  for (auto& g : c->groups) hipLaunchKernelGGL(k_stage, dim3(g.n), dim3(VS_WG), 0, g.st_frm, c->cfg, buf_set(c, c->last_set, g.s0), stage, arg, io);
+  for (auto& g : c->groups) hipLaunchKernelGGL(k_stage, dim3(g.n), dim3(VS_WG), 0, g.st_frm, c->cfg, buf_set(c, c->last_set, g.s0, g.q0_frm), stage, arg, io);
   HIP_TRY(c, hipGetLastError());
   return VSLAM_OK;
 }
@@ -2110,7 +2139,7 @@ VS_API int vslam_track(vslam_ctx* c, int by_appearance) {
   { int rc = flush_pending(c); if (rc) return rc; }     // the candidate kernel reads prior / window / distance before the stage kernel runs
   for (auto& g : c->groups) {
     const int gx = cand_blocks(c, g.n);
-    hipLaunchKernelGGL(k_track_candidates, dim3(gx, g.n), dim3(256), 0, g.st_frm, c->cfg, buf_set(c, c->last_set, g.s0), by_appearance ? 1 : 0);
+    hipLaunchKernelGGL(k_track_candidates, dim3(gx, g.n), dim3(256), 0, g.st_frm, c->cfg, buf_set(c, c->last_set, g.s0, g.q0_frm), by_appearance ? 1 : 0);
   }
   return launch_stage(c, VS_STAGE_TRACK, by_appearance ? 1 : 0, VS_REPORT_TRACK);
 }
