@@ -218,7 +218,9 @@ private:
 
   // initialize() .. registration of one attempt: the image pipeline on ONE image per sequence (DevCfg::mono: grid z = sequences; k_emit with
   // its one-image controller), track, aligner.  Sequences whose bit in
-  // b.active is cleared are skipped by every kernel.
+  // b.active is cleared are skipped by every kernel.  DELIBERATE DEVIATION: the feature list of an attempt is rebuilt from
+  // its own detection; upstream the second and third attempt of a frame see the union of all attempts' keypoints (frame_->keypointsLeft() is
+  // appended to and never cleared between the initialize() calls of one frame: base_framepoint_generator.cpp:424, pose_tracker_3d.cpp:345,393).
   void enqueue_attempt(const DevBuf& b) {
     const DevCfg& d = ic->cfg;
     const dim3 g1(d.TX, (d.c.rows + VS_TILE_H - 1) / VS_TILE_H, B);

@@ -9,7 +9,11 @@
 // default behind vslam_rgbd_*); this one is its cross-check (VSLAM_RGBD_HOST=1) and serves detector_type ORB.  Detector grids of any shape (configuration_icl.yaml:57-58 runs 2 x 2; tum and
 // xtion 1 x 1): one FAST detection, one threshold and one controller per region, keypoints in region-major order.
 //
-// Reference behaviour kept (DESIGN.md "RGB-D mode" lists the citations): initialize() detects and runs the controller on
+// DELIBERATE DEVIATION: on a re-registration attempt the feature list is REBUILT from the new detection; upstream
+// detectKeypoints appends to frame_->keypointsLeft(), which is never cleared between the initialize() calls of one frame
+// (base_framepoint_generator.cpp:424, pose_tracker_3d.cpp:345,393), so its attempts 2 and 3 describe and track the union of all attempts'
+// keypoints, duplicates included.  Device loop, this loop and the checker (tests/rgbd_loop.py) share the rebuilt-list rule.
+// Reference behaviour kept (docs/rounds/ lists the citations): initialize() detects and runs the controller on
 // EVERY call (also on re-registration); temporary points are not cleared between re-registrations; hasUnreliableDepth is
 // inherited along a track; the aligner never sees landmarks (it asks the current point, which has none yet) and its
 // translation weights live in a member vector that is never reset; a previous point linked by an earlier registration
