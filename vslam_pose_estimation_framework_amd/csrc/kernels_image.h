@@ -420,8 +420,11 @@ __device__ __forceinline__ unsigned long long col_mask(int lo, int hi, int wx0) 
   return hi_m & ~((1ull << a) - 1ull);
 }
 
-#define VS_EMIT_WPT 4    // mask words a thread keeps in registers per pass (one pass = 512 * 4 words = 131072 px; 96 VGPRs, no scratch)
-__global__ __launch_bounds__(512, 4) void k_emit(const DevCfg c, const DevBuf b, int border, int run_controller) {
+#ifndef VS_EMIT_WPT
+#define VS_EMIT_WPT 4    // mask words a thread keeps in registers per pass (one pass = 512 * 4 words = 131072 px; 96 VGPRs, no scratch).  Measured (round 4,
+                         // 157 streams, alone on the chip): 4 -> 58 us, 8 -> 67 us, 16 -> 73 us: the kernel is bound by the per-lane emission loops, not by its four passes
+#endif
+__global__ __launch_bounds__(512, VS_EMIT_WPT > 8 ? 2 : 4) void k_emit(const DevCfg c, const DevBuf b, int border, int run_controller) {
   __shared__ int sh_wave[8], sh_total;
   __shared__ int sh_cnt[VSLAM_MAX_REGIONS];
   __shared__ int sh_last;
