@@ -83,6 +83,27 @@ class FrameInfo(C.Structure):
         return d
 
 
+class KeypointsView(C.Structure):
+    """struct vslam_keypoints_view (stage views: pointers into the context's pinned report buffer, valid until the next view call)."""
+    _fields_ = [("n", C.c_int32 * 2), ("xy", C.POINTER(C.c_int16) * 2), ("score", C.POINTER(C.c_uint8) * 2), ("desc", C.POINTER(C.c_uint8) * 2)]
+
+
+class TrackView(C.Structure):
+    _fields_ = [("n_tracked", C.c_int32), ("n_lost", C.c_int32), ("n_tracked_landmarks", C.c_int32),
+                ("tracked4", C.POINTER(C.c_int32)), ("lost", C.POINTER(C.c_int32))]
+
+
+class AlignerView(C.Structure):
+    _fields_ = [("n", C.c_int32), ("n_inliers", C.c_int32), ("n_outliers", C.c_int32), ("iterations", C.c_int32), ("converged", C.c_int32),
+                ("total_error", C.c_double), ("chi", C.POINTER(C.c_double)), ("inlier", C.POINTER(C.c_uint8)), ("T", C.c_double * 12), ("H", C.c_double * 36)]
+
+
+class PointsView(C.Structure):
+    _fields_ = [("n", C.c_int32), ("first_full", C.c_int32), ("kp", C.POINTER(C.c_int16)), ("meta", C.POINTER(C.c_int32)), ("cam", C.POINTER(C.c_double)),
+                ("desc", C.POINTER(C.c_uint8)), ("info", FrameInfo), ("seconds_tracking", C.c_double), ("seconds_pose_optimization", C.c_double),
+                ("seconds_point_recovery", C.c_double), ("seconds_landmark_optimization", C.c_double), ("seconds_point_triangulation", C.c_double)]
+
+
 class DepthParams(C.Structure):
     """struct vslam_depth_params (include/vslam_hip.h)."""
     _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("K_left", C.c_double * 9), ("K_left_inverse", C.c_double * 9),
@@ -269,6 +290,40 @@ class CApi(object):
         self.check(self.fn("get_poses")(self.ctx, C.c_int(stream), C.c_int32(first), C.c_int32(count),
                                         _p(out, C.c_double)))
         return out.reshape(count, 3, 4)
+
+    # -- stage views (copies of what the pointers show, taken at once: the buffer is reused by the next view call) --------------
+    def view_keypoints(self, stream=0):
+        v = KeypointsView()
+        self.check(self.fn("view_keypoints")(self.ctx, C.c_int(stream), C.byref(v)))
+        out = []
+        for d in (0, 1):
+            n = v.n[d]
+            out.append((np.ctypeslib.as_array(v.xy[d], (max(n, 1), 2))[:n].copy(), np.ctypeslib.as_array(v.score[d], (max(n, 1),))[:n].copy(),
+                        np.ctypeslib.as_array(v.desc[d], (max(n, 1), 32))[:n].copy()))
+        return out
+
+    def view_track(self, stream=0):
+        v = TrackView()
+        self.check(self.fn("view_track")(self.ctx, C.c_int(stream), C.byref(v)))
+        return dict(n_tracked_landmarks=v.n_tracked_landmarks, tracked4=np.ctypeslib.as_array(v.tracked4, (max(v.n_tracked, 1), 4))[:v.n_tracked].copy(),
+                    lost=np.ctypeslib.as_array(v.lost, (max(v.n_lost, 1),))[:v.n_lost].copy())
+
+    def view_aligner(self, stream=0):
+        v = AlignerView()
+        self.check(self.fn("view_aligner")(self.ctx, C.c_int(stream), C.byref(v)))
+        return dict(n_inliers=v.n_inliers, n_outliers=v.n_outliers, iterations=v.iterations, converged=v.converged, total_error=v.total_error,
+                    chi=np.ctypeslib.as_array(v.chi, (max(v.n, 1),))[:v.n].copy(), inlier=np.ctypeslib.as_array(v.inlier, (max(v.n, 1),))[:v.n].copy(),
+                    T=np.array(v.T).reshape(3, 4), H=np.array(v.H).reshape(6, 6))
+
+    def view_points(self, stream=0, in_progress=False):
+        v = PointsView()
+        self.check(self.fn("view_points")(self.ctx, C.c_int(stream), C.c_int(1 if in_progress else 0), C.byref(v)))
+        n, f = v.n, v.first_full
+        out = dict(n=n, first_full=f, kp=np.ctypeslib.as_array(v.kp, (max(n, 1), 4))[:n].copy(), meta=np.ctypeslib.as_array(v.meta, (max(n, 1), 6))[:n].copy(),
+                   cam=np.ctypeslib.as_array(v.cam, (max(n, 1), 3))[:n].copy(), info=FrameInfo.from_buffer_copy(bytes(v.info)),
+                   seconds=[v.seconds_tracking, v.seconds_pose_optimization, v.seconds_point_recovery, v.seconds_landmark_optimization, v.seconds_point_triangulation])
+        out["desc"] = np.ctypeslib.as_array(v.desc, (max(n, 1), 64))[:n].copy() if in_progress else None
+        return out
 
     # -- stand-alone stages ---------------------------------------------------------------------
     def fast_detect(self, image, roi, threshold, cap=65536):
