@@ -918,7 +918,11 @@ __device__ __forceinline__ void wg_one_round(const DevCfg& c, const DevBuf& b, i
     AlignRows R;
     // a wavefront without a measurement in this chunk (M ~ 240 of 512 lanes: half of them) skips the rows as well as the sums: it
     // would add exact zeros, and its ~600 fp64 instructions would share a SIMD's issue with a wavefront that does have work
+#ifdef VS_ALIGN_NO_WAVE_SKIP      // probe builds: every wavefront evaluates the rows (round 3 behaviour)
+    const bool wave_has = true;
+#else
     const bool wave_has = base + w * 64 < n;
+#endif
     if (!wave_has) {
       if (base == 0) { chi_reg[0] = -1; inl_reg[0] = 0; }
     } else if (base == 0) {
@@ -931,7 +935,7 @@ __device__ __forceinline__ void wg_one_round(const DevCfg& c, const DevBuf& b, i
       align_rows<UVD>(c, T, P, have, ignore_outliers, R, &chi_w, &inl_w);
       if (have) { chi_o[u] = chi_w; inl_o[u] = inl_w; }
     }
-    if (wave_has) {   // waves without a measurement in this chunk would add exact zeros
+    if (base + w * 64 < n) {   // waves without a measurement in this chunk would add exact zeros
       double (*red)[32] = sh.red4[w];
       const bool fc = base == 0;
       align_reduce4<UVD, 0>(R, red, lane, fc);  align_reduce4<UVD, 4>(R, red, lane, fc);  align_reduce4<UVD, 8>(R, red, lane, fc);

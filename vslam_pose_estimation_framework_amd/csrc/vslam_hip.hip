@@ -314,6 +314,8 @@ static int upload_buffer_tables(vslam_ctx* c) {
   return VSLAM_OK;
 }
 static int init_state(vslam_ctx* c) {
+  c->pend.flags = 0;          // a reset drops setters that were waiting for a stage launch: the fresh state is the state
+  c->report_have = 0;
   std::vector<StreamState> st(c->B);
   for (int s = 0; s < c->B; ++s) fresh_stream_state(c, st[s]);
   bool all_active = true;
@@ -601,6 +603,7 @@ VS_API int vslam_reset_streams(vslam_ctx* c, int32_t n, const int32_t* streams) 
   if (c->frame_begun) return fail(c, VSLAM_ERR_STATE, "vslam_reset_stream called inside a frame");
   if (n == 0) return VSLAM_OK;
   HIP_TRY(c, hipSetDevice(c->device));
+  if (c->B == 1) { c->pend.flags = 0; c->report_have = 0; }     // the one stream starts over: pending setters belong to the old sequence
   // no host synchronisation: each half of the state is reset in order on the HIP stream(s) that own it, one launch per
   // half for up to 63 streams of a group
   for (auto& g : c->groups) {
@@ -633,6 +636,7 @@ VS_API int vslam_reset_streams(vslam_ctx* c, int32_t n, const int32_t* streams) 
 VS_API int vslam_reset_stream(vslam_ctx* c, int s) { const int32_t id = s; return vslam_reset_streams(c, 1, &id); }
 VS_API int vslam_copy_current_poses_device(vslam_ctx* c, double* dst) {
   if (!c || !dst) return VSLAM_ERR_INVALID;
+  { int rc = flush_pending(c); if (rc) return rc; }
   for (auto& g : c->groups)
     hipLaunchKernelGGL(k_gather_poses, dim3((g.n * 12 + 255) / 256), dim3(256), 0, g.st_frm, buf_set(c, c->last_set, g.s0), g.n, dst + (size_t)g.s0 * 12);
   HIP_TRY(c, hipGetLastError());
