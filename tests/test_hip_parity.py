@@ -441,6 +441,39 @@ def test_stage_views_equal_the_array_getters_after_every_stage():
         a.destroy(); ref.destroy(); o.destroy()
 
 
+def test_stage_views_of_any_stream_of_a_multi_stream_context():
+    """The report buffer holds one stream at a time and the folded report is stream 0's: views of the other streams of a three-stream
+    context are packed on demand and equal the getters; setters of a multi-stream context are applied at once (no folding)."""
+    from _oracle import Oracle
+    o = Oracle()
+    scenes = [o.scene_kitti(scale=0.4, seed=50 + i) for i in range(3)]
+    cfg = o.config_for_scene(scenes[0])
+    g = hip.load(); g.create(cfg, 0, 3)
+    try:
+        for k in range(3):
+            imgs = [o.render(sc, k) for sc in scenes]
+            L = np.ascontiguousarray(np.stack([im[0] for im in imgs])); R = np.ascontiguousarray(np.stack([im[1] for im in imgs]))
+            g.check(g.fn("frame_begin")(g.ctx, L.ctypes.data_as(C.c_void_p), R.ctypes.data_as(C.c_void_p), C.c_int32(L.shape[2]), C.c_size_t(L.shape[1] * L.shape[2]), C.c_int(0)))
+            for s in (2, 0, 1):
+                v = g.view_keypoints(s)
+                for side in (0, 1):
+                    xy, sc8, d = g.keypoints(s, side)
+                    assert len(xy) > 100
+                    np.testing.assert_array_equal(v[side][0], xy); np.testing.assert_array_equal(v[side][1], sc8); np.testing.assert_array_equal(v[side][2], d)
+            if k:
+                g.check(g.fn("track")(g.ctx, C.c_int(1)))
+                g.check(g.fn("prune_recover")(g.ctx))
+            g.check(g.fn("compute")(g.ctx))
+            for s in (1, 2, 0):
+                v = g.view_points(s)
+                p = g.points(s)
+                assert v["n"] == len(p["kp"]) > 50
+                np.testing.assert_array_equal(v["kp"], p["kp"]); np.testing.assert_array_equal(v["meta"], p["meta"]); np.testing.assert_array_equal(v["cam"], p["cam"])
+                assert bytes(v["info"]) == bytes(g.frame_info(s))
+    finally:
+        g.destroy(); o.destroy()
+
+
 def test_stage_call_before_frame_begin_is_an_error():
     from vslam_pose_estimation_framework_amd.capi import VslamError, ERR_STATE
     api = hip.load()
