@@ -2219,7 +2219,10 @@ static int report_ready(vslam_ctx* c) {
   L.p_kp = rl_take(&off, P * 8); L.p_meta = rl_take(&off, P * 24); L.p_cam = rl_take(&off, P * 24); L.p_desc = rl_take(&off, P * 64);
   L.total = off;
   void* h = nullptr;
-  HIP_TRY(c, hipHostMalloc(&h, L.total, hipHostMallocMapped));
+  // coherent (fine-grained) on purpose: the GPU's stores go out over PCIe as they are issued and the completion flag's system-scope
+  // release orders them for a host that polls it mid-kernel; with any other flag set and no coherence flag, HIP's default is a
+  // NON-coherent mapping whose lines may sit in the GPU's L2 until the kernel ends
+  HIP_TRY(c, hipHostMalloc(&h, L.total, hipHostMallocMapped | hipHostMallocCoherent));
   void* d = nullptr;
   if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return fail(c, VSLAM_ERR_HIP, "hipHostGetDevicePointer(report buffer)"); }
   std::memset(h, 0, L.total);
