@@ -326,7 +326,9 @@ int vslam_enable_timers(vslam_ctx* ctx, int on);
  * accumulated milliseconds and launch counts of k_fast_box, k_emit, k_brief, k_track_candidates, k_frame (its
  * three phase launches together, counted once), k_recover_brief, k_update_landmarks, k_stereo_dist.
  * Used by bench.py for the roofline of the dominant kernel.  Synchronises; vslam_enable_timers(ctx,1)
- * clears the accumulators. */
+ * clears the accumulators.  Stage path of a one-stream context (vslam_frame_begin): the image pipeline is timed by three events
+ * instead of two per kernel, so k_fast_box's figure covers k_emit as well (ms[0] + ms[1] = keypoint detection either way) and
+ * k_stereo_dist is not timed. */
 int vslam_get_kernel_times(vslam_ctx* ctx, double ms[8], int32_t launches[8]);
 
 /* ---- stand-alone kernels (unit parity, and the reference's optional knnMatch block) -------- */

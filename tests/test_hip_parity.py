@@ -441,13 +441,17 @@ def test_stage_views_equal_the_array_getters_after_every_stage():
         a.destroy(); ref.destroy(); o.destroy()
 
 
-def test_stage_views_of_any_stream_of_a_multi_stream_context():
+@pytest.mark.parametrize("capacities", [None, (1001, 777)])
+def test_stage_views_of_any_stream_of_a_multi_stream_context(capacities):
     """The report buffer holds one stream at a time and the folded report is stream 0's: views of the other streams of a three-stream
-    context are packed on demand and equal the getters; setters of a multi-stream context are applied at once (no folding)."""
+    context are packed on demand and equal the getters; setters of a multi-stream context are applied at once (no folding).  With
+    odd capacities the per-stream arrays start at addresses that are not 16 B aligned: the report kernel copies in narrower units."""
     from _oracle import Oracle
     o = Oracle()
     scenes = [o.scene_kitti(scale=0.4, seed=50 + i) for i in range(3)]
     cfg = o.config_for_scene(scenes[0])
+    if capacities:
+        cfg.max_keypoints, cfg.max_points = capacities
     g = hip.load(); g.create(cfg, 0, 3)
     try:
         for k in range(3):

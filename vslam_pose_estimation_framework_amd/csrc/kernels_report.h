@@ -34,16 +34,28 @@ struct ReportHeader {
   vslam_frame_info info;
 };
 
-// nbytes from src (device) to dst (mapped host memory) by gsz lanes (lane gid); both 16 B aligned at the array starts (capacities are
-// multiples of 64), 16 B per lane with a byte tail
+// nbytes from src (device) to dst (mapped host memory) by gsz lanes (lane gid).  The report offsets are 64 B aligned; the source arrays
+// start at (stream, side) * capacity elements, which is 16 B aligned for the usual capacities (multiples of 64) but only as aligned as
+// the caller's max_keypoints / max_points make it: the widest unit both pointers allow is used (16 B, 4 B or single bytes).
 __device__ __forceinline__ void report_copy(void* dst, const void* src, size_t nbytes, size_t gid, size_t gsz) {
-  const size_t n16 = nbytes >> 4;
-  const uint4* s4 = reinterpret_cast<const uint4*>(src);
-  uint4* d4 = reinterpret_cast<uint4*>(dst);
-  for (size_t i = gid; i < n16; i += gsz) d4[i] = s4[i];
+  const uintptr_t both = reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst);
   const unsigned char* s1 = reinterpret_cast<const unsigned char*>(src);
   unsigned char* d1 = reinterpret_cast<unsigned char*>(dst);
-  for (size_t i = (n16 << 4) + gid; i < nbytes; i += gsz) d1[i] = s1[i];
+  size_t done = 0;
+  if ((both & 15) == 0) {
+    const size_t n16 = nbytes >> 4;
+    const uint4* s4 = reinterpret_cast<const uint4*>(src);
+    uint4* d4 = reinterpret_cast<uint4*>(dst);
+    for (size_t i = gid; i < n16; i += gsz) d4[i] = s4[i];
+    done = n16 << 4;
+  } else if ((both & 3) == 0) {
+    const size_t n4 = nbytes >> 2;
+    const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src);
+    uint32_t* d4 = reinterpret_cast<uint32_t*>(dst);
+    for (size_t i = gid; i < n4; i += gsz) d4[i] = s4[i];
+    done = n4 << 2;
+  }
+  for (size_t i = done + gid; i < nbytes; i += gsz) d1[i] = s1[i];
 }
 
 // what a stage launch carries besides its stage number (by value in the kernel arguments): tracker-owned state the caller set

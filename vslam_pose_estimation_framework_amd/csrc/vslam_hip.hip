@@ -2252,7 +2252,7 @@ static int report_run(vslam_ctx* c, int s, int what, int in_progress, const Repo
   }
   // the report's completion flag (its seq, stored last with system-scope release) is polled in the pinned buffer: the caller's
   // thread sees the stage end a few microseconds after the kernel's last store instead of waiting for the runtime's own
-  // completion path (~10-15 us per synchronisation, five per frame).  Bounded: after ~20 ms without the flag the queue is
+  // completion path (~10-15 us per synchronisation, five per frame).  Bounded: after ~0.1 s without the flag the queue is
   // synchronised the ordinary way (an inactive stream never writes a report: that is the STATE error below)
   const ReportHeader* h = reinterpret_cast<const ReportHeader*>(c->report);
   bool seen = false;
