@@ -258,6 +258,8 @@ public:
   HipContext* hip() { return _hip; }
   //! the device's per-frame report of the frame last finished (counters the tests compare with the fused path)
   vslam_frame_info frameInfo() const { vslam_frame_info info; hipCheck(_hip->ctx, vslam_get_frame_info(_hip->ctx, 0, &info), "frameInfo"); return info; }
+  //! the same report as compute() received it with the frame's last stage view (no device round trip)
+  const vslam_frame_info& lastFrameInfo() const { return _last_info; }
 
 private:
   //! SLAMAssembly::printReport reads getTimeConsumptionSeconds_keypoint_detection / _descriptor_extraction (base generator,
@@ -444,7 +446,7 @@ private:
   bool _timers_enabled = false;
   LazyFeatures _features_left, _features_right;                            // keypoints + descriptors of the current frame
   std::vector<uint32_t> _pixel_left, _pixel_right;                         // (row << 16 | col) of feature i, strictly rising
-  vslam_frame_info _last_info;                                             // the device's report of the frame last finished
+  vslam_frame_info _last_info{};                                           // the device's report of the frame last finished
 };
 
 }  // namespace proslam

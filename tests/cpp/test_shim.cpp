@@ -74,6 +74,8 @@ int main(int argc, char** argv) {
       Frame* frame = h.step(L.data(), R.data(), scene.rows, scene.cols);
       hipCheck(fused, vslam_process_host(fused, L.data(), R.data(), scene.cols, 0), "fused");
       vslam_frame_info ff, fs = generator.frameInfo();
+      { const vslam_frame_info& fl = generator.lastFrameInfo();      // what compute() received with its stage view: the same report
+        REQUIRE(std::memcmp(&fl, &fs, sizeof fs) == 0, "lastFrameInfo differs from vslam_get_frame_info"); }
       hipCheck(fused, vslam_get_frame_info(fused, 0, &ff), "fused info");
       REQUIRE((int)h.status == ff.status, "status %d vs %d", (int)h.status, ff.status);
       REQUIRE(fs.n_keypoints_left == ff.n_keypoints_left && (int)frame->keypointsLeft().size() == ff.n_keypoints_left && (int)frame->keypointsRight().size() == ff.n_keypoints_right, "keypoints");
