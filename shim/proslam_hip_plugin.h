@@ -219,7 +219,7 @@ public:
     hipToArray(frame_->cameraLeftToWorld(), pose);
     hipCheck(_hip->ctx, vslam_set_pose(_hip->ctx, 0, pose), "HipStereoFramePointGenerator::initialize");
     { HIP_PROFILE(BEGIN_CALL); hipCheck(_hip->ctx, vslam_frame_begin(_hip->ctx, L.data, R.data, (int32_t)static_cast<size_t>(L.step), 0, 0), "HipStereoFramePointGenerator::initialize"); }
-    _pruned = false;
+    _pruned = false; _updated = false;
     downloadKeypoints(frame_);   // Frame::keypointsLeft/Right + descriptorsLeft/Right for downstream consumers
   }
 
@@ -251,7 +251,9 @@ public:
   void compute(Frame* frame_) override {
     if (!frame_) throw std::runtime_error("HipStereoFramePointGenerator::compute|called with empty frame");
     if (!_pruned) pruneOnDevice(frame_);     // recovery disabled or no previous frame: _prunePoints alone
-    { HIP_PROFILE(COMPUTE_CALL); hipCheck(_hip->ctx, vslam_compute(_hip->ctx), "HipStereoFramePointGenerator::compute"); }   // landmark update + stereo sweep, one launch
+    { HIP_PROFILE(COMPUTE_CALL);
+      if (_updated) hipCheck(_hip->ctx, vslam_stereo_new(_hip->ctx), "HipStereoFramePointGenerator::compute");   // the landmark update was started by recoverPoints()
+      else hipCheck(_hip->ctx, vslam_compute(_hip->ctx), "HipStereoFramePointGenerator::compute"); }                // landmark update + stereo sweep, one launch
     materializeNewPoints(frame_);  // Frame::createFramepoint(feature_left, feature_right, distance, xyz); chronometers
   }
 
@@ -392,6 +394,10 @@ private:
     if (!previous) return;
     vslam_points_view view;
     { HIP_PROFILE(PRUNE_WAIT); hipCheck(_hip->ctx, vslam_view_points(_hip->ctx, 0, 1, &view), "HipStereoFramePointGenerator::recoverPoints"); }
+    // the frame's point list is final on the device: its landmark update (PoseTracker3D::_updatePoints, the next thing the tracker does on
+    // the host objects) starts now and runs while the recovered points are materialised below; compute() then only runs the stereo sweep
+    hipCheck(_hip->ctx, vslam_update_points(_hip->ctx), "HipStereoFramePointGenerator::recoverPoints");
+    _updated = true;
     HIP_PROFILE(PRUNE_HOST);
     const int32_t n = view.n;
     const int16_t* kp = view.kp; const int32_t* meta = view.meta; const double* cam = view.cam; const uint8_t* desc = view.desc;
@@ -442,7 +448,7 @@ private:
   }
 
   HipContext* _hip;
-  mutable bool _pruned = false;
+  mutable bool _pruned = false, _updated = false;
   bool _timers_enabled = false;
   LazyFeatures _features_left, _features_right;                            // keypoints + descriptors of the current frame
   std::vector<uint32_t> _pixel_left, _pixel_right;                         // (row << 16 | col) of feature i, strictly rising
