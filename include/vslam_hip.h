@@ -308,6 +308,10 @@ typedef struct vslam_points_view {
   double seconds_tracking, seconds_pose_optimization, seconds_point_recovery, seconds_landmark_optimization, seconds_point_triangulation;
 } vslam_points_view;
 int vslam_view_keypoints(vslam_ctx* ctx, int stream, vslam_keypoints_view* out);            /* after vslam_frame_begin    */
+/* The same with desc[] = NULL, as soon as the detector has written coordinates and scores (the descriptors are still being computed): a
+ * caller builds its cv::KeyPoint lists meanwhile and fetches the descriptors with vslam_view_keypoints afterwards.  One-stream contexts
+ * inside a frame; anywhere else it is vslam_view_keypoints. */
+int vslam_view_keypoints_xy(vslam_ctx* ctx, int stream, vslam_keypoints_view* out);
 int vslam_view_track(vslam_ctx* ctx, int stream, vslam_track_view* out);                    /* after vslam_track          */
 int vslam_view_aligner(vslam_ctx* ctx, int stream, vslam_aligner_view* out);                /* after vslam_align          */
 int vslam_view_points(vslam_ctx* ctx, int stream, int in_progress, vslam_points_view* out); /* after vslam_prune_recover (1) / vslam_stereo_new (0) */

@@ -315,17 +315,15 @@ private:
       return &store[slot[i]];
     }
   };
-  //! one stage view -> cv::KeyPoint(x, y, 7, -1, score) + n x 32 CV_8U descriptor rows (frame.h:64-67).  The device lists are
+  //! stage views -> cv::KeyPoint(x, y, 7, -1, score) + n x 32 CV_8U descriptor rows (frame.h:64-67).  The device lists are
   //! image row-major: (row << 16 | col) rises strictly, so the feature at a pixel is found by bisection (compute() needs it for
-  //! the new points)
-  void materializeSide(const vslam_keypoints_view& view_, int side_, std::vector<cv::KeyPoint>& keypoints_, cv::Mat& descriptors_,
-                       LazyFeatures& features_, std::vector<uint32_t>& pixel_keys_) const {
+  //! the new points).  Two steps: coordinates and scores arrive first (vslam_view_keypoints_xy, while the descriptors are still
+  //! being computed on the device), the descriptor rows afterwards.
+  void materializeCoordinates(const vslam_keypoints_view& view_, int side_, std::vector<cv::KeyPoint>& keypoints_, std::vector<uint32_t>& pixel_keys_) const {
     const int32_t n = view_.n[side_];
     const int16_t* xy = view_.xy[side_];
     const uint8_t* score = view_.score[side_];
     keypoints_.resize(n);
-    descriptors_ = cv::Mat(n > 0 ? n : 1, VSLAM_DESC_BYTES, CV_8UC1);
-    if (n > 0) std::memcpy(descriptors_.ptr<uint8_t>(0), view_.desc[side_], (size_t)n * VSLAM_DESC_BYTES);   // freshly created Mat: dense rows
     pixel_keys_.resize(n);
     uint32_t last = 0;
     for (int32_t i = 0; i < n; ++i) {
@@ -334,14 +332,25 @@ private:
       if (i && key <= last) throw std::runtime_error("HipStereoFramePointGenerator|keypoints are not in image row-major order");
       pixel_keys_[i] = last = key;
     }
+  }
+  void materializeDescriptors(const vslam_keypoints_view& view_, int side_, const std::vector<cv::KeyPoint>& keypoints_, cv::Mat& descriptors_,
+                              LazyFeatures& features_) const {
+    const int32_t n = view_.n[side_];
+    if (n != (int32_t)keypoints_.size()) throw std::runtime_error("HipStereoFramePointGenerator|keypoint reports of one frame disagree");
+    descriptors_ = cv::Mat(n > 0 ? n : 1, VSLAM_DESC_BYTES, CV_8UC1);
+    if (n > 0) std::memcpy(descriptors_.ptr<uint8_t>(0), view_.desc[side_], (size_t)n * VSLAM_DESC_BYTES);   // freshly created Mat: dense rows
     features_.reset(keypoints_, descriptors_);
   }
   void downloadKeypoints(Frame* frame_) {
     vslam_keypoints_view view;
-    { HIP_PROFILE(KEYPOINTS_WAIT); hipCheck(_hip->ctx, vslam_view_keypoints(_hip->ctx, 0, &view), "HipStereoFramePointGenerator|keypoints"); }
+    { HIP_PROFILE(KEYPOINTS_WAIT); hipCheck(_hip->ctx, vslam_view_keypoints_xy(_hip->ctx, 0, &view), "HipStereoFramePointGenerator|keypoints"); }
+    { HIP_PROFILE(KEYPOINTS_HOST);
+      materializeCoordinates(view, 0, frame_->keypointsLeft(), _pixel_left);
+      materializeCoordinates(view, 1, frame_->keypointsRight(), _pixel_right); }
+    if (!view.desc[0]) { HIP_PROFILE(KEYPOINTS_WAIT); hipCheck(_hip->ctx, vslam_view_keypoints(_hip->ctx, 0, &view), "HipStereoFramePointGenerator|descriptors"); }
     HIP_PROFILE(KEYPOINTS_HOST);
-    materializeSide(view, 0, frame_->keypointsLeft(), frame_->descriptorsLeft(), _features_left, _pixel_left);
-    materializeSide(view, 1, frame_->keypointsRight(), frame_->descriptorsRight(), _features_right, _pixel_right);
+    materializeDescriptors(view, 0, frame_->keypointsLeft(), frame_->descriptorsLeft(), _features_left);
+    materializeDescriptors(view, 1, frame_->keypointsRight(), frame_->descriptorsRight(), _features_right);
     _number_of_detected_keypoints = (Count)_features_left.size();
   }
   static int32_t featureAt(const std::vector<uint32_t>& pixel_keys_, int16_t x_, int16_t y_) {

@@ -353,6 +353,7 @@ def test_stage_views_equal_the_array_getters_after_every_stage():
     a = hip.load(); a.create(cfg, 0, 1)          # driven with views checked after every stage, compute() as one launch
     ref = hip.load(); ref.create(cfg, 0, 1)      # the plain stage sequence
     checked = {"begin": 0, "track": 0, "align": 0, "prune": 0, "compute": 0}
+    early = {"seen": 0}
 
     class Checked(PoseTracker3D):
         def compute(self, left, right):
@@ -368,7 +369,11 @@ def test_stage_views_equal_the_array_getters_after_every_stage():
                     rc = f(*args)
                     assert rc == 0, (name, rc, api.last_error(api.ctx))
                     if name == "frame_begin":
+                        e = api.view_keypoints_xy(0)         # coordinates and scores first (early report once the report buffer exists)
                         v = api.view_keypoints(0)
+                        for side in (0, 1):
+                            np.testing.assert_array_equal(e[side][0], v[side][0]); np.testing.assert_array_equal(e[side][1], v[side][1])
+                        early["seen"] += 0 if e[0][2] else 1
                         for side in (0, 1):
                             xy, sc8, d = api.keypoints(0, side)
                             np.testing.assert_array_equal(v[side][0], xy); np.testing.assert_array_equal(v[side][1], sc8); np.testing.assert_array_equal(v[side][2], d)
@@ -437,6 +442,7 @@ def test_stage_views_equal_the_array_getters_after_every_stage():
             for key in ("kp", "meta", "cam", "lm"):
                 np.testing.assert_array_equal(pa[key], pr[key])
         assert checked["begin"] == 10 and checked["compute"] == 10 and checked["track"] >= 9 and checked["align"] >= 7 and checked["prune"] == 9, checked
+        assert early["seen"] >= 8, early          # from the second frame on the coordinates came through the early report (no descriptors with it)
     finally:
         a.destroy(); ref.destroy(); o.destroy()
 

@@ -302,6 +302,16 @@ class CApi(object):
                         np.ctypeslib.as_array(v.desc[d], (max(n, 1), 32))[:n].copy()))
         return out
 
+    def view_keypoints_xy(self, stream=0):
+        """Coordinates and scores as soon as the detector has written them (descriptors: view_keypoints afterwards)."""
+        v = KeypointsView()
+        self.check(self.fn("view_keypoints_xy")(self.ctx, C.c_int(stream), C.byref(v)))
+        out = []
+        for d in (0, 1):
+            n = v.n[d]
+            out.append((np.ctypeslib.as_array(v.xy[d], (max(n, 1), 2))[:n].copy(), np.ctypeslib.as_array(v.score[d], (max(n, 1),))[:n].copy(), bool(v.desc[d])))
+        return out
+
     def view_track(self, stream=0):
         v = TrackView()
         self.check(self.fn("view_track")(self.ctx, C.c_int(stream), C.byref(v)))

@@ -1924,7 +1924,8 @@ __global__ __launch_bounds__(VS_WG) void k_recover_alone(const DevCfg c, const D
 // Stage-granular entry points: the same device functions, one reference virtual per launch, with the
 // control flow left to the caller (shim/proslam_hip_plugin.h keeps the reference's PoseTracker3D logic).
 // ==============================================================================================
-enum { VS_STAGE_TRACK = 1, VS_STAGE_ALIGN = 2, VS_STAGE_PRUNE_RECOVER = 3, VS_STAGE_UPDATE = 4, VS_STAGE_STEREO = 5, VS_STAGE_COMPUTE = 6 /* UPDATE then STEREO */ };
+enum { VS_STAGE_TRACK = 1, VS_STAGE_ALIGN = 2, VS_STAGE_PRUNE_RECOVER = 3, VS_STAGE_UPDATE = 4, VS_STAGE_STEREO = 5, VS_STAGE_COMPUTE = 6 /* UPDATE then STEREO */,
+       VS_STAGE_PRUNE_PROJECT = 7, VS_STAGE_RECOVER_APPEND = 8 /* PRUNE_RECOVER as two launches around the wide k_recover_brief */ };
 
 // WorldMap::createFrame + the bookkeeping PoseTracker3D::compute does before initialize() (:36-77)
 // the caller's setters folded into a stage launch (StageIo): applied by one lane before anything reads the stream state
@@ -2008,6 +2009,35 @@ __global__ __launch_bounds__(VS_WG) void k_stage(const DevCfg c, const DevBuf b,
         if (arg) st.ticks[2] += wall_clock64() - t0;
         st.n_cur = sh.n_cur; st.n_after_prune = n_after; st.n_recovered = n_rec;
         info.n_after_prune = n_after; info.n_recovered = n_rec; info.n_points = sh.n_cur;
+      }
+    }
+  } else if (stage == VS_STAGE_PRUNE_PROJECT) {
+    // _prunePoints, then the projection of the lost landmarks; their descriptors are computed by the wide k_recover_brief (one wavefront
+    // per projected point over the whole chip instead of eight wavefronts behind one CU's memory pipe), which reads what it needs from fc
+    if (tid == 0) set_pose(c, b, s, f, st.pose);   // Frame::setRobotToWorld happened on the host side
+    __syncthreads();
+    if (has_prev) {
+      wg_prune(c, b, s, sh, pb_prev, pb_cur, st.aligner_valid != 0);
+      const int n_after = sh.n_cur;
+      __syncthreads();
+      wg_recover_project(c, b, s, sh.n_lost, pb_prev, hpose_of(c, b, s, f) + 12);
+      if (tid == 0) {
+        st.n_cur = n_after; st.n_after_prune = n_after; st.n_recovered = 0;
+        st.fc.n_lost = sh.n_lost; st.fc.tau_gen = st.tau_gen; st.fc.tau_tri = st.tau_tri;
+        info.n_after_prune = n_after; info.n_recovered = 0; info.n_points = n_after;
+      }
+    } else if (tid == 0) {
+      st.fc.n_lost = 0;
+    }
+  } else if (stage == VS_STAGE_RECOVER_APPEND) {
+    if (has_prev) {
+      const unsigned long long t0 = wall_clock64();
+      wg_recover_append(c, b, s, sh, pb_prev, pb_cur);
+      const int n_rec = sh.flag;
+      if (tid == 0) {
+        st.ticks[2] += wall_clock64() - t0;
+        st.n_cur = sh.n_cur; st.n_recovered = n_rec;
+        info.n_recovered = n_rec; info.n_points = sh.n_cur;
       }
     }
   } else if (stage == VS_STAGE_UPDATE || stage == VS_STAGE_STEREO || stage == VS_STAGE_COMPUTE) {

@@ -10,7 +10,8 @@
 #pragma once
 #include "dev_types.h"
 
-enum { VS_REPORT_KEYPOINTS = 1, VS_REPORT_TRACK = 2, VS_REPORT_ALIGNER = 3, VS_REPORT_POINTS = 4 };
+enum { VS_REPORT_KEYPOINTS = 1, VS_REPORT_TRACK = 2, VS_REPORT_ALIGNER = 3, VS_REPORT_POINTS = 4,
+       VS_REPORT_KEYPOINTS_XY = 5 /* coordinates and scores only, as soon as k_emit has written them: published through seq_xy */ };
 
 struct ReportLayout {   // byte offsets into the report buffer (64 B aligned)
   uint32_t kp_xy[2], kp_score[2], desc[2];     // per side: int16 [n][2], u8 [n], u8 [n][32]
@@ -26,7 +27,8 @@ struct ReportHeader {
   int32_t n_trk, n_lost, n_tracked_landmarks;
   int32_t al_n, al_inliers, al_outliers, al_iterations, al_converged;
   int32_t n_points, n_after_prune;
-  int32_t seq, pad;                             // seq: the launch that wrote this report (StageIo::seq); written LAST, system scope: the host may poll it
+  int32_t seq, seq_xy;                          // seq: the launch that wrote this report (StageIo::seq); written LAST, system scope: the host may poll it.
+                                                // seq_xy: the same for the early coordinates-only keypoint report (the full report follows behind k_brief)
   double al_total_error;
   double al_T[12];
   double al_H[36];
@@ -80,7 +82,9 @@ __device__ __forceinline__ void report_body(const DevCfg& c, const DevBuf& b, in
   int n_points = 0;
   if (what == VS_REPORT_POINTS) n_points = in_progress ? st.n_cur : (st.has_prev ? b.n_points[s * 2 + st.cur] : 0);
   if (n_points > c.MAXP) n_points = c.MAXP;
-  if (first) {
+  if (first && what == VS_REPORT_KEYPOINTS_XY) {
+    if (lane == 0) { h->n_kp[0] = b.n_kp[s * 2]; h->n_kp[1] = b.n_kp[s * 2 + 1]; }       // nothing else of the header: the full report owns it
+  } else if (first) {
     if (lane == 0) {
       h->what = what; h->stream = s; h->in_progress = in_progress; h->frame_count = st.frame_count;
       h->n_kp[0] = b.n_kp[s * 2]; h->n_kp[1] = b.n_kp[s * 2 + 1];
@@ -95,14 +99,14 @@ __device__ __forceinline__ void report_body(const DevCfg& c, const DevBuf& b, in
     uint32_t* id = reinterpret_cast<uint32_t*>(&h->info);
     for (int k = lane; k < (int)(sizeof(vslam_frame_info) / 4); k += lanes) id[k] = is[k];
   }
-  if (what == VS_REPORT_KEYPOINTS) {
+  if (what == VS_REPORT_KEYPOINTS || what == VS_REPORT_KEYPOINTS_XY) {
     for (int side = 0; side < 2; ++side) {
       int n = b.n_kp[s * 2 + side];
       if (n > c.NMAX) n = c.NMAX;
       const size_t o = ((size_t)s * 2 + side) * c.NMAX;
       report_copy(out + L.kp_xy[side], b.kp_xy + o * 2, (size_t)n * 4, gid, gsz);
       report_copy(out + L.kp_score[side], b.kp_score + o, (size_t)n, gid, gsz);
-      report_copy(out + L.desc[side], b.desc + o * 32, (size_t)n * 32, gid, gsz);
+      if (what == VS_REPORT_KEYPOINTS) report_copy(out + L.desc[side], b.desc + o * 32, (size_t)n * 32, gid, gsz);
     }
   } else if (what == VS_REPORT_TRACK) {
     report_copy(out + L.trk, b.trk + (size_t)s * c.MAXP * 4, (size_t)st.n_trk * 16, gid, gsz);
@@ -137,9 +141,9 @@ __device__ __forceinline__ void report_body(const DevCfg& c, const DevBuf& b, in
 
 // completion flag of a report, after every lane's stores: release at system scope so that a host polling the header sees the
 // arrays complete (the host does not have to wait for the runtime to notice that the kernel has ended)
-__device__ __forceinline__ void report_publish(unsigned char* out, int seq) {
+__device__ __forceinline__ void report_publish(unsigned char* out, int seq, bool xy = false) {
   ReportHeader* h = reinterpret_cast<ReportHeader*>(out);
-  __hip_atomic_store(&h->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(xy ? &h->seq_xy : &h->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ __launch_bounds__(256) void k_report(const DevCfg c, const DevBuf b, int s, int what, int in_progress, int seq, const ReportLayout L,
@@ -150,6 +154,6 @@ __global__ __launch_bounds__(256) void k_report(const DevCfg c, const DevBuf b, 
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned int arrived = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (arrived == gridDim.x - 1) { __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); report_publish(out, seq); }   // the last block
+    if (arrived == gridDim.x - 1) { __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); report_publish(out, seq, what == VS_REPORT_KEYPOINTS_XY); }   // the last block
   }
 }

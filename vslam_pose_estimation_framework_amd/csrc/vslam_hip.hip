@@ -82,6 +82,7 @@ struct vslam_ctx {
   int xcd_skew = 0;              // VSLAM_XCD_SKEW=k: the image queues' streams k XCDs away from their frame workgroups (measurement aid)
   bool img_on_frm_queue = false;
   int report_seq = 0;                                  // stamps every report launch; the header carries it back
+  int report_xy_seq = -1;                              // the early coordinates-only keypoint report of the frame in flight (-1: none)
   int report_have = 0, report_have_ip = 0, report_have_stream = -1, report_have_seq = -1;   // what the LAST launch on the frame queue packed (0: nothing)
   // setters of a one-stream context wait here for the next stage launch (StageIo); flush_pending() launches them on their own
   struct Pending { int flags = 0; int status = 0, win = 0; double tau = 0; double prior[12], pose[12]; } pend;
@@ -696,6 +697,12 @@ static int launch_image_pipeline(vslam_ctx* c) {
     { KernelTimer t(c, 0, st, true, !coarse); hipLaunchKernelGGL(k_fast_box, g1, dim3(256), VS_FB_DYN_LDS, st, c->cfg, bs); }
     { KernelTimer t(c, 1, st, true, !coarse); hipLaunchKernelGGL(k_emit, dim3(g.n, 2), dim3(512), 0, st, c->cfg, bs, orb ? (int)VSLAM_ORB_BORDER : (int)VSLAM_BRIEF_BORDER, 1); }
     if (e0) { e1 = ev_get(c); (void)hipEventRecord(e1, st); c->evrec.push_back({e0, e1, 0, true}); c->kern_n[1] += 1; }
+    if (c->img_override && c->report && c->B == 1) {
+      // stage path with a view reader: coordinates and scores leave for the host as soon as k_emit has written them, so that the caller
+      // builds its cv::KeyPoint lists while k_brief / k_stereo_dist / k_begin still run (vslam_view_keypoints_xy)
+      c->report_xy_seq = ++c->report_seq;
+      hipLaunchKernelGGL(k_report, dim3(8), dim3(256), 0, st, c->cfg, bs, 0, (int)VS_REPORT_KEYPOINTS_XY, 0, c->report_xy_seq, c->rl, c->report_dev, c->report_done);
+    }
     if (g.st_img != g.st_img2 && !c->img_override) { HIP_TRY(c, hipEventRecord(g.ev_emit[set], st)); g.emit_pending[set] = true; }
     else g.emit_pending[set] = false;
     if (orb) {   // cv::ORB::create() as extractor: Gaussian image (in the box image's memory), steered tests per keypoint
@@ -2107,6 +2114,7 @@ VS_API int vslam_frame_begin(vslam_ctx* c, const uint8_t* L, const uint8_t* R, i
   if (c->sticky != VSLAM_OK) return c->sticky;
   HIP_TRY(c, hipSetDevice(c->device));
   c->img_override = (c->B == 1 && c->groups.size() == 1) ? c->groups[0].st_frm : nullptr;
+  c->report_xy_seq = -1;
   int rc = on_device ? set_images_device(c, L, R, row_stride, image_stride) : upload_images(c, L, R, row_stride, image_stride);
   if (rc == VSLAM_OK) rc = launch_image_pipeline(c);
   c->img_override = nullptr;
@@ -2148,7 +2156,18 @@ VS_API int vslam_track(vslam_ctx* c, int by_appearance) {
   return launch_stage(c, VS_STAGE_TRACK, by_appearance ? 1 : 0, VS_REPORT_TRACK);
 }
 VS_API int vslam_align(vslam_ctx* c, int inverse_depth) { NEED_FRAME("vslam_align"); return launch_stage(c, VS_STAGE_ALIGN, inverse_depth, VS_REPORT_ALIGNER); }
-VS_API int vslam_prune_recover(vslam_ctx* c) { NEED_FRAME("vslam_prune_recover"); return launch_stage(c, VS_STAGE_PRUNE_RECOVER, c->cfg.c.enable_landmark_recovery, VS_REPORT_POINTS, 1); }
+VS_API int vslam_prune_recover(vslam_ctx* c) {
+  NEED_FRAME("vslam_prune_recover");
+  if (!c->cfg.c.enable_landmark_recovery) return launch_stage(c, VS_STAGE_PRUNE_RECOVER, 0, VS_REPORT_POINTS, 1);
+  // with recovery: prune + projection | descriptors of the projected points, wide | append + report — the per-point patch reads of the
+  // descriptors go through every CU's memory pipe instead of one (59 -> ~25 us for one stream)
+  int rc = launch_stage(c, VS_STAGE_PRUNE_PROJECT, 1);
+  if (rc != VSLAM_OK) return rc;
+  for (auto& g : c->groups)
+    hipLaunchKernelGGL(k_recover_brief, dim3(std::max(4, std::min(64, 1024 / std::max(g.n, 1))), g.n), dim3(256), 0, g.st_frm, c->cfg, buf_set(c, c->last_set, g.s0, g.q0_frm));
+  HIP_TRY(c, hipGetLastError());
+  return launch_stage(c, VS_STAGE_RECOVER_APPEND, 1, VS_REPORT_POINTS, 1);
+}
 VS_API int vslam_update_points(vslam_ctx* c) { NEED_FRAME("vslam_update_points"); return launch_stage(c, VS_STAGE_UPDATE, 0); }
 VS_API int vslam_stereo_new(vslam_ctx* c) {
   NEED_FRAME("vslam_stereo_new");
@@ -2264,6 +2283,34 @@ static int report_run(vslam_ctx* c, int s, int what, int in_progress, const Repo
   *hdr = h;
   if (__atomic_load_n(&h->seq, __ATOMIC_ACQUIRE) != seq || h->what != what) return fail(c, VSLAM_ERR_STATE, "stage report is stale (the stream is inactive?)");
   if ((*hdr)->info.error_flags) c->err = "device buffer capacity exceeded (error_flags != 0)";
+  return VSLAM_OK;
+}
+VS_API int vslam_view_keypoints(vslam_ctx* c, int s, vslam_keypoints_view* out);
+// polls a report flag (bounded), falling back to an ordinary synchronisation of the queue
+static int report_wait(vslam_ctx* c, const vslam_ctx::Group& g, const int32_t* flag, int seq) {
+  for (long spin = 0; spin < 4000000L; ++spin) {
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return VSLAM_OK;
+    __builtin_ia32_pause();
+  }
+  HIP_TRY(c, hipStreamSynchronize(g.st_frm));
+  return VSLAM_OK;
+}
+VS_API int vslam_view_keypoints_xy(vslam_ctx* c, int s, vslam_keypoints_view* out) {
+  if (!c || !out) return VSLAM_ERR_INVALID;
+  int rc = check_stream_index(c, s);
+  if (rc) return rc;
+  if (c->sticky != VSLAM_OK) return c->sticky;
+  if (!c->report || s != 0 || c->report_xy_seq < 0 || !c->frame_begun) return vslam_view_keypoints(c, s, out);   // no early report in flight: the full one
+  const ReportHeader* h = reinterpret_cast<const ReportHeader*>(c->report);
+  rc = report_wait(c, c->groups[0], &h->seq_xy, c->report_xy_seq);
+  if (rc) return rc;
+  if (__atomic_load_n(&h->seq_xy, __ATOMIC_ACQUIRE) != c->report_xy_seq) return fail(c, VSLAM_ERR_STATE, "early keypoint report is stale (the stream is inactive?)");
+  for (int d = 0; d < 2; ++d) {
+    out->n[d] = std::min(h->n_kp[d], c->cfg.NMAX);
+    out->xy[d] = reinterpret_cast<const int16_t*>(c->report + c->rl.kp_xy[d]);
+    out->score[d] = c->report + c->rl.kp_score[d];
+    out->desc[d] = nullptr;                       // not there yet: vslam_view_keypoints
+  }
   return VSLAM_OK;
 }
 VS_API int vslam_view_keypoints(vslam_ctx* c, int s, vslam_keypoints_view* out) {
