@@ -9,7 +9,11 @@ as that loop does.  Detector grids of any shape (configuration_icl.yaml runs 2 x
 Reference behaviour restated here (file:line relative to the reference root):
   * initialize() ignores `extract_features`: every re-registration detects again with the thresholds the controller has
     meanwhile moved, and runs the controller again (depth_framepoint_generator.cpp:24-44; one image per adjust: the mean is
-    over ONE detection).
+    over ONE detection).  detectKeypoints APPENDS to frame->keypointsLeft() (base_framepoint_generator.cpp:424), which nothing clears
+    between the initialize() calls of one frame (pose_tracker_3d.cpp:345,393): the second and third attempt describe, store
+    (setFeatures: the lattice keeps the LAST feature written to a pixel, the vector keeps all) and track against the union of
+    all attempts' keypoints, duplicates included, and _number_of_detected_keypoints is the accumulated count.  cv::ORB::compute
+    regroups keypoints that are not sorted by pyramid level (stable, level-major) — the accumulated list of an OrbDetector.
   * track() works on previous points + previous temporary points (:181-184); matches on pixels without depth become
     temporary points of the current frame (:247-256) and the temporary list is NOT cleared between re-registrations.
   * a point inherits hasUnreliableDepth from its predecessor (frame_point.cpp:43-55) even when its own depth is measured;
@@ -127,9 +131,11 @@ class RgbdTracker(object):
         self.info = {}
 
     # -- DepthFramePointGenerator::initialize (every call: detection + controller + descriptors) ---------------------------------
-    def initialize(self, left, depth):
+    def initialize(self, left, depth, first=True):
         api, c = self.api, self.cfg
         self.space, _, _ = api.depth_space_map(self.p, depth)
+        if first:                                               # a new Frame: empty keypointsLeft()
+            self.acc_xy = np.zeros((0, 2), np.float32); self.acc_desc = np.zeros((0, 32), np.uint8); self.acc_level = np.zeros(0, np.int32)
         parts = []
         orb_detector = getattr(self.p, "detector_type", 0) == 1
         for r, (rx, ry, rw, rh) in enumerate(self.regions):     # detectKeypoints: region-major, per-region threshold and controller
@@ -160,12 +166,20 @@ class RgbdTracker(object):
             else:                                               # BriefDescriptorExtractor: level 0, pixel (int)(pt + 0.5)
                 keep, desc = api.brief_describe(left, np.floor(kps[:, :2] + np.float32(0.5)).astype(np.int16))
             sel = keep.astype(bool)
-            self.feat_xy = kps[sel][:, :2].astype(np.float32); self.feat_desc = desc[sel]
+            new_xy = kps[sel][:, :2].astype(np.float32); new_desc = desc[sel]; new_level = kps[sel][:, 5].astype(np.int32)
         else:
             xy = (np.concatenate(parts) if parts else np.zeros((0, 2), np.int32)).astype(np.int16)
             keep, desc = (api.orb_describe(left, xy, -1.0) if self.p.descriptor_type == 1 else api.brief_describe(left, xy))
             sel = keep.astype(bool)
-            self.feat_xy = xy[sel].astype(np.float32); self.feat_desc = desc[sel]
+            new_xy = xy[sel].astype(np.float32); new_desc = desc[sel]; new_level = np.zeros(int(sel.sum()), np.int32)
+        # the frame's keypoint vector: earlier attempts' keypoints (already filtered and described: the extractor gives them the same
+        # descriptors again) followed by this detection's; ORB::compute regroups by level when the vector is not level-sorted
+        self.acc_xy = np.concatenate([self.acc_xy, new_xy.reshape(-1, 2)]); self.acc_desc = np.concatenate([self.acc_desc, new_desc.reshape(-1, 32)])
+        self.acc_level = np.concatenate([self.acc_level, new_level])
+        if self.p.descriptor_type == 1 and len(self.acc_level) and np.any(np.diff(self.acc_level) < 0):
+            o = np.argsort(self.acc_level, kind="stable")
+            self.acc_xy, self.acc_desc, self.acc_level = self.acc_xy[o], self.acc_desc[o], self.acc_level[o]
+        self.feat_xy = self.acc_xy.copy(); self.feat_desc = self.acc_desc.copy()
         # IntensityFeature: row = (int)pt.y, col = (int)pt.x (frame_point.h:18-35)
         self.feat_rc = np.stack([self.feat_xy[:, 1], self.feat_xy[:, 0]], axis=1).astype(np.int32) if len(self.feat_xy) else np.zeros((0, 2), np.int32)
         self.matched = np.zeros(len(self.feat_xy), bool)
@@ -255,7 +269,7 @@ class RgbdTracker(object):
         if self.n_tracked_landmarks == 0 or rel < 0.1:
             if recursion < 2:
                 self.prior = np.hstack([np.eye(3), np.zeros((3, 1))])
-                self.initialize(left, depth); self.track(cur, prev, True); self.register_recursive(cur, prev, left, depth, recursion + 1)
+                self.initialize(left, depth, first=False); self.track(cur, prev, True); self.register_recursive(cur, prev, left, depth, recursion + 1)
             else:
                 self.break_track(cur, prev)
             return
@@ -265,7 +279,7 @@ class RgbdTracker(object):
         elif recursion < 2:
             if self.win < c.maximum_projection_tracking_distance_pixels:
                 self.win += 1
-            self.initialize(left, depth); self.track(cur, prev, False); self.register_recursive(cur, prev, left, depth, recursion + 1)
+            self.initialize(left, depth, first=False); self.track(cur, prev, False); self.register_recursive(cur, prev, left, depth, recursion + 1)
         else:
             self.break_track(cur, prev)
 

@@ -356,7 +356,7 @@ def test_rgbd_reregistration_paths(impl, monkeypatch):
     ref = PyLoop(o, cfg, p)
     prod = RgbdTracker(g, cfg, p)
     try:
-        seen = set()
+        seen, union = set(), []
         for k in [0, 1, 2, 3, 4, 5, 6, 7, 8, 16, 17, 18]:
             L, D = o.render(scene, k)[0], o.render_depth(scene, k, 2e-3)
             a = ref.process(L, D)
@@ -371,6 +371,18 @@ def test_rgbd_reregistration_paths(impl, monkeypatch):
             assert a["thresholds"] == list(fi.thresholds)[:len(a["thresholds"])] and a["n_temporary"] == n_temp and a["tau_track"] == fi.tau_track
             To, Tg = a["pose"], np.array(fi.camera_left_to_world).reshape(3, 4)
             assert np.linalg.norm(Tg - To) / np.linalg.norm(To) <= POSE_RTOL
+            pts, cur = prod.points(), ref.frames[-1]          # the frame's points, one by one (new points of duplicated keypoints included)
+            assert len(pts["xy"]) == len(cur.points)
+            for i, q in enumerate(cur.points):
+                assert np.array_equal(pts["xy"][i].view(np.uint32), q.xy.view(np.uint32)), (k, i)
+                np.testing.assert_array_equal(pts["desc"][i], q.desc)
+                np.testing.assert_allclose(pts["cam"][i], q.cam, rtol=1e-12, atol=0)
+            if fi.track_attempts > 1:
+                # keypointsLeft() is appended to by every initialize() of the frame (base_framepoint_generator.cpp:424): the union of the
+                # attempts' detections, corners found again on the same pixel twice in it
+                rc = ref.feat_rc
+                union.append((fi.track_attempts, len(rc), len(rc) - len(np.unique(rc[:, 0].astype(np.int64) * 100000 + rc[:, 1]))))
+                assert fi.n_keypoints_left == len(rc)
             if fi.track_attempts == 2 and fi.aligner_ran and fi.window_pixels < cfg.maximum_projection_tracking_distance_pixels // 2:
                 seen.add("second attempt by projection")
             if fi.track_attempts == 2 and fi.aligner_ran and fi.window_pixels >= cfg.maximum_projection_tracking_distance_pixels // 2:
@@ -378,6 +390,7 @@ def test_rgbd_reregistration_paths(impl, monkeypatch):
             if fi.track_attempts == 3 and fi.track_broken:
                 seen.add("track broken after three attempts")
         assert seen == {"second attempt by projection", "second attempt by appearance", "track broken after three attempts"}, seen
+        assert any(a == 3 for a, _, _ in union) and all(d > 0 for _, _, d in union), union     # every repeated detection found some corners again
     finally:
         prod.destroy(); o.destroy()
 
@@ -427,6 +440,52 @@ def test_rgbd_tracker_with_the_orb_detector(descriptor, monkeypatch):
         assert fi.status == 1 and fi.n_tracked > 20 and fi.n_keypoints_left > 300, (fi.status, fi.n_tracked, fi.n_keypoints_left)
         assert shared > 0                                  # keypoints of several pyramid levels did land on the same pixel
         assert len(set(a["thresholds"])) > 1               # the four detectors' FAST thresholds moved apart
+    finally:
+        prod.destroy(); o.destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("descriptor", [1, 0])
+def test_rgbd_orb_detector_reregistration_keeps_the_union_of_keypoints(descriptor, monkeypatch):
+    """A lost track with the OrbDetector: the second and third initialize() of the frame append their detections to keypointsLeft()
+    (base_framepoint_generator.cpp:424); cv::ORB::compute then regroups the no longer level-sorted vector level-major (extractor ORB), BRIEF
+    leaves the order alone.  Product (host-driven loop) == checker loop over the oracle, counters, poses and every point."""
+    from _oracle import Oracle
+    monkeypatch.setenv("VSLAM_RGBD_HOST", "0")
+    o = Oracle()
+    scene, cfg, p = setup(o, "tum", descriptor=descriptor, seed=67)
+    p.detector_type = 1
+    o.create(cfg, 0, 1)
+    g = hip.load()
+    ref = PyLoop(o, cfg, p)
+    prod = RgbdTracker(g, cfg, p)
+    try:
+        most, levels = 0, 0
+        for k in [0, 1, 2, 3, 4, 5, 19, 20, 21]:
+            L, D = o.render(scene, k)[0], o.render_depth(scene, k, 2e-3)
+            a = ref.process(L, D)
+            fi, n_temp = prod.process(L, D)
+            for name, field in (("status", "status"), ("n_keypoints", "n_keypoints_left"), ("n_tracked", "n_tracked"), ("n_lost", "n_lost"),
+                                ("n_tracked_landmarks", "n_tracked_landmarks"), ("aligner_ran", "aligner_ran"), ("n_inliers", "n_inliers"),
+                                ("n_after_prune", "n_after_prune"), ("n_recovered", "n_recovered"), ("n_active_landmarks", "n_active_landmarks"),
+                                ("n_new", "n_new_stereo"), ("n_points", "n_points"), ("window_pixels", "window_pixels"),
+                                ("track_attempts", "track_attempts"), ("fallback", "fallback"), ("track_broken", "track_broken")):
+                assert a[name] == getattr(fi, field), (k, name, a[name], getattr(fi, field))
+            assert a["thresholds"] == list(fi.thresholds)[:len(a["thresholds"])] and a["n_temporary"] == n_temp
+            To, Tg = a["pose"], np.array(fi.camera_left_to_world).reshape(3, 4)
+            assert np.linalg.norm(Tg - To) / np.linalg.norm(To) <= POSE_RTOL
+            pts, cur = prod.points(), ref.frames[-1]
+            assert len(pts["xy"]) == len(cur.points)
+            for i, q in enumerate(cur.points):
+                assert np.array_equal(pts["xy"][i].view(np.uint32), q.xy.view(np.uint32)), (k, i)
+                np.testing.assert_array_equal(pts["desc"][i], q.desc)
+                np.testing.assert_allclose(pts["cam"][i], q.cam, rtol=1e-12, atol=0)
+            if fi.track_attempts > 1:
+                most = max(most, fi.track_attempts)
+                levels = max(levels, int(ref.acc_level.max()))
+                if descriptor == 1:
+                    assert np.all(np.diff(ref.acc_level) >= 0)          # ORB::compute left the union level-major
+        assert most >= 2 and levels >= 1, (most, levels)
     finally:
         prod.destroy(); o.destroy()
 

@@ -16,7 +16,11 @@
 //                           window / descriptor-distance adaptation, and what the registration does next
 //   k_rgbd_align            UVDAligner::initialize + converge (wg_align_converge<UVD>), then accept / fall back / ask for another attempt
 //        ... a frame whose registration asks for another attempt (pose_tracker_3d.cpp:333-418, rare) gets the block from the image pipeline to
-//        k_rgbd_align enqueued again by the host (it reads RgbdState::done); the tail below is enqueued optimistically and skips itself until then
+//        k_rgbd_align enqueued again by the host (it reads RgbdState::done); the tail below is enqueued optimistically and skips itself until then.
+//        detectKeypoints appends to the frame's keypoint vector (base_framepoint_generator.cpp:424; nothing clears it between the initialize()
+//        calls of one frame), so such an attempt works on the UNION of the frame's detections: k_rgbd_save_features keeps the list so far,
+//        k_rgbd_merge_features merges the new detection into it (row-major like k_emit's, equal pixels in attempt order, CSR = the sum of the
+//        two, the reference's vector order [earlier attempts..., this detection], the lattice's last-writer-wins as visibility flags)
 //   k_rgbd_prune            _prunePoints; projection of the lost points' landmarks
 //   k_rgbd_describe_at, k_rgbd_recover_finish      recoverPoints: descriptors at the projections, gates, new framepoints
 //   k_rgbd_landmarks        wide, eight lanes per framepoint: Landmark::Landmark / Landmark::update of its track, measurements in the reference's order
@@ -56,6 +60,7 @@ struct RgbdState {
   double al_total, al_T[12], c2w[12], w2c[12];
   int32_t tcounts[4], ccounts[2], rcount, n_rem;
   int32_t n_temporary;
+  int32_t n_acc, merged;       // features of the frame's earlier attempts kept by k_rgbd_save_features; 1: the live feature list is a merged one (fvis / order are the merge's)
   vslam_frame_info info;
 };
 
@@ -69,6 +74,12 @@ struct RgbdBuf {
   // features of the last initialize(): the inner context's keypoints / descriptors / CSR of image 0, plus
   int32_t* order;             // [NMAX] feature index (row-major numbering) of the j-th feature in the reference's order
   uint8_t* matched;           // [NMAX]
+  // the frame's keypoint vector over re-registration attempts: the list of the earlier attempts (a_*: a copy of the inner context's arrays, its order
+  // and visibility), the new detection while it is merged in (t_*), the merged list's visibility (fvis: 0 = a later feature sits on the same pixel)
+  int16_t* a_kxy; uint8_t* a_desc; uint8_t* a_score; int32_t* a_rowcell; int32_t* a_order; uint8_t* a_vis;
+  int16_t* t_kxy; uint8_t* t_desc; uint8_t* t_score; int32_t* t_order; int32_t* m_rank;
+  uint8_t* fvis;
+  int32_t ncsr;               // rows * (CW + 1): entries of a row / cell CSR
   // space map
   const uint16_t* depth; unsigned long long* dkey; int32_t* dlast; float* space; int16_t* row_map; int16_t* col_map;
   // track scratch
@@ -101,6 +112,8 @@ __device__ __forceinline__ RgbdBuf rgbd_stream(const RgbdBuf& a, int stream) {
   r.st += s;
   rgbd_list_at(r.fl[0], s, P, a.TR); rgbd_list_at(r.fl[1], s, P, a.TR); rgbd_list_at(r.tmp, s, P, a.TR);
   r.order += s * N; r.matched += s * N;
+  r.a_kxy += s * N * 2; r.a_desc += s * N * 32; r.a_score += s * N; r.a_rowcell += s * (size_t)a.ncsr; r.a_order += s * N; r.a_vis += s * N;
+  r.t_kxy += s * N * 2; r.t_desc += s * N * 32; r.t_score += s * N; r.t_order += s * N; r.m_rank += s * N * 2; r.fvis += s * N;
   r.depth += s * X; r.dkey += s * X; r.dlast += s * X; r.space += s * X * 3; r.row_map += s * X; r.col_map += s * X;
   r.hold += s * N * 2; r.pick += s * P; r.cand += s * P * (VS_DT_K + 1); r.out2 += s * P * 2; r.xyz += s * P * 3; r.temp2 += s * P * 2; r.lost_raw += s * P;
   r.lost += s * P; r.lost_has += s * P; r.lost_lm += s * P * 3; r.lost_desc += s * P * 32;
@@ -143,7 +156,7 @@ __global__ void k_rgbd_begin(const RgbdBuf all) {
   st.n_points = 0; st.n_temps = 0; st.n_lost = 0; st.n_tracked = 0; st.n_tracked_lm = 0; st.attempts = 0; st.recursion = 0;
   st.do_align = 0; st.inverse_depth = 0; st.aligner_valid = 0; st.al_inliers = 0; st.al_iterations = 0; st.al_total = 0; st.al_n = 0;
   st.n_registered = 0; st.n_after_prune = 0; st.n_recovered = 0; st.n_active = 0; st.n_new = 0; st.fallback = 0; st.broken = 0;
-  st.tail_done = 0;
+  st.tail_done = 0; st.n_acc = 0; st.merged = 0;
   st.done = st.frame_count == 0 ? 1 : 0;                 // the first frame has nothing to register against
   st.next_by_app = st.status == VSLAM_LOCALIZING ? 1 : 0;  // _track(..., _status == Localizing)
 }
@@ -152,36 +165,116 @@ __global__ void k_rgbd_begin(const RgbdBuf all) {
 // detectKeypoints concatenates the regions' keypoints in region order (base_framepoint_generator.cpp:355-429); k_emit leaves them row-major.
 // A corner lies in exactly one region's FAST-valid area (the regions overlap by 2-4 px, FAST's border is 3), so the reference's order is a
 // stable partition of the row-major list by region.  First part of k_rgbd_track (1024 threads).
+// out[j] = index (row-major numbering) of the j-th keypoint of ONE detection in the reference's order
+__device__ __forceinline__ void rgbd_region_order(const DevCfg& c, const int16_t* kxy, int n, int32_t* out, int* sh) {
+  const int tid = threadIdx.x, NT = blockDim.x;
+  if (c.n_regions == 1) {
+    for (int i = tid; i < n; i += NT) out[i] = i;
+    return;
+  }
+  int base = 0;
+  for (int q = 0; q < c.n_regions; ++q) {
+    const DevRegion R = c.regions[q];
+    for (int i0 = 0; i0 < n; i0 += NT) {
+      const int i = i0 + tid;
+      int in = 0;
+      if (i < n) { const int x = kxy[2 * i], y = kxy[2 * i + 1]; in = (x >= R.x + 3 && x < R.x + R.w - 3 && y >= R.y + 3 && y < R.y + R.h - 3) ? 1 : 0; }
+      int total;
+      const int at = base + block_exclusive_scan(in, sh, &total);
+      if (in) out[at] = i;
+      base += total;
+    }
+  }
+}
 __device__ __forceinline__ void rgbd_features(const DevCfg& c, const DevBuf& b, const RgbdBuf& r, int sq, int* sh) {
   RgbdState& st = *r.st;
   const int tid = threadIdx.x, NT = blockDim.x;
   const int n = b.n_kp[2 * sq];
-  const int16_t* kxy = kpxy_of(c, b, sq, 0);
-  for (int i = tid; i < n; i += NT) r.matched[i] = 0;
-  if (c.n_regions == 1) {
-    for (int i = tid; i < n; i += NT) r.order[i] = i;
-  } else {
-    int base = 0;
-    for (int q = 0; q < c.n_regions; ++q) {
-      const DevRegion R = c.regions[q];
-      for (int i0 = 0; i0 < n; i0 += NT) {
-        const int i = i0 + tid;
-        int in = 0;
-        if (i < n) { const int x = kxy[2 * i], y = kxy[2 * i + 1]; in = (x >= R.x + 3 && x < R.x + R.w - 3 && y >= R.y + 3 && y < R.y + R.h - 3) ? 1 : 0; }
-        int total;
-        const int at = base + block_exclusive_scan(in, sh, &total);
-        if (in) r.order[at] = i;
-        base += total;
-      }
-    }
-  }
+  for (int i = tid; i < n; i += NT) r.matched[i] = 0;                       // setFeatures: a fresh store per initialize()
+  if (!st.merged) rgbd_region_order(c, kpxy_of(c, b, sq, 0), n, r.order, sh);   // a merged list carries the order k_rgbd_merge_features gave it
   if (tid == 0) {
-    st.n_detected = n;
+    st.n_detected = n;                                                      // _number_of_detected_keypoints = keypointsLeft().size(): all attempts'
     int raw = 0;
     for (int q = 0; q < c.n_regions; ++q) raw += b.iinfo[sq].raw_count[0][q];
     st.n_raw = raw;
   }
   __syncthreads();
+}
+
+// ---- the frame's keypoint vector over re-registration attempts -------------------------------------------------------------------------------
+// Before attempt 2 / 3 detects: keep the list so far (the inner context's keypoint arrays of image 0 are about to be overwritten).
+__global__ __launch_bounds__(1024) void k_rgbd_save_features(const DevCfg c, const DevBuf b, const RgbdBuf all) {
+  const int sq = blockIdx.x;
+  if (!vs_active(b, sq)) return;
+  const RgbdBuf r = rgbd_stream(all, sq);
+  RgbdState& st = *r.st;
+  if (st.done) return;
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int n = b.n_kp[2 * sq];
+  const int16_t* kxy = kpxy_of(c, b, sq, 0);
+  const uint8_t* desc = desc_of(c, b, sq, 0);
+  const uint8_t* ksc = kpscore_of(c, b, sq, 0);
+  const int32_t* rc = rowcell_of(c, b, sq, 0);
+  for (int i = tid; i < n; i += NT) {
+    reinterpret_cast<int32_t*>(r.a_kxy)[i] = reinterpret_cast<const int32_t*>(kxy)[i];
+    r.a_score[i] = ksc[i]; r.a_order[i] = r.order[i]; r.a_vis[i] = st.merged ? r.fvis[i] : (uint8_t)1;
+  }
+  for (int i = tid; i < 2 * n; i += NT) reinterpret_cast<uint4*>(r.a_desc)[i] = reinterpret_cast<const uint4*>(desc)[i];
+  for (int i = tid; i < r.ncsr; i += NT) r.a_rowcell[i] = rc[i];
+  __syncthreads();
+  if (tid == 0) st.n_acc = n;
+}
+
+// After the attempt's k_emit + descriptors: the inner context holds the new detection B (row-major, CSR); merge the kept list A into it.
+// Row-major by (row, column), equal pixels in vector order (A's first); rank of A[i] = i + #{B < A[i]}, of B[j] = j + #{A <= B[j]}.
+__device__ __forceinline__ uint32_t rgbd_pixel_key(const int16_t* kxy, int i) { return ((uint32_t)(uint16_t)kxy[2 * i + 1] << 16) | (uint16_t)kxy[2 * i]; }
+__global__ __launch_bounds__(1024) void k_rgbd_merge_features(const DevCfg c, const DevBuf b, const RgbdBuf all) {
+  __shared__ int sh[17];
+  const int sq = blockIdx.x;
+  if (!vs_active(b, sq)) return;
+  const RgbdBuf r = rgbd_stream(all, sq);
+  RgbdState& st = *r.st;
+  if (st.done) return;
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int nA = st.n_acc, nB = b.n_kp[2 * sq];
+  if (nA + nB > c.NMAX) {                     // the frame fails with VSLAM_ERR_CAPACITY (bit 0, like k_emit's overflow)
+    if (tid == 0) { atomicOr(&st.error_flags, 1); st.merged = 0; }
+    return;
+  }
+  int16_t* kxy = kpxy_of(c, b, sq, 0);
+  uint8_t* desc = desc_of(c, b, sq, 0);
+  uint8_t* ksc = kpscore_of(c, b, sq, 0);
+  int32_t* rc = rowcell_of(c, b, sq, 0);
+  rgbd_region_order(c, kxy, nB, r.t_order, sh);
+  for (int i = tid; i < nB; i += NT) { reinterpret_cast<int32_t*>(r.t_kxy)[i] = reinterpret_cast<const int32_t*>(kxy)[i]; r.t_score[i] = ksc[i]; }
+  for (int i = tid; i < 2 * nB; i += NT) reinterpret_cast<uint4*>(r.t_desc)[i] = reinterpret_cast<const uint4*>(desc)[i];
+  __syncthreads();
+  auto place = [&](int at, const int16_t* sxy, const uint8_t* sdesc, const uint8_t* ssc, int i, uint8_t vis) {
+    reinterpret_cast<int32_t*>(kxy)[at] = reinterpret_cast<const int32_t*>(sxy)[i];
+    rgbd_copy_desc(desc + (size_t)32 * at, sdesc + (size_t)32 * i);
+    ksc[at] = ssc[i]; r.fvis[at] = vis;
+  };
+  for (int i = tid; i < nA; i += NT) {
+    const uint32_t key = rgbd_pixel_key(r.a_kxy, i);
+    int lo = 0, hi = nB;                                   // lower bound: B's entries with a smaller key
+    while (lo < hi) { const int m = (lo + hi) >> 1; if (rgbd_pixel_key(r.t_kxy, m) < key) lo = m + 1; else hi = m; }
+    const bool covered = lo < nB && rgbd_pixel_key(r.t_kxy, lo) == key;      // this detection found the pixel again: it owns the lattice cell now
+    r.m_rank[i] = i + lo;
+    place(i + lo, r.a_kxy, r.a_desc, r.a_score, i, (uint8_t)((r.a_vis[i] && !covered) ? 1 : 0));
+  }
+  for (int j = tid; j < nB; j += NT) {
+    const uint32_t key = rgbd_pixel_key(r.t_kxy, j);
+    int lo = 0, hi = nA;                                   // upper bound: A's entries with a key <= this one
+    while (lo < hi) { const int m = (lo + hi) >> 1; if (rgbd_pixel_key(r.a_kxy, m) <= key) lo = m + 1; else hi = m; }
+    r.m_rank[c.NMAX + j] = j + lo;
+    place(j + lo, r.t_kxy, r.t_desc, r.t_score, j, 1);
+  }
+  for (int i = tid; i < r.ncsr; i += NT) rc[i] = min(rc[i] + r.a_rowcell[i], c.NMAX);
+  __syncthreads();
+  // keypointsLeft(): [earlier attempts' keypoints in their order, this detection region-major]
+  for (int j = tid; j < nA; j += NT) r.order[j] = r.m_rank[r.a_order[j]];
+  for (int j = tid; j < nB; j += NT) r.order[nA + j] = r.m_rank[c.NMAX + r.t_order[j]];
+  if (tid == 0) { b.n_kp[2 * sq] = nA + nB; st.merged = 1; }
 }
 
 // ---- _track (pose_tracker_3d.cpp:225-298) around DepthFramePointGenerator::track (:166-287) --------------------------------------------------
@@ -196,7 +289,7 @@ __device__ __forceinline__ void rgbd_track_args(const DevCfg& c, const DevBuf& b
   a.nP = st.last_all; a.nL = b.n_kp[2 * sq]; a.CW = c.CW;
   a.cam = pv.cam; a.pdesc = pv.desc; a.pflags = pv.flags;
   a.kxy = kpxy_of(c, b, sq, 0); a.desc = desc_of(c, b, sq, 0); a.rowcell = rowcell_of(c, b, sq, 0);
-  a.space = r.space; a.fvis = nullptr;       // FAST leaves one feature per pixel
+  a.space = r.space; a.fvis = st.merged ? r.fvis : nullptr;       // one detection: FAST leaves one feature per pixel; a merged list: the lattice's last writer
   a.hold = r.hold; a.pick = r.pick; a.cand = r.cand; a.counts = r.st->tcounts; a.out2 = r.out2; a.xyz = r.xyz; a.temp2 = r.temp2; a.lost = r.lost_raw;
 }
 

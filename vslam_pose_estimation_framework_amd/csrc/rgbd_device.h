@@ -56,6 +56,9 @@ public:
       if (l != &rb.tmp) A(&l->trail, MAXP * (size_t)TR);
     }
     A(&rb.order, NMAX); A(&rb.matched, NMAX);
+    rb.ncsr = (int32_t)((size_t)ic->cfg.c.rows * (ic->cfg.CW + 1));
+    A(&rb.a_kxy, NMAX * 2); A(&rb.a_desc, NMAX * 32); A(&rb.a_score, NMAX); A(&rb.a_rowcell, (size_t)rb.ncsr); A(&rb.a_order, NMAX); A(&rb.a_vis, NMAX);
+    A(&rb.t_kxy, NMAX * 2); A(&rb.t_desc, NMAX * 32); A(&rb.t_score, NMAX); A(&rb.t_order, NMAX); A(&rb.m_rank, NMAX * 2); A(&rb.fvis, NMAX);
     A(&d_depth, npx); A(&rb.dkey, npx); A(&rb.dlast, npx); A(&rb.space, npx * 3); A(&rb.row_map, npx); A(&rb.col_map, npx);
     A(&rb.hold, NMAX * 2); A(&rb.pick, MAXP); A(&rb.cand, MAXP * (VS_DT_K + 1)); A(&rb.out2, MAXP * 2); A(&rb.xyz, MAXP * 3); A(&rb.temp2, MAXP * 2); A(&rb.lost_raw, MAXP);
     A(&rb.lost, MAXP); A(&rb.lost_has, MAXP); A(&rb.lost_lm, MAXP * 3); A(&rb.lost_desc, MAXP * 32);
@@ -217,13 +220,14 @@ private:
   }
 
   // initialize() .. registration of one attempt: the image pipeline on ONE image per sequence (DevCfg::mono: grid z = sequences; k_emit with
-  // its one-image controller), track, aligner.  Sequences whose bit in
-  // b.active is cleared are skipped by every kernel.  DELIBERATE DEVIATION: the feature list of an attempt is rebuilt from
-  // its own detection; upstream the second and third attempt of a frame see the union of all attempts' keypoints (frame_->keypointsLeft() is
-  // appended to and never cleared between the initialize() calls of one frame: base_framepoint_generator.cpp:424, pose_tracker_3d.cpp:345,393).
-  void enqueue_attempt(const DevBuf& b) {
+  // its one-image controller), track, aligner.  Sequences whose bit in b.active is cleared are skipped by every kernel.
+  // again: attempt 2 / 3 of a frame — its keypoint vector keeps the earlier attempts' keypoints (frame_->keypointsLeft() is appended to and never
+  // cleared between the initialize() calls of one frame: base_framepoint_generator.cpp:424, pose_tracker_3d.cpp:345,393): the list so far is
+  // saved before the detection overwrites it and merged with the new one before anything reads the features.
+  void enqueue_attempt(const DevBuf& b, bool again = false) {
     const DevCfg& d = ic->cfg;
     const dim3 g1(d.TX, (d.c.rows + VS_TILE_H - 1) / VS_TILE_H, B);
+    if (again) hipLaunchKernelGGL(k_rgbd_save_features, dim3(B), dim3(1024), 0, q, d, b, rb);
     hipLaunchKernelGGL(k_fast_box, g1, dim3(256), VS_FB_DYN_LDS, q, d, b);
     const bool orb = d.c.descriptor_type == VSLAM_DESCRIPTOR_ORB;
     hipLaunchKernelGGL(k_emit, dim3(B, 1), dim3(512), 0, q, d, b, orb ? (int)VSLAM_ORB_BORDER : (int)VSLAM_BRIEF_BORDER, 2);
@@ -235,6 +239,7 @@ private:
     } else {
       hipLaunchKernelGGL(k_brief, g3, dim3(256), 0, q, d, b);
     }
+    if (again) hipLaunchKernelGGL(k_rgbd_merge_features, dim3(B), dim3(1024), 0, q, d, b, rb);
     if (depth_pending) { (void)hipStreamWaitEvent(q, ev_depth, 0); depth_pending = false; }     // the space map is first read here
     hipLaunchKernelGGL(k_rgbd_track_candidates, dim3(std::max(8, std::min(256, 4096 / B)), B), dim3(256), 0, q, d, b, rb);
     hipLaunchKernelGGL(k_rgbd_track, dim3(B), dim3(wg1), 0, q, d, b, rb);
@@ -373,7 +378,7 @@ private:
         DevBuf b2 = bs;
         std::memset(b2.active, 0, sizeof b2.active);
         for (int s = 0; s < B; ++s) if (!hosts[s].tail_done) b2.active[s >> 5] |= 1u << (s & 31);
-        enqueue_attempt(b2);
+        enqueue_attempt(b2, true);
         enqueue_tail(b2);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(pinned, rb.st, sizeof(RgbdState) * (size_t)B, hipMemcpyDeviceToHost, q);

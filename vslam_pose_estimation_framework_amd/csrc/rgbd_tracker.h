@@ -9,10 +9,11 @@
 // default behind vslam_rgbd_*); this one is its cross-check (VSLAM_RGBD_HOST=1) and serves detector_type ORB.  Detector grids of any shape (configuration_icl.yaml:57-58 runs 2 x 2; tum and
 // xtion 1 x 1): one FAST detection, one threshold and one controller per region, keypoints in region-major order.
 //
-// DELIBERATE DEVIATION: on a re-registration attempt the feature list is REBUILT from the new detection; upstream
-// detectKeypoints appends to frame_->keypointsLeft(), which is never cleared between the initialize() calls of one frame
-// (base_framepoint_generator.cpp:424, pose_tracker_3d.cpp:345,393), so its attempts 2 and 3 describe and track the union of all attempts'
-// keypoints, duplicates included.  Device loop, this loop and the checker (tests/rgbd_loop.py) share the rebuilt-list rule.
+// Re-registration attempts of a frame ACCUMULATE its keypoints, as upstream: detectKeypoints appends to frame_->keypointsLeft(), which is
+// never cleared between the initialize() calls of one frame (base_framepoint_generator.cpp:424, pose_tracker_3d.cpp:345,393), so attempts 2
+// and 3 describe, store and track against the union of all attempts' keypoints, duplicates included (the lattice keeps the last feature
+// written to a pixel, the feature vector keeps all: intensity_feature_matcher.cpp:48-70); cv::ORB::compute regroups a keypoint vector that
+// is not sorted by pyramid level (stable, level-major).  Device loop, this loop and the checker (tests/rgbd_loop.py) agree on it.
 // Reference behaviour kept (docs/rounds/ lists the citations): initialize() detects and runs the controller on
 // EVERY call (also on re-registration); temporary points are not cleared between re-registrations; hasUnreliableDepth is
 // inherited along a track; the aligner never sees landmarks (it asks the current point, which has none yet) and its
@@ -127,7 +128,7 @@ private:
     frames.emplace_back();
     set_pose(frames[fi], world);
     n_tracked = 0; n_tracked_lm = 0; aligner_valid = false; lost.clear(); attempts = 0;
-    int rc = initialize();
+    int rc = initialize(true);
     if (rc) return rc;
     if (fi > 0) {
       rc = track(fi, status == VSLAM_LOCALIZING);
@@ -196,7 +197,7 @@ private:
   // the current frame's inputs and features
   const uint8_t* img = nullptr; int32_t img_stride = 0; const uint16_t* dep = nullptr; int32_t dep_stride = 0;
   std::vector<float> fxy;        // keypoint.pt of every feature (integers for FAST, level coordinates x scale for an OrbDetector)
-  std::vector<uint8_t> fdesc; std::vector<int32_t> frc; std::vector<uint8_t> matched;
+  std::vector<uint8_t> fdesc; std::vector<int32_t> frc, flevel; std::vector<uint8_t> matched;
 
   int fail(int rc, const char* where) { err = std::string(where) + ": " + vslam_last_error(ctx); return rc; }
   static void set_pose(Fr& f, const double* c2w) { std::memcpy(f.c2w, c2w, 96); tf_inv(c2w, f.w2c); }
@@ -266,7 +267,7 @@ private:
 
   // DepthFramePointGenerator::initialize (depth_framepoint_generator.cpp:24-44): depth map, FAST + controller over ONE image,
   // descriptors; runs in full on every call (extract_features_ is ignored upstream)
-  int initialize() {
+  int initialize(bool first = false) {
     int rc = vslam_depth_space_map(ctx, &p, dep, dep_stride, nullptr, nullptr, nullptr);
     if (rc) return fail(rc, "depth_space_map");
     const int cap = 65535;
@@ -280,7 +281,7 @@ private:
       }
       thr[r] = (int)std::rint(t / 1);
     };
-    fxy.clear(); fdesc.clear(); frc.clear();
+    if (first) { fxy.clear(); fdesc.clear(); frc.clear(); flevel.clear(); }     // a new Frame: empty keypointsLeft(); otherwise this detection is appended
     if (p.detector_type == VSLAM_DETECTOR_ORB) {
       // OrbDetector (base_framepoint_generator.cpp:52-70): cv::ORB::create(5000, 1.2f, 8, 31, 0, 2, HARRIS_SCORE, 31, threshold)->detect on the
       // region's VIEW of the image (its pyramid is the region's), keypoint.pt += region corner (float), lists concatenated; then the configured
@@ -312,6 +313,7 @@ private:
         fxy.push_back(x); fxy.push_back(y);
         frc.push_back((int32_t)y); frc.push_back((int32_t)x);          // IntensityFeature: row = (int)pt.y, col = (int)pt.x
         fdesc.insert(fdesc.end(), desc.begin() + (size_t)32 * i, desc.begin() + (size_t)32 * i + 32);
+        flevel.push_back((int32_t)kps[6 * (size_t)i + 5]);
       }
     } else {
     std::vector<int16_t> xy((size_t)cap * 2); std::vector<int32_t> score(cap);
@@ -338,7 +340,22 @@ private:
       fxy.push_back((float)xy[2 * i]); fxy.push_back((float)xy[2 * i + 1]);
       frc.push_back(xy[2 * i + 1]); frc.push_back(xy[2 * i]);
       fdesc.insert(fdesc.end(), desc.begin() + (size_t)32 * i, desc.begin() + (size_t)32 * i + 32);
+      flevel.push_back(0);
     }
+    }
+    // ORB::compute on the frame's whole keypoint vector: earlier attempts' keypoints get the same descriptors again; a vector that is not
+    // sorted by level is regrouped level-major, stable (only an OrbDetector's accumulated list is not)
+    if (p.descriptor_type == VSLAM_DESCRIPTOR_ORB && !std::is_sorted(flevel.begin(), flevel.end())) {
+      const size_t n = flevel.size();
+      std::vector<int> o(n);
+      for (size_t i = 0; i < n; ++i) o[i] = (int)i;
+      std::stable_sort(o.begin(), o.end(), [&](int a, int b) { return flevel[a] < flevel[b]; });
+      std::vector<float> xy2(2 * n); std::vector<int32_t> rc2(2 * n), lv2(n); std::vector<uint8_t> ds2(32 * n);
+      for (size_t i = 0; i < n; ++i) {
+        xy2[2 * i] = fxy[2 * o[i]]; xy2[2 * i + 1] = fxy[2 * o[i] + 1]; rc2[2 * i] = frc[2 * o[i]]; rc2[2 * i + 1] = frc[2 * o[i] + 1]; lv2[i] = flevel[o[i]];
+        std::memcpy(&ds2[32 * i], &fdesc[(size_t)32 * o[i]], 32);
+      }
+      fxy.swap(xy2); frc.swap(rc2); flevel.swap(lv2); fdesc.swap(ds2);
     }
     n_detected = (int)fxy.size() / 2;
     matched.assign(n_detected, 0);
