@@ -327,6 +327,28 @@ def test_rgbd_device_loop_capacity_and_short_history(monkeypatch):
         assert e.value.code == ERR_CAPACITY          # the same frame overflows again: the state was reset, the capacity was not
     finally:
         t.destroy()
+    # a lost track: the frame's second / third detection is appended to its keypoint vector — the union must fit max_keypoints too
+    full = RgbdTracker(g, cfg, p)
+    try:
+        for L, D in frames[:4]:
+            fi, _ = full.process(L, D)
+        one_detection = fi.n_keypoints_left
+        jump = (o.render(scene, 40)[0], o.render_depth(scene, 40, 2e-3))
+        fi, _ = full.process(*jump)
+        assert fi.track_attempts == 3 and fi.n_keypoints_left > 2 * one_detection, (fi.track_attempts, fi.n_keypoints_left, one_detection)
+        union = fi.n_keypoints_left
+    finally:
+        full.destroy()
+    tight = cfg.copy(); tight.max_keypoints = (one_detection + union) // 2
+    t = RgbdTracker(g, tight, p)
+    try:
+        for L, D in frames[:4]:
+            t.process(L, D)
+        with pytest.raises(VslamError) as e:
+            t.process(*jump)
+        assert e.value.code == ERR_CAPACITY and "max_keypoints" in str(e.value)
+    finally:
+        t.destroy()
     short = cfg.copy(); short.max_history_frames = 5
     t = RgbdTracker(g, short, p)
     try:

@@ -1,13 +1,19 @@
 """Per-stream, per-step phase durations of k_frame (in-kernel clocks; build the library with
 `make -C vslam_pose_estimation_framework_amd/csrc clean all EXTRA=-DVS_PROFILE_PHASES` first): where the slowest stream of a step spends
-its time.  Usage: python tools/probe/phase_clocks_per_stream.py [B] [K]"""
+its time.  Usage: python tools/probe/phase_clocks_per_stream.py [B] [K]      (HEAVY=1: the scene of bench.py --contrast 2 --speed 0.3 --bin 11;
+VSLAM_HIP_LIB=<variant library> selects a probe build without touching the product's)"""
 import sys, os, ctypes as C
 sys.path.insert(0, os.getcwd())
 import torch, numpy as np
 from vslam_pose_estimation_framework_amd import hip, synth
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 160
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-api = hip.load(); sy = synth.Synth(); scene = sy.scene_kitti(7); cfg = synth.config_for_scene(api, scene)
+api = hip.load(); sy = synth.Synth(); scene = sy.scene_kitti(7)
+if os.environ.get("HEAVY"):
+    scene.speed_m = 0.3; scene.contrast = 2.0
+cfg = synth.config_for_scene(api, scene)
+if os.environ.get("HEAVY"):
+    cfg.bin_size_pixels = 11; cfg.max_keypoints = 16384; cfg.max_points = 8192
 cfg.max_history_frames = K + 2
 stride = 1280; img = cfg.rows * stride
 dev = torch.device("cuda", 0)
