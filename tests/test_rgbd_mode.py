@@ -332,14 +332,14 @@ def test_rgbd_device_loop_capacity_and_short_history(monkeypatch):
     try:
         for L, D in frames[:4]:
             fi, _ = full.process(L, D)
-        one_detection = fi.n_keypoints_left
         jump = (o.render(scene, 40)[0], o.render_depth(scene, 40, 2e-3))
         fi, _ = full.process(*jump)
-        assert fi.track_attempts == 3 and fi.n_keypoints_left > 2 * one_detection, (fi.track_attempts, fi.n_keypoints_left, one_detection)
+        # n_detected_left: the corners of the LAST detection alone (border corners included); n_keypoints_left: the frame's whole vector
+        assert fi.track_attempts == 3 and fi.n_keypoints_left > fi.n_detected_left, (fi.track_attempts, fi.n_keypoints_left, fi.n_detected_left)
         union = fi.n_keypoints_left
     finally:
         full.destroy()
-    tight = cfg.copy(); tight.max_keypoints = (one_detection + union) // 2
+    tight = cfg.copy(); tight.max_keypoints = union - 1           # every single detection fits, the three together do not
     t = RgbdTracker(g, tight, p)
     try:
         for L, D in frames[:4]:
