@@ -92,20 +92,21 @@ def run_sequence(oracle_cls, scene_kw, n_frames, n_streams=1, which="kitti", cfg
     if cfg_edit:
         cfg_edit(cfg)
     o.create(cfg, 0, n_streams)
-    # both launch sequences of the frame: the library's choice for this stream count (two launches around the wide recovery
-    # kernel up to 4 streams, one fused launch above) and the other one forced through VSLAM_SPLIT
+    # every launch sequence of the frame: the library's choice for this stream count (up to 64 streams sequence 4: phase launches around the wide
+    # recovery kernel with the landmark kernel on a second queue beside the last phase; one fused launch above) and, forced through VSLAM_SPLIT:
+    # the fused launch (0), the two launches around the wide recovery kernel (2), and registration + wide recovery + the frame's tail as the small
+    # co-schedulable kernel (3; k_tail: 256 threads, stereo sweep band by band, bin competition on 16-bit tables, landmark cache one measurement deep)
     g = create_hip(cfg, n_streams)
-    g2 = create_hip(cfg, n_streams, split=0 if n_streams <= 4 else 2)
-    # third launch sequence: registration, wide recovery kernel, then the frame's tail as the small co-schedulable kernel (k_tail:
-    # 256 threads, stereo sweep band by band, bin competition on 16-bit tables, landmark cache one measurement deep)
+    g2 = create_hip(cfg, n_streams, split=0)
     g3 = create_hip(cfg, n_streams, split=3)
+    g4 = create_hip(cfg, n_streams, split=2)
     try:
         for k in range(n_frames):
             imgs = [o.render(sc, k) for sc in scenes]
             L = np.stack([im[0] for im in imgs])
             R = np.stack([im[1] for im in imgs])
             o.process_host(L, R)
-            for h in (g, g2, g3):
+            for h in (g, g2, g3, g4):
                 h.process_host(L, R)
                 for s in range(n_streams):
                     compare_frame(o, h, s, k)
@@ -115,6 +116,7 @@ def run_sequence(oracle_cls, scene_kw, n_frames, n_streams=1, which="kitti", cfg
         g.destroy()
         g2.destroy()
         g3.destroy()
+        g4.destroy()
         o.destroy()
 
 

@@ -9,8 +9,8 @@ as that loop does.  Detector grids of any shape (configuration_icl.yaml runs 2 x
 Reference behaviour restated here (file:line relative to the reference root):
   * initialize() ignores `extract_features`: every re-registration detects again with the thresholds the controller has
     meanwhile moved, and runs the controller again (depth_framepoint_generator.cpp:24-44; one image per adjust: the mean is
-    over ONE detection).  detectKeypoints APPENDS to frame->keypointsLeft() (base_framepoint_generator.cpp:424), which nothing clears
-    between the initialize() calls of one frame (pose_tracker_3d.cpp:345,393): the second and third attempt describe, store
+    over ONE detection).  detectKeypoints APPENDS to frame->keypointsLeft() (base_framepoint_generator.cpp:422), which nothing clears
+    between the initialize() calls of one frame (pose_tracker_3d.cpp:320,402): the second and third attempt describe, store
     (setFeatures: the lattice keeps the LAST feature written to a pixel, the vector keeps all) and track against the union of
     all attempts' keypoints, duplicates included, and _number_of_detected_keypoints is the accumulated count.  cv::ORB::compute
     regroups keypoints that are not sorted by pyramid level (stable, level-major) — the accumulated list of an OrbDetector.

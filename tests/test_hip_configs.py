@@ -331,7 +331,7 @@ def test_chunk_pipeline_21_streams_restarts_all_launch_sequences_vs_oracle():
     dev = torch.device("cuda", 0)
     Ld, Rd = torch.from_numpy(Lh).to(dev), torch.from_numpy(Rh).to(dev)
     o.create(cfg, 0, B)
-    hs = [create_hip(cfg, B), create_hip(cfg, B, split=2), create_hip(cfg, B, split=3)]
+    hs = [create_hip(cfg, B), create_hip(cfg, B, split=0), create_hip(cfg, B, split=3)]     # sequence 4 (the library's choice at 21 streams), fused, tail kernel
     n_restarts, tracking = 0, 0
     try:
         for k in range(2 * J + 2):

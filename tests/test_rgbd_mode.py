@@ -327,19 +327,20 @@ def test_rgbd_device_loop_capacity_and_short_history(monkeypatch):
         assert e.value.code == ERR_CAPACITY          # the same frame overflows again: the state was reset, the capacity was not
     finally:
         t.destroy()
-    # a lost track: the frame's second / third detection is appended to its keypoint vector — the union must fit max_keypoints too
-    full = RgbdTracker(g, cfg, p)
+    # a lost track: the frame's second / third detection is appended to its keypoint vector — the union must fit max_keypoints too.
+    # With the detector threshold pinned every detection of a frame finds the same corners: the vector grows to 2 x and 3 x one detection.
+    pinned = cfg.copy(); pinned.detector_threshold_minimum = pinned.detector_threshold_maximum = 25
+    jump = (o.render(scene, 40)[0], o.render_depth(scene, 40, 2e-3))
+    full = RgbdTracker(g, pinned, p)
     try:
-        for L, D in frames[:4]:
-            fi, _ = full.process(L, D)
-        jump = (o.render(scene, 40)[0], o.render_depth(scene, 40, 2e-3))
+        singles = [full.process(L, D)[0].n_keypoints_left for L, D in frames[:4]]
         fi, _ = full.process(*jump)
-        # n_detected_left: the corners of the LAST detection alone (border corners included); n_keypoints_left: the frame's whole vector
-        assert fi.track_attempts == 3 and fi.n_keypoints_left > fi.n_detected_left, (fi.track_attempts, fi.n_keypoints_left, fi.n_detected_left)
+        assert fi.track_attempts == 3 and fi.n_keypoints_left % 3 == 0 and fi.n_keypoints_left > max(singles), (fi.track_attempts, fi.n_keypoints_left, singles)
         union = fi.n_keypoints_left
     finally:
         full.destroy()
-    tight = cfg.copy(); tight.max_keypoints = union - 1           # every single detection fits, the three together do not
+    tight = pinned.copy(); tight.max_keypoints = max(max(singles), 2 * union // 3) + 1      # every frame and two detections of the jump frame fit, three do not
+    assert tight.max_keypoints < union
     t = RgbdTracker(g, tight, p)
     try:
         for L, D in frames[:4]:
@@ -400,7 +401,7 @@ def test_rgbd_reregistration_paths(impl, monkeypatch):
                 np.testing.assert_array_equal(pts["desc"][i], q.desc)
                 np.testing.assert_allclose(pts["cam"][i], q.cam, rtol=1e-12, atol=0)
             if fi.track_attempts > 1:
-                # keypointsLeft() is appended to by every initialize() of the frame (base_framepoint_generator.cpp:424): the union of the
+                # keypointsLeft() is appended to by every initialize() of the frame (base_framepoint_generator.cpp:422): the union of the
                 # attempts' detections, corners found again on the same pixel twice in it
                 rc = ref.feat_rc
                 union.append((fi.track_attempts, len(rc), len(rc) - len(np.unique(rc[:, 0].astype(np.int64) * 100000 + rc[:, 1]))))
@@ -470,7 +471,7 @@ def test_rgbd_tracker_with_the_orb_detector(descriptor, monkeypatch):
 @pytest.mark.parametrize("descriptor", [1, 0])
 def test_rgbd_orb_detector_reregistration_keeps_the_union_of_keypoints(descriptor, monkeypatch):
     """A lost track with the OrbDetector: the second and third initialize() of the frame append their detections to keypointsLeft()
-    (base_framepoint_generator.cpp:424); cv::ORB::compute then regroups the no longer level-sorted vector level-major (extractor ORB), BRIEF
+    (base_framepoint_generator.cpp:422); cv::ORB::compute then regroups the no longer level-sorted vector level-major (extractor ORB), BRIEF
     leaves the order alone.  Product (host-driven loop) == checker loop over the oracle, counters, poses and every point."""
     from _oracle import Oracle
     monkeypatch.setenv("VSLAM_RGBD_HOST", "0")

@@ -64,7 +64,8 @@ struct DevCfg {
 // scalars of the frame in flight, handed from one phase kernel of the frame to the next
 struct FrameCarry {
   int32_t status, status0, win, attempts, broken, fallback, n_after_prune, aligner_valid, n_tracked_landmarks;
-  int32_t n_cur, n_lost, n_recovered, n_active, pad;
+  int32_t n_cur, n_lost, n_recovered, n_active;
+  int32_t lm_pb, lm_f;    // point buffer and frame index of the frame whose landmarks k_update_landmarks refines (it may run beside the frame's last phase, which advances StreamState::cur / frame_count)
   double tau_track, tau_gen, tau_tri;
   double prior[12];
   unsigned long long t0;

@@ -824,17 +824,92 @@ __device__ __forceinline__ void wg_update_points(const DevCfg& c, const DevBuf& 
 }
 
 // fused path: one thread per framepoint of every stream
-__global__ __launch_bounds__(256) void k_update_landmarks(const DevCfg c, const DevBuf b) {
+// count: 1 = the kernel also counts the frame's active landmarks into FrameCarry::n_active (it runs BETWEEN phase 1 and phase 2); 0 = phase 4 has
+// counted them (a point is active iff its track is long enough: the refinement's outcome does not enter) and the kernel runs BESIDE phase 2
+__global__ __launch_bounds__(256) void k_update_landmarks(const DevCfg c, const DevBuf b, int count) {
   const int s = b.s0 + blockIdx.y;
   if (!vs_active(b, s)) return;
   StreamState& st = b.st[s];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = st.fc.n_cur;
   if (blockIdx.x * blockDim.x >= n) return;
-  const PtView cv = pts_of(c, b, s, st.cur ^ 1);
-  const bool act = i < n && landmark_point(c, b, s, cv, st.frame_count, i);
+  const PtView cv = pts_of(c, b, s, st.fc.lm_pb);
+  const bool act = i < n && landmark_point(c, b, s, cv, st.fc.lm_f, i);
   const int cnt = __popcll(__ballot(act));
-  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&st.fc.n_active, cnt);
+  if (count && (threadIdx.x & 63) == 0 && cnt) atomicAdd(&st.fc.n_active, cnt);
+}
+
+// The same refinement spread over `gridDim.x` workgroups per stream, each with the frame workgroup's own machinery (poses of the last VS_LM_NP frames
+// and every lane's first measurements in LDS, teams of eight lanes for long tracks: landmark_team / landmark_point_t<true>, i.e. the operations of
+// k_frame's landmark phase in the same order): launch sequence 4 runs it on a second queue beside the frame's last phase, where the wide
+// one-thread-per-track kernel above (56 us for one KITTI-sized stream) would be longer than the phase it hides behind.
+__global__ __launch_bounds__(VS_WG) void k_update_landmarks_teams(const DevCfg c, const DevBuf b, int count) {
+  __shared__ __align__(16) unsigned char arena[VS_ARENA];
+  __shared__ int n_short, n_long_sh, scan[17];
+  const int s = b.s0 + blockIdx.y, tid = threadIdx.x, g = blockIdx.x, G = gridDim.x;
+  if (!vs_active(b, s)) return;
+  StreamState& st = b.st[s];
+  const int n_cur = st.fc.n_cur, f = st.fc.lm_f;
+  const PtView cvu = pts_of(c, b, s, st.fc.lm_pb);
+  LmCache* lc = reinterpret_cast<LmCache*>(arena);
+  for (int t = tid; t < VS_LM_NP * 12; t += VS_WG) { const int k = t / 12; if (f - k >= 0 && k < c.HCAP) lc->w2c[k][t - 12 * k] = hpose_of(c, b, s, f - k)[12 + t - 12 * k]; }
+  if (tid == 0) { n_short = 0; n_long_sh = 0; }
+  __syncthreads();
+  lm_stage_rtr(lc, f, c.HCAP, VS_WG);
+  int active = 0;
+#if VS_LM_TEAMS
+  constexpr int LIST_CAP = (VS_ARENA - (int)sizeof(LmCache) - VS_LM_TEAM_LDS) / 2;
+  LmTerm* team_terms = reinterpret_cast<LmTerm*>(arena + VS_ARENA - VS_LM_TEAM_LDS);
+#else
+  constexpr int LIST_CAP = (VS_ARENA - (int)sizeof(LmCache)) / 2;
+#endif
+  uint16_t* work = reinterpret_cast<uint16_t*>(arena + sizeof(LmCache));
+  const bool listed = n_cur <= LIST_CAP && n_cur <= 65535;
+  __syncthreads();
+  if (listed) {
+    // a workgroup's share: the points i with i % G == g (the lists' order depends on the order of the atomics: a share must not be defined through it);
+    // its two work lists: short tracks from the front, long ones from the end
+    for (int i0 = 0; i0 < n_cur; i0 += VS_WG) {
+      const int i = i0 + tid;
+      const int32_t* mi = cvu.meta + (size_t)min(i, n_cur - 1) * META;
+      const bool need = i < n_cur && (i % G) == g && mi[M_TLEN] >= c.c.minimum_track_length_for_landmark_creation;
+#if VS_LM_TEAMS
+      const bool lng = need && landmark_is_long(c, mi);
+#else
+      const bool lng = false;
+#endif
+      const unsigned long long m = __ballot(need && !lng), ml = __ballot(lng);
+      int base = 0, basel = 0;
+      if ((tid & 63) == 0 && m) base = atomicAdd(&n_short, __popcll(m));
+      if ((tid & 63) == 0 && ml) basel = atomicAdd(&n_long_sh, __popcll(ml));
+      base = __builtin_amdgcn_readfirstlane(base); basel = __builtin_amdgcn_readfirstlane(basel);
+      if (need && !lng) work[base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)i;
+      if (lng) work[LIST_CAP - 1 - (basel + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ml >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ml, 0u)))] = (uint16_t)i;
+    }
+    __syncthreads();
+    const int n_work = n_short;
+#if VS_LM_TEAMS
+    const int n_long = n_long_sh;
+    constexpr int TEAMS = VS_LM_TEAM_WAVES * (64 / VS_LM_TEAM_G);      // teams of a workgroup
+    if ((tid >> 6) < VS_LM_TEAM_WAVES) {
+      const int team = tid / VS_LM_TEAM_G, gl = tid % VS_LM_TEAM_G;
+      for (int q = team; q < n_long; q += TEAMS)
+        active += (landmark_team(c, b, s, cvu, f, work[LIST_CAP - 1 - q], lc, team_terms + team * VS_LM_TEAM_G, gl) && gl == 0) ? 1 : 0;
+    } else {
+      constexpr int SH = VS_WG - 64 * VS_LM_TEAM_WAVES;
+      for (int q = tid - 64 * VS_LM_TEAM_WAVES; q < n_work; q += SH) active += landmark_point_t<true>(c, b, s, cvu, f, work[q], lc) ? 1 : 0;
+    }
+#else
+    for (int q = tid; q < n_work; q += VS_WG) active += landmark_point_t<true>(c, b, s, cvu, f, work[q], lc) ? 1 : 0;
+#endif
+  } else {
+    for (int i = g * VS_WG + tid; i < n_cur; i += G * VS_WG) active += landmark_point_t<true>(c, b, s, cvu, f, i, lc) ? 1 : 0;
+  }
+  if (count) {
+    int total;
+    block_exclusive_scan(active, scan, &total);
+    if (tid == 0 && total) atomicAdd(&st.fc.n_active, total);
+  }
 }
 
 // sdist[i][k], k < 16: Hamming distance of left feature i to right feature g0 + w0 + k of its row [g0, g1), where the
@@ -1492,6 +1567,8 @@ __device__ __forceinline__ void set_pose(const DevCfg& c, const DevBuf& b, int s
 //   [k_update_landmarks] landmark creation / refinement, one thread per framepoint; [k_stereo_dist] L-R distances
 //   phase 2  status switch, stereo sweep + binning + emission, report
 // phase < 0 runs everything in one launch (the wide steps inside the workgroup).
+// phase 4 = phase 1 + the count of active landmarks: k_update_landmarks then runs on a second queue BESIDE phase 2 (launch sequence 4, few streams:
+// nothing of phase 2 reads what the refinement writes — landmark coordinates and update counts of the tracked points; the next frame's phase 0 does).
 // phase 3 = phases 1 and 2 in one launch with the landmark refinement inside the workgroup: with phase 0 and the wide recovery
 // kernel in front this is the two-launch sequence used for few streams (the ~140 recovery patches of a frame spread over the
 // idle CUs: 67 -> 9 us; the wide landmark kernel, one thread per track, is slower than the workgroup's LDS-cached one).
@@ -1684,7 +1761,7 @@ __global__ VS_FRAME_BOUNDS void k_frame(ConstDevCfg* cp, ConstDevBuf* bp, int ph
   if (phase == 0) return;
   }  // phase 0
 
-  if (phase == 1 || phase < 0 || phase == 3) {   // ========================== phase 1 ==========================
+  if (phase == 1 || phase < 0 || phase == 3 || phase == 4) {   // ========================== phase 1 (4: + the count of active landmarks) ==========================
     if (tid == 0) { sh.n_cur = fc.n_cur; sh.n_lost = fc.n_lost; sh.flag = 0; }
     __syncthreads();
     if (has_prev && c.c.enable_landmark_recovery) {
@@ -1697,8 +1774,19 @@ __global__ VS_FRAME_BOUNDS void k_frame(ConstDevCfg* cp, ConstDevBuf* bp, int ph
       if (tid == 0) { st.ticks[2] += wall_clock64() - tr; fc.n_recovered = sh.flag; }
     }
     wg_publish_history(c, b, s, sh.n_cur, pb_cur, f);
-    if (tid == 0) { fc.n_cur = sh.n_cur; fc.n_active = 0; }
+    if (tid == 0) { fc.n_cur = sh.n_cur; fc.n_active = 0; fc.lm_pb = pb_cur; fc.lm_f = f; }
     __syncthreads();
+    if (phase == 4) {
+      // the landmark kernel will run BESIDE phase 2: the number of active landmarks — what the status switch needs — is the number of points
+      // whose track is long enough for a landmark (landmark_point_t returns false for nothing else)
+      const PtView cvc = pts_of(c, b, s, pb_cur);
+      int active = 0;
+      for (int i = tid; i < sh.n_cur; i += VS_WG) active += cvc.meta[(size_t)i * META + M_TLEN] >= c.c.minimum_track_length_for_landmark_creation ? 1 : 0;
+      int total;
+      block_exclusive_scan(active, sh.scan, &total);
+      if (tid == 0) fc.n_active = total;
+      return;
+    }
     if (phase == 1) return;
   }
 

@@ -17,7 +17,7 @@
 //   k_rgbd_align            UVDAligner::initialize + converge (wg_align_converge<UVD>), then accept / fall back / ask for another attempt
 //        ... a frame whose registration asks for another attempt (pose_tracker_3d.cpp:333-418, rare) gets the block from the image pipeline to
 //        k_rgbd_align enqueued again by the host (it reads RgbdState::done); the tail below is enqueued optimistically and skips itself until then.
-//        detectKeypoints appends to the frame's keypoint vector (base_framepoint_generator.cpp:424; nothing clears it between the initialize()
+//        detectKeypoints appends to the frame's keypoint vector (base_framepoint_generator.cpp:422; nothing clears it between the initialize()
 //        calls of one frame), so such an attempt works on the UNION of the frame's detections: k_rgbd_save_features keeps the list so far,
 //        k_rgbd_merge_features merges the new detection into it (row-major like k_emit's, equal pixels in attempt order, CSR = the sum of the
 //        two, the reference's vector order [earlier attempts..., this detection], the lattice's last-writer-wins as visibility flags)

@@ -222,7 +222,7 @@ private:
   // initialize() .. registration of one attempt: the image pipeline on ONE image per sequence (DevCfg::mono: grid z = sequences; k_emit with
   // its one-image controller), track, aligner.  Sequences whose bit in b.active is cleared are skipped by every kernel.
   // again: attempt 2 / 3 of a frame — its keypoint vector keeps the earlier attempts' keypoints (frame_->keypointsLeft() is appended to and never
-  // cleared between the initialize() calls of one frame: base_framepoint_generator.cpp:424, pose_tracker_3d.cpp:345,393): the list so far is
+  // cleared between the initialize() calls of one frame: base_framepoint_generator.cpp:422, pose_tracker_3d.cpp:320,402): the list so far is
   // saved before the detection overwrites it and merged with the new one before anything reads the features.
   void enqueue_attempt(const DevBuf& b, bool again = false) {
     const DevCfg& d = ic->cfg;

@@ -10,7 +10,7 @@
 // xtion 1 x 1): one FAST detection, one threshold and one controller per region, keypoints in region-major order.
 //
 // Re-registration attempts of a frame ACCUMULATE its keypoints, as upstream: detectKeypoints appends to frame_->keypointsLeft(), which is
-// never cleared between the initialize() calls of one frame (base_framepoint_generator.cpp:424, pose_tracker_3d.cpp:345,393), so attempts 2
+// never cleared between the initialize() calls of one frame (base_framepoint_generator.cpp:422, pose_tracker_3d.cpp:320,402), so attempts 2
 // and 3 describe, store and track against the union of all attempts' keypoints, duplicates included (the lattice keeps the last feature
 // written to a pixel, the feature vector keeps all: intensity_feature_matcher.cpp:48-70); cv::ORB::compute regroups a keypoint vector that
 // is not sorted by pyramid level (stable, level-major).  Device loop, this loop and the checker (tests/rgbd_loop.py) agree on it.
