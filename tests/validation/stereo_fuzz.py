@@ -2,7 +2,7 @@
 """The stereo pipeline against the CPU oracle on random worlds and random configurations (the checker is the oracle, as in the tests): image sizes,
 detector grids, bin sizes, threshold ranges, epipolar offsets, extractor, recovery / binning switches, damping, track length for landmarks,
 1 - 3 streams — every frame compared completely (tests/pipeline_compare.py: integers, keypoints, descriptors, framepoint tuples, aligner results,
-all three launch sequences).  usage: stereo_fuzz.py [runs] [frames]"""
+all four launch sequences).  usage: stereo_fuzz.py [runs] [frames]"""
 import json, os, sys, time, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
