@@ -219,7 +219,7 @@ public:
     hipToArray(frame_->cameraLeftToWorld(), pose);
     hipCheck(_hip->ctx, vslam_set_pose(_hip->ctx, 0, pose), "HipStereoFramePointGenerator::initialize");
     { HIP_PROFILE(BEGIN_CALL); hipCheck(_hip->ctx, vslam_frame_begin(_hip->ctx, L.data, R.data, (int32_t)static_cast<size_t>(L.step), 0, 0), "HipStereoFramePointGenerator::initialize"); }
-    _pruned = false; _updated = false;
+    _pruned = false; _computed = false;
     downloadKeypoints(frame_);   // Frame::keypointsLeft/Right + descriptorsLeft/Right for downstream consumers
   }
 
@@ -252,8 +252,9 @@ public:
     if (!frame_) throw std::runtime_error("HipStereoFramePointGenerator::compute|called with empty frame");
     if (!_pruned) pruneOnDevice(frame_);     // recovery disabled or no previous frame: _prunePoints alone
     { HIP_PROFILE(COMPUTE_CALL);
-      if (_updated) hipCheck(_hip->ctx, vslam_stereo_new(_hip->ctx), "HipStereoFramePointGenerator::compute");   // the landmark update was started by recoverPoints()
-      else hipCheck(_hip->ctx, vslam_compute(_hip->ctx), "HipStereoFramePointGenerator::compute"); }                // landmark update + stereo sweep, one launch
+      // landmark update + stereo sweep, one launch — already under way when recoverPoints() ran (it starts them as soon as it has read the
+      // recovered points' report): PoseTracker3D::compute calls _updatePoints (host objects only) and this function next, unconditionally
+      if (!_computed) hipCheck(_hip->ctx, vslam_compute(_hip->ctx), "HipStereoFramePointGenerator::compute"); }
     materializeNewPoints(frame_);  // Frame::createFramepoint(feature_left, feature_right, distance, xyz); chronometers
   }
 
@@ -403,33 +404,38 @@ private:
     if (!previous) return;
     vslam_points_view view;
     { HIP_PROFILE(PRUNE_WAIT); hipCheck(_hip->ctx, vslam_view_points(_hip->ctx, 0, 1, &view), "HipStereoFramePointGenerator::recoverPoints"); }
-    // the frame's point list is final on the device: its landmark update (PoseTracker3D::_updatePoints, the next thing the tracker does on
-    // the host objects) starts now and runs while the recovered points are materialised below; compute() then only runs the stereo sweep
-    hipCheck(_hip->ctx, vslam_update_points(_hip->ctx), "HipStereoFramePointGenerator::recoverPoints");
-    _updated = true;
     HIP_PROFILE(PRUNE_HOST);
     const int32_t n = view.n;
-    const int16_t* kp = view.kp; const int32_t* meta = view.meta; const double* cam = view.cam; const uint8_t* desc = view.desc;
     FramePointPointerVector& points(frame_->points());
     const int32_t n_kept = (int32_t)points.size();
     if (n < n_kept || view.first_full != n_kept) throw std::runtime_error("HipStereoFramePointGenerator::recoverPoints|host and device frames diverged (prune)");
     for (int32_t i = 0; i < n_kept; ++i)
-      if (points[i]->keypointLeft().pt.x != (float)kp[4 * i] || points[i]->keypointLeft().pt.y != (float)kp[4 * i + 1])
+      if (points[i]->keypointLeft().pt.x != (float)view.kp[4 * i] || points[i]->keypointLeft().pt.y != (float)view.kp[4 * i + 1])
         throw std::runtime_error("HipStereoFramePointGenerator::recoverPoints|host and device frames diverged (prune order)");
+    // The frame's point list is final on the device: its landmark update (PoseTracker3D::_updatePoints, the next thing the tracker does on the
+    // host objects) and the stereo sweep of compute() start NOW and run while the recovered points are materialised below.  The stage view's
+    // memory is reused by that launch's report, so the few recovered entries are copied out first.
+    const int32_t n_rec = n - n_kept;
+    _rec_kp.assign(view.kp + 4 * (size_t)n_kept, view.kp + 4 * (size_t)n);
+    _rec_meta.assign(view.meta + 6 * (size_t)n_kept, view.meta + 6 * (size_t)n);
+    _rec_cam.assign(view.cam + 3 * (size_t)n_kept, view.cam + 3 * (size_t)n);
+    _rec_desc.assign(view.desc + 64 * (size_t)n_kept, view.desc + 64 * (size_t)n);
+    hipCheck(_hip->ctx, vslam_compute(_hip->ctx), "HipStereoFramePointGenerator::recoverPoints");
+    _computed = true;
     points.resize(n);
-    for (int32_t i = n_kept; i < n; ++i) {
-      const int32_t ip = meta[6 * i + 2];
+    for (int32_t k = 0; k < n_rec; ++k) {
+      const int32_t ip = _rec_meta[6 * k + 2];
       if (ip < 0 || ip >= (int32_t)previous->points().size()) throw std::runtime_error("HipStereoFramePointGenerator::recoverPoints|bad previous index");
       FramePoint* point_previous = previous->points()[ip];
       cv::Mat descriptor_left(1, VSLAM_DESC_BYTES, CV_8UC1), descriptor_right(1, VSLAM_DESC_BYTES, CV_8UC1);
-      std::memcpy(descriptor_left.ptr<uint8_t>(0), &desc[(size_t)64 * i], VSLAM_DESC_BYTES);
-      std::memcpy(descriptor_right.ptr<uint8_t>(0), &desc[(size_t)64 * i + VSLAM_DESC_BYTES], VSLAM_DESC_BYTES);
+      std::memcpy(descriptor_left.ptr<uint8_t>(0), &_rec_desc[(size_t)64 * k], VSLAM_DESC_BYTES);
+      std::memcpy(descriptor_right.ptr<uint8_t>(0), &_rec_desc[(size_t)64 * k + VSLAM_DESC_BYTES], VSLAM_DESC_BYTES);
       cv::KeyPoint keypoint_left(point_previous->keypointLeft()), keypoint_right(point_previous->keypointRight());
-      keypoint_left.pt.x = kp[4 * i]; keypoint_left.pt.y = kp[4 * i + 1];
-      keypoint_right.pt.x = kp[4 * i + 2]; keypoint_right.pt.y = kp[4 * i + 3];
+      keypoint_left.pt.x = _rec_kp[4 * k]; keypoint_left.pt.y = _rec_kp[4 * k + 1];
+      keypoint_right.pt.x = _rec_kp[4 * k + 2]; keypoint_right.pt.y = _rec_kp[4 * k + 3];
       const IntensityFeature feature_left(keypoint_left, descriptor_left, 0), feature_right(keypoint_right, descriptor_right, 0);
-      points[i] = frame_->createFramepoint(&feature_left, &feature_right, (real)meta[6 * i],
-                                           PointCoordinates(cam[3 * i], cam[3 * i + 1], cam[3 * i + 2]), point_previous);
+      points[n_kept + k] = frame_->createFramepoint(&feature_left, &feature_right, (real)_rec_meta[6 * k],
+                                                    PointCoordinates(_rec_cam[3 * k], _rec_cam[3 * k + 1], _rec_cam[3 * k + 2]), point_previous);
     }
   }
 
@@ -457,7 +463,8 @@ private:
   }
 
   HipContext* _hip;
-  mutable bool _pruned = false, _updated = false;
+  mutable bool _pruned = false, _computed = false;
+  mutable std::vector<int16_t> _rec_kp; mutable std::vector<int32_t> _rec_meta; mutable std::vector<double> _rec_cam; mutable std::vector<uint8_t> _rec_desc;   // recovered points' report entries (copied out of the stage view)
   bool _timers_enabled = false;
   LazyFeatures _features_left, _features_right;                            // keypoints + descriptors of the current frame
   std::vector<uint32_t> _pixel_left, _pixel_right;                         // (row << 16 | col) of feature i, strictly rising

@@ -808,17 +808,84 @@ __device__ __forceinline__ void wg_publish_history(const DevCfg& c, const DevBuf
   }
 }
 
-__device__ __forceinline__ void wg_update_points(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_cur, int f) {
+// Landmark creation / refinement of the frame's points inside the stream's workgroup (PoseTracker3D::_updatePoints' landmark part): the poses of the
+// last VS_LM_NP frames and every lane's first measurements staged in the LDS arena, short tracks one lane each, long tracks a team of eight lanes
+// (landmark_point_t<true> / landmark_team).  Returns the number of active landmarks (block-uniform).  Used by k_frame's fused launches and by the
+// stage path's UPDATE / COMPUTE stages; history of frame f must have been published (wg_publish_history).
+__device__ __forceinline__ int wg_landmarks_lds(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_cur, int f, unsigned char* arena) {
   const int tid = threadIdx.x;
-  const PtView cv = pts_of(c, b, s, pb_cur);
-  const int n = sh.n_cur;
-  // publish the current frame's cam/prev to the history ring first (chains start here)
-  wg_publish_history(c, b, s, n, pb_cur, f);
-  __syncthreads();
+  const PtView cvu = pts_of(c, b, s, pb_cur);
   int active = 0;
-  for (int i = tid; i < n; i += VS_WG) active += landmark_point(c, b, s, cv, f, i) ? 1 : 0;
+  static_assert(sizeof(LmCache) <= VS_ARENA, "landmark measurement cache must fit the LDS arena");
+  LmCache* lc = reinterpret_cast<LmCache*>(arena);
+  for (int t = tid; t < VS_LM_NP * 12; t += VS_WG) { const int k = t / 12; if (f - k >= 0 && k < c.HCAP) lc->w2c[k][t - 12 * k] = hpose_of(c, b, s, f - k)[12 + t - 12 * k]; }
+  __syncthreads();
+  lm_stage_rtr(lc, f, c.HCAP, VS_WG);
+  // The points that carry a landmark (track long enough: creation or refinement) are compacted into a work list first: ~40 % of
+  // the frame's points, one per thread in a single round instead of two half-empty ones (a thread's refinement is a serial chain).
+#if VS_LM_TEAMS
+  static_assert(sizeof(LmCache) + VS_LM_TEAM_LDS + 4096 <= VS_ARENA, "landmark cache + team terms must leave room for the work lists");
+  constexpr int LIST_CAP = (VS_ARENA - (int)sizeof(LmCache) - VS_LM_TEAM_LDS) / 2;
+  LmTerm* team_terms = reinterpret_cast<LmTerm*>(arena + VS_ARENA - VS_LM_TEAM_LDS);
+#else
+  constexpr int LIST_CAP = (VS_ARENA - (int)sizeof(LmCache)) / 2;
+#endif
+  uint16_t* work = reinterpret_cast<uint16_t*>(arena + sizeof(LmCache));
+  const bool listed = sh.n_cur <= LIST_CAP && sh.n_cur <= 65535;
+  if (tid == 0) { sh.flag = 0; sh.n_proj = 0; }       // n_proj (recovery is over): the count of long tracks
+  __syncthreads();
+  if (listed) {
+    // short tracks (one lane each) from the front of the list, long ones (a team of eight lanes each) from its end
+    for (int i0 = 0; i0 < sh.n_cur; i0 += VS_WG) {
+      const int i = i0 + tid;
+      const int32_t* mi = cvu.meta + (size_t)min(i, sh.n_cur - 1) * META;
+      const bool need = i < sh.n_cur && mi[M_TLEN] >= c.c.minimum_track_length_for_landmark_creation;
+#if VS_LM_TEAMS
+      const bool lng = need && landmark_is_long(c, mi);
+#else
+      const bool lng = false;
+#endif
+      const unsigned long long m = __ballot(need && !lng), ml = __ballot(lng);
+      int base = 0, basel = 0;
+      if ((tid & 63) == 0 && m) base = atomicAdd(&sh.flag, __popcll(m));
+      if ((tid & 63) == 0 && ml) basel = atomicAdd(&sh.n_proj, __popcll(ml));
+      base = __builtin_amdgcn_readfirstlane(base); basel = __builtin_amdgcn_readfirstlane(basel);
+      if (need && !lng) work[base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)i;
+      if (lng) work[LIST_CAP - 1 - (basel + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ml >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ml, 0u)))] = (uint16_t)i;
+    }
+    __syncthreads();
+    const int n_work = sh.flag;
+#if VS_LM_TEAMS
+    const int n_long = sh.n_proj;
+    const int team_waves = min(VS_LM_TEAM_WAVES, (n_long + 64 / VS_LM_TEAM_G - 1) / (64 / VS_LM_TEAM_G));
+    const int wv_ = tid >> 6;
+    if (wv_ < team_waves) {
+      const int team = tid / VS_LM_TEAM_G, gl = tid % VS_LM_TEAM_G;
+      for (int q = team; q < n_long; q += team_waves * (64 / VS_LM_TEAM_G))
+        active += (landmark_team(c, b, s, cvu, f, work[LIST_CAP - 1 - q], lc, team_terms + team * VS_LM_TEAM_G, gl) && gl == 0) ? 1 : 0;
+    } else {
+      for (int q = tid - 64 * team_waves; q < n_work; q += VS_WG - 64 * team_waves) active += landmark_point_t<true>(c, b, s, cvu, f, work[q], lc) ? 1 : 0;
+    }
+#else
+    for (int q = tid; q < n_work; q += VS_WG) active += landmark_point_t<true>(c, b, s, cvu, f, work[q], lc) ? 1 : 0;
+#endif
+  } else {
+    for (int i = tid; i < sh.n_cur; i += VS_WG) active += landmark_point_t<true>(c, b, s, cvu, f, i, lc) ? 1 : 0;
+  }
   int total;
   block_exclusive_scan(active, sh.scan, &total);
+  __syncthreads();
+  if (tid == 0) sh.flag = 0;
+  __syncthreads();
+  return total;
+}
+
+__device__ __forceinline__ void wg_update_points(const DevCfg& c, const DevBuf& b, int s, FrameShared& sh, int pb_cur, int f, unsigned char* arena) {
+  const int tid = threadIdx.x;
+  // publish the current frame's cam/prev to the history ring first (chains start here)
+  wg_publish_history(c, b, s, sh.n_cur, pb_cur, f);
+  __syncthreads();
+  const int total = wg_landmarks_lds(c, b, s, sh, pb_cur, f, arena);     // the fused launch's refinement (LDS-cached, teams): 31 us per KITTI-sized frame where one thread per track took 80
   if (tid == 0) sh.n_lm = total;  // _number_of_active_landmarks
   __syncthreads();
 }
@@ -1795,67 +1862,8 @@ __global__ VS_FRAME_BOUNDS void k_frame(ConstDevCfg* cp, ConstDevBuf* bp, int ph
   __syncthreads();
   if (phase < 0 || phase == 3) {
     const unsigned long long tu = wall_clock64();
-    const PtView cvu = pts_of(c, b, s, pb_cur);
-    int active = 0;
-    static_assert(sizeof(LmCache) <= VS_ARENA, "landmark measurement cache must fit the LDS arena");
-    LmCache* lc = reinterpret_cast<LmCache*>(arena);
-    for (int t = tid; t < VS_LM_NP * 12; t += VS_WG) { const int k = t / 12; if (f - k >= 0 && k < c.HCAP) lc->w2c[k][t - 12 * k] = hpose_of(c, b, s, f - k)[12 + t - 12 * k]; }
-    __syncthreads();
-    lm_stage_rtr(lc, f, c.HCAP, VS_WG);
-    // The points that carry a landmark (track long enough: creation or refinement) are compacted into a work list first: ~40 % of
-    // the frame's points, one per thread in a single round instead of two half-empty ones (a thread's refinement is a serial chain).
-#if VS_LM_TEAMS
-    static_assert(sizeof(LmCache) + VS_LM_TEAM_LDS + 4096 <= VS_ARENA, "landmark cache + team terms must leave room for the work lists");
-    constexpr int LIST_CAP = (VS_ARENA - (int)sizeof(LmCache) - VS_LM_TEAM_LDS) / 2;
-    LmTerm* team_terms = reinterpret_cast<LmTerm*>(arena + VS_ARENA - VS_LM_TEAM_LDS);
-#else
-    constexpr int LIST_CAP = (VS_ARENA - (int)sizeof(LmCache)) / 2;
-#endif
-    uint16_t* work = reinterpret_cast<uint16_t*>(arena + sizeof(LmCache));
-    const bool listed = sh.n_cur <= LIST_CAP && sh.n_cur <= 65535;
-    if (tid == 0) { sh.flag = 0; sh.n_proj = 0; }       // n_proj (recovery is over): the count of long tracks
-    __syncthreads();
-    if (listed) {
-      // short tracks (one lane each) from the front of the list, long ones (a team of eight lanes each) from its end
-      for (int i0 = 0; i0 < sh.n_cur; i0 += VS_WG) {
-        const int i = i0 + tid;
-        const int32_t* mi = cvu.meta + (size_t)min(i, sh.n_cur - 1) * META;
-        const bool need = i < sh.n_cur && mi[M_TLEN] >= c.c.minimum_track_length_for_landmark_creation;
-#if VS_LM_TEAMS
-        const bool lng = need && landmark_is_long(c, mi);
-#else
-        const bool lng = false;
-#endif
-        const unsigned long long m = __ballot(need && !lng), ml = __ballot(lng);
-        int base = 0, basel = 0;
-        if ((tid & 63) == 0 && m) base = atomicAdd(&sh.flag, __popcll(m));
-        if ((tid & 63) == 0 && ml) basel = atomicAdd(&sh.n_proj, __popcll(ml));
-        base = __builtin_amdgcn_readfirstlane(base); basel = __builtin_amdgcn_readfirstlane(basel);
-        if (need && !lng) work[base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)i;
-        if (lng) work[LIST_CAP - 1 - (basel + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ml >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ml, 0u)))] = (uint16_t)i;
-      }
-      __syncthreads();
-      const int n_work = sh.flag;
-#if VS_LM_TEAMS
-      const int n_long = sh.n_proj;
-      const int team_waves = min(VS_LM_TEAM_WAVES, (n_long + 64 / VS_LM_TEAM_G - 1) / (64 / VS_LM_TEAM_G));
-      const int wv_ = tid >> 6;
-      if (wv_ < team_waves) {
-        const int team = tid / VS_LM_TEAM_G, gl = tid % VS_LM_TEAM_G;
-        for (int q = team; q < n_long; q += team_waves * (64 / VS_LM_TEAM_G))
-          active += (landmark_team(c, b, s, cvu, f, work[LIST_CAP - 1 - q], lc, team_terms + team * VS_LM_TEAM_G, gl) && gl == 0) ? 1 : 0;
-      } else {
-        for (int q = tid - 64 * team_waves; q < n_work; q += VS_WG - 64 * team_waves) active += landmark_point_t<true>(c, b, s, cvu, f, work[q], lc) ? 1 : 0;
-      }
-#else
-      for (int q = tid; q < n_work; q += VS_WG) active += landmark_point_t<true>(c, b, s, cvu, f, work[q], lc) ? 1 : 0;
-#endif
-    } else {
-      for (int i = tid; i < sh.n_cur; i += VS_WG) active += landmark_point_t<true>(c, b, s, cvu, f, i, lc) ? 1 : 0;
-    }
-    int total;
-    block_exclusive_scan(active, sh.scan, &total);
-    if (tid == 0) { fc.n_active = total; sh.flag = 0; st.ticks[3] += wall_clock64() - tu; }
+    const int total = wg_landmarks_lds(c, b, s, sh, pb_cur, f, arena);
+    if (tid == 0) { fc.n_active = total; st.ticks[3] += wall_clock64() - tu; }
     __syncthreads();
   }
   const int n_active = fc.n_active;
@@ -2013,7 +2021,8 @@ __global__ __launch_bounds__(VS_WG) void k_recover_alone(const DevCfg c, const D
 // control flow left to the caller (shim/proslam_hip_plugin.h keeps the reference's PoseTracker3D logic).
 // ==============================================================================================
 enum { VS_STAGE_TRACK = 1, VS_STAGE_ALIGN = 2, VS_STAGE_PRUNE_RECOVER = 3, VS_STAGE_UPDATE = 4, VS_STAGE_STEREO = 5, VS_STAGE_COMPUTE = 6 /* UPDATE then STEREO */,
-       VS_STAGE_PRUNE_PROJECT = 7, VS_STAGE_RECOVER_APPEND = 8 /* PRUNE_RECOVER as two launches around the wide k_recover_brief */ };
+       VS_STAGE_PRUNE_PROJECT = 7, VS_STAGE_RECOVER_APPEND = 8 /* PRUNE_RECOVER as two launches around the wide k_recover_brief */,
+       VS_STAGE_STEREO_COUNT = 9 /* STEREO + the COUNT of active landmarks: their refinement runs beside this launch (k_update_landmarks_teams on a second queue) */ };
 
 // WorldMap::createFrame + the bookkeeping PoseTracker3D::compute does before initialize() (:36-77)
 // the caller's setters folded into a stage launch (StageIo): applied by one lane before anything reads the stream state
@@ -2128,10 +2137,27 @@ __global__ __launch_bounds__(VS_WG) void k_stage(const DevCfg c, const DevBuf b,
         info.n_recovered = n_rec; info.n_points = sh.n_cur;
       }
     }
-  } else if (stage == VS_STAGE_UPDATE || stage == VS_STAGE_STEREO || stage == VS_STAGE_COMPUTE) {
+    if (arg & 2) {
+      // the frame's point list is final: publish it to the history ring here, so that the landmark kernel of the next call (vslam_compute of a
+      // one-stream context: k_update_landmarks_teams beside the stereo stage) finds what wg_update_points would have published first
+      __syncthreads();
+      wg_publish_history(c, b, s, sh.n_cur, pb_cur, f);
+      if (tid == 0) { st.fc.n_cur = sh.n_cur; st.fc.lm_pb = pb_cur; st.fc.lm_f = f; }
+    }
+  } else if (stage == VS_STAGE_UPDATE || stage == VS_STAGE_STEREO || stage == VS_STAGE_COMPUTE || stage == VS_STAGE_STEREO_COUNT) {
+    if (stage == VS_STAGE_STEREO_COUNT) {
+      // _number_of_active_landmarks without the refinement: a point is active iff its track is long enough for a landmark
+      const PtView cvc = pts_of(c, b, s, pb_cur);
+      int active = 0;
+      for (int i = tid; i < sh.n_cur; i += VS_WG) active += cvc.meta[(size_t)i * META + M_TLEN] >= c.c.minimum_track_length_for_landmark_creation ? 1 : 0;
+      int total;
+      block_exclusive_scan(active, sh.scan, &total);
+      if (tid == 0) { st.n_active = total; info.n_active_landmarks = total; }
+      __syncthreads();
+    } else
     if (stage != VS_STAGE_STEREO) {
       const unsigned long long t0 = wall_clock64();
-      wg_update_points(c, b, s, sh, pb_cur, f);
+      wg_update_points(c, b, s, sh, pb_cur, f, arena);
       if (tid == 0) { st.n_active = sh.n_lm; info.n_active_landmarks = sh.n_lm; st.ticks[3] += wall_clock64() - t0; }
     }
     if (stage == VS_STAGE_COMPUTE) {     // the two launches of compute() in one: the shared scalars start over as a new launch would read them

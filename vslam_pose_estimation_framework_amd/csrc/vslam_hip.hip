@@ -93,6 +93,7 @@ struct vslam_ctx {
   int split = 0;   // 0: one frame launch; 1: three phase launches with wide recovery / landmark kernels in between (measured slower);
                    // 2: two phase launches around the wide recovery kernel
                    // 4: three phase launches, the wide landmark kernel on a second queue beside the last one (fastest up to VS_SPLIT4_MAX_STREAMS streams)
+  bool lm_published = false;                            // vslam_prune_recover has published the frame's history (one stream, second queue present): vslam_compute may fork the landmark kernel
   hipStream_t st_lm = nullptr;                         // launch sequence 4: the landmark kernel's queue, forked after phase 1 and joined behind phase 2
   hipEvent_t ev_lm_fork = nullptr, ev_lm_join = nullptr;
   int sticky = VSLAM_OK;
@@ -2140,6 +2141,7 @@ VS_API int vslam_frame_begin(vslam_ctx* c, const uint8_t* L, const uint8_t* R, i
   HIP_TRY(c, hipSetDevice(c->device));
   c->img_override = (c->B == 1 && c->groups.size() == 1) ? c->groups[0].st_frm : nullptr;
   c->report_xy_seq = -1;
+  c->lm_published = false;
   int rc = on_device ? set_images_device(c, L, R, row_stride, image_stride) : upload_images(c, L, R, row_stride, image_stride);
   if (rc == VSLAM_OK) rc = launch_image_pipeline(c);
   c->img_override = nullptr;
@@ -2191,9 +2193,14 @@ VS_API int vslam_prune_recover(vslam_ctx* c) {
   for (auto& g : c->groups)
     hipLaunchKernelGGL(k_recover_brief, dim3(std::max(4, std::min(64, 1024 / std::max(g.n, 1))), g.n), dim3(256), 0, g.st_frm, c->cfg, buf_set(c, c->last_set, g.s0, g.q0_frm));
   HIP_TRY(c, hipGetLastError());
-  return launch_stage(c, VS_STAGE_RECOVER_APPEND, 1, VS_REPORT_POINTS, 1);
+  // one stream with a second queue (launch sequence 4's): the stage also publishes the frame's history, so that vslam_compute can run the landmark
+  // refinement beside the stereo stage instead of in front of it
+  const bool side = c->B == 1 && c->st_lm != nullptr;
+  rc = launch_stage(c, VS_STAGE_RECOVER_APPEND, side ? 3 : 1, VS_REPORT_POINTS, 1);
+  c->lm_published = rc == VSLAM_OK && side;
+  return rc;
 }
-VS_API int vslam_update_points(vslam_ctx* c) { NEED_FRAME("vslam_update_points"); return launch_stage(c, VS_STAGE_UPDATE, 0); }
+VS_API int vslam_update_points(vslam_ctx* c) { NEED_FRAME("vslam_update_points"); c->lm_published = false; return launch_stage(c, VS_STAGE_UPDATE, 0); }
 VS_API int vslam_stereo_new(vslam_ctx* c) {
   NEED_FRAME("vslam_stereo_new");
   c->frame_begun = false;  // compute() is the last call PoseTracker3D::compute makes on a frame
@@ -2203,6 +2210,31 @@ VS_API int vslam_stereo_new(vslam_ctx* c) {
 VS_API int vslam_compute(vslam_ctx* c) {     // vslam_update_points + vslam_stereo_new in one launch
   NEED_FRAME("vslam_compute");
   c->frame_begun = false;
+  if (c->lm_published && c->st_lm) {
+    // one stream, its history already published by vslam_prune_recover: the landmark refinement (k_update_landmarks_teams, the frame workgroup's
+    // refinement spread over several workgroups) runs on the second queue BESIDE the stereo stage, which only counts the active landmarks; the
+    // report — it carries the landmark update counts — is packed behind the join
+    c->lm_published = false;
+    vslam_ctx::Group& g = c->groups[0];
+    int rc = flush_pending(c);
+    if (rc != VSLAM_OK) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev_lm_fork, g.st_frm));
+    HIP_TRY(c, hipStreamWaitEvent(c->st_lm, c->ev_lm_fork, 0));
+    { KernelTimer t(c, 6, c->st_lm); hipLaunchKernelGGL(k_update_landmarks_teams, dim3(16, 1), dim3(VS_WG), 0, c->st_lm, c->cfg, buf_set(c, c->last_set, g.s0, g.q0_frm), 0); }
+    HIP_TRY(c, hipEventRecord(c->ev_lm_join, c->st_lm));
+    rc = launch_stage(c, VS_STAGE_STEREO_COUNT, 0);
+    if (rc != VSLAM_OK) return rc;
+    HIP_TRY(c, hipStreamWaitEvent(g.st_frm, c->ev_lm_join, 0));
+    if (c->report) {
+      const int seq = ++c->report_seq;
+      hipLaunchKernelGGL(k_report, dim3(16), dim3(256), 0, g.st_frm, c->cfg, buf_set(c, c->last_set, g.s0), 0, (int)VS_REPORT_POINTS, 0, seq, c->rl, c->report_dev, c->report_done);
+      HIP_TRY(c, hipGetLastError());
+      c->report_have = VS_REPORT_POINTS; c->report_have_ip = 0; c->report_have_stream = 0; c->report_have_seq = seq;
+    } else {
+      c->report_have = 0;
+    }
+    return frame_done(c);
+  }
   int rc = launch_stage(c, VS_STAGE_COMPUTE, 0, VS_REPORT_POINTS, 0);
   return rc == VSLAM_OK ? frame_done(c) : rc;
 }
