@@ -273,8 +273,10 @@ void vslam_host_free(void* p);
  * initialize(), the tracked list after track(), errors()/inliers() after converge(), Frame::points() after recoverPoints() and
  * compute()).  A vslam_view_* call packs exactly the live elements of that stage's results into a pinned host buffer owned by the
  * context (one small kernel, the GPU writes host memory directly) and synchronises the stream's frame queue ONCE; the pointers it
- * returns stay valid until the next vslam_view_* call on the context (one report buffer per context).  Same data, same order and
- * same meaning as the vslam_get_* calls above, which copy array by array. */
+ * returns stay valid until the next vslam_view_* call on the context (one report buffer per context); the keypoint arrays (coordinates,
+ * scores, descriptors) have a region of their own that only the next frame's keypoint report rewrites, so they may still be copied after
+ * vslam_track has been LAUNCHED (the shim copies descriptor rows while the device tracks).  Same data, same order and same meaning as the
+ * vslam_get_* calls above, which copy array by array. */
 typedef struct vslam_keypoints_view {
   int32_t n[2];                /* left, right                                           */
   const int16_t* xy[2];        /* n * (x, y), image row-major                           */

@@ -220,7 +220,7 @@ public:
     hipCheck(_hip->ctx, vslam_set_pose(_hip->ctx, 0, pose), "HipStereoFramePointGenerator::initialize");
     { HIP_PROFILE(BEGIN_CALL); hipCheck(_hip->ctx, vslam_frame_begin(_hip->ctx, L.data, R.data, (int32_t)static_cast<size_t>(L.step), 0, 0), "HipStereoFramePointGenerator::initialize"); }
     _pruned = false; _computed = false;
-    downloadKeypoints(frame_);   // Frame::keypointsLeft/Right + descriptorsLeft/Right for downstream consumers
+    downloadCoordinates(frame_);   // Frame::keypointsLeft/Right now; descriptorsLeft/Right by the next call on this frame (track(): around the device's tracking stage)
   }
 
   //! StereoFramePointGenerator::track (:464-681)
@@ -231,9 +231,13 @@ public:
     _hip->status = frame_->status() == Frame::Localizing ? VSLAM_LOCALIZING : VSLAM_TRACKING;
     _hip->window_pixels = _projection_tracking_distance_pixels;
     _hip->tau_track = _maximum_descriptor_distance_tracking;
+    const bool copy = _descriptors_pending;
+    vslam_keypoints_view keypoint_view;
+    if (copy) waitDescriptors(keypoint_view);  // the descriptors' report is read (header) before the tracking stage's report replaces it
     { HIP_PROFILE(TRACK_CALL);
       pushState(camera_left_previous_in_current_);
       hipCheck(_hip->ctx, vslam_track(_hip->ctx, track_by_appearance_ ? 1 : 0), "HipStereoFramePointGenerator::track"); }
+    if (copy) copyDescriptors(frame_, keypoint_view);   // descriptor rows and feature stores, while the device tracks
     materializeTrackedPoints(frame_, frame_previous_, lost_points_);
     if (_hip->aligner) _hip->aligner->invalidate((Count)frame_->points().size());
   }
@@ -242,6 +246,7 @@ public:
   //! device prunes its own by the same rule and recovers in the same launch
   void recoverPoints(Frame* current_frame_, const FramePointPointerVector& lost_points_) const override {
     (void)lost_points_;   // the device kept the lost list of its own track()
+    const_cast<HipStereoFramePointGenerator*>(this)->ensureKeypoints(current_frame_);
     pruneOnDevice(current_frame_);
     materializeRecoveredPoints(current_frame_);
   }
@@ -250,6 +255,7 @@ public:
   //! device updates its landmarks here (they feed the next frame's aligner)
   void compute(Frame* frame_) override {
     if (!frame_) throw std::runtime_error("HipStereoFramePointGenerator::compute|called with empty frame");
+    ensureKeypoints(frame_);                 // first frame: no track() has filled Frame::keypoints yet
     if (!_pruned) pruneOnDevice(frame_);     // recovery disabled or no previous frame: _prunePoints alone
     { HIP_PROFILE(COMPUTE_CALL);
       // landmark update + stereo sweep, one launch — already under way when recoverPoints() ran (it starts them as soon as it has read the
@@ -318,8 +324,7 @@ private:
   };
   //! stage views -> cv::KeyPoint(x, y, 7, -1, score) + n x 32 CV_8U descriptor rows (frame.h:64-67).  The device lists are
   //! image row-major: (row << 16 | col) rises strictly, so the feature at a pixel is found by bisection (compute() needs it for
-  //! the new points).  Two steps: coordinates and scores arrive first (vslam_view_keypoints_xy, while the descriptors are still
-  //! being computed on the device), the descriptor rows afterwards.
+  //! the new points).
   void materializeCoordinates(const vslam_keypoints_view& view_, int side_, std::vector<cv::KeyPoint>& keypoints_, std::vector<uint32_t>& pixel_keys_) const {
     const int32_t n = view_.n[side_];
     const int16_t* xy = view_.xy[side_];
@@ -334,25 +339,44 @@ private:
       pixel_keys_[i] = last = key;
     }
   }
-  void materializeDescriptors(const vslam_keypoints_view& view_, int side_, const std::vector<cv::KeyPoint>& keypoints_, cv::Mat& descriptors_,
-                              LazyFeatures& features_) const {
-    const int32_t n = view_.n[side_];
-    if (n != (int32_t)keypoints_.size()) throw std::runtime_error("HipStereoFramePointGenerator|keypoint reports of one frame disagree");
-    descriptors_ = cv::Mat(n > 0 ? n : 1, VSLAM_DESC_BYTES, CV_8UC1);
-    if (n > 0) std::memcpy(descriptors_.ptr<uint8_t>(0), view_.desc[side_], (size_t)n * VSLAM_DESC_BYTES);   // freshly created Mat: dense rows
-    features_.reset(keypoints_, descriptors_);
-  }
-  void downloadKeypoints(Frame* frame_) {
+  //! Frame::keypointsLeft/Right + descriptorsLeft/Right in three steps that interleave with the device: (1) initialize(): coordinates and scores
+  //! arrive right after the detector (vslam_view_keypoints_xy) and the cv::KeyPoint lists are built while the device still describes; (2) track()
+  //! waits for the descriptors' report, (3) launches the tracking stage and copies the descriptor rows / resets the feature stores while it runs.
+  //! A stage launch leaves the keypoint regions of the report buffer alone (they are rewritten by the next frame's keypoint report only).
+  //! PoseTracker3D::compute reads none of this between initialize() and _track().
+  void downloadCoordinates(Frame* frame_) {
     vslam_keypoints_view view;
     { HIP_PROFILE(KEYPOINTS_WAIT); hipCheck(_hip->ctx, vslam_view_keypoints_xy(_hip->ctx, 0, &view), "HipStereoFramePointGenerator|keypoints"); }
-    { HIP_PROFILE(KEYPOINTS_HOST);
-      materializeCoordinates(view, 0, frame_->keypointsLeft(), _pixel_left);
-      materializeCoordinates(view, 1, frame_->keypointsRight(), _pixel_right); }
-    if (!view.desc[0]) { HIP_PROFILE(KEYPOINTS_WAIT); hipCheck(_hip->ctx, vslam_view_keypoints(_hip->ctx, 0, &view), "HipStereoFramePointGenerator|descriptors"); }
     HIP_PROFILE(KEYPOINTS_HOST);
-    materializeDescriptors(view, 0, frame_->keypointsLeft(), frame_->descriptorsLeft(), _features_left);
-    materializeDescriptors(view, 1, frame_->keypointsRight(), frame_->descriptorsRight(), _features_right);
+    materializeCoordinates(view, 0, frame_->keypointsLeft(), _pixel_left);
+    materializeCoordinates(view, 1, frame_->keypointsRight(), _pixel_right);
+    _descriptors_pending = true;
+  }
+  void waitDescriptors(vslam_keypoints_view& view_) {
+    HIP_PROFILE(KEYPOINTS_WAIT);
+    hipCheck(_hip->ctx, vslam_view_keypoints(_hip->ctx, 0, &view_), "HipStereoFramePointGenerator|descriptors");
+  }
+  void copyDescriptors(Frame* frame_, const vslam_keypoints_view& view_) {
+    HIP_PROFILE(KEYPOINTS_HOST);
+    cv::Mat* descriptors[2] = {&frame_->descriptorsLeft(), &frame_->descriptorsRight()};
+    const std::vector<cv::KeyPoint>* keypoints[2] = {&frame_->keypointsLeft(), &frame_->keypointsRight()};
+    for (int side = 0; side < 2; ++side) {
+      const int32_t n = view_.n[side];
+      if (n != (int32_t)keypoints[side]->size()) throw std::runtime_error("HipStereoFramePointGenerator|keypoint reports of one frame disagree");
+      *descriptors[side] = cv::Mat(n > 0 ? n : 1, VSLAM_DESC_BYTES, CV_8UC1);
+      if (n > 0) std::memcpy(descriptors[side]->ptr<uint8_t>(0), view_.desc[side], (size_t)n * VSLAM_DESC_BYTES);   // freshly created Mat: dense rows
+    }
+    _features_left.reset(frame_->keypointsLeft(), frame_->descriptorsLeft());
+    _features_right.reset(frame_->keypointsRight(), frame_->descriptorsRight());
     _number_of_detected_keypoints = (Count)_features_left.size();
+    _descriptors_pending = false;
+  }
+  //! every path that needs the frame's descriptors without a track() in front of it (first frame; a caller that skips track())
+  void ensureKeypoints(Frame* frame_) {
+    if (!_descriptors_pending) return;
+    vslam_keypoints_view view;
+    waitDescriptors(view);
+    copyDescriptors(frame_, view);
   }
   static int32_t featureAt(const std::vector<uint32_t>& pixel_keys_, int16_t x_, int16_t y_) {
     const uint32_t key = ((uint32_t)(uint16_t)y_ << 16) | (uint16_t)x_;
@@ -464,6 +488,7 @@ private:
 
   HipContext* _hip;
   mutable bool _pruned = false, _computed = false;
+  bool _descriptors_pending = false;   // Frame::descriptorsLeft/Right and the feature stores of the frame are still to be filled
   mutable std::vector<int16_t> _rec_kp; mutable std::vector<int32_t> _rec_meta; mutable std::vector<double> _rec_cam; mutable std::vector<uint8_t> _rec_desc;   // recovered points' report entries (copied out of the stage view)
   bool _timers_enabled = false;
   LazyFeatures _features_left, _features_right;                            // keypoints + descriptors of the current frame

@@ -101,7 +101,7 @@ def test_chronometer_members_exist_where_the_stubs_put_them():
 
 def test_inherited_members_the_shim_touches_exist_in_the_reference():
     shim = strip_comments(read(os.path.join(ROOT, "shim", "proslam_hip_plugin.h")))
-    own = {"_hip", "_pruned", "_computed", "_rec_kp", "_rec_meta", "_rec_cam", "_rec_desc", "_timers_enabled", "_features_left", "_features_right", "_pixel_left", "_pixel_right", "_last_info"}
+    own = {"_hip", "_pruned", "_computed", "_descriptors_pending", "_rec_kp", "_rec_meta", "_rec_cam", "_rec_desc", "_timers_enabled", "_features_left", "_features_right", "_pixel_left", "_pixel_right", "_last_info"}
     used = set(re.findall(r"(?<![\w.>])(_[a-z][a-z_0-9]*)\b", shim)) - own
     ref_text = "\n".join(strip_comments(read(os.path.join(REF, h))) for hs in PAIRS.values() for h in hs)
     expanded = ref_text + " " + " ".join("_time_consumption_seconds_" + n for n in re.findall(r"CREATE_CHRONOMETER\((\w+)\)", ref_text))
