@@ -176,6 +176,7 @@ class RgbdTracker(object):
         # descriptors again) followed by this detection's; ORB::compute regroups by level when the vector is not level-sorted
         self.acc_xy = np.concatenate([self.acc_xy, new_xy.reshape(-1, 2)]); self.acc_desc = np.concatenate([self.acc_desc, new_desc.reshape(-1, 32)])
         self.acc_level = np.concatenate([self.acc_level, new_level])
+        self.detections = ([] if first else self.detections) + [len(new_level)]   # keypoints each initialize() of the frame added (kept by the extractor's border filter)
         if self.p.descriptor_type == 1 and len(self.acc_level) and np.any(np.diff(self.acc_level) < 0):
             o = np.argsort(self.acc_level, kind="stable")
             self.acc_xy, self.acc_desc, self.acc_level = self.acc_xy[o], self.acc_desc[o], self.acc_level[o]

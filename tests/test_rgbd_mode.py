@@ -110,6 +110,34 @@ def test_python_loop_over_the_oracle_runs_every_configuration(which):
     o.destroy()
 
 
+def test_python_loop_over_the_oracle_keeps_the_union_of_keypoints_over_reregistrations():
+    """CPU: a jump in the sequence loses the track — _registerRecursive calls initialize() twice more (pose_tracker_3d.cpp:320,402), detectKeypoints
+    appends to the frame's keypoint vector every time (base_framepoint_generator.cpp:422) and setFeatures stores all of them: the checker's feature
+    list of such a frame is the union of three detections, corners found again sit on one pixel twice (only the last one is in the lattice), and
+    compute() turns features of every attempt into framepoints."""
+    from _oracle import Oracle
+    o = Oracle()
+    scene, cfg, p = setup(o, "icl", descriptor=0, max_depth=30.0, seed=41)
+    cfg.minimum_number_of_landmarks_to_track = 30
+    o.create(cfg, 0, 1)
+    tr = PyLoop(o, cfg, p)
+    try:
+        for k in [0, 1, 2, 3, 4, 5, 6, 7, 8]:
+            info = tr.process(o.render(scene, k)[0], o.render_depth(scene, k, 2e-3))
+            assert len(tr.detections) == max(info["track_attempts"], 1) and info["n_keypoints"] == sum(tr.detections)
+        info = tr.process(o.render(scene, 16)[0], o.render_depth(scene, 16, 2e-3))            # the jump
+        rc = tr.feat_rc
+        assert info["track_attempts"] == 3 and info["track_broken"] == 1, info
+        assert len(tr.detections) == 3 and min(tr.detections) > 100 and info["n_keypoints"] == len(rc) == sum(tr.detections), (info["n_keypoints"], tr.detections)
+        pixels = rc[:, 0].astype(np.int64) * 100000 + rc[:, 1]
+        assert len(np.unique(pixels)) < len(rc)                                              # the same corner, detected again
+        new = [q for q in tr.frames[-1].points if q.previous is None]
+        pts = np.array([q.row * 100000 + q.col for q in new], np.int64)
+        assert len(new) == info["n_new"] > 0 and len(np.unique(pts)) <= len(pts)
+    finally:
+        o.destroy()
+
+
 def test_python_loop_over_the_oracle_with_the_orb_detector():
     """The checker loop itself with detector_type ORB (CPU only): keypoints of several pyramid levels, ORB::compute on their own level and
     angle, features sharing pixels — the scene is tracked."""
