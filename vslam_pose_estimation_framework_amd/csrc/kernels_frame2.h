@@ -910,11 +910,11 @@ __global__ __launch_bounds__(256) void k_update_landmarks(const DevCfg c, const 
 // and every lane's first measurements in LDS, teams of eight lanes for long tracks: landmark_team / landmark_point_t<true>, i.e. the operations of
 // k_frame's landmark phase in the same order): launch sequence 4 runs it on a second queue beside the frame's last phase, where the wide
 // one-thread-per-track kernel above (56 us for one KITTI-sized stream) would be longer than the phase it hides behind.
-__global__ __launch_bounds__(VS_WG) void k_update_landmarks_teams(const DevCfg c, const DevBuf b, int count) {
-  __shared__ __align__(16) unsigned char arena[VS_ARENA];
-  __shared__ int n_short, n_long_sh, scan[17];
-  const int s = b.s0 + blockIdx.y, tid = threadIdx.x, g = blockIdx.x, G = gridDim.x;
-  if (!vs_active(b, s)) return;
+// share g of G of stream s; n_short / n_long_sh / scan: workgroup-shared scratch (two counters, 17 ints); tick: the share-0 workgroup adds its duration to the
+// stream's landmark chronometer (the callers that are not timed by HIP events)
+__device__ __forceinline__ void lm_teams_body(const DevCfg& c, const DevBuf& b, int s, int g, int G, int count, bool tick, unsigned char* arena, int& n_short, int& n_long_sh, int* scan) {
+  const int tid = threadIdx.x;
+  const unsigned long long t_begin = wall_clock64();
   StreamState& st = b.st[s];
   const int n_cur = st.fc.n_cur, f = st.fc.lm_f;
   const PtView cvu = pts_of(c, b, s, st.fc.lm_pb);
@@ -977,7 +977,16 @@ __global__ __launch_bounds__(VS_WG) void k_update_landmarks_teams(const DevCfg c
     block_exclusive_scan(active, scan, &total);
     if (tid == 0 && total) atomicAdd(&st.fc.n_active, total);
   }
+  if (tick && g == 0 && tid == 0) st.ticks[3] += wall_clock64() - t_begin;
 }
+__global__ __launch_bounds__(VS_WG) void k_update_landmarks_teams(const DevCfg c, const DevBuf b, int count) {
+  __shared__ __align__(16) unsigned char arena[VS_ARENA];
+  __shared__ int n_short, n_long_sh, scan[17];
+  const int s = b.s0 + blockIdx.y;
+  if (!vs_active(b, s)) return;
+  lm_teams_body(c, b, s, blockIdx.x, gridDim.x, count, false, arena, n_short, n_long_sh, scan);
+}
+
 
 // sdist[i][k], k < 16: Hamming distance of left feature i to right feature g0 + w0 + k of its row [g0, g1), where the
 // window [w0, m) holds the (up to 16) nearest right features at or left of the left feature: m = number of right
@@ -1627,6 +1636,41 @@ __device__ __forceinline__ void set_pose(const DevCfg& c, const DevBuf& b, int s
 }
 
 
+// Phase 2 of the frame (status switch, stereo sweep + binning + emission, the frame's report and the state carried to the next frame): the end of
+// k_frame, and the frame workgroups of k_tail_lm.  sh.n_cur / sh.n_cand are set by the caller.
+__device__ __forceinline__ void frame_phase2(const DevCfg& c, const DevBuf& b, int s, StreamState& st, vslam_frame_info& info, FrameCarry& fc, FrameShared& sh,
+                                             int pb_cur, int f, unsigned char* arena) {
+  const int tid = threadIdx.x;
+  const int n_active = fc.n_active;
+  int status = fc.status;
+  if (n_active > c.c.minimum_number_of_landmarks_to_track) status = VSLAM_TRACKING;
+  const double tau_tri2 = fc.tau_tri;
+  const unsigned long long ts = wall_clock64();
+  wg_stereo(c, b, s, sh, pb_cur, tau_tri2, f, arena, VS_ARENA);
+  if (tid == 0) {
+    st.ticks[4] += wall_clock64() - ts;
+    const double* c2w = hpose_of(c, b, s, f);
+    *pts_of(c, b, s, pb_cur).n = sh.n_cur;
+    st.status = status; st.win = fc.win; st.tau_track = fc.tau_track; st.tau_tri = tau_tri2;
+    for (int k = 0; k < 12; ++k) { st.prior[k] = fc.prior[k]; st.pose[k] = c2w[k]; }
+    st.n_tracked_landmarks_prev = n_active;
+    st.frame_count = f + 1; st.has_prev = 1; st.cur = pb_cur; st.aligner_valid = fc.aligner_valid;
+    info.frame_index = f + 1; info.status = status; info.status_at_start = fc.status0;
+    info.n_keypoints_left = b.n_kp[s * 2]; info.n_keypoints_right = b.n_kp[s * 2 + 1];
+    int rl = 0, rr = 0;
+    for (int r = 0; r < c.n_regions; ++r) { rl += b.iinfo[s].raw_count[0][r]; rr += b.iinfo[s].raw_count[1][r]; info.thresholds[r] = b.iinfo[s].thr_after[r]; }
+    for (int r = c.n_regions; r < VSLAM_MAX_REGIONS; ++r) info.thresholds[r] = 0;
+    info.n_detected_left = rl; info.n_detected_right = rr;
+    info.track_attempts = fc.attempts; info.n_after_prune = fc.n_after_prune; info.n_recovered = fc.n_recovered;
+    info.n_active_landmarks = n_active; info.n_new_stereo = sh.n_cand; info.n_points = sh.n_cur;
+    info.track_broken = fc.broken; info.fallback = fc.fallback; info.window_pixels = fc.win;
+    info.error_flags = st.error_flags; info.tau_track = fc.tau_track; info.tau_triangulation = tau_tri2;
+    for (int k = 0; k < 12; ++k) { info.camera_left_to_world[k] = c2w[k]; info.previous_to_current[k] = fc.prior[k]; }
+    if (f < VS_POSE_LOG) { double* pl = b.pose_log + ((size_t)s * VS_POSE_LOG + f) * 12; for (int k = 0; k < 12; ++k) pl[k] = c2w[k]; }
+    st.dbg[8] += wall_clock64() - fc.t0;
+  }
+}
+
 // The frame is processed by three phase launches of this kernel with wide kernels in between (fused path):
 //   phase 0  track resolution, registration (aligner, recursion, fallback / break), prune, recovery projection
 //   [k_recover_brief]   BRIEF of the projected lost points, all streams, one wavefront each
@@ -1866,33 +1910,33 @@ __global__ VS_FRAME_BOUNDS void k_frame(ConstDevCfg* cp, ConstDevBuf* bp, int ph
     if (tid == 0) { fc.n_active = total; st.ticks[3] += wall_clock64() - tu; }
     __syncthreads();
   }
-  const int n_active = fc.n_active;
-  int status = fc.status;
-  if (n_active > c.c.minimum_number_of_landmarks_to_track) status = VSLAM_TRACKING;
-  const double tau_tri2 = fc.tau_tri;
-  const unsigned long long ts = wall_clock64();
-  wg_stereo(c, b, s, sh, pb_cur, tau_tri2, f, arena, VS_ARENA);
-  if (tid == 0) {
-    st.ticks[4] += wall_clock64() - ts;
-    const double* c2w = hpose_of(c, b, s, f);
-    *pts_of(c, b, s, pb_cur).n = sh.n_cur;
-    st.status = status; st.win = fc.win; st.tau_track = fc.tau_track; st.tau_tri = tau_tri2;
-    for (int k = 0; k < 12; ++k) { st.prior[k] = fc.prior[k]; st.pose[k] = c2w[k]; }
-    st.n_tracked_landmarks_prev = n_active;
-    st.frame_count = f + 1; st.has_prev = 1; st.cur = pb_cur; st.aligner_valid = fc.aligner_valid;
-    info.frame_index = f + 1; info.status = status; info.status_at_start = fc.status0;
-    info.n_keypoints_left = b.n_kp[s * 2]; info.n_keypoints_right = b.n_kp[s * 2 + 1];
-    int rl = 0, rr = 0;
-    for (int r = 0; r < c.n_regions; ++r) { rl += b.iinfo[s].raw_count[0][r]; rr += b.iinfo[s].raw_count[1][r]; info.thresholds[r] = b.iinfo[s].thr_after[r]; }
-    for (int r = c.n_regions; r < VSLAM_MAX_REGIONS; ++r) info.thresholds[r] = 0;
-    info.n_detected_left = rl; info.n_detected_right = rr;
-    info.track_attempts = fc.attempts; info.n_after_prune = fc.n_after_prune; info.n_recovered = fc.n_recovered;
-    info.n_active_landmarks = n_active; info.n_new_stereo = sh.n_cand; info.n_points = sh.n_cur;
-    info.track_broken = fc.broken; info.fallback = fc.fallback; info.window_pixels = fc.win;
-    info.error_flags = st.error_flags; info.tau_track = fc.tau_track; info.tau_triangulation = tau_tri2;
-    for (int k = 0; k < 12; ++k) { info.camera_left_to_world[k] = c2w[k]; info.previous_to_current[k] = fc.prior[k]; }
-    if (f < VS_POSE_LOG) { double* pl = b.pose_log + ((size_t)s * VS_POSE_LOG + f) * 12; for (int k = 0; k < 12; ++k) pl[k] = c2w[k]; }
-    st.dbg[8] += wall_clock64() - fc.t0;
+  frame_phase2(c, b, s, st, info, fc, sh, pb_cur, f, arena);
+}
+
+// Launch sequence 4's last launch: the n frame workgroups run phase 2, G more workgroups per stream the landmark refinement (lm_teams_body) — ONE launch
+// instead of a second queue with a fork and a join around it (each costs the frame queue ~7 us).  Nothing in phase 2 reads what the refinement writes.
+// (Folding the recovery descriptors and phase 1 into the same launch as well — workgroups handing over through counters — was measured: every
+// workgroup of a launch carries the frame workgroup's 140 KB of LDS, so the recovery workers own whole CUs and the next frame's image kernels lose
+// them: 0.226 -> 0.232 ms for one stream, 0.292 -> 0.353 for eleven.)
+__global__ VS_FRAME_BOUNDS void k_tail_lm(ConstDevCfg* cp, ConstDevBuf* bp, int n, int G) {
+  const DevCfg& c = *(const DevCfg*)cp;
+  const DevBuf& b = *(const DevBuf*)bp;
+  __shared__ FrameShared sh;
+  __shared__ __align__(16) unsigned char arena[VS_ARENA];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < n) {
+    const int s = b.s0 + xcd_local_stream(blockIdx.x, n, b.xcd_rot);
+    if (!vs_active(b, s)) return;
+    StreamState& st = b.st[s];
+    FrameCarry& fc = st.fc;
+    if (tid == 0) { sh.n_cur = fc.n_cur; sh.n_cand = 0; }
+    __syncthreads();
+    frame_phase2(c, b, s, st, b.info[s], fc, sh, st.cur ^ 1, st.frame_count, arena);
+  } else {
+    const int i = (int)blockIdx.x - n, sl = i / G;
+    const int s = b.s0 + sl;
+    if (!vs_active(b, s)) return;
+    lm_teams_body(c, b, s, i - sl * G, G, 0, true, arena, sh.flag, sh.n_proj, sh.scan);
   }
 }
 

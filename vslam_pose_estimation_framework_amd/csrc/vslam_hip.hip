@@ -20,9 +20,9 @@
 static thread_local std::string g_create_error;
 
 #ifndef VS_SPLIT4_MAX_STREAMS
-#define VS_SPLIT4_MAX_STREAMS 64  // up to this many streams the frame runs as launch sequence 4 (phase launches around the wide recovery kernel, the landmark
-                                  // kernel on a second queue beside the last phase).  Measured, ms per step fused / sequence 4: 1 stream 0.255 (two launches) / 0.238,
-                                  // 6: 0.339 / 0.303, 11: 0.343 / 0.312, 16: 0.358 / 0.330, 32: 0.400 / 0.380, 64: 0.491 / 0.482, 96: 0.577 / 0.578, 157: 0.73 / 0.81
+#define VS_SPLIT4_MAX_STREAMS 96  // up to this many streams the frame runs as launch sequence 4 (phase 0 | wide recovery kernel | phase 4 | phase 2 with the landmark
+                                  // refinement in workgroups of its own in the same launch).  Measured, ms per step fused / sequence 4: 1 stream 0.255 (two launches) /
+                                  // 0.223, 4: 0.296 / 0.258, 11: 0.343 / 0.292, 32: 0.400 / 0.353, 64: 0.491 / 0.452, 96: 0.584 / 0.561, 128: 0.664 / 0.667, 157: 0.73 / 0.81
 #endif
 struct vslam_ctx {
   DevCfg cfg;
@@ -772,17 +772,14 @@ static int launch_frame(vslam_ctx* c) {
       if (c->cfg.c.enable_landmark_recovery) { KernelTimer t(c, 5, g.st_frm); hipLaunchKernelGGL(k_recover_brief, dim3(std::max(4, std::min(64, 1024 / std::max(g.n, 1))), g.n), dim3(256), 0, g.st_frm, c->cfg, bs); }
       { KernelTimer t(c, 6, g.st_frm); hipLaunchKernelGGL(k_tail, dim3(g.n), dim3(VS_TAIL_WG), 0, g.st_frm, kc, kb); }
     } else if (c->split == 4 && c->st_lm) {
-      // few streams on an otherwise idle chip: the landmark refinement (a serial chain per track) leaves the frame's critical path — it runs on
-      // its own queue beside the stereo sweep and is joined behind it, so whatever follows on the frame queue sees its results
+      // few streams on an otherwise idle chip: the landmark refinement (a serial chain per track) leaves the frame's critical path — it runs in
+      // workgroups of its own beside the stereo sweep, inside the frame's last launch
       { KernelTimer t(c, 4, g.st_frm, false); hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, kc, kb, 0); }
       if (c->cfg.c.enable_landmark_recovery) { KernelTimer t(c, 5, g.st_frm); hipLaunchKernelGGL(k_recover_brief, dim3(std::max(4, std::min(64, 1024 / std::max(g.n, 1))), g.n), dim3(256), 0, g.st_frm, c->cfg, bs); }
       { KernelTimer t(c, 4, g.st_frm, false); hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, kc, kb, 4); }
-      HIP_TRY(c, hipEventRecord(c->ev_lm_fork, g.st_frm));
-      HIP_TRY(c, hipStreamWaitEvent(c->st_lm, c->ev_lm_fork, 0));
-      { KernelTimer t(c, 6, c->st_lm); hipLaunchKernelGGL(k_update_landmarks_teams, dim3(std::max(1, std::min(16, 64 / std::max(g.n, 1))), g.n), dim3(VS_WG), 0, c->st_lm, c->cfg, bs, 0); }
-      HIP_TRY(c, hipEventRecord(c->ev_lm_join, c->st_lm));
-      { KernelTimer t(c, 4, g.st_frm); hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, kc, kb, 2); }
-      HIP_TRY(c, hipStreamWaitEvent(g.st_frm, c->ev_lm_join, 0));
+      // phase 2 and the landmark refinement in ONE launch: n frame workgroups + G refinement workgroups per stream (k_tail_lm)
+      { KernelTimer t(c, 4, g.st_frm); const int G = std::max(1, std::min(16, 64 / std::max(g.n, 1)));
+        hipLaunchKernelGGL(k_tail_lm, dim3(g.n * (1 + G)), dim3(VS_WG), 0, g.st_frm, kc, kb, g.n, G); }
     } else if (c->split == 2 || c->split == 4) {
       { KernelTimer t(c, 4, g.st_frm, false); hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, kc, kb, 0); }
       { KernelTimer t(c, 5, g.st_frm); hipLaunchKernelGGL(k_recover_brief, dim3(std::max(4, std::min(64, 1024 / std::max(g.n, 1))), g.n), dim3(256), 0, g.st_frm, c->cfg, bs); }
