@@ -2096,10 +2096,8 @@ __global__ __launch_bounds__(256) void k_begin(const DevCfg c, const DevBuf b, c
   }
 }
 
-__global__ __launch_bounds__(VS_WG) void k_stage(const DevCfg c, const DevBuf b, int stage, int arg, const StageIo io) {
-  __shared__ FrameShared sh;
-  __shared__ __align__(16) unsigned char arena[VS_ARENA];
-  const int s = b.s0 + xcd_local_stream(blockIdx.x, gridDim.x, b.xcd_rot), tid = threadIdx.x;
+__device__ __forceinline__ void stage_body(const DevCfg& c, const DevBuf& b, int stage, int arg, const StageIo& io, FrameShared& sh, unsigned char* arena, int bx, int gx) {
+  const int s = b.s0 + xcd_local_stream(bx, gx, b.xcd_rot), tid = threadIdx.x;
   if (!vs_active(b, s)) return;
   StreamState& st = b.st[s];
   vslam_frame_info& info = b.info[s];
@@ -2241,6 +2239,22 @@ __global__ __launch_bounds__(VS_WG) void k_stage(const DevCfg c, const DevBuf b,
     __syncthreads();
     if (tid == 0) report_publish(io.out, io.seq);
   }
+}
+__global__ __launch_bounds__(VS_WG) void k_stage(const DevCfg c, const DevBuf b, int stage, int arg, const StageIo io) {
+  __shared__ FrameShared sh;
+  __shared__ __align__(16) unsigned char arena[VS_ARENA];
+  stage_body(c, b, stage, arg, io, sh, arena, blockIdx.x, gridDim.x);
+}
+// vslam_compute of a context whose vslam_prune_recover has published the frame's history: the n stream workgroups run the stage (STEREO_COUNT: the
+// stereo sweep with the active landmarks counted, not refined), G more workgroups per stream refine the landmarks beside it (lm_teams_body) — one launch
+__global__ __launch_bounds__(VS_WG) void k_stage_lm(const DevCfg c, const DevBuf b, int stage, int arg, const StageIo io, int n, int G) {
+  __shared__ FrameShared sh;
+  __shared__ __align__(16) unsigned char arena[VS_ARENA];
+  if ((int)blockIdx.x < n) { stage_body(c, b, stage, arg, io, sh, arena, blockIdx.x, n); return; }
+  const int i = (int)blockIdx.x - n, sl = i / G;
+  const int s = b.s0 + sl;
+  if (!vs_active(b, s)) return;
+  lm_teams_body(c, b, s, i - sl * G, G, 0, true, arena, sh.flag, sh.n_proj, sh.scan);
 }
 
 // vslam_reset_stream, asynchronous: the stream state has an image-pipeline half (the detector thresholds, written by k_emit

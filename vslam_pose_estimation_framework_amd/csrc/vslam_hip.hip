@@ -92,10 +92,8 @@ struct vslam_ctx {
   hipEvent_t pin_ev[2] = {nullptr, nullptr}; bool pin_used[2] = {false, false};
   int split = 0;   // 0: one frame launch; 1: three phase launches with wide recovery / landmark kernels in between (measured slower);
                    // 2: two phase launches around the wide recovery kernel
-                   // 4: three phase launches, the wide landmark kernel on a second queue beside the last one (fastest up to VS_SPLIT4_MAX_STREAMS streams)
-  bool lm_published = false;                            // vslam_prune_recover has published the frame's history (one stream, second queue present): vslam_compute may fork the landmark kernel
-  hipStream_t st_lm = nullptr;                         // launch sequence 4: the landmark kernel's queue, forked after phase 1 and joined behind phase 2
-  hipEvent_t ev_lm_fork = nullptr, ev_lm_join = nullptr;
+                   // 4: phase launches around the wide recovery kernel, the landmark refinement in workgroups of its own inside the last one (fastest up to VS_SPLIT4_MAX_STREAMS streams)
+  bool lm_published = false;                            // vslam_prune_recover has published the frame's history (one stream): vslam_compute runs the landmark refinement beside the stereo stage
   int sticky = VSLAM_OK;
 };
 
@@ -470,11 +468,7 @@ static int create_internal(const vslam_config* cfg, int device, int n_streams, v
     c->own_stream = true;
     c->split = n_streams <= VS_SPLIT4_MAX_STREAMS ? 4 : 0;
     if (const char* e = getenv("VSLAM_SPLIT")) c->split = std::max(0, std::min(4, atoi(e)));
-    if (c->split == 4) {   // one stream group only (few streams); without the second queue the sequence falls back to 2
-      const bool ok = c->groups.size() == 1 && hipStreamCreateWithFlags(&c->st_lm, hipStreamNonBlocking) == hipSuccess &&
-                      hipEventCreateWithFlags(&c->ev_lm_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_lm_join, hipEventDisableTiming) == hipSuccess;
-      if (!ok) { (void)hipGetLastError(); if (c->st_lm) { (void)hipStreamDestroy(c->st_lm); c->st_lm = nullptr; } }
-    }
+    if (c->split == 4 && c->groups.size() != 1) c->split = 2;     // one stream group only
   }
   const DevCfg& d = c->cfg;
   DevBuf& b = c->buf;
@@ -584,9 +578,6 @@ VS_API void vslam_destroy(vslam_ctx* c) {
   for (int q = 0; q < 2; ++q) { if (c->pin_img[q]) (void)hipHostFree(c->pin_img[q]); if (c->pin_ev[q]) (void)hipEventDestroy(c->pin_ev[q]); }
   for (int i = 0; i < 6; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   harvest_events(c);
-  if (c->ev_lm_fork) (void)hipEventDestroy(c->ev_lm_fork);
-  if (c->ev_lm_join) (void)hipEventDestroy(c->ev_lm_join);
-  if (c->st_lm) (void)hipStreamDestroy(c->st_lm);
   for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
   for (auto& g : c->groups) {
     for (int q = 0; q < 2; ++q) { (void)hipEventDestroy(g.ev_img[q]); (void)hipEventDestroy(g.ev_frm[q]); (void)hipEventDestroy(g.ev_emit[q]); }
@@ -771,7 +762,7 @@ static int launch_frame(vslam_ctx* c) {
       { KernelTimer t(c, 4, g.st_frm); hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, kc, kb, 0); }
       if (c->cfg.c.enable_landmark_recovery) { KernelTimer t(c, 5, g.st_frm); hipLaunchKernelGGL(k_recover_brief, dim3(std::max(4, std::min(64, 1024 / std::max(g.n, 1))), g.n), dim3(256), 0, g.st_frm, c->cfg, bs); }
       { KernelTimer t(c, 6, g.st_frm); hipLaunchKernelGGL(k_tail, dim3(g.n), dim3(VS_TAIL_WG), 0, g.st_frm, kc, kb); }
-    } else if (c->split == 4 && c->st_lm) {
+    } else if (c->split == 4) {
       // few streams on an otherwise idle chip: the landmark refinement (a serial chain per track) leaves the frame's critical path — it runs in
       // workgroups of its own beside the stereo sweep, inside the frame's last launch
       { KernelTimer t(c, 4, g.st_frm, false); hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, kc, kb, 0); }
@@ -780,7 +771,7 @@ static int launch_frame(vslam_ctx* c) {
       // phase 2 and the landmark refinement in ONE launch: n frame workgroups + G refinement workgroups per stream (k_tail_lm)
       { KernelTimer t(c, 4, g.st_frm); const int G = std::max(1, std::min(16, 64 / std::max(g.n, 1)));
         hipLaunchKernelGGL(k_tail_lm, dim3(g.n * (1 + G)), dim3(VS_WG), 0, g.st_frm, kc, kb, g.n, G); }
-    } else if (c->split == 2 || c->split == 4) {
+    } else if (c->split == 2) {
       { KernelTimer t(c, 4, g.st_frm, false); hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, kc, kb, 0); }
       { KernelTimer t(c, 5, g.st_frm); hipLaunchKernelGGL(k_recover_brief, dim3(std::max(4, std::min(64, 1024 / std::max(g.n, 1))), g.n), dim3(256), 0, g.st_frm, c->cfg, bs); }
       { KernelTimer t(c, 4, g.st_frm); hipLaunchKernelGGL(k_frame, dim3(g.n), dim3(VS_WG), 0, g.st_frm, kc, kb, 3); }
@@ -2190,9 +2181,9 @@ VS_API int vslam_prune_recover(vslam_ctx* c) {
   for (auto& g : c->groups)
     hipLaunchKernelGGL(k_recover_brief, dim3(std::max(4, std::min(64, 1024 / std::max(g.n, 1))), g.n), dim3(256), 0, g.st_frm, c->cfg, buf_set(c, c->last_set, g.s0, g.q0_frm));
   HIP_TRY(c, hipGetLastError());
-  // one stream with a second queue (launch sequence 4's): the stage also publishes the frame's history, so that vslam_compute can run the landmark
-  // refinement beside the stereo stage instead of in front of it
-  const bool side = c->B == 1 && c->st_lm != nullptr;
+  // one stream: the stage also publishes the frame's history, so that vslam_compute can run the landmark refinement beside the stereo stage
+  // instead of in front of it
+  const bool side = c->B == 1;
   rc = launch_stage(c, VS_STAGE_RECOVER_APPEND, side ? 3 : 1, VS_REPORT_POINTS, 1);
   c->lm_published = rc == VSLAM_OK && side;
   return rc;
@@ -2207,28 +2198,21 @@ VS_API int vslam_stereo_new(vslam_ctx* c) {
 VS_API int vslam_compute(vslam_ctx* c) {     // vslam_update_points + vslam_stereo_new in one launch
   NEED_FRAME("vslam_compute");
   c->frame_begun = false;
-  if (c->lm_published && c->st_lm) {
-    // one stream, its history already published by vslam_prune_recover: the landmark refinement (k_update_landmarks_teams, the frame workgroup's
-    // refinement spread over several workgroups) runs on the second queue BESIDE the stereo stage, which only counts the active landmarks; the
-    // report — it carries the landmark update counts — is packed behind the join
+  if (c->lm_published) {
+    // one stream, its history already published by vslam_prune_recover: the landmark refinement (lm_teams_body, the frame workgroup's refinement
+    // spread over several workgroups) runs BESIDE the stereo stage in the same launch (k_stage_lm); the stage only counts the active landmarks.
+    // The report — it carries the landmark update counts — is packed by the next launch on the queue.
     c->lm_published = false;
     vslam_ctx::Group& g = c->groups[0];
-    int rc = flush_pending(c);
-    if (rc != VSLAM_OK) return rc;
-    HIP_TRY(c, hipEventRecord(c->ev_lm_fork, g.st_frm));
-    HIP_TRY(c, hipStreamWaitEvent(c->st_lm, c->ev_lm_fork, 0));
-    { KernelTimer t(c, 6, c->st_lm); hipLaunchKernelGGL(k_update_landmarks_teams, dim3(16, 1), dim3(VS_WG), 0, c->st_lm, c->cfg, buf_set(c, c->last_set, g.s0, g.q0_frm), 0); }
-    HIP_TRY(c, hipEventRecord(c->ev_lm_join, c->st_lm));
-    rc = launch_stage(c, VS_STAGE_STEREO_COUNT, 0);
-    if (rc != VSLAM_OK) return rc;
-    HIP_TRY(c, hipStreamWaitEvent(g.st_frm, c->ev_lm_join, 0));
+    const StageIo io = stage_io(c, 0, 0);
+    { KernelTimer t(c, 6, g.st_frm, true, false);
+      hipLaunchKernelGGL(k_stage_lm, dim3(g.n * (1 + 16)), dim3(VS_WG), 0, g.st_frm, c->cfg, buf_set(c, c->last_set, g.s0, g.q0_frm), (int)VS_STAGE_STEREO_COUNT, 0, io, g.n, 16); }
+    HIP_TRY(c, hipGetLastError());
     if (c->report) {
       const int seq = ++c->report_seq;
       hipLaunchKernelGGL(k_report, dim3(16), dim3(256), 0, g.st_frm, c->cfg, buf_set(c, c->last_set, g.s0), 0, (int)VS_REPORT_POINTS, 0, seq, c->rl, c->report_dev, c->report_done);
       HIP_TRY(c, hipGetLastError());
       c->report_have = VS_REPORT_POINTS; c->report_have_ip = 0; c->report_have_stream = 0; c->report_have_seq = seq;
-    } else {
-      c->report_have = 0;
     }
     return frame_done(c);
   }
