@@ -908,8 +908,9 @@ __global__ __launch_bounds__(256) void k_update_landmarks(const DevCfg c, const 
 
 // The same refinement spread over `gridDim.x` workgroups per stream, each with the frame workgroup's own machinery (poses of the last VS_LM_NP frames
 // and every lane's first measurements in LDS, teams of eight lanes for long tracks: landmark_team / landmark_point_t<true>, i.e. the operations of
-// k_frame's landmark phase in the same order): launch sequence 4 runs it on a second queue beside the frame's last phase, where the wide
-// one-thread-per-track kernel above (56 us for one KITTI-sized stream) would be longer than the phase it hides behind.
+// k_frame's landmark phase in the same order): launch sequence 4 (k_tail_lm) and the stage path of a one-stream context (k_stage_lm) run it beside the
+// frame's last phase / stage, inside the same launch, where the wide one-thread-per-track kernel above (56 us for one KITTI-sized stream) would be
+// longer than what it hides behind.
 // share g of G of stream s; n_short / n_long_sh / scan: workgroup-shared scratch (two counters, 17 ints); tick: the share-0 workgroup adds its duration to the
 // stream's landmark chronometer (the callers that are not timed by HIP events)
 __device__ __forceinline__ void lm_teams_body(const DevCfg& c, const DevBuf& b, int s, int g, int G, int count, bool tick, unsigned char* arena, int& n_short, int& n_long_sh, int* scan) {
@@ -979,15 +980,6 @@ __device__ __forceinline__ void lm_teams_body(const DevCfg& c, const DevBuf& b, 
   }
   if (tick && g == 0 && tid == 0) st.ticks[3] += wall_clock64() - t_begin;
 }
-__global__ __launch_bounds__(VS_WG) void k_update_landmarks_teams(const DevCfg c, const DevBuf b, int count) {
-  __shared__ __align__(16) unsigned char arena[VS_ARENA];
-  __shared__ int n_short, n_long_sh, scan[17];
-  const int s = b.s0 + blockIdx.y;
-  if (!vs_active(b, s)) return;
-  lm_teams_body(c, b, s, blockIdx.x, gridDim.x, count, false, arena, n_short, n_long_sh, scan);
-}
-
-
 // sdist[i][k], k < 16: Hamming distance of left feature i to right feature g0 + w0 + k of its row [g0, g1), where the
 // window [w0, m) holds the (up to 16) nearest right features at or left of the left feature: m = number of right
 // features of the row with x <= xl, w0 = max(m - 16, 0).  Nothing is written for m = 0 or m >= 255.
@@ -1678,7 +1670,7 @@ __device__ __forceinline__ void frame_phase2(const DevCfg& c, const DevBuf& b, i
 //   [k_update_landmarks] landmark creation / refinement, one thread per framepoint; [k_stereo_dist] L-R distances
 //   phase 2  status switch, stereo sweep + binning + emission, report
 // phase < 0 runs everything in one launch (the wide steps inside the workgroup).
-// phase 4 = phase 1 + the count of active landmarks: k_update_landmarks then runs on a second queue BESIDE phase 2 (launch sequence 4, few streams:
+// phase 4 = phase 1 + the count of active landmarks: the refinement then runs in workgroups of its own BESIDE phase 2 (k_tail_lm, launch sequence 4, few streams:
 // nothing of phase 2 reads what the refinement writes — landmark coordinates and update counts of the tracked points; the next frame's phase 0 does).
 // phase 3 = phases 1 and 2 in one launch with the landmark refinement inside the workgroup: with phase 0 and the wide recovery
 // kernel in front this is the two-launch sequence used for few streams (the ~140 recovery patches of a frame spread over the
@@ -2066,7 +2058,7 @@ __global__ __launch_bounds__(VS_WG) void k_recover_alone(const DevCfg c, const D
 // ==============================================================================================
 enum { VS_STAGE_TRACK = 1, VS_STAGE_ALIGN = 2, VS_STAGE_PRUNE_RECOVER = 3, VS_STAGE_UPDATE = 4, VS_STAGE_STEREO = 5, VS_STAGE_COMPUTE = 6 /* UPDATE then STEREO */,
        VS_STAGE_PRUNE_PROJECT = 7, VS_STAGE_RECOVER_APPEND = 8 /* PRUNE_RECOVER as two launches around the wide k_recover_brief */,
-       VS_STAGE_STEREO_COUNT = 9 /* STEREO + the COUNT of active landmarks: their refinement runs beside this launch (k_update_landmarks_teams on a second queue) */ };
+       VS_STAGE_STEREO_COUNT = 9 /* STEREO + the COUNT of active landmarks: their refinement runs beside the stage in the same launch (k_stage_lm) */ };
 
 // WorldMap::createFrame + the bookkeeping PoseTracker3D::compute does before initialize() (:36-77)
 // the caller's setters folded into a stage launch (StageIo): applied by one lane before anything reads the stream state
@@ -2181,7 +2173,7 @@ __device__ __forceinline__ void stage_body(const DevCfg& c, const DevBuf& b, int
     }
     if (arg & 2) {
       // the frame's point list is final: publish it to the history ring here, so that the landmark kernel of the next call (vslam_compute of a
-      // one-stream context: k_update_landmarks_teams beside the stereo stage) finds what wg_update_points would have published first
+      // one-stream context: lm_teams_body beside the stereo stage, k_stage_lm) finds what wg_update_points would have published first
       __syncthreads();
       wg_publish_history(c, b, s, sh.n_cur, pb_cur, f);
       if (tid == 0) { st.fc.n_cur = sh.n_cur; st.fc.lm_pb = pb_cur; st.fc.lm_f = f; }

@@ -2205,8 +2205,7 @@ VS_API int vslam_compute(vslam_ctx* c) {     // vslam_update_points + vslam_ster
     c->lm_published = false;
     vslam_ctx::Group& g = c->groups[0];
     const StageIo io = stage_io(c, 0, 0);
-    { KernelTimer t(c, 6, g.st_frm, true, false);
-      hipLaunchKernelGGL(k_stage_lm, dim3(g.n * (1 + 16)), dim3(VS_WG), 0, g.st_frm, c->cfg, buf_set(c, c->last_set, g.s0, g.q0_frm), (int)VS_STAGE_STEREO_COUNT, 0, io, g.n, 16); }
+    { hipLaunchKernelGGL(k_stage_lm, dim3(g.n * (1 + 16)), dim3(VS_WG), 0, g.st_frm, c->cfg, buf_set(c, c->last_set, g.s0, g.q0_frm), (int)VS_STAGE_STEREO_COUNT, 0, io, g.n, 16); }
     HIP_TRY(c, hipGetLastError());
     if (c->report) {
       const int seq = ++c->report_seq;
